@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator (TEST INFRASTRUCTURE; runs only in the build container).
+
+Imports the UNMODIFIED reference implementation from /root/reference/src (through the
+import stubs in oracle/ref_stubs/ for pyhocon / cv2 / torchvision / dotmap, none of which is
+used by the hot path at run time -- SURVEY.md Appendix B), builds the reference
+`PixelNeRFNet` + `NeRFRenderer`, loads the seeded synthetic weights / scenes of
+pixelnerf_amd.synthetic, pins every random draw by substituting pre-drawn noise in the
+reference's draw order, runs `NeRFRenderer.forward` on CPU and freezes inputs + outputs
+(+ intermediate z samples and per-point rgb/sigma captured by wrapping `composite`) into
+tests/golden/<scenario>.npz.
+
+The reference repository has no tests or golden vectors of its own, so these
+fixtures ARE the parity pin for oracle/pnr_oracle.py and, through it, for the HIP path.
+
+Usage:  python oracle/make_goldens.py            (writes tests/golden/*.npz)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("PIXELNERF_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "ref_stubs"))
+sys.path.insert(1, os.path.join(REF, "src"))
+sys.path.insert(2, ROOT)
+
+from pixelnerf_amd import synthetic  # noqa: E402
+
+# name: (scene, n_coarse, n_fine, n_fine_depth, rays/object, lindisp, use mlp_fine)
+SCENARIOS = {
+    "sn64_c32":        ("sn64", 32, 0, 0, 192, False, True),     # BASELINE config (1) sampling
+    "sn64_64_128":     ("sn64", 64, 128, 16, 96, False, True),   # BASELINE metric sampling
+    "srn_mini_64_128": ("srn_mini", 64, 128, 16, 64, False, True),   # NS=2 mean pooling
+    "dtu_mini_64_128": ("dtu_mini", 64, 128, 16, 64, False, True),   # NS=3, black bkgd, fx!=fy
+    "train_64_32":     ("train", 64, 32, 16, 32, False, True),   # SB=4 (config 5 shapes)
+    "mv_mini_lindisp": ("mv_mini", 32, 16, 0, 32, True, True),   # SB=2 x NS=2, lindisp, Kfd=0
+    "sn64_coarse_only_mlp": ("sn64", 16, 16, 16, 32, False, False),  # mlp_fine=None, Kf-Kfd=0
+}
+MLP_SEED_COARSE, MLP_SEED_FINE, SCENE_SEED = 11, 12, 2
+
+
+class Conf(dict):
+    """dict-backed stand-in for a pyhocon ConfigTree (get_* with defaults, conf['sub'])."""
+
+    def _get(self, k, d=None):
+        return self[k] if k in self else d
+
+    get_bool = get_int = get_float = get_string = get_list = _get
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        return Conf(v) if isinstance(v, dict) and not isinstance(v, Conf) else v
+
+
+def model_conf():
+    """conf/default.conf:3-48 + conf/default_mv.conf:3-22 (the one shape every shipped
+    experiment resolves to)."""
+    mlp = dict(type="resnet", n_blocks=5, d_hidden=512, combine_layer=3, combine_type="average")
+    return Conf(
+        use_encoder=True, use_global_encoder=False, use_xyz=True, canon_xyz=False,
+        use_code=True, code=dict(num_freqs=6, freq_factor=1.5, include_input=True),
+        use_viewdirs=True, use_code_viewdirs=False,
+        mlp_coarse=dict(mlp), mlp_fine=dict(mlp),
+        encoder=dict(backbone="resnet34", pretrained=False, num_layers=4),
+    )
+
+
+class _TorchProxy:
+    """Stands in for the `torch` global of reference module render.nerf: forwards everything
+    to torch but serves rand / rand_like / randn_like from a pre-drawn queue."""
+
+    def __init__(self, queue):
+        self._q = queue
+
+    def __getattr__(self, k):
+        return getattr(torch, k)
+
+    def _pop(self, kind, shape):
+        k, t = self._q.pop(0)
+        assert k == kind, (k, kind)
+        assert tuple(t.shape) == tuple(shape), (k, t.shape, shape)
+        return t.clone()
+
+    def rand(self, *shape, **kw):
+        return self._pop("rand", shape)
+
+    def rand_like(self, t):
+        return self._pop("rand_like", t.shape)
+
+    def randn_like(self, t):
+        return self._pop("randn_like", t.shape)
+
+
+def build_reference_net(use_fine):
+    import model as ref_model
+
+    net = ref_model.make_model(model_conf())
+    net.mlp_coarse.load_state_dict(synthetic.make_mlp_params(MLP_SEED_COARSE))
+    if use_fine:
+        net.mlp_fine.load_state_dict(synthetic.make_mlp_params(MLP_SEED_FINE))
+    else:
+        net.mlp_fine = None  # eval/eval.py:140
+    return net.eval()
+
+
+def set_encode_state(net, scene):
+    """What PixelNeRFNet.encode() leaves behind (models.py:111-141, encoder.py:160-163)."""
+    lat = scene["latent"]
+    net.encoder.latent = lat
+    ls = torch.tensor([lat.shape[-1], lat.shape[-2]], dtype=torch.float32)
+    net.encoder.latent_scaling = ls / (ls - 1) * 2.0
+    net.poses = scene["poses"]
+    net.image_shape = scene["image_shape"]
+    net.focal = scene["focal"]
+    net.c = scene["c"]
+    net.num_objs = scene["SB"]
+    net.num_views_per_obj = scene["NS"]
+
+
+def run_scenario(name):
+    import render.nerf as ref_nerf
+
+    scene_name, Kc, Kf, Kfd, n_rays, lindisp, use_fine = SCENARIOS[name]
+    scene, meta = synthetic.make_scene(scene_name, seed=SCENE_SEED)
+    rays = synthetic.target_rays(meta, n_rays=n_rays)  # (SB, n_rays, 8)
+    SB = rays.shape[0]
+    R = SB * n_rays
+    noise = synthetic.make_noise(R, Kc, Kf, Kfd)
+
+    queue = [("rand_like", noise["u1"])]
+    if Kf > 0:
+        if Kf - Kfd > 0:
+            queue += [("rand", noise["u2"]), ("rand_like", noise["u3"])]
+        if Kfd > 0:
+            queue += [("randn_like", noise["n4"])]
+
+    net = build_reference_net(use_fine)
+    set_encode_state(net, scene)
+    renderer = ref_nerf.NeRFRenderer(
+        n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, depth_std=0.01,
+        white_bkgd=meta["white_bkgd"], lindisp=lindisp, eval_batch_size=50000,
+    ).eval()
+
+    captured = []
+    orig_composite = renderer.composite
+
+    def composite_spy(model, rays_, z_samp, coarse=True, sb=0):
+        outs = []
+        orig_forward = model.forward
+
+        def fwd_spy(*a, **k):
+            o = orig_forward(*a, **k)
+            outs.append(o)
+            return o
+
+        model.forward = fwd_spy
+        try:
+            res = orig_composite(model, rays_, z_samp, coarse=coarse, sb=sb)
+        finally:
+            del model.forward
+        out = torch.cat(outs, dim=1).reshape(z_samp.shape[0], z_samp.shape[1], 4)
+        captured.append((z_samp.clone(), out.clone()))
+        return res
+
+    renderer.composite = composite_spy
+    real_torch = ref_nerf.torch
+    ref_nerf.torch = _TorchProxy(queue)
+    try:
+        with torch.no_grad():
+            out = renderer(net, rays, want_weights=True)
+    finally:
+        ref_nerf.torch = real_torch
+    assert len(queue) == 0, "noise queue not fully consumed"
+
+    rec = dict(
+        scene=scene_name, n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, lindisp=int(lindisp),
+        use_mlp_fine=int(use_fine), white_bkgd=int(meta["white_bkgd"]), depth_std=0.01,
+        mlp_seed_coarse=MLP_SEED_COARSE, mlp_seed_fine=MLP_SEED_FINE, scene_seed=SCENE_SEED,
+        rays=rays.numpy(),
+    )
+    for k, v in noise.items():
+        rec["noise_" + k] = v.numpy()
+    rec["coarse_rgb"] = out.coarse.rgb.numpy()
+    rec["coarse_depth"] = out.coarse.depth.numpy()
+    rec["coarse_weights"] = out.coarse.weights.numpy()
+    rec["coarse_z"] = captured[0][0].numpy()
+    rec["coarse_rgbsigma"] = captured[0][1].numpy()
+    if Kf > 0:
+        rec["fine_rgb"] = out.fine.rgb.numpy()
+        rec["fine_depth"] = out.fine.depth.numpy()
+        rec["fine_weights"] = out.fine.weights.numpy()
+        rec["fine_z"] = captured[1][0].numpy()
+        rec["fine_rgbsigma"] = captured[1][1].numpy()
+    return rec
+
+
+def stage_goldens():
+    """Stage-level fixtures from the reference modules themselves: PositionalEncoding
+    (src/model/code.py), SpatialEncoder.index (src/model/encoder.py:80-109) and
+    PixelNeRFNet.forward (src/model/models.py:146-266) on seeded random query points."""
+    from model.code import PositionalEncoding
+
+    rs = np.random.RandomState(99)
+    rec = {}
+    x = torch.from_numpy(rs.uniform(-3, 3, (257, 3)).astype(np.float32))
+    code = PositionalEncoding(num_freqs=6, d_in=3, freq_factor=1.5, include_input=True)
+    rec["posenc_x"] = x.numpy()
+    rec["posenc_out"] = code(x).numpy()
+
+    for scene_name in ("sn64", "dtu_mini", "mv_mini"):
+        scene, meta = synthetic.make_scene(scene_name, seed=SCENE_SEED)
+        net = build_reference_net(True)
+        set_encode_state(net, scene)
+        SB, NS = scene["SB"], scene["NS"]
+        B = 200
+        # query points around the object, plus some that project outside the source images
+        xyz = torch.from_numpy(rs.uniform(-1.0, 1.0, (SB, B, 3)).astype(np.float32))
+        xyz[:, :20] *= 4.0
+        vd = torch.from_numpy(rs.randn(SB, B, 3).astype(np.float32))
+        vd = vd / vd.norm(dim=-1, keepdim=True)
+        with torch.no_grad():
+            out_c = net(xyz, coarse=True, viewdirs=vd)
+            out_f = net(xyz, coarse=False, viewdirs=vd)
+            uv = torch.from_numpy(
+                rs.uniform(-8, meta["W"] + 8, (SB * NS, 64, 2)).astype(np.float32))
+            idx = net.encoder.index(uv, None, net.image_shape)
+        rec[f"{scene_name}_xyz"] = xyz.numpy()
+        rec[f"{scene_name}_viewdirs"] = vd.numpy()
+        rec[f"{scene_name}_out_coarse"] = out_c.numpy()
+        rec[f"{scene_name}_out_fine"] = out_f.numpy()
+        rec[f"{scene_name}_uv"] = uv.numpy()
+        rec[f"{scene_name}_index"] = idx.numpy()
+    return rec
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    names = sys.argv[1:] or (list(SCENARIOS) + ["stages"])
+    for name in names:
+        rec = stage_goldens() if name == "stages" else run_scenario(name)
+        path = os.path.join(outdir, name + ".npz")
+        np.savez_compressed(path, **rec)
+        print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

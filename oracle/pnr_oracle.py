@@ -1,0 +1,286 @@
+"""
+CPU ORACLE for the pixelNeRF volume-rendering hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, fp32) restatement of the reference algorithm.  It is
+imported only by tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg; the
+product path (pixel-nerf_amd/) never imports it and fails loudly when the HIP library is
+missing.
+
+Parity pin: the reference repository ships NO tests / golden vectors for this path
+(SURVEY.md §4, §8c).  The oracle is therefore pinned against outputs of the reference
+itself: `oracle/make_goldens.py` imports the unmodified reference code from
+/root/reference (through the import stubs in oracle/ref_stubs/), runs it on the seeded
+scenes of `oracle/scenes.py` with pre-drawn noise, and freezes the outputs under
+tests/golden/*.npz.  tests/test_oracle_vs_golden.py checks this restatement against those
+fixtures to ~1e-6.
+
+Every function cites the reference file:line it follows (paths relative to the reference
+repository root).  All random draws are explicit inputs, in the reference's draw order
+(src/render/nerf.py:111,135,141,158):
+    u1 ~ U[0,1) (R, Kc)          coarse stratified jitter
+    u2 ~ U[0,1) (R, Kf - Kfd)    inverse-CDF uniforms
+    u3 ~ U[0,1) (R, Kf - Kfd)    in-bin jitter
+    n4 ~ N(0,1) (R, Kfd)         depth-sample noise
+"""
+import math
+
+import torch
+
+# --------------------------------------------------------------------------------------
+# model side
+# --------------------------------------------------------------------------------------
+
+
+def positional_encoding(x, num_freqs=6, freq_factor=1.5, include_input=True):
+    """src/model/code.py:11-42.  x (N, d_in) -> (N, d_in*(2*num_freqs+1)).
+
+    Layout: [x, sin(f0 x), sin(f0 x + pi/2), sin(f1 x), ...] with f_k = freq_factor * 2^k;
+    the cosine is computed as a phase-shifted sine with fp32(pi/2) exactly as the reference
+    does (code.py:24-26,38).
+    """
+    freqs = freq_factor * 2.0 ** torch.arange(0, num_freqs)  # code.py:15
+    _freqs = torch.repeat_interleave(freqs, 2).view(1, -1, 1)  # code.py:21-23
+    _phases = torch.zeros(2 * num_freqs)
+    _phases[1::2] = math.pi * 0.5  # code.py:26-27
+    _phases = _phases.view(1, -1, 1)
+    embed = x.unsqueeze(1).repeat(1, num_freqs * 2, 1)  # code.py:37
+    embed = torch.sin(torch.addcmul(_phases, embed, _freqs))  # code.py:38
+    embed = embed.view(x.shape[0], -1)
+    if include_input:
+        embed = torch.cat((x, embed), dim=-1)  # code.py:40-41
+    return embed
+
+
+def index_latent(latent, uv, image_shape):
+    """src/model/encoder.py:80-109 + :161-163, with F.grid_sample(bilinear, border,
+    align_corners=True) written out.
+
+    latent (NV, C, Hl, Wl); uv (NV, N, 2) in source-image pixels; image_shape (W, H).
+    Returns (NV, C, N).
+    """
+    NV, C, Hl, Wl = latent.shape
+    # encoder.py:161-163  latent_scaling = [Wl, Hl] / ([Wl, Hl] - 1) * 2
+    ls = torch.tensor([Wl, Hl], dtype=torch.float32)
+    ls = ls / (ls - 1) * 2.0
+    scale = ls / image_shape.to(torch.float32)  # encoder.py:98
+    g = uv * scale - 1.0  # encoder.py:99
+    # grid_sample, align_corners=True: pix = (g + 1) / 2 * (size - 1)
+    ix = ((g[..., 0] + 1) / 2) * (Wl - 1)
+    iy = ((g[..., 1] + 1) / 2) * (Hl - 1)
+    # padding_mode='border': clip coordinates into [0, size-1]
+    ix = torch.clamp(ix, 0, Wl - 1)
+    iy = torch.clamp(iy, 0, Hl - 1)
+    ix0 = torch.floor(ix)
+    iy0 = torch.floor(iy)
+    ix1 = ix0 + 1
+    iy1 = iy0 + 1
+    w_nw = (ix1 - ix) * (iy1 - iy)
+    w_ne = (ix - ix0) * (iy1 - iy)
+    w_sw = (ix1 - ix) * (iy - iy0)
+    w_se = (ix - ix0) * (iy - iy0)
+
+    def corner(iyc, ixc, w):
+        inb = (ixc >= 0) & (ixc <= Wl - 1) & (iyc >= 0) & (iyc <= Hl - 1)
+        ixl = ixc.clamp(0, Wl - 1).long()
+        iyl = iyc.clamp(0, Hl - 1).long()
+        flat = (iyl * Wl + ixl)  # (NV, N)
+        vals = torch.gather(
+            latent.reshape(NV, C, Hl * Wl), 2, flat.unsqueeze(1).expand(-1, C, -1)
+        )  # (NV, C, N)
+        return vals * (w * inb.to(w.dtype)).unsqueeze(1)
+
+    out = corner(iy0, ix0, w_nw)
+    out = out + corner(iy0, ix1, w_ne)
+    out = out + corner(iy1, ix0, w_sw)
+    out = out + corner(iy1, ix1, w_se)
+    return out
+
+
+def resnetfc_forward(p, zx, combine_inner_dims, d_latent=512, n_blocks=5, combine_layer=3):
+    """src/model/resnetfc.py:132-184 (ReLU activations, combine_type='average',
+    use_spade=False) with ResnetBlockFC.forward (resnetfc.py:53-62) inlined.
+
+    p: dict of tensors with the reference state_dict names (lin_in.weight, ...).
+    zx: (rows, d_latent + d_in).  combine_inner_dims = (NS, B).
+    """
+    z = zx[..., :d_latent]  # resnetfc.py:142
+    x = zx[..., d_latent:]
+    x = torch.nn.functional.linear(x, p["lin_in.weight"], p["lin_in.bias"])  # :147
+    for b in range(n_blocks):
+        if b == combine_layer:
+            # util.combine_interleaved, src/util/util.py:461-471
+            if not (len(combine_inner_dims) == 1 and combine_inner_dims[0] == 1):
+                x = x.reshape(-1, *combine_inner_dims, *x.shape[1:]).mean(dim=1)
+        if d_latent > 0 and b < combine_layer:
+            tz = torch.nn.functional.linear(z, p[f"lin_z.{b}.weight"], p[f"lin_z.{b}.bias"])
+            x = x + tz  # resnetfc.py:175-180
+        # ResnetBlockFC.forward resnetfc.py:55-62
+        net = torch.nn.functional.linear(
+            torch.relu(x), p[f"blocks.{b}.fc_0.weight"], p[f"blocks.{b}.fc_0.bias"]
+        )
+        dx = torch.nn.functional.linear(
+            torch.relu(net), p[f"blocks.{b}.fc_1.weight"], p[f"blocks.{b}.fc_1.bias"]
+        )
+        x = x + dx
+    out = torch.nn.functional.linear(torch.relu(x), p["lin_out.weight"], p["lin_out.bias"])
+    return out  # resnetfc.py:183
+
+
+def repeat_interleave(t, repeats):
+    """src/util/util.py:58-65."""
+    out = t.unsqueeze(1).expand(-1, repeats, *t.shape[1:])
+    return out.reshape(-1, *t.shape[1:])
+
+
+def pixelnerf_forward(scene, mlp, xyz, viewdirs):
+    """src/model/models.py:146-266 for the shipped configuration (use_encoder, use_xyz,
+    normalize_z, use_code{6, 1.5, include_input}, use_viewdirs, not use_code_viewdirs,
+    no global encoder).
+
+    scene: dict(latent (SB*NS,C,Hl,Wl), poses (SB*NS,3,4) world->cam as stored by
+    encode() models.py:112-114, focal (SB|1, 2) with fy already negated models.py:129-130,
+    c (SB|1, 2), image_shape (2,)=(W,H), NS).
+    xyz (SB, B, 3), viewdirs (SB, B, 3) -> (SB, B, 4) rgb sigma.
+    """
+    SB, B, _ = xyz.shape
+    NS = scene["NS"]
+    poses = scene["poses"]
+    xyz = repeat_interleave(xyz, NS)  # models.py:161
+    xyz_rot = torch.matmul(poses[:, None, :3, :3], xyz.unsqueeze(-1))[..., 0]  # :162-164
+    xyz_cam = xyz_rot + poses[:, None, :3, 3]  # :165
+    z_feature = xyz_rot.reshape(-1, 3)  # :169-171 (normalize_z)
+    z_feature = positional_encoding(z_feature)  # :180-182
+    vd = viewdirs.reshape(SB, B, 3, 1)  # :188
+    vd = repeat_interleave(vd, NS)
+    vd = torch.matmul(poses[:, None, :3, :3], vd).reshape(-1, 3)  # :190-193
+    z_feature = torch.cat((z_feature, vd), dim=1)  # :194-196
+    uv = -xyz_cam[:, :, :2] / xyz_cam[:, :, 2:]  # :206
+    focal, c = scene["focal"], scene["c"]
+    uv = uv * repeat_interleave(focal.unsqueeze(1), NS if focal.shape[0] > 1 else 1)  # :207-209
+    uv = uv + repeat_interleave(c.unsqueeze(1), NS if c.shape[0] > 1 else 1)  # :210-212
+    latent = index_latent(scene["latent"], uv, scene["image_shape"])  # :213-215
+    latent = latent.transpose(1, 2).reshape(-1, latent.shape[1])  # :219-221
+    mlp_input = torch.cat((latent, z_feature), dim=-1)  # :227
+    out = resnetfc_forward(mlp, mlp_input, (NS, B))  # :242-255
+    out = out.reshape(-1, B, 4)
+    rgb = torch.sigmoid(out[..., :3])  # :260-263
+    sigma = torch.relu(out[..., 3:4])
+    return torch.cat([rgb, sigma], dim=-1).reshape(SB, B, -1)
+
+
+# --------------------------------------------------------------------------------------
+# renderer side
+# --------------------------------------------------------------------------------------
+
+
+def _z_from_steps(rays, z_steps, lindisp):
+    near, far = rays[:, -2:-1], rays[:, -1:]
+    if not lindisp:
+        return near * (1 - z_steps) + far * z_steps  # nerf.py:113
+    return 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)  # nerf.py:115
+
+
+def sample_coarse(rays, u1, n_coarse, lindisp=False):
+    """src/render/nerf.py:98-118.  rays (R,8), u1 (R,Kc) -> (R,Kc)."""
+    step = 1.0 / n_coarse
+    R = rays.shape[0]
+    z_steps = torch.linspace(0, 1 - step, n_coarse)  # :109
+    z_steps = z_steps.unsqueeze(0).repeat(R, 1)
+    z_steps = z_steps + u1 * step  # :111
+    return _z_from_steps(rays, z_steps, lindisp)
+
+
+def sample_fine(rays, weights, u2, u3, n_coarse, lindisp=False):
+    """src/render/nerf.py:120-148.  weights (R,Kc) detached; u2,u3 (R,Kf-Kfd)."""
+    weights = weights.detach() + 1e-5  # :130
+    pdf = weights / torch.sum(weights, -1, keepdim=True)  # :131
+    cdf = torch.cumsum(pdf, -1)  # :132
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)  # :133
+    inds = torch.searchsorted(cdf, u2.contiguous(), right=True).float() - 1.0  # :138
+    inds = torch.clamp_min(inds, 0.0)  # :139
+    z_steps = (inds + u3) / n_coarse  # :141
+    return _z_from_steps(rays, z_steps, lindisp)
+
+
+def sample_fine_depth(rays, depth, n4, depth_std):
+    """src/render/nerf.py:150-161.  depth (R,), n4 (R,Kfd)."""
+    z = depth.unsqueeze(1).repeat((1, n4.shape[1]))
+    z = z + n4 * depth_std  # :158
+    z = torch.max(torch.min(z, rays[:, -1:]), rays[:, -2:-1])  # :160
+    return z
+
+
+def composite_from_rgbsigma(rays, z_samp, out, white_bkgd):
+    """src/render/nerf.py:178-182 (deltas) and :223-249 (alpha compositing).
+    z_samp (R,K), out (R,K,4) -> weights (R,K), rgb (R,3), depth (R)."""
+    deltas = z_samp[:, 1:] - z_samp[:, :-1]
+    delta_inf = rays[:, -1:] - z_samp[:, -1:]  # :181 (far - z_last, not 1e10)
+    deltas = torch.cat([deltas, delta_inf], -1)
+    rgbs = out[..., :3]
+    sigmas = out[..., 3]
+    alphas = 1 - torch.exp(-deltas * torch.relu(sigmas))  # :228
+    alphas_shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
+    T = torch.cumprod(alphas_shifted, -1)  # :234
+    weights = alphas * T[:, :-1]  # :235
+    rgb_final = torch.sum(weights.unsqueeze(-1) * rgbs, -2)  # :239
+    depth_final = torch.sum(weights * z_samp, -1)  # :240
+    if white_bkgd:
+        pix_alpha = weights.sum(dim=1)
+        rgb_final = rgb_final + 1 - pix_alpha.unsqueeze(-1)  # :241-244
+    return weights, rgb_final, depth_final
+
+
+def composite(scene, mlp, rays, z_samp, sb, white_bkgd):
+    """src/render/nerf.py:163-249 without the eval_batch_size chunk loop (chunking does not
+    change results: the model is pointwise)."""
+    R, K = z_samp.shape
+    points = rays[:, None, :3] + z_samp.unsqueeze(2) * rays[:, None, 3:6]  # :185
+    points = points.reshape(sb, -1, 3)  # :193-195
+    viewdirs = rays[:, None, 3:6].expand(-1, K, -1).reshape(sb, -1, 3)  # :204-206
+    out = pixelnerf_forward(scene, mlp, points, viewdirs)
+    out = out.reshape(R, K, -1)  # :219
+    return composite_from_rgbsigma(rays, z_samp, out, white_bkgd) + (out,)
+
+
+def render(scene, mlp_coarse, mlp_fine, rays, noise, n_coarse, n_fine, n_fine_depth,
+           depth_std=0.01, white_bkgd=False, lindisp=False):
+    """src/render/nerf.py:251-303.  rays (SB, B, 8); noise = dict(u1,u2,u3,n4) (missing keys
+    allowed when the corresponding stage is skipped).  Returns a nested dict
+    {coarse:{rgb,depth,weights,z,rgbsigma}, fine:{...}}; `fine` absent when n_fine == 0.
+    mlp_fine=None falls back to mlp_coarse (models.py:242)."""
+    assert rays.dim() == 3  # :269
+    SB = rays.shape[0]
+    rays = rays.reshape(-1, 8)
+    z_coarse = sample_coarse(rays, noise["u1"], n_coarse, lindisp)  # :273
+    wc, rgbc, depthc, outc = composite(scene, mlp_coarse, rays, z_coarse, SB, white_bkgd)
+
+    def fmt(w, rgb, depth, z, out):
+        return dict(
+            rgb=rgb.reshape(SB, -1, 3), depth=depth.reshape(SB, -1),
+            weights=w.reshape(SB, -1, w.shape[-1]), z=z.reshape(SB, -1, z.shape[-1]),
+            rgbsigma=out.reshape(SB, -1, out.shape[-2], 4),
+        )
+
+    ret = dict(coarse=fmt(wc, rgbc, depthc, z_coarse, outc))
+    if n_fine > 0:  # using_fine, :87,:284
+        all_samps = [z_coarse]
+        if n_fine - n_fine_depth > 0:
+            all_samps.append(
+                sample_fine(rays, wc.detach(), noise["u2"], noise["u3"], n_coarse, lindisp)
+            )  # :286-289
+        if n_fine_depth > 0:
+            all_samps.append(sample_fine_depth(rays, depthc, noise["n4"], depth_std))  # :290-293
+        z_combine = torch.cat(all_samps, dim=-1)
+        z_sorted, _ = torch.sort(z_combine, dim=-1)  # :294-295
+        mf = mlp_fine if mlp_fine is not None else mlp_coarse
+        wf, rgbf, depthf, outf = composite(scene, mf, rays, z_sorted, SB, white_bkgd)  # :296
+        ret["fine"] = fmt(wf, rgbf, depthf, z_sorted, outf)
+    return ret
+
+
+def psnr(pred, target):
+    """src/util/util.py:474-481."""
+    mse = ((pred - target) ** 2).mean().item()
+    if mse == 0:
+        return float("inf")
+    return -10 * math.log10(mse)

@@ -1,0 +1,218 @@
+"""
+Seeded synthetic scenes (SURVEY.md §8d "common synthetic scene recipe").
+
+There are no datasets or checkpoints in this environment, so every parity test, golden
+fixture and benchmark uses these generators.  Everything is produced with
+numpy.random.RandomState (bit-stable across numpy versions and machines), so the GPU box
+regenerates exactly the tensors the golden fixtures were made from; only rays / noise /
+outputs are stored in tests/golden/.
+
+Camera conventions follow the reference: poses are camera-to-world 4x4
+(src/util/util.py:309-323 pose_spherical), rays are [origin(3), dir(3), near, far]
+(src/util/util.py:238-276 gen_rays).
+"""
+import math
+
+import numpy as np
+import torch
+
+MLP_SHAPE = dict(d_in=42, d_latent=512, d_hidden=512, n_blocks=5, combine_layer=3, d_out=4)
+
+
+def mlp_param_names(n_blocks=5, combine_layer=3):
+    """State-dict key order of the reference ResnetFC (src/model/resnetfc.py:66-130)."""
+    names = ["lin_in", "lin_out"]
+    for b in range(n_blocks):
+        names += [f"blocks.{b}.fc_0", f"blocks.{b}.fc_1"]
+    for b in range(min(combine_layer, n_blocks)):
+        names.append(f"lin_z.{b}")
+    return names
+
+
+def make_mlp_params(seed, d_in=42, d_latent=512, d_hidden=512, n_blocks=5, combine_layer=3,
+                    d_out=4):
+    """Random ResnetFC parameters as {state_dict_key: float32 torch tensor}.
+
+    Kaiming-normal fan-in scale for every Linear (reference init, resnetfc.py:36-39,89-94,
+    116-117) except fc_1, which the reference zero-initialises; here fc_1 ~ N(0, 0.03^2)
+    and all biases ~ N(0, 0.01^2) so that every term of the network is exercised
+    (SURVEY.md §8a R10)."""
+    rs = np.random.RandomState(seed)
+    p = {}
+
+    def lin(name, fan_out, fan_in, std=None):
+        s = math.sqrt(2.0 / fan_in) if std is None else std
+        p[name + ".weight"] = torch.from_numpy((rs.randn(fan_out, fan_in) * s).astype(np.float32))
+        p[name + ".bias"] = torch.from_numpy((rs.randn(fan_out) * 0.01).astype(np.float32))
+
+    lin("lin_in", d_hidden, d_in)
+    lin("lin_out", d_out, d_hidden)
+    for b in range(n_blocks):
+        lin(f"blocks.{b}.fc_0", d_hidden, d_hidden)
+        lin(f"blocks.{b}.fc_1", d_hidden, d_hidden, std=0.03)
+    for b in range(min(combine_layer, n_blocks)):
+        lin(f"lin_z.{b}", d_hidden, d_latent)
+    return p
+
+
+# ---------------------------------------------------------------------------- cameras
+
+
+def pose_spherical(theta, phi, radius):
+    """Camera-to-world pose on a sphere; restates src/util/util.py:279-323."""
+    def trans_t(t):
+        return np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, t], [0, 0, 0, 1]], np.float32)
+
+    def rot_phi(a):
+        return np.array([[1, 0, 0, 0], [0, np.cos(a), -np.sin(a), 0],
+                         [0, np.sin(a), np.cos(a), 0], [0, 0, 0, 1]], np.float32)
+
+    def rot_theta(a):
+        return np.array([[np.cos(a), 0, -np.sin(a), 0], [0, 1, 0, 0],
+                         [np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]], np.float32)
+
+    c2w = trans_t(radius)
+    c2w = rot_phi(phi / 180.0 * np.pi) @ c2w
+    c2w = rot_theta(theta / 180.0 * np.pi) @ c2w
+    c2w = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32) @ c2w
+    return torch.from_numpy(c2w.astype(np.float32))
+
+
+def coord_from_blender():
+    """src/util/util.py:146-157."""
+    return torch.tensor([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]],
+                        dtype=torch.float32)
+
+
+def unproj_map(width, height, f, c=None):
+    """src/util/util.py:113-143: unit camera-space ray per pixel, (H, W, 3)."""
+    if c is None:
+        c = [width * 0.5, height * 0.5]
+    fx, fy = (f, f) if isinstance(f, (float, int)) else (float(f[0]), float(f[1]))
+    Y, X = torch.meshgrid(
+        torch.arange(height, dtype=torch.float32) - float(c[1]),
+        torch.arange(width, dtype=torch.float32) - float(c[0]),
+        indexing="ij",
+    )
+    X = X / float(fx)
+    Y = Y / float(fy)
+    Z = torch.ones_like(X)
+    unproj = torch.stack((X, -Y, -Z), dim=-1)
+    unproj /= torch.norm(unproj, dim=-1).unsqueeze(-1)
+    return unproj
+
+
+def gen_rays(poses, width, height, focal, z_near, z_far, c=None):
+    """src/util/util.py:238-276 (ndc=False): (B, H, W, 8) rays."""
+    num_images = poses.shape[0]
+    cam_unproj_map = unproj_map(width, height, focal, c=c).unsqueeze(0).repeat(num_images, 1, 1, 1)
+    cam_centers = poses[:, None, None, :3, 3].expand(-1, height, width, -1)
+    cam_raydir = torch.matmul(poses[:, None, None, :3, :3], cam_unproj_map.unsqueeze(-1))[..., 0]
+    cam_nears = torch.full((num_images, height, width, 1), float(z_near))
+    cam_fars = torch.full((num_images, height, width, 1), float(z_far))
+    return torch.cat((cam_centers, cam_raydir, cam_nears, cam_fars), dim=-1)
+
+
+def encode_state(src_poses_c2w, focal, c, W, H):
+    """The camera part of PixelNeRFNet.encode (src/model/models.py:112-141): world->camera
+    [R^T | -R^T t], focal (fx, -fy), principal point, image_shape (W, H)."""
+    rot = src_poses_c2w[:, :3, :3].transpose(1, 2)
+    trans = -torch.bmm(rot, src_poses_c2w[:, :3, 3:])
+    poses = torch.cat((rot, trans), dim=-1).contiguous()
+    focal_t = torch.tensor([[focal[0], -focal[1]]], dtype=torch.float32)
+    c_t = torch.tensor([[c[0], c[1]]], dtype=torch.float32)
+    return poses, focal_t, c_t, torch.tensor([float(W), float(H)])
+
+
+# ---------------------------------------------------------------------------- scenes
+
+# name -> geometry.  *_mini variants shrink the grids so golden generation on the CPU
+# reference stays in seconds; the full-size ones are the BASELINE.json configs.
+SCENES = {
+    # BASELINE configs (1)(2): NMR 64x64, 1 source view
+    "sn64": dict(W=64, H=64, NS=1, SB=1, Hl=32, Wl=32, focal=(119.4256, 119.4256), c=(32.0, 32.0),
+                 z_near=1.2, z_far=4.0, radius=2.732, src=[(30.0, -20.0)], tgt=(75.0, -20.0),
+                 white_bkgd=True, blender=False),
+    # BASELINE config (3): SRN cars 128x128, 2 source views (S3)
+    "srn_car": dict(W=128, H=128, NS=2, SB=1, Hl=64, Wl=64, focal=(131.25, 131.25), c=(64.0, 64.0),
+                    z_near=0.8, z_far=1.8, radius=1.3, src=[(0.0, -20.0), (60.0, -20.0)],
+                    tgt=(30.0, -20.0), white_bkgd=True, blender=True),
+    "srn_mini": dict(W=32, H=32, NS=2, SB=1, Hl=16, Wl=16, focal=(32.8125, 32.8125), c=(16.0, 16.0),
+                     z_near=0.8, z_far=1.8, radius=1.3, src=[(0.0, -20.0), (60.0, -20.0)],
+                     tgt=(30.0, -20.0), white_bkgd=True, blender=True),
+    # BASELINE config (4): DTU 400x300, 3 source views, black background (S4)
+    "dtu": dict(W=400, H=300, NS=3, SB=1, Hl=150, Wl=200, focal=(723.0, 723.0), c=(200.0, 150.0),
+                z_near=0.1, z_far=5.0, radius=2.0, src=[(-20.0, -15.0), (0.0, -25.0), (20.0, -15.0)],
+                tgt=(0.0, -15.0), white_bkgd=False, blender=False),
+    "dtu_mini": dict(W=40, H=30, NS=3, SB=1, Hl=15, Wl=20, focal=(72.3, 70.1), c=(20.5, 14.25),
+                     z_near=0.1, z_far=5.0, radius=2.0,
+                     src=[(-20.0, -15.0), (0.0, -25.0), (20.0, -15.0)],
+                     tgt=(0.0, -15.0), white_bkgd=False, blender=False),
+    # BASELINE config (5) geometry: 4 objects x 1 view (S5)
+    "train": dict(W=64, H=64, NS=1, SB=4, Hl=32, Wl=32, focal=(119.4256, 119.4256), c=(32.0, 32.0),
+                  z_near=1.2, z_far=4.0, radius=2.732,
+                  src=[(30.0, -20.0), (100.0, -30.0), (200.0, -10.0), (300.0, -25.0)],
+                  tgt=(75.0, -20.0), white_bkgd=True, blender=False),
+    # 2 objects x 2 views: exercises object-major view indexing (row = obj*NS + view)
+    "mv_mini": dict(W=32, H=32, NS=2, SB=2, Hl=16, Wl=16, focal=(59.7, 59.7), c=(16.0, 16.0),
+                    z_near=1.2, z_far=4.0, radius=2.732,
+                    src=[(30.0, -20.0), (80.0, -30.0), (200.0, -10.0), (250.0, -25.0)],
+                    tgt=(75.0, -20.0), white_bkgd=True, blender=False),
+}
+
+
+def make_scene(name, seed=2, latent_scale=0.5):
+    """Returns (scene, meta).  scene holds exactly what PixelNeRFNet.encode() leaves behind
+    (SURVEY.md §3.4): latent NCHW (SB*NS,512,Hl,Wl), poses (SB*NS,3,4), focal (1,2), c (1,2),
+    image_shape (2), NS, SB.  Source views are object-major: row = obj*NS + view."""
+    g = SCENES[name]
+    rs = np.random.RandomState(seed)
+    NV = g["SB"] * g["NS"]
+    latent = torch.from_numpy(
+        (rs.randn(NV, 512, g["Hl"], g["Wl"]) * latent_scale).astype(np.float32))
+    pre = coord_from_blender() if g["blender"] else torch.eye(4)
+    assert len(g["src"]) == NV
+    src = torch.stack([pre @ pose_spherical(t, p, g["radius"]) for (t, p) in g["src"]], 0)
+    poses, focal, c, image_shape = encode_state(src, g["focal"], g["c"], g["W"], g["H"])
+    scene = dict(latent=latent, poses=poses, focal=focal, c=c, image_shape=image_shape,
+                 NS=g["NS"], SB=g["SB"])
+    return scene, dict(g, src_c2w=src, pre=pre)
+
+
+def target_rays(meta, n_rays=None, seed=7):
+    """All rays of the target view, (SB, H*W, 8) (each object sees the same target camera,
+    rotated by 40 deg per object so objects differ), optionally a seeded random subset of
+    n_rays per object (the reference's train-time pixel sampling, train/train.py:143-179)."""
+    g = meta
+    rays_all = []
+    rs = np.random.RandomState(seed)
+    for o in range(g["SB"]):
+        t, p = g["tgt"]
+        pose = g["pre"] @ pose_spherical(t + 40.0 * o, p, g["radius"])
+        r = gen_rays(pose[None], g["W"], g["H"], g["focal"], g["z_near"], g["z_far"],
+                     c=g["c"]).reshape(-1, 8)
+        if n_rays is not None:
+            idx = torch.from_numpy(rs.choice(r.shape[0], n_rays, replace=False)).long()
+            r = r[idx]
+        rays_all.append(r)
+    return torch.stack(rays_all, 0).contiguous()
+
+
+def make_noise(R, n_coarse, n_fine, n_fine_depth, seed=1234):
+    """Pre-drawn random numbers in the reference's draw order (src/render/nerf.py:111,135,
+    141,158).  float32, u in [0,1)."""
+    rs = np.random.RandomState(seed)
+    n_imp = max(n_fine - n_fine_depth, 0)
+
+    def uni(*shape):
+        u = rs.random_sample(shape).astype(np.float32)
+        return torch.from_numpy(np.minimum(u, np.float32(1.0 - 2 ** -24)))
+
+    noise = dict(u1=uni(R, n_coarse))
+    if n_fine > 0:
+        if n_imp > 0:
+            noise["u2"] = uni(R, n_imp)
+            noise["u3"] = uni(R, n_imp)
+        if n_fine_depth > 0:
+            noise["n4"] = torch.from_numpy(rs.randn(R, n_fine_depth).astype(np.float32))
+    return noise

@@ -1,0 +1,13 @@
+"""
+Import alias: the product package lives in the directory `pixel-nerf_amd/` (the name the
+project layout prescribes), which is not a valid Python identifier.  This thin package makes
+it importable as `pixelnerf_amd` by pointing its submodule search path at that directory and
+executing its __init__.py in this namespace.
+"""
+import os as _os
+
+_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "pixel-nerf_amd")
+__path__ = [_real]
+with open(_os.path.join(_real, "__init__.py")) as _f:
+    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
+del _f

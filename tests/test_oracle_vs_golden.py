@@ -1,0 +1,112 @@
+"""
+CPU tests: the oracle restatement (oracle/pnr_oracle.py) against the golden vectors frozen
+from the UNMODIFIED reference (oracle/make_goldens.py -> tests/golden/*.npz).
+
+Tolerances: both sides are torch CPU fp32 running the same arithmetic in (almost) the same
+order, so agreement is at rounding level: 2e-5 abs on rgb/sigma/weights (values in [0,1]),
+1e-5 * (far-near) on z.  The explicit bilinear lookup vs F.grid_sample differs only in
+fp32 rounding of the corner weights.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (RENDER_SCENARIOS, assert_close_frac, golden_setup, load_golden, mlp_params,
+                     scene_for)
+from oracle import pnr_oracle as O
+
+
+def test_positional_encoding_matches_reference():
+    g = load_golden("stages")
+    out = O.positional_encoding(torch.from_numpy(g["posenc_x"]))
+    assert out.shape == (257, 39)
+    np.testing.assert_allclose(out.numpy(), g["posenc_out"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("scene_name", ["sn64", "dtu_mini", "mv_mini"])
+def test_index_latent_matches_reference_grid_sample(scene_name):
+    g = load_golden("stages")
+    scene, _ = scene_for(scene_name)
+    out = O.index_latent(scene["latent"], torch.from_numpy(g[f"{scene_name}_uv"]),
+                         scene["image_shape"])
+    np.testing.assert_allclose(out.numpy(), g[f"{scene_name}_index"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("scene_name", ["sn64", "dtu_mini", "mv_mini"])
+def test_pixelnerf_forward_matches_reference(scene_name):
+    g = load_golden("stages")
+    scene, _ = scene_for(scene_name)
+    xyz = torch.from_numpy(g[f"{scene_name}_xyz"])
+    vd = torch.from_numpy(g[f"{scene_name}_viewdirs"])
+    for which, seed in (("coarse", 11), ("fine", 12)):
+        out = O.pixelnerf_forward(scene, mlp_params(seed), xyz, vd)
+        ref = g[f"{scene_name}_out_{which}"]
+        np.testing.assert_allclose(out[..., :3].numpy(), ref[..., :3], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out[..., 3].numpy(), ref[..., 3], rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", RENDER_SCENARIOS)
+def test_sampling_and_compositing_stagewise_match_reference(name):
+    """Stage-wise, fed with the reference's own intermediates so that no discontinuity can
+    amplify rounding: coarse z from u1; fine z from the golden coarse weights/depth;
+    compositing from the golden per-point rgb/sigma."""
+    g, scene, meta, mc, mf, rays, noise = golden_setup(name)
+    Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])
+    lindisp, white = bool(g["lindisp"]), bool(g["white_bkgd"])
+    span = float(meta["z_far"] - meta["z_near"])
+    r = rays.reshape(-1, 8)
+    zc = O.sample_coarse(r, noise["u1"], Kc, lindisp)
+    np.testing.assert_allclose(zc.numpy(), g["coarse_z"], rtol=0, atol=1e-6 * span)
+    w, rgb, depth = O.composite_from_rgbsigma(r, torch.from_numpy(g["coarse_z"]),
+                                              torch.from_numpy(g["coarse_rgbsigma"]), white)
+    np.testing.assert_allclose(w.numpy(), g["coarse_weights"].reshape(-1, Kc), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rgb.numpy(), g["coarse_rgb"].reshape(-1, 3), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(depth.numpy(), g["coarse_depth"].reshape(-1), rtol=0, atol=1e-5)
+    if Kf > 0:
+        samps = [torch.from_numpy(g["coarse_z"])]
+        wc = torch.from_numpy(g["coarse_weights"]).reshape(-1, Kc)
+        if Kf - Kfd > 0:
+            samps.append(O.sample_fine(r, wc, noise["u2"], noise["u3"], Kc, lindisp))
+        if Kfd > 0:
+            samps.append(O.sample_fine_depth(r, torch.from_numpy(g["coarse_depth"]).reshape(-1),
+                                             noise["n4"], float(g["depth_std"])))
+        zf = torch.sort(torch.cat(samps, -1), dim=-1)[0]
+        np.testing.assert_allclose(zf.numpy(), g["fine_z"], rtol=0, atol=1e-6 * span)
+        w, rgb, depth = O.composite_from_rgbsigma(r, torch.from_numpy(g["fine_z"]),
+                                                  torch.from_numpy(g["fine_rgbsigma"]), white)
+        np.testing.assert_allclose(w.numpy(), g["fine_weights"].reshape(-1, Kc + Kf), rtol=0,
+                                   atol=1e-6)
+        np.testing.assert_allclose(rgb.numpy(), g["fine_rgb"].reshape(-1, 3), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", RENDER_SCENARIOS)
+def test_render_end_to_end_matches_reference(name):
+    g, scene, meta, mc, mf, rays, noise = golden_setup(name)
+    Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])
+    out = O.render(scene, mc, mf, rays, noise, Kc, Kf, Kfd, depth_std=float(g["depth_std"]),
+                   white_bkgd=bool(g["white_bkgd"]), lindisp=bool(g["lindisp"]))
+    span = float(meta["z_far"] - meta["z_near"])
+    SB = rays.shape[0]
+    assert ("fine" in out) == (Kf > 0)
+    # coarse pass: continuous in its inputs -> rounding-level agreement everywhere
+    K = Kc
+    np.testing.assert_allclose(out["coarse"]["z"].reshape(-1, K).numpy(), g["coarse_z"], rtol=0,
+                               atol=1e-6 * span)
+    np.testing.assert_allclose(out["coarse"]["rgbsigma"].reshape(-1, K, 4)[..., :3].numpy(),
+                               g["coarse_rgbsigma"][..., :3], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(out["coarse"]["weights"].numpy(), g["coarse_weights"], rtol=0,
+                               atol=5e-5)
+    np.testing.assert_allclose(out["coarse"]["rgb"].numpy(), g["coarse_rgb"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["coarse"]["depth"].numpy(), g["coarse_depth"], rtol=0,
+                               atol=5e-5 * span)
+    assert out["coarse"]["rgb"].shape == (SB, rays.shape[1], 3)
+    if Kf > 0:
+        # fine pass: allow <=0.2% of samples to sit in a neighbouring importance bin
+        K = Kc + Kf
+        assert_close_frac(out["fine"]["z"].reshape(-1, K).numpy(), g["fine_z"], 1e-5 * span,
+                          max_frac=2e-3, loose_atol=span / Kc * 1.01, what="fine z")
+        assert_close_frac(out["fine"]["rgb"].numpy(), g["fine_rgb"], 5e-5, max_frac=2e-2,
+                          loose_atol=2e-2, what="fine rgb")
+        assert_close_frac(out["fine"]["depth"].numpy(), g["fine_depth"], 5e-5 * span,
+                          max_frac=2e-2, loose_atol=2e-2 * span, what="fine depth")
+        assert O.psnr(out["fine"]["rgb"], torch.from_numpy(g["fine_rgb"])) > 70.0
