@@ -1,0 +1,150 @@
+/*
+ * pixelnerf_hip.h -- C ABI of libpixelnerf_hip.so: the MI355X (gfx950) native pixelNeRF
+ * volume-rendering hot path.
+ *
+ * The reference (sxyu/pixel-nerf) has no FFI of its own: its seam is two Python classes,
+ * NeRFRenderer (src/render/nerf.py:45-371) and PixelNeRFNet (src/model/models.py:14-316).
+ * Every entry point below replaces a span of those classes; the span is cited per function
+ * (paths relative to the reference repository root).  The Python host layer
+ * (pixel-nerf_amd/render, pixel-nerf_amd/model) binds these through ctypes and presents the
+ * reference's API on top; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP, current device) unless marked "host";
+ *   - tensors are dense, row-major, fp32 unless stated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued on it, nothing synchronises;
+ *   - return value: 0 = ok, negative = PNR_E_* ; pnr_last_error() gives a message (host,
+ *     thread-local);
+ *   - memory is owned by the caller (torch tensors in the Python host); the library
+ *     allocates nothing.
+ */
+#ifndef PIXELNERF_HIP_H
+#define PIXELNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNR_OK 0
+#define PNR_E_INVALID (-1)   /* bad argument / unsupported shape          */
+#define PNR_E_HIP (-2)       /* a HIP runtime call or kernel launch failed */
+
+/* arithmetic of the 512-wide linear layers (operands of the MFMA; accumulation is fp32) */
+#define PNR_PREC_F16 0       /* fp16 operands, v_mfma_f32_32x32x16_f16  */
+#define PNR_PREC_BF16 1      /* bf16 operands, v_mfma_f32_32x32x16_bf16 */
+
+/* Encoded-scene state: exactly what PixelNeRFNet.encode() leaves in module buffers
+ * (src/model/models.py:111-141, src/model/encoder.py:160-163), except that the feature grid
+ * is channel-last so one bilinear corner is a contiguous 2 KiB row. */
+typedef struct PnrScene {
+    const float *latent_nhwc; /* (SB*NS, Hl, Wl, 512)  encoder.latent permuted NCHW->NHWC   */
+    const float *poses;       /* (SB*NS, 3, 4) world->camera [R^T | -R^T t]  models.py:112-114 */
+    const float *focal;       /* (n_focal, 2)  (fx, -fy)                     models.py:129-130 */
+    const float *c;           /* (n_c, 2)      principal point               models.py:132-141 */
+    int32_t SB;               /* objects                                                    */
+    int32_t NS;               /* source views per object (row = obj*NS + view)              */
+    int32_t Hl, Wl;           /* latent grid size                                           */
+    int32_t n_focal, n_c;     /* 1 (broadcast) or SB (per object)            models.py:207-212 */
+    float img_w, img_h;       /* net.image_shape = (W, H)                    models.py:116-117 */
+} PnrScene;
+
+/* One ResnetFC (src/model/resnetfc.py:66-130) at the only shape the reference ships:
+ * d_in=42, d_latent=512, d_hidden=512, n_blocks=5, combine_layer=3, d_out=4, ReLU, average
+ * pooling.  nn.Linear layout: weight (out, in) row-major, bias (out). */
+typedef struct PnrMlpWeights {
+    const float *lin_in_w, *lin_in_b;       /* (512,42), (512)  */
+    const float *lin_z_w[3], *lin_z_b[3];   /* (512,512), (512) */
+    const float *fc0_w[5], *fc0_b[5];       /* blocks[b].fc_0   */
+    const float *fc1_w[5], *fc1_b[5];       /* blocks[b].fc_1   */
+    const float *lin_out_w, *lin_out_b;     /* (4,512), (4)     */
+} PnrMlpWeights;
+
+const char *pnr_last_error(void);
+
+/* Library / device facts (host out-params may be NULL). */
+int pnr_version(int *major, int *minor);
+int pnr_device_info(int *num_cus, int *lds_bytes_per_block);
+
+/* ---- one-time weight repack ------------------------------------------------------------
+ * Replaces nothing in the reference (it feeds nn.Linear weights to addmm directly,
+ * resnetfc.py:147,175,55-62,183); needed because the fused kernel streams MFMA fragments.
+ * Re-run whenever the parameters change.  `packed` must hold pnr_packed_mlp_bytes() bytes. */
+size_t pnr_packed_mlp_bytes(void);
+int pnr_pack_mlp(const PnrMlpWeights *w /*host struct of device ptrs*/, int precision,
+                 void *packed, void *stream);
+
+/* encoder.latent NCHW -> NHWC (layout change for the lookup in src/model/encoder.py:80-109). */
+int pnr_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, void *stream);
+
+/* ---- ray sampling ------------------------------------------------------------------------
+ * NeRFRenderer.sample_coarse, src/render/nerf.py:98-118.  rays (R,8), u1 (R,Kc) uniforms
+ * (the reference's torch.rand_like at :111) -> z (R,Kc). */
+int pnr_sample_coarse(const float *rays, const float *u1, int R, int Kc, int lindisp, float *z,
+                      void *stream);
+
+/* NeRFRenderer.sample_fine + sample_fine_depth + cat + sort, src/render/nerf.py:120-161 and
+ * :285-295.  weights_c (R,Kc), depth_c (R), z_coarse (R,Kc); u2,u3 (R,Kimp) uniforms (:135,
+ * :141), n4 (R,Kfd) normals (:158); Kimp = n_fine - n_fine_depth.  Either count may be 0
+ * (the pointers are then ignored).  z_sorted (R, Kc+Kimp+Kfd) ascending. */
+int pnr_sample_fine(const float *rays, const float *weights_c, const float *depth_c,
+                    const float *z_coarse, const float *u2, const float *u3, const float *n4,
+                    int R, int Kc, int Kimp, int Kfd, float depth_std, int lindisp,
+                    float *z_sorted, void *stream);
+
+/* ---- the fused per-point network ---------------------------------------------------------
+ * PixelNeRFNet.forward, src/model/models.py:146-266, including PositionalEncoding
+ * (src/model/code.py:30-42), SpatialEncoder.index (src/model/encoder.py:80-109),
+ * ResnetFC.forward (src/model/resnetfc.py:132-184), view mean pooling
+ * (src/util/util.py:461-471) and the output activations (models.py:260-265).
+ *
+ * Variant A (renderer path; also fuses nerf.py:185,204 "points = o + z d, viewdirs = d"):
+ *   rays (R,8), z (R,K) -> rgbsigma (R,K,4).  rays_per_obj = R / SB. */
+int pnr_eval_ray_samples(const PnrScene *scene /*host*/, const void *packed, int precision,
+                         const float *rays, const float *z, int R, int rays_per_obj, int K,
+                         float *rgbsigma, void *stream);
+/* Variant B (direct net(xyz, viewdirs) calls): xyz, viewdirs (SB,B,3) -> rgbsigma (SB,B,4). */
+int pnr_eval_points(const PnrScene *scene /*host*/, const void *packed, int precision,
+                    const float *xyz, const float *viewdirs, int B, float *rgbsigma,
+                    void *stream);
+
+/* ---- alpha compositing -------------------------------------------------------------------
+ * NeRFRenderer.composite after the model call, src/render/nerf.py:178-182 and :223-249.
+ * rays (R,8), z (R,K), rgbsigma (R,K,4) -> weights (R,K) (may be NULL), rgb (R,3), depth (R). */
+int pnr_composite(const float *rays, const float *z, const float *rgbsigma, int R, int K,
+                  int white_bkgd, float *weights, float *rgb, float *depth, void *stream);
+
+/* ---- whole renderer forward --------------------------------------------------------------
+ * NeRFRenderer.forward, src/render/nerf.py:251-303 (inference; no autograd).
+ * Noise pointers follow the reference's draw order (u1 :111, u2 :135, u3 :141, n4 :158).
+ * packed_fine == NULL falls back to the coarse network (models.py:242).
+ * Outputs: *_c (coarse), *_f (fine; ignored when Kf == 0); weights pointers may be NULL.
+ * workspace: pnr_render_workspace_bytes(R,Kc,Kf) bytes of scratch. */
+size_t pnr_render_workspace_bytes(int R, int Kc, int Kf);
+int pnr_render_forward(const PnrScene *scene /*host*/, const void *packed_coarse,
+                       const void *packed_fine, int precision, const float *rays, int R,
+                       int rays_per_obj, int Kc, int Kf, int Kfd, float depth_std,
+                       int white_bkgd, int lindisp, const float *u1, const float *u2,
+                       const float *u3, const float *n4, float *rgb_c, float *depth_c,
+                       float *weights_c, float *rgb_f, float *depth_f, float *weights_f,
+                       void *workspace, void *stream);
+
+/* ---- next-row helpers -----------------------------------------------
+ * util.gen_rays / unproj_map, src/util/util.py:113-143,238-276 (ndc=False).
+ * poses (NV,4,4) camera-to-world -> rays (NV,H,W,8). */
+int pnr_gen_rays(const float *poses, int NV, int W, int H, float fx, float fy, float cx, float cy,
+                 float z_near, float z_far, float *rays, void *stream);
+
+/* Timing hook for bench.py: seconds spent in the fused network kernel launches issued on
+ * `stream` since the last reset, measured with HIP events recorded around each launch on
+ * that stream (call only after the stream has been synchronised). */
+int pnr_profile_enable(int on);
+int pnr_profile_read(double *mlp_kernel_ms, int *mlp_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXELNERF_HIP_H */

@@ -96,7 +96,8 @@ def index_latent(latent, uv, image_shape):
     return out
 
 
-def resnetfc_forward(p, zx, combine_inner_dims, d_latent=512, n_blocks=5, combine_layer=3):
+def resnetfc_forward(p, zx, combine_inner_dims, d_latent=512, n_blocks=5, combine_layer=3,
+                     return_hidden=False):
     """src/model/resnetfc.py:132-184 (ReLU activations, combine_type='average',
     use_spade=False) with ResnetBlockFC.forward (resnetfc.py:53-62) inlined.
 
@@ -123,6 +124,8 @@ def resnetfc_forward(p, zx, combine_inner_dims, d_latent=512, n_blocks=5, combin
         )
         x = x + dx
     out = torch.nn.functional.linear(torch.relu(x), p["lin_out.weight"], p["lin_out.bias"])
+    if return_hidden:
+        return out, x
     return out  # resnetfc.py:183
 
 
@@ -132,7 +135,7 @@ def repeat_interleave(t, repeats):
     return out.reshape(-1, *t.shape[1:])
 
 
-def pixelnerf_forward(scene, mlp, xyz, viewdirs):
+def pixelnerf_forward(scene, mlp, xyz, viewdirs, return_hidden=False):
     """src/model/models.py:146-266 for the shipped configuration (use_encoder, use_xyz,
     normalize_z, use_code{6, 1.5, include_input}, use_viewdirs, not use_code_viewdirs,
     no global encoder).
@@ -161,11 +164,17 @@ def pixelnerf_forward(scene, mlp, xyz, viewdirs):
     latent = index_latent(scene["latent"], uv, scene["image_shape"])  # :213-215
     latent = latent.transpose(1, 2).reshape(-1, latent.shape[1])  # :219-221
     mlp_input = torch.cat((latent, z_feature), dim=-1)  # :227
-    out = resnetfc_forward(mlp, mlp_input, (NS, B))  # :242-255
+    out = resnetfc_forward(mlp, mlp_input, (NS, B), return_hidden=return_hidden)  # :242-255
+    hidden = None
+    if return_hidden:
+        out, hidden = out
     out = out.reshape(-1, B, 4)
     rgb = torch.sigmoid(out[..., :3])  # :260-263
     sigma = torch.relu(out[..., 3:4])
-    return torch.cat([rgb, sigma], dim=-1).reshape(SB, B, -1)
+    res = torch.cat([rgb, sigma], dim=-1).reshape(SB, B, -1)
+    if return_hidden:
+        return res, hidden.reshape(SB, B, -1)  # residual stream in front of lin_out
+    return res
 
 
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,123 @@
+"""
+ctypes binding of libpixelnerf_hip.so (C ABI: include/pixelnerf_hip.h).
+
+The shared library is built in-tree (pixel-nerf_amd/csrc/libpixelnerf_hip.so) by
+`build_library()` (called from __graft_entry__.build()); there is NO fallback: if the library
+is missing or fails to load, every product entry point raises.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libpixelnerf_hip.so")
+SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip"]
+HEADERS = ["pnr_common.h", "pnr_layout.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
+
+PREC_F16, PREC_BF16 = 0, 1
+PRECISIONS = {"f16": PREC_F16, "fp16": PREC_F16, "bf16": PREC_BF16}
+
+c_float_p = ctypes.c_void_p  # device pointers travel as plain addresses
+
+
+class PnrScene(ctypes.Structure):
+    _fields_ = [
+        ("latent_nhwc", ctypes.c_void_p), ("poses", ctypes.c_void_p), ("focal", ctypes.c_void_p),
+        ("c", ctypes.c_void_p),
+        ("SB", ctypes.c_int32), ("NS", ctypes.c_int32), ("Hl", ctypes.c_int32), ("Wl", ctypes.c_int32),
+        ("n_focal", ctypes.c_int32), ("n_c", ctypes.c_int32),
+        ("img_w", ctypes.c_float), ("img_h", ctypes.c_float),
+    ]
+
+
+class PnrMlpWeights(ctypes.Structure):
+    _fields_ = [
+        ("lin_in_w", ctypes.c_void_p), ("lin_in_b", ctypes.c_void_p),
+        ("lin_z_w", ctypes.c_void_p * 3), ("lin_z_b", ctypes.c_void_p * 3),
+        ("fc0_w", ctypes.c_void_p * 5), ("fc0_b", ctypes.c_void_p * 5),
+        ("fc1_w", ctypes.c_void_p * 5), ("fc1_b", ctypes.c_void_p * 5),
+        ("lin_out_w", ctypes.c_void_p), ("lin_out_b", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/pixelnerf_hip.h declares: name -> (restype, argtypes)
+_I, _F, _P, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+PROTOTYPES = {
+    "pnr_last_error": (ctypes.c_char_p, []),
+    "pnr_version": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "pnr_device_info": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "pnr_packed_mlp_bytes": (_SZ, []),
+    "pnr_pack_mlp": (_I, [ctypes.POINTER(PnrMlpWeights), _I, _P, _P]),
+    "pnr_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "pnr_sample_coarse": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "pnr_sample_fine": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "pnr_eval_ray_samples": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _I, _I, _P, _P]),
+    "pnr_eval_points": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _P, _P]),
+    "pnr_composite": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "pnr_render_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "pnr_render_forward": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I,
+                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pnr_gen_rays": (_I, [_P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "pnr_profile_enable": (_I, [_I]),
+    "pnr_profile_read": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),
+}
+# test hook exported by the library but not part of the public header
+_EXTRA = {"pnr_debug_set_x_dump": (_I, [_P])}
+
+_lib = None
+
+
+class PixelNerfHipError(RuntimeError):
+    pass
+
+
+def _needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    for f in SOURCES + HEADERS:
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into csrc/libpixelnerf_hip.so (hipcc cross-compiles
+    without a GPU).  No-op when the library is newer than every source."""
+    if not force and not _needs_build():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise PixelNerfHipError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and bind every prototype; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PixelNerfHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(pixelnerf_amd has no non-HIP fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in list(PROTOTYPES.items()) + list(_EXTRA.items()):
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().pnr_last_error()
+        raise PixelNerfHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

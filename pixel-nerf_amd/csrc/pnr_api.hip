@@ -1,0 +1,43 @@
+// pnr_api.hip -- error plumbing and library facts for libpixelnerf_hip.so.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "pnr_common.h"
+#include "pnr_layout.h"
+
+static thread_local char g_err[512] = "";
+
+int pnr_fail(int code, const char *msg) {
+    std::snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+    return code;
+}
+
+int pnr_check_hip(hipError_t e, const char *where) {
+    if (e == hipSuccess) return PNR_OK;
+    std::snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return PNR_E_HIP;
+}
+
+int pnr_check_launch(const char *where) { return pnr_check_hip(hipGetLastError(), where); }
+
+extern "C" const char *pnr_last_error(void) { return g_err; }
+
+extern "C" int pnr_version(int *major, int *minor) {
+    if (major) *major = 0;
+    if (minor) *minor = 1;
+    return PNR_OK;
+}
+
+extern "C" int pnr_device_info(int *num_cus, int *lds_bytes_per_block) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return pnr_check_hip(e, "hipGetDevice");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return pnr_check_hip(e, "hipGetDeviceProperties");
+    if (num_cus) *num_cus = prop.multiProcessorCount;
+    if (lds_bytes_per_block) *lds_bytes_per_block = pnr::LDS_TOTAL;
+    return PNR_OK;
+}

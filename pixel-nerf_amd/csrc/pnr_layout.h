@@ -1,0 +1,94 @@
+// pnr_layout.h -- tile geometry and packed-weight layout shared by the repack kernel
+// (pnr_pack.hip) and the fused network kernel (pnr_mlp.hip).  gfx950 only.
+//
+// Fused-kernel geometry:
+//   workgroup = NW=8 waves (512 threads, 2 waves per SIMD), one workgroup per CU, persistent;
+//   point tile = MT=64 sample points = JT=2 MFMA column tiles of 32 points;
+//   wave w owns hidden features [64w, 64w+64) = IT=2 MFMA row tiles of 32 features;
+//   every 512x512 linear is computed as  Y^T[feature][point] = W[feature][k] * X^T[k][point]
+//   with v_mfma_f32_32x32x16_{f16,bf16}: A operand = weights (streamed from L2 straight into
+//   VGPRs, pre-packed in fragment order), B operand = activations (LDS, or registers for
+//   lin_out), C/D = fp32 accumulators that hold the residual stream.
+//
+// MFMA 32x32x16 fragment maps (lane l, h = l>>5):
+//   A: row i = l&31, k = 8h+e (e=0..7)      B: col j = l&31, k = 8h+e
+//   D: col j = l&31, row i = (r&3) + 8*(r>>2) + 4h  (r=0..15)
+#pragma once
+#include <stdint.h>
+
+namespace pnr {
+
+constexpr int C_LAT = 512;   // latent channels (encoder.latent_size, encoder.py:68)
+constexpr int D_HID = 512;   // d_hidden
+constexpr int D_IN = 42;     // 39 positional code + 3 view direction (models.py:47-60)
+constexpr int D_IN_PAD = 64; // padded K of lin_in
+constexpr int D_OUT = 4;
+constexpr int N_BLOCKS = 5;
+constexpr int COMBINE_LAYER = 3;
+
+constexpr int NW = 8;             // waves per workgroup
+constexpr int NTHREADS = NW * 64; // 512
+constexpr int SL = D_HID / NW;    // hidden features per wave (64)
+constexpr int IT = SL / 32;       // feature tiles per wave (2)
+constexpr int MT = 64;            // points per tile
+constexpr int JT = MT / 32;       // point tiles (2)
+
+// ---- per-wave weight stream, in "ring steps" (one ring step = IT fragments of 1 KiB) ----
+constexpr int KS_IN = D_IN_PAD / 16;  // 4
+constexpr int KS_BIG = D_HID / 16;    // 32
+constexpr int KS_OUT = 4;             // lin_out: 4 real k-steps packed into ring steps 0,1 (x IT); 2,3 zero
+// execution order of the GEMMs
+enum Gemm {
+    G_LIN_IN = 0, G_Z0, G_FC0_0, G_FC1_0, G_Z1, G_FC0_1, G_FC1_1, G_Z2, G_FC0_2, G_FC1_2,
+    G_FC0_3, G_FC1_3, G_FC0_4, G_FC1_4, G_OUT, NGEMM
+};
+__host__ __device__ constexpr int gemm_ksteps(int g) {
+    return g == G_LIN_IN ? KS_IN : (g == G_OUT ? KS_OUT : KS_BIG);
+}
+__host__ __device__ constexpr int gemm_offset(int g) {  // first ring step of GEMM g
+    int o = 0;
+    for (int i = 0; i < g; ++i) o += gemm_ksteps(i);
+    return o;
+}
+constexpr int RS_VIEW_END = gemm_offset(G_FC0_3);  // 292: end of the per-view segment (blocks 0-2)
+constexpr int RS_TOTAL = gemm_offset(NGEMM);       // 424
+static_assert(RS_VIEW_END % 4 == 0 && RS_TOTAL % 4 == 0, "ring depth 4 needs aligned segments");
+
+constexpr int FRAG_ELEMS = 64 * 8;  // 64 lanes x 8 elements (1 KiB of 16-bit)
+constexpr size_t WSTREAM_ELEMS_PER_WAVE = (size_t)RS_TOTAL * IT * FRAG_ELEMS;
+constexpr size_t WSTREAM_BYTES = WSTREAM_ELEMS_PER_WAVE * NW * 2;  // 6,946,816 B
+
+// ---- bias slots: one per accumulator (re)initialisation, already summed where two linears
+// accumulate into the residual stream back to back ----
+enum BiasSlot {
+    B_IN_Z0 = 0,   // lin_in.bias + lin_z[0].bias
+    B_FC0_0, B_FC1_0_Z1,  // blocks[0].fc_0 ; blocks[0].fc_1 + lin_z[1]
+    B_FC0_1, B_FC1_1_Z2,
+    B_FC0_2, B_FC1_2,
+    B_FC0_3, B_FC1_3, B_FC0_4, B_FC1_4, NBIAS
+};
+constexpr int BIAS_FLOATS_PER_WAVE = IT * 2 * 16;  // [it][h][r]
+constexpr size_t BIAS_OFFSET_BYTES = WSTREAM_BYTES;
+constexpr size_t BIAS_BYTES = (size_t)NBIAS * NW * BIAS_FLOATS_PER_WAVE * 4;
+constexpr size_t BOUT_OFFSET_BYTES = BIAS_OFFSET_BYTES + BIAS_BYTES;
+constexpr size_t PACKED_BYTES = BOUT_OFFSET_BYTES + 16;
+
+// hidden feature held by D-register r of half h in feature tile T (global tile index 0..15)
+__host__ __device__ constexpr int feat_of(int T, int h, int r) {
+    return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+// ---- LDS map of the fused kernel (bytes) ----
+constexpr int ROW_ACT = D_HID * 2 + 16;      // 1040 B per point row: 1024 B of 16-bit activations + one
+                                             // 16-B slot of padding, so the 32 rows a ds_read_b128 touches
+                                             // fall on distinct 16-B bank slots (65 slots/row, odd)
+constexpr int ROW_IN = D_IN_PAD * 2 + 16;    // 144 B: 9 slots/row -> conflict-free b128 reads
+constexpr int LDS_Z = 0;                     // latent features of the tile     65 KiB
+constexpr int LDS_A = LDS_Z + MT * ROW_ACT;  // relu(x) / relu(net) operand     65 KiB
+constexpr int LDS_IN = LDS_A + MT * ROW_ACT; // positional code + viewdir       9 KiB
+constexpr int LDS_META = LDS_IN + MT * ROW_IN;      // per point: 4 corner offsets + 4 weights
+constexpr int LDS_OUT = LDS_META + MT * 32;         // lin_out partials [NW][MT][4] floats
+constexpr int LDS_TOTAL = LDS_OUT + NW * MT * 16;   // 152,576 B  (<= 160 KiB)
+static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+
+}  // namespace pnr

@@ -1,0 +1,293 @@
+// pnr_render.hip -- ray sampling, inverse-CDF resampling + merge sort, alpha compositing and ray
+// generation for gfx950.  One 64-lane wavefront per ray; prefix sums / products are wavefront
+// scans (shuffles), reductions are wavefront butterflies.  These stages move <= 2 KiB per ray
+// and are bandwidth/latency-trivial next to the fused network.
+#include <hip/hip_runtime.h>
+
+#include "pnr_common.h"
+
+namespace pnr {
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int MAX_KC = 256;    // coarse samples per ray supported by sample_fine
+constexpr int MAX_KTOT = 512;  // coarse + fine samples per ray supported by sample_fine
+
+#pragma clang fp contract(off)  // keep the reference's separately-rounded mul/add sequences
+
+// z = near (1-t) + far t   or its linear-in-disparity form (nerf.py:112-115,143-147)
+__device__ __forceinline__ float z_from_t(float near, float far, float t, int lindisp) {
+    if (!lindisp) return near * (1.f - t) + far * t;
+    return 1.f / (1.f / near * (1.f - t) + 1.f / far * t);
+}
+
+// torch.linspace(0, 1-step, n)[i] as ATen's CPU kernel evaluates it (symmetric halves)
+__device__ __forceinline__ float linspace_at(float end, int n, int i) {
+    if (n <= 1) return 0.f;
+    const float step = end / (float)(n - 1);
+    const int half = n / 2;
+    return i < half ? step * (float)i : end - step * (float)(n - i - 1);
+}
+
+// NeRFRenderer.sample_coarse, nerf.py:98-118
+__global__ void sample_coarse_kernel(const float *__restrict__ rays, const float *__restrict__ u1, int R, int Kc,
+                                     int lindisp, float *__restrict__ z) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)R * Kc) return;
+    const int r = (int)(idx / Kc), i = (int)(idx % Kc);
+    const float near = rays[(size_t)r * 8 + 6], far = rays[(size_t)r * 8 + 7];
+    const float step = 1.0f / (float)Kc;
+    float t = linspace_at(1.f - step, Kc, i);
+    t = t + u1[idx] * step;
+    z[idx] = z_from_t(near, far, t, lindisp);
+}
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// inclusive scans across the 64 lanes of a wavefront
+__device__ __forceinline__ double wave_scan_add(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}
+
+// NeRFRenderer.sample_fine (nerf.py:120-148) + sample_fine_depth (:150-161) + cat/sort (:294-295)
+__global__ void __launch_bounds__(WAVES_PER_BLOCK * 64)
+sample_fine_kernel(const float *__restrict__ rays, const float *__restrict__ wc, const float *__restrict__ depth_c,
+                   const float *__restrict__ zc, const float *__restrict__ u2, const float *__restrict__ u3,
+                   const float *__restrict__ n4, int R, int Kc, int Kimp, int Kfd, float depth_std, int lindisp,
+                   float *__restrict__ zout) {
+    __shared__ float s_cdf[WAVES_PER_BLOCK][MAX_KC + 1];
+    __shared__ float s_z[WAVES_PER_BLOCK][MAX_KTOT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * WAVES_PER_BLOCK + wv;
+    const bool active = r0 < R;  // inactive wavefronts still take part in the block barriers
+    const int r = active ? r0 : R - 1;
+    float *cdf = s_cdf[wv], *zs = s_z[wv];
+    const float near = rays[(size_t)r * 8 + 6], far = rays[(size_t)r * 8 + 7];
+    const int Ktot = Kc + Kimp + Kfd;
+
+    if (Kimp > 0) {
+        // weights + 1e-5, pdf, cdf with leading 0 (nerf.py:130-133).  The running sum is kept in
+        // fp64 like ATen's CPU cumsum (acc_type<float> = double) and rounded per element.
+        float part = 0.f;
+        for (int i = lane; i < Kc; i += 64) part += wc[(size_t)r * Kc + i] + 1e-5f;
+        const float tot = wave_sum(part);
+        double run = 0.0;
+        for (int c0 = 0; c0 < Kc; c0 += 64) {
+            const int i = c0 + lane;
+            const float pdf = i < Kc ? (wc[(size_t)r * Kc + i] + 1e-5f) / tot : 0.f;
+            const double inc = wave_scan_add((double)pdf, lane) + run;
+            if (i < Kc) cdf[i + 1] = (float)inc;
+            run = __shfl(inc, 63, 64);
+        }
+        if (lane == 0) cdf[0] = 0.f;
+    }
+    for (int i = lane; i < Kc; i += 64) zs[i] = zc[(size_t)r * Kc + i];
+    __syncthreads();
+    for (int j = lane; j < Kimp; j += 64) {
+        const float u = u2[(size_t)r * Kimp + j];
+        // searchsorted(cdf, u, right=True): number of entries <= u      (nerf.py:138)
+        int lo = 0, hi = Kc + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const float ind = fmaxf((float)lo - 1.0f, 0.0f);  // :138-139 (may equal Kc)
+        const float t = (ind + u3[(size_t)r * Kimp + j]) / (float)Kc;  // :141
+        zs[Kc + j] = z_from_t(near, far, t, lindisp);
+    }
+    for (int j = lane; j < Kfd; j += 64) {
+        float z = depth_c[r] + n4[(size_t)r * Kfd + j] * depth_std;  // :157-158
+        z = fmaxf(fminf(z, far), near);                              // :160
+        zs[Kc + Kimp + j] = z;
+    }
+    __syncthreads();
+    if (!active) return;
+    // ascending sort by rank counting (ties broken by position; K^2/64 LDS broadcasts per lane)
+    for (int e = lane; e < Ktot; e += 64) {
+        const float v = zs[e];
+        int rank = 0;
+        for (int j = 0; j < Ktot; ++j) {
+            const float o = zs[j];
+            rank += (o < v || (o == v && j < e)) ? 1 : 0;
+        }
+        zout[(size_t)r * Ktot + rank] = v;
+    }
+}
+
+// NeRFRenderer.composite, nerf.py:178-182 (deltas) and :223-249
+__global__ void __launch_bounds__(WAVES_PER_BLOCK * 64)
+composite_kernel(const float *__restrict__ rays, const float *__restrict__ z, const float4 *__restrict__ rgbs, int R,
+                 int K, int white_bkgd, float *__restrict__ weights, float *__restrict__ rgb,
+                 float *__restrict__ depth) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * WAVES_PER_BLOCK + wv;
+    if (r >= R) return;
+    const float far = rays[(size_t)r * 8 + 7];
+    const float *zr = z + (size_t)r * K;
+    float carry = 1.f;  // transmittance in front of this chunk: prod_{j<c0} (1 - a_j + 1e-10)
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_w = 0.f;
+    for (int c0 = 0; c0 < K; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < K;
+        float zi = 0.f, alpha = 0.f;
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            zi = zr[i];
+            const float znext = (i + 1 < K) ? zr[i + 1] : far;  // :181 last delta = far - z_last
+            const float delta = znext - zi;
+            cs = rgbs[(size_t)r * K + i];
+            alpha = 1.f - expf(-delta * fmaxf(cs.w, 0.f));  // :228
+        }
+        const float tfac = valid ? (1.f - alpha + 1e-10f) : 1.f;  // :230-232
+        const float incl = wave_scan_mul(tfac, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;  // cumprod shifted by one, :234-235
+        const float w = alpha * T;
+        if (valid) {
+            if (weights) weights[(size_t)r * K + i] = w;
+            acc_r += w * cs.x; acc_g += w * cs.y; acc_b += w * cs.z;  // :239
+            acc_d += w * zi;                                          // :240
+            acc_w += w;
+        }
+        carry = carry * __shfl(incl, 63, 64);
+    }
+    acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);
+    acc_d = wave_sum(acc_d); acc_w = wave_sum(acc_w);
+    if (lane == 0) {
+        if (white_bkgd) {  // :241-244
+            acc_r = acc_r + 1.f - acc_w; acc_g = acc_g + 1.f - acc_w; acc_b = acc_b + 1.f - acc_w;
+        }
+        rgb[(size_t)r * 3 + 0] = acc_r; rgb[(size_t)r * 3 + 1] = acc_g; rgb[(size_t)r * 3 + 2] = acc_b;
+        depth[r] = acc_d;
+    }
+}
+
+// util.gen_rays + unproj_map (util.py:113-143,238-276, ndc=False)
+__global__ void gen_rays_kernel(const float *__restrict__ poses, int NV, int W, int H, float fx, float fy, float cx,
+                                float cy, float z_near, float z_far, float *__restrict__ rays) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)NV * H * W) return;
+    const int px = (int)(idx % W), py = (int)((idx / W) % H), n = (int)(idx / ((long long)W * H));
+    const float X = ((float)px - cx) / fx, Y = ((float)py - cy) / fy;
+    float d0 = X, d1 = -Y, d2 = -1.f;
+    const float nrm = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    d0 /= nrm; d1 /= nrm; d2 /= nrm;
+    const float *P = poses + (size_t)n * 16;
+    float *o = rays + idx * 8;
+    o[0] = P[3]; o[1] = P[7]; o[2] = P[11];
+    o[3] = P[0] * d0 + P[1] * d1 + P[2] * d2;
+    o[4] = P[4] * d0 + P[5] * d1 + P[6] * d2;
+    o[5] = P[8] * d0 + P[9] * d1 + P[10] * d2;
+    o[6] = z_near; o[7] = z_far;
+}
+#pragma clang fp contract(fast)
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" int pnr_sample_coarse(const float *rays, const float *u1, int R, int Kc, int lindisp, float *z,
+                                 void *stream) {
+    if (R < 0 || Kc <= 0) return pnr_fail(PNR_E_INVALID, "pnr_sample_coarse: bad sizes");
+    if (R == 0) return PNR_OK;
+    if (!rays || !u1 || !z) return pnr_fail(PNR_E_INVALID, "pnr_sample_coarse: null argument");
+    const long long n = (long long)R * Kc;
+    hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays,
+                       u1, R, Kc, lindisp, z);
+    return pnr_check_launch("pnr_sample_coarse");
+}
+
+extern "C" int pnr_sample_fine(const float *rays, const float *weights_c, const float *depth_c, const float *z_coarse,
+                               const float *u2, const float *u3, const float *n4, int R, int Kc, int Kimp, int Kfd,
+                               float depth_std, int lindisp, float *z_sorted, void *stream) {
+    if (R < 0 || Kc <= 0 || Kimp < 0 || Kfd < 0) return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: bad sizes");
+    if (Kc > MAX_KC || Kc + Kimp + Kfd > MAX_KTOT)
+        return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: supports n_coarse <= 256 and n_coarse + n_fine <= 512");
+    if (R == 0) return PNR_OK;
+    if (!rays || !z_coarse || !z_sorted || (Kimp > 0 && (!weights_c || !u2 || !u3)) || (Kfd > 0 && (!depth_c || !n4)))
+        return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: null argument");
+    hipLaunchKernelGGL(sample_fine_kernel, dim3((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(WAVES_PER_BLOCK * 64),
+                       0, (hipStream_t)stream, rays, weights_c, depth_c, z_coarse, u2, u3, n4, R, Kc, Kimp, Kfd,
+                       depth_std, lindisp, z_sorted);
+    return pnr_check_launch("pnr_sample_fine");
+}
+
+extern "C" int pnr_composite(const float *rays, const float *z, const float *rgbsigma, int R, int K, int white_bkgd,
+                             float *weights, float *rgb, float *depth, void *stream) {
+    if (R < 0 || K <= 0) return pnr_fail(PNR_E_INVALID, "pnr_composite: bad sizes");
+    if (R == 0) return PNR_OK;
+    if (!rays || !z || !rgbsigma || !rgb || !depth) return pnr_fail(PNR_E_INVALID, "pnr_composite: null argument");
+    hipLaunchKernelGGL(composite_kernel, dim3((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(WAVES_PER_BLOCK * 64), 0,
+                       (hipStream_t)stream, rays, z, (const float4 *)rgbsigma, R, K, white_bkgd, weights, rgb, depth);
+    return pnr_check_launch("pnr_composite");
+}
+
+extern "C" int pnr_gen_rays(const float *poses, int NV, int W, int H, float fx, float fy, float cx, float cy,
+                            float z_near, float z_far, float *rays, void *stream) {
+    if (NV < 0 || W <= 0 || H <= 0) return pnr_fail(PNR_E_INVALID, "pnr_gen_rays: bad sizes");
+    if (NV == 0) return PNR_OK;
+    if (!poses || !rays) return pnr_fail(PNR_E_INVALID, "pnr_gen_rays: null argument");
+    const long long n = (long long)NV * W * H;
+    hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, poses, NV,
+                       W, H, fx, fy, cx, cy, z_near, z_far, rays);
+    return pnr_check_launch("pnr_gen_rays");
+}
+
+// workspace layout (floats): z_c [R*Kc] | rgbs_c [R*Kc*4] | w_c [R*Kc] | z_f [R*Kt] | rgbs_f [R*Kt*4]
+static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+extern "C" size_t pnr_render_workspace_bytes(int R, int Kc, int Kf) {
+    if (R <= 0 || Kc <= 0 || Kf < 0) return 0;
+    const size_t r = (size_t)R, kc = (size_t)Kc, kt = (size_t)(Kc + Kf);
+    size_t fl = align64(r * kc) + align64(r * kc * 4) + align64(r * kc);
+    if (Kf > 0) fl += align64(r * kt) + align64(r * kt * 4);
+    return fl * sizeof(float);
+}
+
+extern "C" int pnr_render_forward(const PnrScene *scene, const void *packed_coarse, const void *packed_fine,
+                                  int precision, const float *rays, int R, int rays_per_obj, int Kc, int Kf, int Kfd,
+                                  float depth_std, int white_bkgd, int lindisp, const float *u1, const float *u2,
+                                  const float *u3, const float *n4, float *rgb_c, float *depth_c, float *weights_c,
+                                  float *rgb_f, float *depth_f, float *weights_f, void *workspace, void *stream) {
+    if (R < 0 || Kc <= 0 || Kf < 0 || Kfd < 0 || Kfd > Kf)
+        return pnr_fail(PNR_E_INVALID, "pnr_render_forward: bad sample counts");
+    if (R == 0) return PNR_OK;
+    if (!workspace || !rgb_c || !depth_c || (Kf > 0 && (!rgb_f || !depth_f)))
+        return pnr_fail(PNR_E_INVALID, "pnr_render_forward: null output / workspace");
+    const size_t r = (size_t)R, kc = (size_t)Kc, kt = (size_t)(Kc + Kf);
+    float *ws = (float *)workspace;
+    float *z_c = ws; ws += align64(r * kc);
+    float *rgbs_c = ws; ws += align64(r * kc * 4);
+    float *w_c = ws; ws += align64(r * kc);
+    float *z_f = ws; ws += align64(r * kt);
+    float *rgbs_f = ws;
+    if (weights_c) w_c = weights_c;  // write straight into the caller's buffer
+    int rc;
+    if ((rc = pnr_sample_coarse(rays, u1, R, Kc, lindisp, z_c, stream))) return rc;
+    if ((rc = pnr_eval_ray_samples(scene, packed_coarse, precision, rays, z_c, R, rays_per_obj, Kc, rgbs_c, stream))) return rc;
+    if ((rc = pnr_composite(rays, z_c, rgbs_c, R, Kc, white_bkgd, w_c, rgb_c, depth_c, stream))) return rc;
+    if (Kf > 0) {
+        const void *pf = packed_fine ? packed_fine : packed_coarse;  // models.py:242
+        if ((rc = pnr_sample_fine(rays, w_c, depth_c, z_c, u2, u3, n4, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, stream))) return rc;
+        if ((rc = pnr_eval_ray_samples(scene, pf, precision, rays, z_f, R, rays_per_obj, Kc + Kf, rgbs_f, stream))) return rc;
+        if ((rc = pnr_composite(rays, z_f, rgbs_f, R, Kc + Kf, white_bkgd, weights_f, rgb_f, depth_f, stream))) return rc;
+    }
+    return PNR_OK;
+}

@@ -1,0 +1,287 @@
+"""
+torch.Tensor front-end of the C ABI (include/pixelnerf_hip.h).  PyTorch is plumbing here:
+device memory, the current HIP stream and tensor shapes; every computation below is a call
+into libpixelnerf_hip.so.  Nothing in this module has a CPU or eager-PyTorch fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_MLP_KEYS = (
+    ["lin_in.weight", "lin_in.bias", "lin_out.weight", "lin_out.bias"]
+    + [f"lin_z.{b}.{s}" for b in range(3) for s in ("weight", "bias")]
+    + [f"blocks.{b}.fc_{j}.{s}" for b in range(5) for j in (0, 1) for s in ("weight", "bias")]
+)
+_MLP_SHAPES = {"lin_in.weight": (512, 42), "lin_out.weight": (4, 512), "lin_out.bias": (4,)}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t, name, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise _lib.PixelNerfHipError(f"{name}: tensor must live on a HIP device (got {t.device}); "
+                                     "pixelnerf_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if shape is not None:
+        if len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape)):
+            raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class PackedMLP:
+    """A ResnetFC's parameters repacked into the fused kernel's fragment stream."""
+
+    def __init__(self, buf, precision):
+        self.buf = buf
+        self.precision = precision
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr())
+
+
+def pack_mlp(state, precision="f16"):
+    """state: {reference ResnetFC state_dict key: float32 HIP tensor}
+    (src/model/resnetfc.py:66-130: lin_in, lin_out, blocks.N.fc_0/fc_1, lin_z.N)."""
+    lib = _lib.load()
+    prec = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+    keep = {}
+    for k in _MLP_KEYS:
+        if k not in state:
+            raise KeyError(f"pack_mlp: missing parameter '{k}' (only the shipped ResnetFC shape "
+                           "d_hidden=512, n_blocks=5, combine_layer=3 is supported)")
+        shape = _MLP_SHAPES.get(k, (512, 512) if k.endswith("weight") else (512,))
+        keep[k] = _f32(state[k].detach(), k, shape)
+    w = _lib.PnrMlpWeights()
+    w.lin_in_w, w.lin_in_b = keep["lin_in.weight"].data_ptr(), keep["lin_in.bias"].data_ptr()
+    w.lin_out_w, w.lin_out_b = keep["lin_out.weight"].data_ptr(), keep["lin_out.bias"].data_ptr()
+    for b in range(3):
+        w.lin_z_w[b] = keep[f"lin_z.{b}.weight"].data_ptr()
+        w.lin_z_b[b] = keep[f"lin_z.{b}.bias"].data_ptr()
+    for b in range(5):
+        w.fc0_w[b] = keep[f"blocks.{b}.fc_0.weight"].data_ptr()
+        w.fc0_b[b] = keep[f"blocks.{b}.fc_0.bias"].data_ptr()
+        w.fc1_w[b] = keep[f"blocks.{b}.fc_1.weight"].data_ptr()
+        w.fc1_b[b] = keep[f"blocks.{b}.fc_1.bias"].data_ptr()
+    dev = keep["lin_in.weight"].device
+    buf = torch.empty(lib.pnr_packed_mlp_bytes(), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_pack_mlp(ctypes.byref(w), prec, _p(buf), _stream()), "pnr_pack_mlp")
+    return PackedMLP(buf, prec)
+
+
+class Scene:
+    """Device-side encoded-scene state (what PixelNeRFNet.encode() leaves behind)."""
+
+    def __init__(self, latent_nhwc, poses, focal, c, image_shape, NS):
+        NV, Hl, Wl, C = latent_nhwc.shape
+        if C != 512:
+            raise ValueError("latent must have 512 channels (encoder.latent_size of the shipped configs)")
+        if NV % NS != 0:
+            raise ValueError("latent rows must be SB*NS")
+        self.latent_nhwc = _f32(latent_nhwc, "latent_nhwc")
+        self.poses = _f32(poses, "poses", (NV, 3, 4))
+        self.focal = _f32(focal, "focal", (None, 2))
+        self.c = _f32(c, "c", (None, 2))
+        self.NS, self.SB = int(NS), NV // int(NS)
+        for nm, t in (("focal", self.focal), ("c", self.c)):
+            if t.shape[0] not in (1, self.SB):
+                raise ValueError(f"{nm} must have 1 or SB rows")
+        s = _lib.PnrScene()
+        s.latent_nhwc, s.poses = self.latent_nhwc.data_ptr(), self.poses.data_ptr()
+        s.focal, s.c = self.focal.data_ptr(), self.c.data_ptr()
+        s.SB, s.NS, s.Hl, s.Wl = self.SB, self.NS, Hl, Wl
+        s.n_focal, s.n_c = self.focal.shape[0], self.c.shape[0]
+        s.img_w, s.img_h = float(image_shape[0]), float(image_shape[1])
+        self.struct = s
+        self.device = self.latent_nhwc.device
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.struct)
+
+
+def nchw_to_nhwc(latent):
+    lib = _lib.load()
+    latent = _f32(latent, "latent")
+    N, C, H, W = latent.shape
+    out = torch.empty((N, H, W, C), dtype=torch.float32, device=latent.device)
+    with torch.cuda.device(latent.device):
+        _lib.check(lib.pnr_nchw_to_nhwc(_p(latent), _p(out), N, C, H, W, _stream()), "pnr_nchw_to_nhwc")
+    return out
+
+
+def make_scene(latent_nchw, poses, focal, c, image_shape, NS):
+    """latent_nchw (SB*NS,512,Hl,Wl) as stored in encoder.latent."""
+    return Scene(nchw_to_nhwc(latent_nchw), poses, focal, c, image_shape, NS)
+
+
+def sample_coarse(rays, u1, lindisp=False):
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    u1 = _f32(u1, "u1", (R, None))
+    Kc = u1.shape[1]
+    z = torch.empty((R, Kc), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.pnr_sample_coarse(_p(rays), _p(u1), R, Kc, int(lindisp), _p(z), _stream()),
+                   "pnr_sample_coarse")
+    return z
+
+
+def sample_fine(rays, weights_c, depth_c, z_coarse, u2, u3, n4, depth_std=0.01, lindisp=False):
+    """-> z_sorted (R, Kc + Kimp + Kfd).  u2/u3 may be None (no importance samples), n4 may be
+    None (no depth samples)."""
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z_coarse = _f32(z_coarse, "z_coarse", (R, None))
+    Kc = z_coarse.shape[1]
+    Kimp = 0 if u2 is None else u2.shape[1]
+    Kfd = 0 if n4 is None else n4.shape[1]
+    if Kimp:
+        weights_c = _f32(weights_c, "weights_c", (R, Kc))
+        u2, u3 = _f32(u2, "u2", (R, Kimp)), _f32(u3, "u3", (R, Kimp))
+    if Kfd:
+        depth_c, n4 = _f32(depth_c, "depth_c", (R,)), _f32(n4, "n4", (R, Kfd))
+    z = torch.empty((R, Kc + Kimp + Kfd), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.pnr_sample_fine(_p(rays), _p(weights_c) if Kimp else None, _p(depth_c) if Kfd else None,
+                                       _p(z_coarse), _p(u2) if Kimp else None, _p(u3) if Kimp else None,
+                                       _p(n4) if Kfd else None, R, Kc, Kimp, Kfd, float(depth_std),
+                                       int(lindisp), _p(z), _stream()), "pnr_sample_fine")
+    return z
+
+
+def eval_ray_samples(scene, packed, rays, z):
+    """rays (R,8), z (R,K) -> rgbsigma (R,K,4); R = SB * rays_per_obj."""
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z = _f32(z, "z", (R, None))
+    K = z.shape[1]
+    if R % scene.SB != 0:
+        raise ValueError("number of rays must be a multiple of the number of objects")
+    out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.pnr_eval_ray_samples(scene.ref, packed.ptr, packed.precision, _p(rays), _p(z), R,
+                                            max(R // scene.SB, 1), K, _p(out), _stream()),
+                   "pnr_eval_ray_samples")
+    return out
+
+
+def eval_points(scene, packed, xyz, viewdirs):
+    """xyz, viewdirs (SB,B,3) -> (SB,B,4)."""
+    lib = _lib.load()
+    xyz = _f32(xyz, "xyz", (scene.SB, None, 3))
+    B = xyz.shape[1]
+    viewdirs = _f32(viewdirs, "viewdirs", (scene.SB, B, 3))
+    out = torch.empty((scene.SB, B, 4), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(lib.pnr_eval_points(scene.ref, packed.ptr, packed.precision, _p(xyz), _p(viewdirs), B,
+                                       _p(out), _stream()), "pnr_eval_points")
+    return out
+
+
+def composite(rays, z, rgbsigma, white_bkgd=False, want_weights=True):
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z = _f32(z, "z", (R, None))
+    K = z.shape[1]
+    rgbsigma = _f32(rgbsigma, "rgbsigma", (R, K, 4))
+    dev = rays.device
+    weights = torch.empty((R, K), dtype=torch.float32, device=dev) if want_weights else None
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((R,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_composite(_p(rays), _p(z), _p(rgbsigma), R, K, int(bool(white_bkgd)), _p(weights),
+                                     _p(rgb), _p(depth), _stream()), "pnr_composite")
+    return weights, rgb, depth
+
+
+def render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_fine_depth, noise,
+                   depth_std=0.01, white_bkgd=False, lindisp=False, want_weights=False):
+    """Whole NeRFRenderer.forward (nerf.py:251-303) for rays (R,8) in object-major order.
+    noise: dict(u1[,u2,u3][,n4]).  Returns {"coarse": {...}, "fine": {...}} of flat tensors."""
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R, dev = rays.shape[0], rays.device
+    Kc, Kf, Kfd = int(n_coarse), int(n_fine), int(n_fine_depth)
+    Kimp = Kf - Kfd
+    if Kf > 0 and Kimp < 0:
+        raise ValueError("n_fine_depth must not exceed n_fine")
+    if R % scene.SB != 0:
+        raise ValueError("number of rays must be a multiple of the number of objects")
+    u1 = _f32(noise["u1"], "u1", (R, Kc))
+    u2 = u3 = n4 = None
+    if Kf > 0 and Kimp > 0:
+        u2, u3 = _f32(noise["u2"], "u2", (R, Kimp)), _f32(noise["u3"], "u3", (R, Kimp))
+    if Kf > 0 and Kfd > 0:
+        n4 = _f32(noise["n4"], "n4", (R, Kfd))
+
+    def outs(K):
+        return (torch.empty((R, 3), dtype=torch.float32, device=dev),
+                torch.empty((R,), dtype=torch.float32, device=dev),
+                torch.empty((R, K), dtype=torch.float32, device=dev) if want_weights else None)
+
+    rgb_c, depth_c, w_c = outs(Kc)
+    rgb_f, depth_f, w_f = outs(Kc + Kf) if Kf > 0 else (None, None, None)
+    ws = torch.empty(max(lib.pnr_render_workspace_bytes(R, Kc, Kf), 16), dtype=torch.uint8, device=dev)
+    if packed_fine is not None and packed_fine.precision != packed_coarse.precision:
+        raise ValueError("coarse and fine networks must be packed at the same precision")
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_render_forward(
+            scene.ref, packed_coarse.ptr, packed_fine.ptr if packed_fine is not None else None,
+            packed_coarse.precision, _p(rays), R, max(R // scene.SB, 1), Kc, Kf, Kfd, float(depth_std),
+            int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4),
+            _p(rgb_c), _p(depth_c), _p(w_c), _p(rgb_f), _p(depth_f), _p(w_f), _p(ws), _stream()),
+            "pnr_render_forward")
+    ret = {"coarse": {"rgb": rgb_c, "depth": depth_c}}
+    if want_weights:
+        ret["coarse"]["weights"] = w_c
+    if Kf > 0:
+        ret["fine"] = {"rgb": rgb_f, "depth": depth_f}
+        if want_weights:
+            ret["fine"]["weights"] = w_f
+    return ret
+
+
+def gen_rays(poses, width, height, focal, z_near, z_far, c=None):
+    """util.gen_rays (src/util/util.py:238-276, ndc=False): poses (NV,4,4) -> (NV,H,W,8)."""
+    lib = _lib.load()
+    poses = _f32(poses, "poses", (None, 4, 4))
+    NV = poses.shape[0]
+    fx, fy = (float(focal), float(focal)) if not hasattr(focal, "__len__") else (float(focal[0]), float(focal[-1]))
+    cx, cy = (width * 0.5, height * 0.5) if c is None else (float(c[0]), float(c[1]))
+    rays = torch.empty((NV, height, width, 8), dtype=torch.float32, device=poses.device)
+    with torch.cuda.device(poses.device):
+        _lib.check(lib.pnr_gen_rays(_p(poses), NV, int(width), int(height), fx, fy, cx, cy, float(z_near),
+                                    float(z_far), _p(rays), _stream()), "pnr_gen_rays")
+    return rays
+
+
+def profile_enable(on=True):
+    _lib.check(_lib.load().pnr_profile_enable(int(bool(on))), "pnr_profile_enable")
+
+
+def profile_read():
+    ms, n = ctypes.c_double(0), ctypes.c_int(0)
+    _lib.check(_lib.load().pnr_profile_read(ctypes.byref(ms), ctypes.byref(n)), "pnr_profile_read")
+    return ms.value, n.value
+
+
+def debug_set_x_dump(t):
+    """test hook: dump the residual stream before lin_out of subsequent launches into t (P,512)."""
+    _lib.check(_lib.load().pnr_debug_set_x_dump(_p(t)), "pnr_debug_set_x_dump")

@@ -1,0 +1,70 @@
+"""CPU tests: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/pixelnerf_hip.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from pixelnerf_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build_library()
+    return _lib.load()
+
+
+def header_functions(repo_root):
+    src = open(os.path.join(repo_root, "include", "pixelnerf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pnr_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib, repo_root):
+    names = header_functions(repo_root)
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/pixelnerf_hip.h but not exported"
+    assert sorted(_lib.PROTOTYPES) == names, "ctypes prototypes and header out of sync"
+
+
+def test_struct_layouts_match_header():
+    # PnrScene: 4 pointers, 6 int32, 2 floats; PnrMlpWeights: 30 pointers
+    assert ctypes.sizeof(_lib.PnrScene) == 4 * 8 + 6 * 4 + 2 * 4
+    assert ctypes.sizeof(_lib.PnrMlpWeights) == 30 * 8
+
+
+def test_host_only_entry_points(lib):
+    major, minor = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert lib.pnr_version(ctypes.byref(major), ctypes.byref(minor)) == 0
+    assert (major.value, minor.value) == (0, 1)
+    # packed stream: 8 waves x 424 ring steps x 2 fragments x 1 KiB + biases + b_out
+    assert lib.pnr_packed_mlp_bytes() == 8 * 424 * 2 * 1024 + 11 * 8 * 64 * 4 + 16
+    assert lib.pnr_render_workspace_bytes(0, 64, 128) == 0
+    r, kc, kf = 100, 64, 128
+    fl = lambda n: (n + 63) // 64 * 64
+    expect = 4 * (fl(r * kc) + fl(r * kc * 4) + fl(r * kc) + fl(r * (kc + kf)) + fl(r * (kc + kf) * 4))
+    assert lib.pnr_render_workspace_bytes(r, kc, kf) == expect
+
+
+def test_argument_validation_without_gpu(lib):
+    # invalid arguments are rejected on the host before any HIP call
+    assert lib.pnr_sample_coarse(None, None, 4, 0, 0, None, None) == -1
+    assert b"bad sizes" in lib.pnr_last_error()
+    assert lib.pnr_sample_fine(None, None, None, None, None, None, None, 4, 300, 0, 0, 0.01, 0, None, None) == -1
+    assert b"n_coarse <= 256" in lib.pnr_last_error()
+    assert lib.pnr_composite(None, None, None, 3, 8, 0, None, None, None, None) == -1
+    assert lib.pnr_pack_mlp(None, 0, None, None) == -1
+    # empty batches are a successful no-op (reference: empty output, nerf.py:23-27)
+    assert lib.pnr_sample_coarse(None, None, 0, 8, 0, None, None) == 0
+    assert lib.pnr_composite(None, None, None, 0, 8, 0, None, None, None, None) == 0
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from pixelnerf_amd import ops
+    with pytest.raises(_lib.PixelNerfHipError):
+        ops.sample_coarse(torch.zeros(2, 8), torch.zeros(2, 4))
+    with pytest.raises(_lib.PixelNerfHipError):
+        ops.composite(torch.zeros(2, 8), torch.zeros(2, 4), torch.zeros(2, 4, 4))

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Quick kernel-level timing of the fused network (GPU box): points/s and TFLOP/s."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pixelnerf_amd import ops, synthetic  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    for scene_name, R, K in (("sn64", 16384, 64), ("sn64", 16384, 192), ("srn_car", 8192, 192)):
+        scene, meta = synthetic.make_scene(scene_name)
+        NS = scene["NS"]
+        sc = ops.make_scene(scene["latent"].to(dev), scene["poses"].to(dev), scene["focal"].to(dev),
+                            scene["c"].to(dev), scene["image_shape"], NS)
+        rays = synthetic.target_rays(meta).reshape(-1, 8)
+        rays = rays.repeat((R + rays.shape[0] - 1) // rays.shape[0], 1)[:R].contiguous().to(dev)
+        u = torch.rand(R, K, device=dev)
+        z = ops.sample_coarse(rays, u)
+        z, _ = torch.sort(z, dim=-1)
+        for prec in ("f16", "bf16"):
+            pk = ops.pack_mlp({k: v.to(dev) for k, v in synthetic.make_mlp_params(11).items()}, prec)
+            for _ in range(2):
+                ops.eval_ray_samples(sc, pk, rays, z)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 3
+            for _ in range(n):
+                ops.eval_ray_samples(sc, pk, rays, z)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            flop_pt = (4.7616e6 * NS + 2.1012e6)
+            print(f"{scene_name} NS={NS} R={R} K={K} {prec}: {dt*1e3:8.2f} ms  {R*K/dt/1e6:8.2f} Mpts/s  "
+                  f"{R*K*flop_pt/dt/1e12:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
