@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""
+bench.py -- rays/sec of the pixelNeRF volume-rendering hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--prec f16|bf16] [--rays R]
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): sn64 NMR
+geometry, 64x64 target views, 1 source view, 64 coarse + 128 fine samples (112 importance +
+16 depth), separate coarse / fine ResnetFC (d_hidden 512, 5 blocks), synthetic feature grid
+and random-init weights (no datasets / checkpoints offline).  One step = one
+`render_par(rays)` call, exactly what eval/eval.py:277 times in the reference: R = 65536 rays
+(16 target views) per GPU, through NeRFRenderer/_RenderWrapper (noise draws included).
+`value` = rays rendered by all ranks / wall time of the K timed steps (inputs resident in HBM).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling -- every rank
+renders its own R rays; each timed step also contains the single feature-grid broadcast from
+rank 0 and the final gather of (rgb, depth) to rank 0.
+
+The JSON line also carries
+  roofline     : the fused network kernel (>= 99 % of the work) against the dense MFMA peak:
+                 algorithmic FLOP of the launches in the timed region / their HIP-event time;
+  cpu_baseline : the CPU oracle (restatement of the reference, kind "port") timed on this
+                 host's cores on a bounded sample of the same workload, rank 0 / N=1 only;
+  psnr_db      : PSNR of the HIP render vs that CPU render on the sample (identical rays,
+                 weights, grid and noise) -- the "matched PSNR" of the metric.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_POINT_VIEW = 4.7616e6   # lin_in + 3 lin_z + 3 blocks, per (point, view)   SURVEY.md §8a
+FLOP_PER_POINT_POOLED = 2.1012e6  # 2 blocks + lin_out, per point
+PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0}  # dense MFMA peak, MI355X_MICROARCH.md
+
+
+def build(dev, prec, scene_name="sn64"):
+    from pixelnerf_amd import synthetic
+    from pixelnerf_amd.model import make_model
+    from pixelnerf_amd.render import NeRFRenderer
+    from pixelnerf_amd.util.conf import default_model_conf
+
+    scene, meta = synthetic.make_scene(scene_name)
+    net = make_model(default_model_conf(), precision=prec).to(dev).eval()
+    mc, mf = synthetic.make_mlp_params(11), synthetic.make_mlp_params(12)
+    net.mlp_coarse.load_state_dict(mc)
+    net.mlp_fine.load_state_dict(mf)
+    lat = scene["latent"].to(dev)
+    net.encoder.latent = lat
+    ls = torch.tensor([lat.shape[-1], lat.shape[-2]], dtype=torch.float32, device=dev)
+    net.encoder.latent_scaling = ls / (ls - 1) * 2.0
+    net.poses, net.image_shape = scene["poses"].to(dev), scene["image_shape"].to(dev)
+    net.focal, net.c = scene["focal"].to(dev), scene["c"].to(dev)
+    net.num_objs, net.num_views_per_obj = scene["SB"], scene["NS"]
+    renderer = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, depth_std=0.01,
+                            white_bkgd=meta["white_bkgd"], lindisp=False).to(dev).eval()
+    return scene, meta, net, renderer, (mc, mf)
+
+
+def make_rays(meta, R, rank):
+    """R rays: whole 64x64 target views on the sn64 camera circle (different views per rank)."""
+    from pixelnerf_amd import synthetic
+    n_img = (R + meta["W"] * meta["H"] - 1) // (meta["W"] * meta["H"])
+    poses = torch.stack([synthetic.pose_spherical(75.0 + 360.0 * (i + rank * n_img) / (n_img * 8 + 1), -20.0,
+                                                  meta["radius"]) for i in range(n_img)])
+    rays = synthetic.gen_rays(poses, meta["W"], meta["H"], meta["focal"], meta["z_near"], meta["z_far"], c=meta["c"])
+    return rays.reshape(-1, 8)[:R].contiguous()
+
+
+def cpu_baseline(scene, mlps, rays_sample, noise, threads=None):
+    """Oracle (CPU restatement of the reference) on a bounded sample; returns rays/s + render."""
+    from oracle import pnr_oracle as O
+    if threads:
+        torch.set_num_threads(threads)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        out = O.render(scene, mlps[0], mlps[1], rays_sample[None], noise, 64, 128, 16, white_bkgd=True)
+        dt = time.perf_counter() - t0
+    return rays_sample.shape[0] / dt, dt, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prec", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step")
+    ap.add_argument("--cpu-rays", type=int, default=0, help="CPU-baseline sample size (0 = auto, ~15 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pixelnerf_amd import ops, synthetic
+    from pixelnerf_amd.dist import broadcast_encoded
+
+    scene, meta, net, renderer, mlps = build(dev, args.prec)
+    R = args.rays
+    rays = make_rays(meta, R, rank).to(dev)
+    render_par = renderer.bind_parallel(net, None, simple_output=True).eval()
+
+    def step():
+        if world > 1:
+            broadcast_encoded(net, src=0)  # the single feature-grid broadcast (2 MiB for sn64)
+        with torch.no_grad():
+            rgb, depth = render_par(rays[None])
+        if world > 1:
+            out = torch.cat([rgb[0], depth[0].unsqueeze(-1)], dim=-1)  # 16 B/ray
+            bufs = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
+            dist.gather(out, bufs, dst=0)
+        return rgb
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    torch.manual_seed(1234 + rank)
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms, n_launch = ops.profile_read()
+    ops.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        NS = scene["NS"]
+        flop_per_ray = (64 + 192) * (FLOP_PER_POINT_VIEW * NS + FLOP_PER_POINT_POOLED)
+        rays_per_s = world * R * args.steps / elapsed
+        # roofline of the dominant kernel: algorithmic FLOP of rank 0's launches / their HIP-event time
+        ach = (R * args.steps * flop_per_ray) / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        res = {
+            "metric": "rays/sec (64 coarse + 128 fine samples) at matched PSNR vs reference",
+            "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+            "config": {"workload": "sn64 NMR 64x64, 1 input view, 64+128 samples (BASELINE configs[1]); "
+                                   "%d rays (%d target views) per GPU per step; synthetic 1x512x32x32 feature grid, "
+                                   "random-init ResnetFC coarse+fine (d_hidden 512, 5 blocks)" % (R, R // 4096),
+                       "rays_per_gpu_per_step": R, "n_coarse": 64, "n_fine": 128, "n_fine_depth": 16,
+                       "source_views": NS, "api": "NeRFRenderer.bind_parallel(net, simple_output=True)(rays)"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.prec], "unit": "TFLOP/s",
+                         "frac": ach / PEAK_TFLOPS[args.prec], "traffic": None,
+                         "kernel": "pnr::eval_kernel (fused per-point network)", "launches": n_launch,
+                         "avg_launch_ms": kern_ms / max(n_launch, 1),
+                         "flop_per_ray": flop_per_ray, "kernel_time_frac_of_step": kern_ms * 1e-3 / elapsed},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # bounded CPU sample of the same workload; also yields the matched-PSNR figure
+            # torch's intra-op pool does not scale to every core of a many-socket host on 512-wide
+            # GEMMs: pick the thread count that is FASTEST on a 64-ray probe (fair to the CPU), then
+            # time the real sample with it.  `cores` reports the threads actually used.
+            n0 = 64
+            rs = rays[:4096].cpu()
+            noise0 = synthetic.make_noise(n0, 64, 128, 16, seed=99)
+            ncpu = os.cpu_count() or 1
+            cpu_baseline(scene, mlps, rs[:n0], noise0, threads=min(ncpu, 16))  # warm-up
+            best = (0.0, 1)
+            for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, ncpu)}):
+                rate_t, _, _ = cpu_baseline(scene, mlps, rs[:n0], noise0, threads=th)
+                if rate_t > best[0]:
+                    best = (rate_t, th)
+            rate0 = best[0]
+            torch.set_num_threads(best[1])
+            n = args.cpu_rays or int(min(4096, max(256, rate0 * 15.0)) // 64 * 64)
+            noise = synthetic.make_noise(n, 64, 128, 16, seed=100)
+            rate, dt, ref = cpu_baseline(scene, mlps, rs[:n], noise, threads=best[1])
+            with torch.no_grad():
+                out = renderer(net, rs[:n].to(dev)[None], _noise={k: v.to(dev) for k, v in noise.items()})
+            from oracle import pnr_oracle as O
+            res["psnr_db"] = O.psnr(out.fine.rgb.cpu(), ref["fine"]["rgb"])
+            res["depth_abs_err_p99"] = float(torch.quantile((out.fine.depth.cpu() - ref["fine"]["depth"]).abs().flatten(), 0.99))
+            res["cpu_baseline"] = {"value": rate, "unit": "rays/s", "cores": best[1], "host_cpus": ncpu, "kind": "port",
+                                   "sample": "%d rays of the same workload (64+128, same weights/grid), %.1f s, "
+                                             "oracle/pnr_oracle.py (torch CPU fp32 restatement of the reference)" % (n, dt)}
+            res["speedup_vs_cpu_baseline"] = rays_per_s / rate
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -238,13 +238,34 @@ def stage_goldens():
     return rec
 
 
+def state_dict_manifest():
+    """Names and shapes of the reference net's state_dict (encoder.* excluded: the torchvision
+    backbone is a stub here) and of the renderer's -- the checkpoint-compatibility contract
+    (SURVEY.md §5 'Checkpoint / resume')."""
+    import render.nerf as ref_nerf
+
+    net = build_reference_net(True)
+    lines = []
+    for k, v in net.state_dict().items():
+        if not k.startswith("encoder."):
+            lines.append("net %s %s" % (k, "x".join(str(d) for d in v.shape)))
+    for k, v in ref_nerf.NeRFRenderer(n_coarse=64, n_fine=32).state_dict().items():
+        lines.append("renderer %s %s" % (k, "x".join(str(d) for d in v.shape) or "scalar"))
+    return lines
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    names = sys.argv[1:] or (list(SCENARIOS) + ["stages"])
+    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "manifest"])
     for name in names:
+        if name == "manifest":
+            path = os.path.join(outdir, "state_dict_manifest.txt")
+            open(path, "w").write("\n".join(state_dict_manifest()) + "\n")
+            print("wrote", path)
+            continue
         rec = stage_goldens() if name == "stages" else run_scenario(name)
         path = os.path.join(outdir, name + ".npz")
         np.savez_compressed(path, **rec)

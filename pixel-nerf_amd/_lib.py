@@ -104,6 +104,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as
+    # /opt/rocm's).  Streams and device pointers are shared with torch, so torch's copy must be
+    # the one in the process: import torch BEFORE dlopen so our DT_NEEDED resolves to it.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise PixelNerfHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

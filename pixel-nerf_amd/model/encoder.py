@@ -1,0 +1,146 @@
+"""SpatialEncoder: the ResNet-34 image encoder stays in PyTorch-ROCm (BASELINE north_star).
+torchvision is not available here, so the trunk is written out in plain torch with
+torchvision's parameter names (`model.conv1`, `model.bn1`, `model.layerN.i.convK` ...), which
+keeps reference checkpoints loadable (src/model/encoder.py:13-178).
+
+forward() builds the (SB*NS, 512, Hl, Wl) feature pyramid exactly as the reference does
+(encoder.py:111-164); the per-sample bilinear lookup `index()` (encoder.py:80-109) is NOT
+called by the product path -- it is fused into the HIP network kernel, which reads the
+channel-last copy of `latent` made by `latent_nhwc()`."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+
+
+class _BasicBlock(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), norm_layer(planes))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class _ResNet(nn.Module):
+    """torchvision.models.resnet{18,34} layout (BasicBlock)."""
+
+    def __init__(self, layers, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        inpl = 64
+        for i, (planes, n) in enumerate(zip((64, 128, 256, 512), layers)):
+            blocks = []
+            for j in range(n):
+                blocks.append(_BasicBlock(inpl, planes, (1 if i == 0 else 2) if j == 0 else 1, norm_layer))
+                inpl = planes
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        self.avgpool = nn.Sequential()  # encoder.py:66-67
+        self.fc = nn.Sequential()
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+
+class SpatialEncoder(nn.Module):
+    def __init__(self, backbone="resnet34", pretrained=True, num_layers=4, index_interp="bilinear",
+                 index_padding="border", upsample_interp="bilinear", feature_scale=1.0, use_first_pool=True,
+                 norm_type="batch"):
+        super().__init__()
+        if backbone not in ("resnet34", "resnet18"):
+            raise NotImplementedError("only the resnet18/34 backbones of the shipped configs (encoder.py:56)")
+        if norm_type != "batch":
+            raise NotImplementedError("norm_type != batch is not used by any shipped config")
+        # `pretrained` ImageNet weights cannot be fetched offline: load them through the
+        # reference checkpoint (state_dict keys encoder.model.*) instead.
+        self.feature_scale = feature_scale
+        self.use_first_pool = use_first_pool
+        self.model = _ResNet([3, 4, 6, 3] if backbone == "resnet34" else [2, 2, 2, 2])
+        self.latent_size = [0, 64, 128, 256, 512, 1024][num_layers]
+        self.num_layers = num_layers
+        self.index_interp, self.index_padding, self.upsample_interp = index_interp, index_padding, upsample_interp
+        self.register_buffer("latent", torch.empty(1, 1, 1, 1), persistent=False)
+        self.register_buffer("latent_scaling", torch.empty(2, dtype=torch.float32), persistent=False)
+        self._nhwc = None
+
+    def forward(self, x):
+        """encoder.py:111-164."""
+        if self.feature_scale != 1.0:
+            x = F.interpolate(x, scale_factor=self.feature_scale,
+                              mode="bilinear" if self.feature_scale > 1.0 else "area",
+                              align_corners=True if self.feature_scale > 1.0 else None,
+                              recompute_scale_factor=True)
+        x = x.to(device=self.latent.device)
+        x = self.model.relu(self.model.bn1(self.model.conv1(x)))
+        latents = [x]
+        if self.num_layers > 1:
+            if self.use_first_pool:
+                x = self.model.maxpool(x)
+            x = self.model.layer1(x)
+            latents.append(x)
+        if self.num_layers > 2:
+            x = self.model.layer2(x)
+            latents.append(x)
+        if self.num_layers > 3:
+            x = self.model.layer3(x)
+            latents.append(x)
+        if self.num_layers > 4:
+            x = self.model.layer4(x)
+            latents.append(x)
+        self.latents = latents
+        align_corners = None if self.index_interp == "nearest " else True
+        latent_sz = latents[0].shape[-2:]
+        for i in range(len(latents)):
+            latents[i] = F.interpolate(latents[i], latent_sz, mode=self.upsample_interp, align_corners=align_corners)
+        self.latent = torch.cat(latents, dim=1)
+        self.latent_scaling[0] = self.latent.shape[-1]
+        self.latent_scaling[1] = self.latent.shape[-2]
+        self.latent_scaling = self.latent_scaling / (self.latent_scaling - 1) * 2.0
+        return self.latent
+
+    def latent_nhwc(self):
+        """Channel-last copy of `latent` for the fused kernel (one bilinear corner = one
+        contiguous 2 KiB row); cached until `latent` is replaced or modified."""
+        lat = self.latent
+        key = (lat.data_ptr(), lat._version, tuple(lat.shape))
+        if self._nhwc is None or self._nhwc[0] != key:
+            self._nhwc = (key, ops.nchw_to_nhwc(lat.detach().float()))
+        return self._nhwc[1]
+
+    def index(self, uv, cam_z=None, image_size=(), z_bounds=None):
+        """encoder.py:80-109, for callers that use the encoder on its own (the renderer does
+        not: the lookup is fused into the network kernel)."""
+        if uv.shape[0] == 1 and self.latent.shape[0] > 1:
+            uv = uv.expand(self.latent.shape[0], -1, -1)
+        if len(image_size) > 0:
+            if len(image_size) == 1:
+                image_size = (image_size, image_size)
+            scale = self.latent_scaling / image_size
+            uv = uv * scale - 1.0
+        uv = uv.unsqueeze(2)
+        samples = F.grid_sample(self.latent, uv, align_corners=True, mode=self.index_interp,
+                                padding_mode=self.index_padding)
+        return samples[:, :, :, 0]
+
+    @classmethod
+    def from_conf(cls, conf):
+        return cls(conf.get_string("backbone"), pretrained=conf.get_bool("pretrained", True),
+                   num_layers=conf.get_int("num_layers", 4), index_interp=conf.get_string("index_interp", "bilinear"),
+                   index_padding=conf.get_string("index_padding", "border"),
+                   upsample_interp=conf.get_string("upsample_interp", "bilinear"),
+                   feature_scale=conf.get_float("feature_scale", 1.0),
+                   use_first_pool=conf.get_bool("use_first_pool", True))

@@ -1,0 +1,187 @@
+"""
+PixelNeRFNet with the reference's constructor, attributes, state_dict and call contract
+(src/model/models.py:14-316); its forward is one call into the fused HIP network kernel.
+
+  net = make_model(conf["model"]).to(device)      # same conf keys as the reference
+  net.encode(images, poses, focal, c=c)           # ResNet-34 in PyTorch-ROCm (unchanged maths)
+  rgbsigma = net(xyz, coarse=True, viewdirs=d)    # (SB,B,3),(SB,B,3) -> (SB,B,4)   [HIP]
+
+State left by encode() (models.py:111-141) is kept in the same attributes (`poses`, `focal`,
+`c`, `image_shape`, `num_objs`, `num_views_per_obj`, `encoder.latent`, `encoder.latent_scaling`)
+and may be set by hand exactly as with the reference; the device-side scene descriptor is
+rebuilt lazily whenever one of them changes.
+"""
+import os
+import os.path as osp
+import warnings
+
+import torch
+
+from .. import ops
+from ..util import repeat_interleave  # noqa: F401  (re-exported like the reference module)
+from .code import PositionalEncoding
+from .model_util import make_encoder, make_mlp
+
+
+class PixelNeRFNet(torch.nn.Module):
+    def __init__(self, conf, stop_encoder_grad=False, precision="f16"):
+        """:param conf PyHocon-like config subtree 'model' (util.Conf or a real ConfigTree)
+        :param precision operand type of the 512-wide linears on the matrix cores: 'f16'
+        (default; PSNR >= 52 dB vs the fp32 reference) or 'bf16' (>= 36 dB)."""
+        super().__init__()
+        self.encoder = make_encoder(conf["encoder"])
+        self.use_encoder = conf.get_bool("use_encoder", True)
+        self.use_xyz = conf.get_bool("use_xyz", False)
+        assert self.use_encoder or self.use_xyz
+        self.normalize_z = conf.get_bool("normalize_z", True)
+        self.stop_encoder_grad = stop_encoder_grad
+        self.use_code = conf.get_bool("use_code", False)
+        self.use_code_viewdirs = conf.get_bool("use_code_viewdirs", True)
+        self.use_viewdirs = conf.get_bool("use_viewdirs", False)
+        self.use_global_encoder = conf.get_bool("use_global_encoder", False)
+
+        d_latent = self.encoder.latent_size if self.use_encoder else 0
+        d_in = 3 if self.use_xyz else 1
+        if self.use_viewdirs and self.use_code_viewdirs:
+            d_in += 3
+        if self.use_code and d_in > 0:
+            self.code = PositionalEncoding.from_conf(conf["code"], d_in=d_in)
+            d_in = self.code.d_out
+        if self.use_viewdirs and not self.use_code_viewdirs:
+            d_in += 3
+        if self.use_global_encoder:
+            raise NotImplementedError("use_global_encoder=True is not used by any shipped config")
+        d_out = 4
+        self.latent_size = self.encoder.latent_size
+        self.mlp_coarse = make_mlp(conf["mlp_coarse"], d_in, d_latent, d_out=d_out)
+        self.mlp_fine = make_mlp(conf["mlp_fine"], d_in, d_latent, d_out=d_out, allow_empty=True)
+        self.register_buffer("poses", torch.empty(1, 3, 4), persistent=False)
+        self.register_buffer("image_shape", torch.empty(2), persistent=False)
+        self.d_in, self.d_out, self.d_latent = d_in, d_out, d_latent
+        self.register_buffer("focal", torch.empty(1, 2), persistent=False)
+        self.register_buffer("c", torch.empty(1, 2), persistent=False)
+        self.num_objs = 0
+        self.num_views_per_obj = 1
+        self.precision = precision
+        self._scene = None
+
+    # ------------------------------------------------------------------ encode (PyTorch-ROCm)
+    def encode(self, images, poses, focal, z_bounds=None, c=None):
+        """src/model/models.py:89-144, unchanged semantics.
+        :param images (NS,3,H,W) or (SB,NS,3,H,W); poses (NS,4,4) / (SB,NS,4,4) camera-to-world;
+        focal () | (2) | (NS) | (NS,2); c None | () | (2) | (NS) | (NS,2)."""
+        self.num_objs = images.size(0)
+        if len(images.shape) == 5:
+            assert len(poses.shape) == 4
+            assert poses.size(1) == images.size(1)
+            self.num_views_per_obj = images.size(1)
+            images = images.reshape(-1, *images.shape[2:])
+            poses = poses.reshape(-1, 4, 4)
+        else:
+            self.num_views_per_obj = 1
+        self.encoder(images)
+        rot = poses[:, :3, :3].transpose(1, 2)
+        trans = -torch.bmm(rot, poses[:, :3, 3:])
+        self.poses = torch.cat((rot, trans), dim=-1)
+        self.image_shape[0] = images.shape[-1]
+        self.image_shape[1] = images.shape[-2]
+        if len(focal.shape) == 0:
+            focal = focal[None, None].repeat((1, 2))
+        elif len(focal.shape) == 1:
+            focal = focal.unsqueeze(-1).repeat((1, 2))
+        else:
+            focal = focal.clone()
+        self.focal = focal.float()
+        self.focal[..., 1] *= -1.0
+        if c is None:
+            c = (self.image_shape * 0.5).unsqueeze(0)
+        elif len(c.shape) == 0:
+            c = c[None, None].repeat((1, 2))
+        elif len(c.shape) == 1:
+            c = c.unsqueeze(-1).repeat((1, 2))
+        self.c = c
+
+    # ------------------------------------------------------------------ device scene
+    def _check_supported(self):
+        ok = (self.use_encoder and self.use_xyz and self.normalize_z and self.use_code
+              and self.use_viewdirs and not self.use_code_viewdirs and not self.use_global_encoder
+              and self.code.num_freqs == 6 and abs(self.code.freq_factor - 1.5) < 1e-12
+              and self.code.include_input and self.d_in == 42 and self.d_latent == 512)
+        if not ok:
+            raise NotImplementedError(
+                "the fused HIP network implements the model configuration every shipped experiment "
+                "uses (conf/default.conf + default_mv.conf: use_encoder, use_xyz, normalize_z, "
+                "code{6,1.5,include_input}, use_viewdirs, use_code_viewdirs=False, latent 512)")
+
+    def scene(self):
+        """ops.Scene for the current encode() state (rebuilt only when that state changed)."""
+        lat = self.encoder.latent
+        if not lat.is_cuda:
+            raise ops._lib.PixelNerfHipError("PixelNeRFNet must live on a HIP device (no CPU path): net.to('cuda')")
+        NS = int(self.num_views_per_obj)
+        tens = (lat, self.poses, self.focal, self.c, self.image_shape)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tens) + (NS,)
+        if self._scene is None or self._scene[0] != key:
+            dev = lat.device
+            focal = self.focal.to(dev).float().reshape(-1, 2)
+            c = self.c.to(dev).float().reshape(-1, 2)
+            SB = lat.shape[0] // NS
+            # reference broadcasting (models.py:207-212): 1 row = shared, >1 rows = one per object
+            if focal.shape[0] not in (1, SB) or c.shape[0] not in (1, SB):
+                raise ValueError("focal / c must have 1 row or one row per object")
+            img = self.image_shape.detach().cpu().tolist()
+            sc = ops.Scene(self.encoder.latent_nhwc(), self.poses.to(dev).float(), focal, c, img, NS)
+            self._scene = (key, sc)
+        return self._scene[1]
+
+    def packed(self, coarse=True):
+        """models.py:242: the fine network falls back to the coarse one when mlp_fine is None."""
+        mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
+        return mlp.packed(self.precision)
+
+    def _no_autograd(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "pixelnerf_amd round 1 implements the forward (inference) path in HIP; the backward "
+                "pass is not built yet -- call under torch.no_grad() (as eval/*.py do)")
+
+    # ------------------------------------------------------------------ forward (HIP)
+    def forward(self, xyz, coarse=True, viewdirs=None, far=False):
+        """Predict (r,g,b,sigma) at world-space points; src/model/models.py:146-266.
+        :param xyz (SB,B,3), viewdirs (SB,B,3) -> (SB,B,4)."""
+        self._check_supported()
+        self._no_autograd()
+        assert viewdirs is not None  # models.py:186
+        SB, B, _ = xyz.shape
+        sc = self.scene()
+        if SB != sc.SB:
+            raise ValueError(f"xyz has {SB} objects but encode() saw {sc.SB}")
+        return ops.eval_points(sc, self.packed(coarse), xyz.float(), viewdirs.reshape(SB, B, 3).float())
+
+    # ------------------------------------------------------------------ checkpoints
+    def load_weights(self, args, opt_init=False, strict=True, device=None):
+        """src/model/models.py:268-298."""
+        if opt_init and not args.resume:
+            return
+        ckpt_name = "pixel_nerf_init" if opt_init or not args.resume else "pixel_nerf_latest"
+        model_path = "%s/%s/%s" % (args.checkpoints_path, args.name, ckpt_name)
+        if device is None:
+            device = self.poses.device
+        if os.path.exists(model_path):
+            print("Load", model_path)
+            self.load_state_dict(torch.load(model_path, map_location=device), strict=strict)
+        elif not opt_init:
+            warnings.warn("WARNING: {} does not exist, not loaded!! Model will be re-initialized.".format(model_path))
+        return self
+
+    def save_weights(self, args, opt_init=False):
+        """src/model/models.py:300-316."""
+        from shutil import copyfile
+        ckpt_name = "pixel_nerf_init" if opt_init else "pixel_nerf_latest"
+        backup_name = "pixel_nerf_init_backup" if opt_init else "pixel_nerf_backup"
+        ckpt_path = osp.join(args.checkpoints_path, args.name, ckpt_name)
+        ckpt_backup_path = osp.join(args.checkpoints_path, args.name, backup_name)
+        if osp.exists(ckpt_path):
+            copyfile(ckpt_path, ckpt_backup_path)
+        torch.save(self.state_dict(), ckpt_path)
+        return self

@@ -1,0 +1,84 @@
+"""ResnetFC / ResnetBlockFC: parameter containers with the reference's names, shapes and
+initialisation (src/model/resnetfc.py:10-130), so that reference checkpoints load unchanged
+(`mlp_coarse.lin_in.weight`, `mlp_coarse.blocks.N.fc_0.weight`, `mlp_coarse.lin_z.N.weight`...).
+
+The arithmetic of ResnetFC.forward (resnetfc.py:132-184) runs inside the fused HIP kernel
+(csrc/pnr_mlp.hip); `packed(precision)` hands the kernel its fragment stream and re-packs
+whenever a parameter changed."""
+from torch import nn
+
+from .. import ops
+
+
+class ResnetBlockFC(nn.Module):
+    def __init__(self, size_in, size_out=None, size_h=None, beta=0.0):
+        super().__init__()
+        size_out = size_in if size_out is None else size_out
+        size_h = min(size_in, size_out) if size_h is None else size_h
+        if size_in != size_out or beta > 0:
+            raise NotImplementedError("fused kernel: 512->512 ReLU blocks only (all shipped configs)")
+        self.size_in, self.size_h, self.size_out = size_in, size_h, size_out
+        self.fc_0 = nn.Linear(size_in, size_h)
+        self.fc_1 = nn.Linear(size_h, size_out)
+        nn.init.constant_(self.fc_0.bias, 0.0)
+        nn.init.kaiming_normal_(self.fc_0.weight, a=0, mode="fan_in")
+        nn.init.constant_(self.fc_1.bias, 0.0)
+        nn.init.zeros_(self.fc_1.weight)
+        self.activation = nn.ReLU()
+        self.shortcut = None
+
+
+class ResnetFC(nn.Module):
+    def __init__(self, d_in, d_out=4, n_blocks=5, d_latent=0, d_hidden=128, beta=0.0, combine_layer=1000,
+                 combine_type="average", use_spade=False):
+        super().__init__()
+        self.lin_in = nn.Linear(d_in, d_hidden)
+        nn.init.constant_(self.lin_in.bias, 0.0)
+        nn.init.kaiming_normal_(self.lin_in.weight, a=0, mode="fan_in")
+        self.lin_out = nn.Linear(d_hidden, d_out)
+        nn.init.constant_(self.lin_out.bias, 0.0)
+        nn.init.kaiming_normal_(self.lin_out.weight, a=0, mode="fan_in")
+        self.n_blocks, self.d_latent, self.d_in, self.d_out, self.d_hidden = n_blocks, d_latent, d_in, d_out, d_hidden
+        self.combine_layer, self.combine_type, self.use_spade = combine_layer, combine_type, use_spade
+        self.blocks = nn.ModuleList([ResnetBlockFC(d_hidden, beta=beta) for _ in range(n_blocks)])
+        if d_latent != 0:
+            n_lin_z = min(combine_layer, n_blocks)
+            self.lin_z = nn.ModuleList([nn.Linear(d_latent, d_hidden) for _ in range(n_lin_z)])
+            for i in range(n_lin_z):
+                nn.init.constant_(self.lin_z[i].bias, 0.0)
+                nn.init.kaiming_normal_(self.lin_z[i].weight, a=0, mode="fan_in")
+        self.activation = nn.ReLU()
+        self._packed = {}
+
+    def supported(self):
+        """The one shape the fused kernel implements = the one shape the reference ships."""
+        return (self.d_in == 42 and self.d_out == 4 and self.n_blocks == 5 and self.d_latent == 512
+                and self.d_hidden == 512 and self.combine_layer == 3 and self.combine_type == "average"
+                and not self.use_spade)
+
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self, precision="f16"):
+        if not self.supported():
+            raise NotImplementedError(
+                "fused HIP network supports d_in=42, d_latent=512, d_hidden=512, n_blocks=5, "
+                "combine_layer=3, combine_type=average (conf/default_mv.conf); got a different ResnetFC")
+        fp = self._fingerprint()
+        hit = self._packed.get(precision)
+        if hit is None or hit[0] != fp:
+            state = {k: v for k, v in self.state_dict().items()}
+            self._packed[precision] = (fp, ops.pack_mlp(state, precision))
+        return self._packed[precision][1]
+
+    def forward(self, zx, combine_inner_dims=(1,), combine_index=None, dim_size=None):
+        raise NotImplementedError(
+            "ResnetFC.forward is fused into the HIP network kernel together with the feature lookup; "
+            "call PixelNeRFNet.forward / NeRFRenderer instead")
+
+    @classmethod
+    def from_conf(cls, conf, d_in, **kwargs):
+        return cls(d_in, n_blocks=conf.get_int("n_blocks", 5), d_hidden=conf.get_int("d_hidden", 128),
+                   beta=conf.get_float("beta", 0.0), combine_layer=conf.get_int("combine_layer", 1000),
+                   combine_type=conf.get_string("combine_type", "average"),
+                   use_spade=conf.get_bool("use_spade", False), **kwargs)

@@ -1,0 +1,217 @@
+"""
+NeRFRenderer / _RenderWrapper with the reference's API (src/render/nerf.py:15-371); the work
+is done by libpixelnerf_hip.so.
+
+With a pixelnerf_amd PixelNeRFNet the whole forward (coarse sampling -> fused network ->
+compositing -> inverse-CDF + depth resampling + sort -> fused network -> compositing) is one
+C call (pnr_render_forward).  Any other `model(xyz, coarse=, viewdirs=)` callable still works:
+sampling and compositing run as HIP kernels around the caller's model, chunked by
+eval_batch_size exactly like the reference.
+
+Random numbers are drawn with torch's generator on the ray device in the reference's draw
+order (nerf.py:111,135,141,158), so a seeded run consumes the same stream as the reference
+on that device; tests inject pre-drawn noise through `_noise`.
+"""
+import torch
+
+from .. import ops
+from ..util.dotmap import DotMap
+
+
+class _RenderWrapper(torch.nn.Module):
+    """src/render/nerf.py:15-42."""
+
+    def __init__(self, net, renderer, simple_output):
+        super().__init__()
+        self.net = net
+        self.renderer = renderer
+        self.simple_output = simple_output
+
+    def forward(self, rays, want_weights=False):
+        if rays.shape[0] == 0:
+            return (torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device))
+        outputs = self.renderer(self.net, rays, want_weights=want_weights and not self.simple_output)
+        if self.simple_output:
+            if self.renderer.using_fine:
+                return outputs.fine.rgb, outputs.fine.depth
+            return outputs.coarse.rgb, outputs.coarse.depth
+        return outputs.toDict()
+
+
+class NeRFRenderer(torch.nn.Module):
+    """NeRF renderer; parameters as src/render/nerf.py:45-96."""
+
+    def __init__(self, n_coarse=128, n_fine=0, n_fine_depth=0, noise_std=0.0, depth_std=0.01,
+                 eval_batch_size=100000, white_bkgd=False, lindisp=False, sched=None):
+        super().__init__()
+        self.n_coarse, self.n_fine, self.n_fine_depth = n_coarse, n_fine, n_fine_depth
+        self.noise_std, self.depth_std = noise_std, depth_std
+        self.eval_batch_size = eval_batch_size
+        self.white_bkgd = white_bkgd
+        self.lindisp = lindisp
+        if lindisp:
+            print("Using linear displacement rays")
+        self.using_fine = n_fine > 0
+        self.sched = sched
+        if sched is not None and len(sched) == 0:
+            self.sched = None
+        self.register_buffer("iter_idx", torch.tensor(0, dtype=torch.long), persistent=True)
+        self.register_buffer("last_sched", torch.tensor(0, dtype=torch.long), persistent=True)
+
+    # ---- stage methods (same names / shapes as the reference; HIP kernels underneath) ----
+    def sample_coarse(self, rays, _u=None):
+        """nerf.py:98-118.  rays (B,8) -> (B,Kc)."""
+        u = torch.rand(rays.shape[0], self.n_coarse, device=rays.device) if _u is None else _u
+        return ops.sample_coarse(rays, u, self.lindisp)
+
+    def sample_fine(self, rays, weights, _u2=None, _u3=None):
+        """nerf.py:120-148.  -> (B, Kf-Kfd), unsorted, like the reference."""
+        n = self.n_fine - self.n_fine_depth
+        B, dev = rays.shape[0], rays.device
+        u2 = torch.rand(B, n, dtype=torch.float32, device=dev) if _u2 is None else _u2
+        u3 = torch.rand(B, n, dtype=torch.float32, device=dev) if _u3 is None else _u3
+        # the kernel returns sorted([z_coarse, z_fine]); feeding `near` as every coarse sample and
+        # dropping the Kc smallest leaves the sorted importance samples (their order is irrelevant
+        # downstream: forward() sorts everything, :295)
+        Kc = weights.shape[1]
+        z0 = rays[:, 6:7].expand(-1, Kc).contiguous()
+        z = ops.sample_fine(rays, weights.detach(), None, z0, u2, u3, None, self.depth_std, self.lindisp)
+        return z[:, Kc:].contiguous()
+
+    def sample_fine_depth(self, rays, depth, _n=None):
+        """nerf.py:150-161.  -> (B, Kfd)."""
+        n = torch.randn(rays.shape[0], self.n_fine_depth, device=rays.device) if _n is None else _n
+        z0 = rays[:, 6:7].contiguous()
+        z = ops.sample_fine(rays, None, depth, z0, None, None, n, self.depth_std, self.lindisp)
+        return z[:, 1:].contiguous()  # drop the placeholder coarse sample (= near, the minimum)
+
+    def composite(self, model, rays, z_samp, coarse=True, sb=0):
+        """nerf.py:163-249 for an arbitrary model callable: points/viewdirs, chunked model
+        calls (eval_batch_size), then the HIP compositing kernel.
+        :return weights (B,K), rgb (B,3), depth (B)"""
+        B, K = z_samp.shape
+        points = (rays[:, None, :3] + z_samp.unsqueeze(2) * rays[:, None, 3:6]).reshape(-1, 3)
+        use_viewdirs = hasattr(model, "use_viewdirs") and model.use_viewdirs
+        if sb > 0:
+            points = points.reshape(sb, -1, 3)
+            eval_batch_size = (self.eval_batch_size - 1) // sb + 1
+            dim = 1
+        else:
+            eval_batch_size = self.eval_batch_size
+            dim = 0
+        val_all = []
+        split_points = torch.split(points, eval_batch_size, dim=dim)
+        if use_viewdirs:
+            viewdirs = rays[:, None, 3:6].expand(-1, K, -1)
+            viewdirs = viewdirs.reshape(sb, -1, 3) if sb > 0 else viewdirs.reshape(-1, 3)
+            for pnts, dirs in zip(split_points, torch.split(viewdirs, eval_batch_size, dim=dim)):
+                val_all.append(model(pnts.contiguous(), coarse=coarse, viewdirs=dirs.contiguous()))
+        else:
+            for pnts in split_points:
+                val_all.append(model(pnts.contiguous(), coarse=coarse))
+        out = torch.cat(val_all, dim=dim).reshape(B, K, -1)
+        if self.training and self.noise_std > 0.0:
+            out = torch.cat([out[..., :3], out[..., 3:4] + torch.randn_like(out[..., 3:4]) * self.noise_std], -1)
+        return ops.composite(rays, z_samp, out[..., :4].contiguous(), self.white_bkgd, want_weights=True)
+
+    # ---- forward ----
+    def _draw_noise(self, R, dev):
+        """torch draws in the reference's order: rand_like (R,Kc) :111, rand (R,Kf-Kfd) :135,
+        rand_like :141, randn_like (R,Kfd) :158."""
+        noise = {"u1": torch.rand(R, self.n_coarse, device=dev)}
+        if self.using_fine:
+            n_imp = self.n_fine - self.n_fine_depth
+            if n_imp > 0:
+                noise["u2"] = torch.rand(R, n_imp, dtype=torch.float32, device=dev)
+                noise["u3"] = torch.rand(R, n_imp, dtype=torch.float32, device=dev)
+            if self.n_fine_depth > 0:
+                noise["n4"] = torch.randn(R, self.n_fine_depth, device=dev)
+        return noise
+
+    def forward(self, model, rays, want_weights=False, _noise=None):
+        """src/render/nerf.py:251-303.
+        :param model nerf model: (SB,B,3) points [+ viewdirs] -> (SB,B,4) rgb sigma
+        :param rays [origins(3), directions(3), near, far] (SB,B,8)
+        :return DotMap {coarse:{rgb (SB,B,3), depth (SB,B)[, weights (SB,B,K)]}, fine:{...}}"""
+        if self.sched is not None and self.last_sched.item() > 0:
+            self.n_coarse = self.sched[1][self.last_sched.item() - 1]
+            self.n_fine = self.sched[2][self.last_sched.item() - 1]
+        assert len(rays.shape) == 3
+        SB = rays.shape[0]
+        rays = rays.reshape(-1, 8).float().contiguous()
+        R = rays.shape[0]
+        noise = self._draw_noise(R, rays.device) if _noise is None else _noise
+        Kf = self.n_fine if self.using_fine else 0
+        Kfd = min(self.n_fine_depth, Kf)
+
+        if hasattr(model, "scene") and hasattr(model, "packed"):  # pixelnerf_amd.PixelNeRFNet: one C call
+            if self.training and self.noise_std > 0.0:
+                raise NotImplementedError("noise_std > 0 (unused by every shipped config) is not fused")
+            model._check_supported()
+            model._no_autograd()
+            res = ops.render_forward(model.scene(), model.packed(True), model.packed(False) if Kf > 0 else None,
+                                     rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
+                                     white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights)
+            outputs = DotMap(coarse=self._format(res["coarse"], SB, want_weights))
+            if Kf > 0:
+                outputs.fine = self._format(res["fine"], SB, want_weights)
+            return outputs
+
+        # generic model callable: reference control flow, HIP kernels for every renderer stage
+        z_coarse = self.sample_coarse(rays, _u=noise["u1"])
+        wc, rgbc, depthc = self.composite(model, rays, z_coarse, coarse=True, sb=SB)
+        outputs = DotMap(coarse=self._format(dict(rgb=rgbc, depth=depthc, weights=wc), SB, want_weights))
+        if Kf > 0:
+            z_all = ops.sample_fine(rays, wc.detach(), depthc, z_coarse, noise.get("u2"), noise.get("u3"),
+                                    noise.get("n4") if Kfd > 0 else None, self.depth_std, self.lindisp)
+            wf, rgbf, depthf = self.composite(model, rays, z_all, coarse=False, sb=SB)
+            outputs.fine = self._format(dict(rgb=rgbf, depth=depthf, weights=wf), SB, want_weights)
+        return outputs
+
+    @staticmethod
+    def _format(d, SB, want_weights):
+        """nerf.py:305-316."""
+        ret = DotMap(rgb=d["rgb"].reshape(SB, -1, 3), depth=d["depth"].reshape(SB, -1))
+        if want_weights:
+            ret.weights = d["weights"].reshape(SB, -1, d["weights"].shape[-1])
+        return ret
+
+    def sched_step(self, steps=1):
+        """nerf.py:318-338."""
+        if self.sched is None:
+            return
+        self.iter_idx += steps
+        while (self.last_sched.item() < len(self.sched[0])
+               and self.iter_idx.item() >= self.sched[0][self.last_sched.item()]):
+            self.n_coarse = self.sched[1][self.last_sched.item()]
+            self.n_fine = self.sched[2][self.last_sched.item()]
+            print("INFO: NeRF sampling resolution changed on schedule ==> c", self.n_coarse, "f", self.n_fine)
+            self.last_sched += 1
+
+    @classmethod
+    def from_conf(cls, conf, white_bkgd=False, lindisp=False, eval_batch_size=100000):
+        """nerf.py:340-352."""
+        return cls(conf.get_int("n_coarse", 128), conf.get_int("n_fine", 0),
+                   n_fine_depth=conf.get_int("n_fine_depth", 0), noise_std=conf.get_float("noise_std", 0.0),
+                   depth_std=conf.get_float("depth_std", 0.01), white_bkgd=conf.get_float("white_bkgd", white_bkgd),
+                   lindisp=lindisp, eval_batch_size=conf.get_int("eval_batch_size", eval_batch_size),
+                   sched=conf.get_list("sched", None))
+
+    def bind_parallel(self, net, gpus=None, simple_output=False):
+        """nerf.py:354-371.  Returns a module callable as `(rays (SB,B,8), want_weights=False)`.
+        The reference wraps it in single-process torch.nn.DataParallel(dim=1), which re-broadcasts
+        the whole network and feature grid on every call.  Here multi-GPU means one process per
+        GPU (torchrun) over RCCL: when torch.distributed is initialised with world_size > 1 and
+        more than one GPU is requested, rays are sharded on dim 1 across ranks and the results
+        all-gathered (pixelnerf_amd.dist.ShardedRenderWrapper)."""
+        wrapped = _RenderWrapper(net, self, simple_output=simple_output)
+        if gpus is not None and len(gpus) > 1:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from ..dist import ShardedRenderWrapper
+                print("Using multi-GPU", gpus)
+                return ShardedRenderWrapper(wrapped)
+            raise NotImplementedError(
+                "multi-GPU rendering runs one process per GPU: launch with `python -m torch.distributed.run "
+                "--nproc-per-node N ...`, init_process_group('nccl'), then bind_parallel(net, gpus)")
+        return wrapped

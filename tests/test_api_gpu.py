@@ -1,0 +1,172 @@
+"""GPU tests (-m gpu) of the reference-API layer: NeRFRenderer / _RenderWrapper / PixelNeRFNet
+driven the way eval/eval.py and train/train.py drive the reference, checked against the goldens
+frozen from the reference.  Tolerances: see tests/test_hip_parity.py (f16 operands)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_setup, load_golden, mlp_params, scene_for
+from oracle import pnr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def build_net(dev, scene, use_fine=True, precision="f16"):
+    """Same hand-set encode state the golden generator gives the reference net."""
+    from pixelnerf_amd.model import make_model
+    from pixelnerf_amd.util.conf import default_model_conf
+    net = make_model(default_model_conf(), precision=precision).to(dev).eval()
+    net.mlp_coarse.load_state_dict(mlp_params(11))
+    if use_fine:
+        net.mlp_fine.load_state_dict(mlp_params(12))
+    else:
+        net.mlp_fine = None  # eval/eval.py:140
+    lat = scene["latent"].to(dev)
+    net.encoder.latent = lat
+    ls = torch.tensor([lat.shape[-1], lat.shape[-2]], dtype=torch.float32, device=dev)
+    net.encoder.latent_scaling = ls / (ls - 1) * 2.0
+    net.poses, net.image_shape = scene["poses"].to(dev), scene["image_shape"].to(dev)
+    net.focal, net.c = scene["focal"].to(dev), scene["c"].to(dev)
+    net.num_objs, net.num_views_per_obj = scene["SB"], scene["NS"]
+    return net
+
+
+@pytest.mark.parametrize("name", ["sn64_64_128", "srn_mini_64_128", "dtu_mini_64_128", "train_64_32",
+                                  "mv_mini_lindisp", "sn64_coarse_only_mlp", "sn64_c32"])
+def test_renderer_api_matches_reference(dev, name):
+    from pixelnerf_amd.render import NeRFRenderer
+    g, scene, meta, mc, mf, rays, noise = golden_setup(name)
+    Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])
+    net = build_net(dev, scene, use_fine=mf is not None)
+    renderer = NeRFRenderer(n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, depth_std=float(g["depth_std"]),
+                            white_bkgd=bool(g["white_bkgd"]), lindisp=bool(g["lindisp"])).to(dev).eval()
+    nz = {k: v.to(dev) for k, v in noise.items()}
+    with torch.no_grad():
+        out = renderer(net, rays.to(dev), want_weights=True, _noise=nz)
+    SB, B = rays.shape[:2]
+    assert (len(out.fine) > 0) == (Kf > 0)
+    for p in ["coarse"] + (["fine"] if Kf > 0 else []):
+        K = Kc if p == "coarse" else Kc + Kf
+        o = out[p]
+        assert o.rgb.shape == (SB, B, 3) and o.depth.shape == (SB, B) and o.weights.shape == (SB, B, K)
+        assert O.psnr(o.rgb.cpu(), torch.from_numpy(g[f"{p}_rgb"])) >= 52.0
+    # plain-dict / tuple outputs of the bound wrapper (nerf.py:29-42)
+    full = renderer.bind_parallel(net, None, simple_output=False).eval()
+    simple = renderer.bind_parallel(net, [0], simple_output=True).eval()
+    with torch.no_grad():
+        torch.manual_seed(5)
+        d = full(rays.to(dev), want_weights=True)
+        torch.manual_seed(5)
+        rgb, depth = simple(rays.to(dev))
+    assert isinstance(d, dict) and set(d) == ({"coarse", "fine"} if Kf > 0 else {"coarse"})
+    assert "weights" in d["coarse"]
+    last = d["fine"] if Kf > 0 else d["coarse"]
+    assert torch.equal(rgb, last["rgb"]) and torch.equal(depth, last["depth"])  # same seed, same stream
+
+
+def test_seeded_noise_stream_follows_reference_draw_order(dev):
+    """A seeded call consumes torch's generator exactly as the reference does:
+    rand(R,Kc), rand(R,Kf-Kfd), rand(R,Kf-Kfd), randn(R,Kfd)  (nerf.py:111,135,141,158)."""
+    from pixelnerf_amd.render import NeRFRenderer
+    g, scene, meta, mc, mf, rays, noise = golden_setup("sn64_64_128")
+    net = build_net(dev, scene)
+    renderer = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=True).to(dev).eval()
+    r = rays.to(dev)
+    R = r.shape[0] * r.shape[1]
+    with torch.no_grad():
+        torch.manual_seed(77)
+        a = renderer(net, r)
+        torch.manual_seed(77)
+        nz = dict(u1=torch.rand(R, 64, device=dev), u2=torch.rand(R, 112, device=dev),
+                  u3=torch.rand(R, 112, device=dev), n4=torch.randn(R, 16, device=dev))
+        b = renderer(net, r, _noise=nz)
+    assert torch.equal(a.fine.rgb, b.fine.rgb) and torch.equal(a.coarse.depth, b.coarse.depth)
+
+
+def test_generic_model_callable_path_equals_fused_path(dev):
+    """NeRFRenderer accepts any model(xyz, coarse=, viewdirs=) like the reference; routed through
+    the chunked composite() it must give the fused one-call result bit for bit."""
+    from pixelnerf_amd.render import NeRFRenderer
+    g, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
+    net = build_net(dev, scene)
+
+    class Plain(torch.nn.Module):
+        use_viewdirs = True
+
+        def forward(self, xyz, coarse=True, viewdirs=None):
+            return net(xyz, coarse=coarse, viewdirs=viewdirs)
+
+    renderer = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True, eval_batch_size=1000).to(dev).eval()
+    nz = {k: v.to(dev) for k, v in noise.items()}
+    with torch.no_grad():
+        a = renderer(net, rays.to(dev), want_weights=True, _noise=nz)
+        b = renderer(Plain(), rays.to(dev), want_weights=True, _noise=nz)
+    for p in ("coarse", "fine"):
+        assert torch.equal(a[p].rgb, b[p].rgb) and torch.equal(a[p].weights, b[p].weights)
+
+
+def test_net_forward_and_stage_methods(dev):
+    from pixelnerf_amd.render import NeRFRenderer
+    g = load_golden("stages")
+    scene, _ = scene_for("mv_mini")
+    net = build_net(dev, scene)
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["mv_mini_xyz"]).to(dev), coarse=False,
+                  viewdirs=torch.from_numpy(g["mv_mini_viewdirs"]).to(dev))
+    assert np.abs(out.cpu().numpy()[..., :3] - g["mv_mini_out_fine"][..., :3]).max() <= 6e-3
+    # reference-named stage methods
+    gg, sc2, meta, mc, mf, rays, noise = golden_setup("sn64_64_128")
+    r = rays.reshape(-1, 8).to(dev)
+    rend = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=True).to(dev)
+    zc = rend.sample_coarse(r, _u=noise["u1"].to(dev))
+    np.testing.assert_allclose(zc.cpu().numpy(), gg["coarse_z"], atol=6e-6)
+    zf = rend.sample_fine(r, torch.from_numpy(gg["coarse_weights"]).reshape(-1, 64).to(dev),
+                          _u2=noise["u2"].to(dev), _u3=noise["u3"].to(dev))
+    zd = rend.sample_fine_depth(r, torch.from_numpy(gg["coarse_depth"]).reshape(-1).to(dev), _n=noise["n4"].to(dev))
+    assert zf.shape == (r.shape[0], 112) and zd.shape == (r.shape[0], 16)
+    z_all = torch.sort(torch.cat([zc, zf, zd], -1), dim=-1)[0].cpu().numpy()
+    bad = np.abs(z_all - gg["fine_z"]) > 1e-5
+    assert bad.mean() <= 2e-3
+
+
+def test_encode_then_render_and_cache_invalidation(dev):
+    """encode() with the plain-torch ResNet-34 trunk (random init) feeds the HIP path; the
+    device scene and the packed weights are rebuilt when their sources change."""
+    from pixelnerf_amd import synthetic
+    from pixelnerf_amd.model import make_model
+    from pixelnerf_amd.render import NeRFRenderer
+    from pixelnerf_amd.util.conf import Conf, default_model_conf
+    torch.manual_seed(0)
+    conf = default_model_conf()
+    conf["encoder"] = Conf(backbone="resnet34", pretrained=False, num_layers=4, use_first_pool=False)
+    net = make_model(conf).to(dev).eval()
+    for m in (net.mlp_coarse, net.mlp_fine):
+        m.load_state_dict(mlp_params(11))
+    scene, meta = scene_for("sn64")
+    rays = synthetic.target_rays(meta, n_rays=128).to(dev)
+    src = meta["src_c2w"].to(dev)
+    rend = NeRFRenderer(n_coarse=16, n_fine=8, n_fine_depth=4, white_bkgd=True).to(dev).eval()
+    render_par = rend.bind_parallel(net, None, simple_output=True).eval()
+    with torch.no_grad():
+        img = (torch.rand(1, 3, 64, 64, device=dev) * 2 - 1)
+        net.encode(img, src, torch.tensor(119.4256, device=dev))
+        assert tuple(net.encoder.latent.shape) == (1, 512, 32, 32)
+        torch.manual_seed(1); a, _ = render_par(rays)
+        torch.manual_seed(1); a2, _ = render_par(rays)
+        assert torch.equal(a, a2) and torch.isfinite(a).all()
+        net.encode(img.flip(-1), src, torch.tensor(119.4256, device=dev))  # new latent -> new scene
+        torch.manual_seed(1); b, _ = render_par(rays)
+        assert not torch.equal(a, b)
+        net.mlp_coarse.lin_out.bias.add_(0.5)  # in-place update -> repack
+        torch.manual_seed(1); c, _ = render_par(rays)
+        assert not torch.equal(b, c)
+        # eval.py --coarse style mutation (eval/eval.py:139-148)
+        net.mlp_fine = None
+        rend.n_coarse, rend.n_fine, rend.using_fine = 64, 128, True
+        rgb, depth = render_par(rays)
+        assert rgb.shape == (1, 128, 3) and depth.shape == (1, 128)

@@ -1,0 +1,84 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU plumbing: ray sharding on dim 1, uneven
+all_gather, and the one-shot broadcast of the encoded scene.  The renderer itself is replaced
+by a deterministic pure function of the rays so the test exercises only the distributed logic
+(the HIP kernels are covered by the -m gpu tests)."""
+import os
+import socket
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pixelnerf_amd.dist import ShardedRenderWrapper, broadcast_encoded, shard_bounds
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 5, 8, 4096, 120000):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class FakeWrapped(torch.nn.Module):
+    def __init__(self, simple):
+        super().__init__()
+        self.simple = simple
+
+    def forward(self, rays, want_weights=False):
+        rgb = rays[..., :3] * 2 + rays[..., 6:7]
+        depth = rays[..., 3:6].sum(-1)
+        if self.simple:
+            return rgb, depth
+        w = rays[..., :5].cumsum(-1)
+        return {"coarse": {"rgb": rgb, "depth": depth, "weights": w}, "fine": {"rgb": rgb + 1, "depth": depth * 2}}
+
+
+def _worker(rank, world, port, B):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        rays = torch.randn(2, B, 8)
+        for simple in (True, False):
+            full = FakeWrapped(simple)(rays)
+            got = ShardedRenderWrapper(FakeWrapped(simple))(rays, want_weights=not simple)
+            if simple:
+                assert all(torch.equal(a, b) for a, b in zip(full, got))
+            else:
+                for k in full:
+                    for kk in full[k]:
+                        assert torch.equal(full[k][kk], got[k][kk]), (k, kk)
+        # encoded-scene broadcast: rank 0 holds the state, rank 1 starts empty
+        enc = SimpleNamespace(latent=torch.zeros(1, 1, 1, 1), latent_scaling=torch.zeros(2))
+        net = SimpleNamespace(encoder=enc, poses=torch.zeros(1, 3, 4), focal=torch.zeros(1, 2), c=torch.zeros(1, 2),
+                              image_shape=torch.zeros(2), num_views_per_obj=1, num_objs=0)
+        g = torch.Generator().manual_seed(3)
+        ref = dict(latent=torch.randn(4, 6, 5, 7, generator=g), poses=torch.randn(4, 3, 4, generator=g),
+                   focal=torch.randn(2, 2, generator=g), c=torch.randn(1, 2, generator=g),
+                   image_shape=torch.tensor([64.0, 48.0]), ls=torch.tensor([2.1, 2.2]))
+        if rank == 0:
+            enc.latent, enc.latent_scaling = ref["latent"].clone(), ref["ls"].clone()
+            net.poses, net.focal, net.c = ref["poses"].clone(), ref["focal"].clone(), ref["c"].clone()
+            net.image_shape, net.num_views_per_obj, net.num_objs = ref["image_shape"].clone(), 2, 2
+        broadcast_encoded(net, src=0)
+        assert torch.equal(enc.latent, ref["latent"]) and torch.equal(net.poses, ref["poses"])
+        assert torch.equal(net.focal, ref["focal"]) and torch.equal(net.c, ref["c"])
+        assert torch.equal(net.image_shape, ref["image_shape"]) and torch.equal(enc.latent_scaling, ref["ls"])
+        assert (net.num_views_per_obj, net.num_objs) == (2, 2)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [7, 64])  # uneven and even splits
+def test_sharded_render_and_scene_broadcast_world2(B):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, B), nprocs=2, join=True)
