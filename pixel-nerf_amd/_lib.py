@@ -11,7 +11,7 @@ import shutil
 import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(CSRC, "libpixelnerf_hip.so")
+LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelnerf_hip.so")  # override: A/B experiments
 SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip"]
 HEADERS = ["pnr_common.h", "pnr_layout.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
 
@@ -63,7 +63,8 @@ PROTOTYPES = {
     "pnr_profile_read": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),
 }
 # test hook exported by the library but not part of the public header
-_EXTRA = {"pnr_debug_set_x_dump": (_I, [_P])}
+_EXTRA = {"pnr_debug_set_x_dump": (_I, [_P]),
+          "pnr_debug_phase_timing": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _I, _I, _I, _P, _P])}
 
 _lib = None
 

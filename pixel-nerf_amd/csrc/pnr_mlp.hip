@@ -65,7 +65,22 @@ struct EvalParams {
     int ntiles;
     float *out;        // (P,4)
     float *dbg;        // optional debug dump of the final residual stream x (P,512), may be null
+    unsigned long long *tim;  // phase-timing accumulators (TIMING instantiation only)
 };
+
+// phase ids of the TIMING instantiation (wave 0 of workgroup 0, s_memtime ticks)
+enum Phase { PH_SYNC_TOP = 0, PH_GEOMETRY, PH_GATHER, PH_GEMM_IN_Z0, PH_BAR1, PH_WRITE_X, PH_BAR2, PH_GEMM_FC0, PH_BAR3,
+             PH_WRITE_NET, PH_BAR4, PH_GEMM_FC1_Z, PH_LIN_OUT, PH_BAR_OUT, PH_FINAL, NPHASE };
+#define PNR_T(ph)                                                         \
+    do {                                                                  \
+        if constexpr (TIMING) {                                           \
+            if ((tid & 63) == 0 && blockIdx.x == 0) {                     \
+                const unsigned long long t_ = __builtin_readcyclecounter(); \
+                atomicAdd(&tim[(tid >> 6) * NPHASE + ph], t_ - tlast);    \
+                tlast = t_;                                               \
+            }                                                             \
+        }                                                                 \
+    } while (0)
 
 __device__ __forceinline__ uint32_t pack2(float a, float b, _Float16) {
     f32x2 v = {a, b};
@@ -129,19 +144,40 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT], const char *smem, ui
     b[0][1] = lds8<P>(smem, baddr1);
 #pragma unroll 1
     for (int body = 0; body < nbody; ++body) {
+
+#ifdef PNR_EXP_FAKE_W  // experiment: refill from a fixed 8 KiB window (no L2 streaming); results are wrong
+        const char *pf = R.wave_base + (size_t)(R.pf_rs & 0) * (IT * 1024);
+#else
         const char *pf = R.wave_base + (size_t)R.pf_rs * (IT * 1024);
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cur = j & 1;
+            // intended step order: LDS reads for step+1 | 4 MFMAs of this step | refill this ring
+            // slot (step+4).  hipcc re-orders this (it batches the 8 refills behind the last MFMA
+            // of the body); pinning the order with sched_barrier (-DPNR_PIN_SCHEDULE) gives the
+            // textbook stream but measured 2-3 % SLOWER (profiles/r01_gemm_experiments.md), so
+            // the compiler's schedule is the default.
             b[cur ^ 1][0] = lds8<P>(smem, baddr0 + (j + 1) * 32);
             b[cur ^ 1][1] = lds8<P>(smem, baddr1 + (j + 1) * 32);
+#ifdef PNR_PIN_SCHEDULE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             const typename P::T8 a0 = R.r[j][0], a1 = R.r[j][1];
-            R.r[j][0] = gload8<P>(pf + j * (IT * 1024));
-            R.r[j][1] = gload8<P>(pf + j * (IT * 1024) + 1024);
             acc[0][0] = P::mfma(a0, b[cur][0], acc[0][0]);
             acc[0][1] = P::mfma(a0, b[cur][1], acc[0][1]);
             acc[1][0] = P::mfma(a1, b[cur][0], acc[1][0]);
             acc[1][1] = P::mfma(a1, b[cur][1], acc[1][1]);
+#ifdef PNR_PIN_SCHEDULE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef PNR_EXP_NO_WLOAD  // experiment: never refill the ring (no weight traffic at all); results are wrong
+            R.r[j][0] = gload8<P>(pf + j * (IT * 1024));
+            R.r[j][1] = gload8<P>(pf + j * (IT * 1024) + 1024);
+#endif
+#ifdef PNR_PIN_SCHEDULE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         baddr0 += 128;
         baddr1 += 128;
@@ -313,27 +349,36 @@ __device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, 
 
 // one residual block (+ the lin_z of the next block when with_z):
 //   net = fc_0(relu(x)); x += fc_1(relu(net)) [+ lin_z[b+1](z)]       resnetfc.py:55-62,174-182
-template <typename P>
+template <typename P, bool TIMING>
 __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b, bool with_z, Ring<P> &R,
                                           int NS, const float *bias_lane, uint32_t a_rd0, uint32_t a_rd1,
-                                          uint32_t z_rd0, uint32_t z_rd1, uint32_t a_wr) {
+                                          uint32_t z_rd0, uint32_t z_rd1, uint32_t a_wr, int tid,
+                                          unsigned long long *tim, unsigned long long &tlast) {
     __syncthreads();  // every wave is done reading LDS_A (previous fc_1)
+    PNR_T(PH_BAR1);
     write_act<P>(x, smem, a_wr);
+    PNR_T(PH_WRITE_X);
     __syncthreads();
+    PNR_T(PH_BAR2);
     {
         f32x16 net[IT][JT];
         add_bias<true>(net, bias_lane, 1 + 2 * b);
         gemm<P>(net, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
+        PNR_T(PH_GEMM_FC0);
         __syncthreads();  // every wave is done reading relu(x)
+        PNR_T(PH_BAR3);
         write_act<P>(net, smem, a_wr);
+        PNR_T(PH_WRITE_NET);
     }
     __syncthreads();
+    PNR_T(PH_BAR4);
     add_bias<false>(x, bias_lane, 2 + 2 * b);
     gemm<P>(x, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
     if (with_z) gemm<P>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);
+    PNR_T(PH_GEMM_FC1_Z);
 }
 
-template <int PREC, bool RAYS, bool MV>
+template <int PREC, bool RAYS, bool MV, bool TIMING = false>
 __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
     typedef Prec<PREC> P;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -360,6 +405,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
         R.r[j][1] = gload8<P>(R.wave_base + j * (IT * 1024) + 1024);
     }
     R.pf_rs = 4;
+    unsigned long long *tim = q.tim;
+    unsigned long long tlast = TIMING ? __builtin_readcyclecounter() : 0ull;
 
     for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
         f32x16 x[IT][JT];
@@ -367,16 +414,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
 #pragma unroll 1
         for (int view = 0; view < NS; ++view) {
             __syncthreads();  // previous users of LDS_IN / LDS_META / LDS_Z are done
+            PNR_T(PH_SYNC_TOP);
             geometry<P, RAYS>(q, smem, tile, view, tid);
             __syncthreads();
+            PNR_T(PH_GEOMETRY);
             gather<P>(q, smem, wv, lane);
             __syncthreads();
+            PNR_T(PH_GATHER);
             add_bias<true>(x, bias_lane, B_IN_Z0);
             gemm<P>(x, smem, in_rd0, in_rd1, KS_IN / 4, R, NS);      // lin_in     resnetfc.py:147
             gemm<P>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);       // lin_z[0]   resnetfc.py:175-180
+            PNR_T(PH_GEMM_IN_Z0);
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b)
-                res_block<P>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr);
+                res_block<P, TIMING>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr,
+                                     tid, tim, tlast);
             if constexpr (MV) {
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
@@ -397,7 +449,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
         }
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b)
-            res_block<P>(x, smem, b, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr);
+            res_block<P, TIMING>(x, smem, b, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr, tid, tim, tlast);
 
         if (q.dbg) {
 #pragma unroll
@@ -445,7 +497,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
                 }
             }
         }
+        PNR_T(PH_LIN_OUT);
         __syncthreads();
+        PNR_T(PH_BAR_OUT);
         if (tid < MT) {
             const long long g = (long long)tile * MT + tid;
             f32x4 s = *reinterpret_cast<const f32x4 *>(q.bout);
@@ -456,6 +510,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
                          fmaxf(s[3], 0.f)};
             if (g < q.P) *reinterpret_cast<f32x4 *>(q.out + g * 4) = res;
         }
+        PNR_T(PH_FINAL);
     }
 }
 
@@ -516,6 +571,37 @@ static int eval_common(const PnrScene *s, const void *packed, int precision, Eva
 }
 
 }  // namespace pnr
+
+// test/diagnostic hook (not in the public header): per-phase s_memtime totals of wave 0 of
+// workgroup 0 for one f16 single-view launch.  tim: NW*NPHASE device counters, zeroed by the caller.
+extern "C" int pnr_debug_phase_timing(const PnrScene *s, const void *packed, const float *rays, const float *z, int R,
+                                      int rays_per_obj, int K, unsigned long long *tim, void *stream) {
+    using namespace pnr;
+    if (!s || !packed || !rays || !z || !tim || s->NS != 1) return pnr_fail(PNR_E_INVALID, "pnr_debug_phase_timing: bad argument");
+    EvalParams q = {};
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.tim = tim;
+    q.latent = s->latent_nhwc; q.poses = s->poses; q.focal = s->focal; q.c = s->c;
+    q.SB = s->SB; q.NS = 1; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
+    q.img_w = s->img_w; q.img_h = s->img_h;
+    q.wstream = (const char *)packed;
+    q.bias = (const float *)((const char *)packed + BIAS_OFFSET_BYTES);
+    q.bout = (const float *)((const char *)packed + BOUT_OFFSET_BYTES);
+    q.ntiles = (int)((q.P + MT - 1) / MT);
+    static float *scratch_out = nullptr;
+    static long long scratch_n = 0;
+    if (scratch_n < q.P) {
+        if (scratch_out) (void)hipFree(scratch_out);
+        if (hipMalloc(&scratch_out, (size_t)q.P * 16) != hipSuccess) return pnr_fail(PNR_E_HIP, "hipMalloc");
+        scratch_n = q.P;
+    }
+    q.out = scratch_out;
+    auto k = eval_kernel<PNR_PREC_F16, true, false, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute");
+    const int grid = q.ntiles < num_cus() ? q.ntiles : num_cus();
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), LDS_TOTAL, (hipStream_t)stream, q);
+    return pnr_check_launch("eval_kernel<timing>");
+}
 
 static float *g_dbg_ptr = nullptr;
 // test hook (not part of the public header): dump the final residual stream of the next launches
