@@ -85,6 +85,31 @@ def cpu_baseline(scene, mlps, rays_sample, noise, threads=None):
     return rays_sample.shape[0] / dt, dt, out
 
 
+def eager_gpu_baseline(scene, mlps, rays, dev, n=16384):
+    """The north_star's "reference single-GPU" comparison point: the same eager PyTorch fp32
+    code path (the oracle restatement of the reference, with F.grid_sample like the reference
+    and its 50 000-ray eval chunking irrelevant at this size) on THIS GPU through PyTorch-ROCm.
+    A reported baseline only -- never part of the product path."""
+    from oracle import pnr_oracle as O
+    from pixelnerf_amd import synthetic
+    O.USE_GRID_SAMPLE = True
+    sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    ms = [{k: v.to(dev) for k, v in m.items()} for m in mlps]
+    r = rays[:n]
+    noise = {k: v.to(dev) for k, v in synthetic.make_noise(r.shape[0], 64, 128, 16, seed=7).items()}
+    with torch.no_grad():
+        O.render(sc, ms[0], ms[1], r[:2048][None], {k: v[:2048] for k, v in noise.items()}, 64, 128, 16,
+                 white_bkgd=True)  # warm-up (rocBLAS / MIOpen heuristics)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        O.render(sc, ms[0], ms[1], r[None], noise, 64, 128, 16, white_bkgd=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    O.USE_GRID_SAMPLE = False
+    return {"value": r.shape[0] / dt, "unit": "rays/s", "kind": "port (oracle restatement, torch fp32 eager on the same MI355X)",
+            "sample": "%d rays, one call, %.2f s" % (r.shape[0], dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +119,8 @@ def main():
     ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step")
     ap.add_argument("--cpu-rays", type=int, default=0, help="CPU-baseline sample size (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eager-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: functional test on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,12 +131,16 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from pixelnerf_amd import ops, synthetic
     from pixelnerf_amd.dist import broadcast_encoded
@@ -204,6 +235,9 @@ def main():
                                    "sample": "%d rays of the same workload (64+128, same weights/grid), %.1f s, "
                                              "oracle/pnr_oracle.py (torch CPU fp32 restatement of the reference)" % (n, dt)}
             res["speedup_vs_cpu_baseline"] = rays_per_s / rate
+        if world == 1 and not args.no_eager_baseline:
+            res["torch_eager_gpu_baseline"] = eager_gpu_baseline(scene, mlps, rays, dev)
+            res["speedup_vs_torch_eager_gpu"] = rays_per_s / res["torch_eager_gpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

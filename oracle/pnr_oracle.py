@@ -39,10 +39,10 @@ def positional_encoding(x, num_freqs=6, freq_factor=1.5, include_input=True):
     does (code.py:24-26,38).
     """
     freqs = freq_factor * 2.0 ** torch.arange(0, num_freqs)  # code.py:15
-    _freqs = torch.repeat_interleave(freqs, 2).view(1, -1, 1)  # code.py:21-23
+    _freqs = torch.repeat_interleave(freqs, 2).view(1, -1, 1).to(x.device)  # code.py:21-23
     _phases = torch.zeros(2 * num_freqs)
     _phases[1::2] = math.pi * 0.5  # code.py:26-27
-    _phases = _phases.view(1, -1, 1)
+    _phases = _phases.view(1, -1, 1).to(x.device)
     embed = x.unsqueeze(1).repeat(1, num_freqs * 2, 1)  # code.py:37
     embed = torch.sin(torch.addcmul(_phases, embed, _freqs))  # code.py:38
     embed = embed.view(x.shape[0], -1)
@@ -51,9 +51,13 @@ def positional_encoding(x, num_freqs=6, freq_factor=1.5, include_input=True):
     return embed
 
 
+USE_GRID_SAMPLE = False  # baselines set this: call F.grid_sample exactly like the reference
+
+
 def index_latent(latent, uv, image_shape):
     """src/model/encoder.py:80-109 + :161-163, with F.grid_sample(bilinear, border,
-    align_corners=True) written out.
+    align_corners=True) written out (or called directly when USE_GRID_SAMPLE, which is what
+    the timed baselines use so that they run the reference's own ATen op).
 
     latent (NV, C, Hl, Wl); uv (NV, N, 2) in source-image pixels; image_shape (W, H).
     Returns (NV, C, N).
@@ -62,8 +66,13 @@ def index_latent(latent, uv, image_shape):
     # encoder.py:161-163  latent_scaling = [Wl, Hl] / ([Wl, Hl] - 1) * 2
     ls = torch.tensor([Wl, Hl], dtype=torch.float32)
     ls = ls / (ls - 1) * 2.0
-    scale = ls / image_shape.to(torch.float32)  # encoder.py:98
+    ls = ls.to(uv.device)
+    scale = ls / image_shape.to(device=uv.device, dtype=torch.float32)  # encoder.py:98
     g = uv * scale - 1.0  # encoder.py:99
+    if USE_GRID_SAMPLE:
+        samples = torch.nn.functional.grid_sample(latent, g.unsqueeze(2), align_corners=True,
+                                                  mode="bilinear", padding_mode="border")
+        return samples[:, :, :, 0]
     # grid_sample, align_corners=True: pix = (g + 1) / 2 * (size - 1)
     ix = ((g[..., 0] + 1) / 2) * (Wl - 1)
     iy = ((g[..., 1] + 1) / 2) * (Hl - 1)
@@ -193,7 +202,7 @@ def sample_coarse(rays, u1, n_coarse, lindisp=False):
     """src/render/nerf.py:98-118.  rays (R,8), u1 (R,Kc) -> (R,Kc)."""
     step = 1.0 / n_coarse
     R = rays.shape[0]
-    z_steps = torch.linspace(0, 1 - step, n_coarse)  # :109
+    z_steps = torch.linspace(0, 1 - step, n_coarse, device=rays.device)  # :109
     z_steps = z_steps.unsqueeze(0).repeat(R, 1)
     z_steps = z_steps + u1 * step  # :111
     return _z_from_steps(rays, z_steps, lindisp)
