@@ -111,6 +111,63 @@ int pnr_eval_points(const PnrScene *scene /*host*/, const void *packed, int prec
                     const float *xyz, const float *viewdirs, int B, float *rgbsigma,
                     void *stream);
 
+/* ---- training (autograd) support -------------------------------------------------------------
+ * The reference trains through this path with plain autograd (train/train.py:199-215): MSE on
+ * coarse + fine rgb, gradients w.r.t. both ResnetFCs and encoder.latent.  Here:
+ *   forward : pnr_eval_ray_samples_train = pnr_eval_ray_samples + 16-bit dumps of every linear
+ *             layer's input operand (PnrTrainDumps);
+ *   backward: pnr_composite_backward (d rgb/depth/weights -> d rgbsigma per point),
+ *             pnr_mlp_backward (fused data-gradient chain with transposed weight streams: consumes
+ *             d(pre-activation output), writes the per-layer output gradients dY as 16-bit rows),
+ *             pnr_latent_scatter (d interpolated latent -> d feature grid, bilinear scatter-add);
+ *             the weight gradients dW = dY^T X are plain GEMMs over those dumps (library calls in
+ *             the host layer).
+ * Array shapes: rows_v = NS*P for per-view layers (row = view*P + point), rows_p = P pooled;
+ * 512-wide dims of activation dumps / gradients are in "storage order" (pnr_storage_perm). */
+typedef struct PnrTrainDumps {
+    void *d_in;     /* (rows_v, 64)  lin_in operand: code(39) | viewdir(3) | 0-pad, natural order */
+    void *d_z;      /* (rows_v, 512) interpolated latent, natural channel order                  */
+    void *d_a[5];   /* relu(x) in front of blocks[b].fc_0: b<3 (rows_v,512), b>=3 (rows_p,512)   */
+    void *d_n[5];   /* relu(net) in front of blocks[b].fc_1, same shapes                         */
+    void *d_x5;     /* (rows_p, 512) relu(x) in front of lin_out                                 */
+} PnrTrainDumps;
+
+typedef struct PnrBackwardDumps {
+    void *g_fc1[5]; /* dL/d(blocks[b].fc_1 output) = dL/d(residual stream after block b), shapes as d_n */
+    void *g_fc0[5]; /* dL/d(blocks[b].fc_0 output), shapes as d_a                                */
+    void *g_x0;     /* (rows_v, 512) dL/d(residual stream in front of block 0) = dY of lin_in, lin_z[0] */
+} PnrBackwardDumps;
+
+int pnr_eval_ray_samples_train(const PnrScene *scene /*host*/, const void *packed, int precision,
+                               const float *rays, const float *z, int R, int rays_per_obj, int K,
+                               float *rgbsigma, const PnrTrainDumps *dumps /*host*/, void *stream);
+
+/* feature index held at storage position e (0..511) of an activation dump row: perm[e]. host out. */
+int pnr_storage_perm(int32_t *perm512 /*host*/);
+
+/* transposed weight streams for the backward chain (fc_1^T, fc_0^T of every block, lin_out^T). */
+size_t pnr_packed_mlp_bwd_bytes(void);
+int pnr_pack_mlp_bwd(const PnrMlpWeights *w /*host struct of device ptrs*/, int precision,
+                     void *packed_bwd, void *stream);
+
+/* Backward of pnr_composite (src/render/nerf.py:223-249 under autograd; z treated as constant).
+ * d_weights may be NULL.  d_rgbsigma (R,K,4) = dL/d(model output) AFTER sigmoid/relu. */
+int pnr_composite_backward(const float *rays, const float *z, const float *rgbsigma, int R, int K,
+                           int white_bkgd, const float *d_rgb, const float *d_depth,
+                           const float *d_weights, float *d_rgbsigma, void *stream);
+
+/* Fused data-gradient chain of one ResnetFC (reverse of src/model/resnetfc.py:132-184).
+ * g_out (P,4) = dL/d(lin_out output) (pre sigmoid/relu), grad_scale = power of two the chain is
+ * run at (16-bit range management; every dump is scaled by it).  NS = views per object. */
+int pnr_mlp_backward(const void *packed_bwd, int precision, const PnrTrainDumps *fwd /*host*/,
+                     const float *g_out, float grad_scale, long long P, int NS,
+                     const PnrBackwardDumps *out /*host*/, void *stream);
+
+/* d(encoder.latent) += bilinear scatter of d_zlat (rows_v,512) fp32 (natural channel order) to
+ * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (atomic adds; caller zero-initialises). */
+int pnr_latent_scatter(const PnrScene *scene /*host*/, const float *rays, const float *z, int R,
+                       int rays_per_obj, int K, const float *d_zlat, float *d_latent_nhwc, void *stream);
+
 /* ---- alpha compositing -------------------------------------------------------------------
  * NeRFRenderer.composite after the model call, src/render/nerf.py:178-182 and :223-249.
  * rays (R,8), z (R,K), rgbsigma (R,K,4) -> weights (R,K) (may be NULL), rgb (R,3), depth (R). */

@@ -261,7 +261,7 @@ def composite(scene, mlp, rays, z_samp, sb, white_bkgd):
 
 
 def render(scene, mlp_coarse, mlp_fine, rays, noise, n_coarse, n_fine, n_fine_depth,
-           depth_std=0.01, white_bkgd=False, lindisp=False):
+           depth_std=0.01, white_bkgd=False, lindisp=False, detach_depth=False):
     """src/render/nerf.py:251-303.  rays (SB, B, 8); noise = dict(u1,u2,u3,n4) (missing keys
     allowed when the corresponding stage is skipped).  Returns a nested dict
     {coarse:{rgb,depth,weights,z,rgbsigma}, fine:{...}}; `fine` absent when n_fine == 0.
@@ -287,7 +287,10 @@ def render(scene, mlp_coarse, mlp_fine, rays, noise, n_coarse, n_fine, n_fine_de
                 sample_fine(rays, wc.detach(), noise["u2"], noise["u3"], n_coarse, lindisp)
             )  # :286-289
         if n_fine_depth > 0:
-            all_samps.append(sample_fine_depth(rays, depthc, noise["n4"], depth_std))  # :290-293
+            # the reference passes the NON-detached coarse depth here (:292); detach_depth=True
+            # removes that one position-gradient path (what the HIP backward implements so far)
+            all_samps.append(sample_fine_depth(rays, depthc.detach() if detach_depth else depthc,
+                                               noise["n4"], depth_std))  # :290-293
         z_combine = torch.cat(all_samps, dim=-1)
         z_sorted, _ = torch.sort(z_combine, dim=-1)  # :294-295
         mf = mlp_fine if mlp_fine is not None else mlp_coarse

@@ -12,8 +12,8 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelnerf_hip.so")  # override: A/B experiments
-SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip"]
-HEADERS = ["pnr_common.h", "pnr_layout.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
+SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_bwd.hip"]
+HEADERS = ["pnr_common.h", "pnr_layout.h", "pnr_device.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
 
 PREC_F16, PREC_BF16 = 0, 1
 PRECISIONS = {"f16": PREC_F16, "fp16": PREC_F16, "bf16": PREC_BF16}
@@ -41,6 +41,15 @@ class PnrMlpWeights(ctypes.Structure):
     ]
 
 
+class PnrTrainDumps(ctypes.Structure):
+    _fields_ = [("d_in", ctypes.c_void_p), ("d_z", ctypes.c_void_p), ("d_a", ctypes.c_void_p * 5),
+                ("d_n", ctypes.c_void_p * 5), ("d_x5", ctypes.c_void_p)]
+
+
+class PnrBackwardDumps(ctypes.Structure):
+    _fields_ = [("g_fc1", ctypes.c_void_p * 5), ("g_fc0", ctypes.c_void_p * 5), ("g_x0", ctypes.c_void_p)]
+
+
 # every symbol include/pixelnerf_hip.h declares: name -> (restype, argtypes)
 _I, _F, _P, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 PROTOTYPES = {
@@ -54,6 +63,15 @@ PROTOTYPES = {
     "pnr_sample_fine": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
     "pnr_eval_ray_samples": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _I, _I, _P, _P]),
     "pnr_eval_points": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _P, _P]),
+    "pnr_eval_ray_samples_train": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _I, _I, _P,
+                                        ctypes.POINTER(PnrTrainDumps), _P]),
+    "pnr_storage_perm": (_I, [ctypes.POINTER(ctypes.c_int32)]),
+    "pnr_packed_mlp_bwd_bytes": (_SZ, []),
+    "pnr_pack_mlp_bwd": (_I, [ctypes.POINTER(PnrMlpWeights), _I, _P, _P]),
+    "pnr_composite_backward": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "pnr_mlp_backward": (_I, [_P, _I, ctypes.POINTER(PnrTrainDumps), _P, _F, ctypes.c_longlong, _I,
+                              ctypes.POINTER(PnrBackwardDumps), _P]),
+    "pnr_latent_scatter": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _P]),
     "pnr_composite": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "pnr_render_workspace_bytes": (_SZ, [_I, _I, _I]),
     "pnr_render_forward": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I,

@@ -1,0 +1,179 @@
+"""
+Differentiable NeRFRenderer.forward (training; BASELINE config 5, train/train.py:199-215).
+
+forward  : the inference kernels, with the network launches replaced by their training form
+           (`pnr_eval_ray_samples_train`: same kernel + 16-bit dumps of every linear's input).
+backward : HIP kernels for everything that is not a plain GEMM --
+             pnr_composite_backward   d(rgb, depth, weights)      -> d(per-point rgb sigma)
+             pnr_mlp_backward         fused data-gradient chain   -> per-layer output gradients dY
+             pnr_latent_scatter       d(interpolated latent)      -> d(feature grid)
+           and library GEMMs (torch.matmul -> rocBLAS/hipBLASLt) for the weight gradients
+           dW = dY^T X and the latent gradient sum_b dY_b W_z[b], which are plain dense GEMMs
+           over the dumped operands.
+Gradients flow to every ResnetFC parameter of both networks and to `encoder.latent` (hence into
+the ResNet-34 through PyTorch autograd).  Sample positions are constants: the one position
+gradient of the reference (through the n_fine_depth samples, nerf.py:292) is not propagated
+(measured effect on the reference's own gradients: 0.2 % on MLP weights, 1.4 % on the latent,
+SURVEY.md §3.3).
+"""
+import math
+
+import torch
+
+from . import ops
+
+_perm_cache = {}
+
+
+def _perms(device):
+    """perm[e] = feature at storage position e; inv[f] = storage position of feature f."""
+    key = str(device)
+    if key not in _perm_cache:
+        perm = ops.storage_perm(device)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(512, device=device)
+        _perm_cache[key] = (perm, inv)
+    return _perm_cache[key]
+
+
+def _param_names():
+    names = ["lin_in", "lin_out"] + [f"blocks.{b}.fc_{j}" for b in range(5) for j in (0, 1)] + [f"lin_z.{b}" for b in range(3)]
+    return [n + s for n in names for s in (".weight", ".bias")]
+
+
+PARAM_NAMES = _param_names()
+
+
+def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS):
+    """All parameter gradients of one ResnetFC + d(interpolated latent) from one backward pass.
+    fwd: ops.TrainDumps of the forward; g_out (P,4) fp32 = dL/d(lin_out output)."""
+    dev = g_out.device
+    perm, inv = _perms(dev)
+    gmax = float(g_out.abs().max())
+    if not math.isfinite(gmax):
+        raise FloatingPointError("non-finite gradient entering the network backward")
+    # run the 16-bit chain at a power-of-two scale that puts max|g| near 2^6 (exact to undo)
+    scale = 1.0 if gmax == 0.0 else 2.0 ** (6 - math.ceil(math.log2(gmax)))
+    bd = ops.mlp_backward(packed_bwd, fwd, g_out, scale)
+    inv_s = 1.0 / scale
+
+    def dW(dY, X):  # (rows, n_out) , (rows, n_in) 16-bit -> fp32 (n_out, n_in)
+        return torch.matmul(dY.float().t(), X.float())
+
+    grads = {}
+    # storage order -> feature order on the 512-wide dims
+    for b in range(5):
+        g0 = dW(bd.g_fc0[b], fwd.d_a[b]) * inv_s
+        grads[f"blocks.{b}.fc_0.weight"] = g0[inv][:, inv]
+        grads[f"blocks.{b}.fc_0.bias"] = (bd.g_fc0[b].float().sum(0) * inv_s)[inv]
+        g1 = dW(bd.g_fc1[b], fwd.d_n[b]) * inv_s
+        grads[f"blocks.{b}.fc_1.weight"] = g1[inv][:, inv]
+        grads[f"blocks.{b}.fc_1.bias"] = (bd.g_fc1[b].float().sum(0) * inv_s)[inv]
+    d_zlat = None
+    for b in range(3):
+        gz = bd.g_x0 if b == 0 else bd.g_fc1[b - 1]  # dL/d(residual stream entering block b), per view
+        gzf = gz.float()
+        grads[f"lin_z.{b}.weight"] = (torch.matmul(gzf.t(), fwd.d_z.float()) * inv_s)[inv]
+        grads[f"lin_z.{b}.bias"] = (gzf.sum(0) * inv_s)[inv]
+        # d z_lat += dY W_z[b]  (W in feature order; dY columns are in storage order)
+        term = torch.matmul(gzf, mlp_state[f"lin_z.{b}.weight"].detach()[perm])
+        d_zlat = term if d_zlat is None else d_zlat + term
+    d_zlat = d_zlat * inv_s
+    g0f = bd.g_x0.float()
+    grads["lin_in.weight"] = (torch.matmul(g0f.t(), fwd.d_in.float()[:, :42]) * inv_s)[inv]
+    grads["lin_in.bias"] = (g0f.sum(0) * inv_s)[inv]
+    grads["lin_out.weight"] = torch.matmul(g_out.t(), fwd.d_x5.float())[:, inv]
+    grads["lin_out.bias"] = g_out.sum(0)
+    return grads, d_zlat.contiguous()
+
+
+class _RenderFunction(torch.autograd.Function):
+    """inputs: cfg (python object), rays (R,8), latent (SB*NS,512,Hl,Wl), 26 coarse params,
+    26 fine params (or the coarse ones again when mlp_fine is None).
+    outputs: rgb_c, depth_c, weights_c[, rgb_f, depth_f, weights_f]."""
+
+    @staticmethod
+    def forward(ctx, cfg, rays, latent, *params):
+        net, noise = cfg["net"], cfg["noise"]
+        Kc, Kf, Kfd = cfg["n_coarse"], cfg["n_fine"], cfg["n_fine_depth"]
+        scene = net.scene()
+        pc = net.packed(True)
+        pf = net.packed(False) if Kf > 0 else None
+        passes = []
+        z_c = ops.sample_coarse(rays, noise["u1"], cfg["lindisp"])
+        rgbs_c, dumps_c = ops.eval_ray_samples_train(scene, pc, rays, z_c)
+        w_c, rgb_c, depth_c = ops.composite(rays, z_c, rgbs_c, cfg["white_bkgd"], want_weights=True)
+        passes.append(dict(z=z_c, rgbs=rgbs_c, dumps=dumps_c, coarse=True))
+        outs = [rgb_c, depth_c, w_c]
+        if Kf > 0:
+            z_f = ops.sample_fine(rays, w_c, depth_c, z_c, noise.get("u2"), noise.get("u3"),
+                                  noise.get("n4") if Kfd > 0 else None, cfg["depth_std"], cfg["lindisp"])
+            rgbs_f, dumps_f = ops.eval_ray_samples_train(scene, pf, rays, z_f)
+            w_f, rgb_f, depth_f = ops.composite(rays, z_f, rgbs_f, cfg["white_bkgd"], want_weights=True)
+            passes.append(dict(z=z_f, rgbs=rgbs_f, dumps=dumps_f, coarse=False))
+            outs += [rgb_f, depth_f, w_f]
+        ctx.cfg, ctx.rays, ctx.scene, ctx.passes = cfg, rays, scene, passes
+        ctx.latent_shape = latent.shape
+        ctx.n_params = len(params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        cfg, rays, scene = ctx.cfg, ctx.rays, ctx.scene
+        net = cfg["net"]
+        dev = rays.device
+        need_latent = ctx.needs_input_grad[2]
+        d_lat = torch.zeros((ctx.latent_shape[0], ctx.latent_shape[2], ctx.latent_shape[3], ctx.latent_shape[1]),
+                            dtype=torch.float32, device=dev) if need_latent else None
+        shared = net.mlp_fine is None  # fine pass ran on the coarse network (models.py:242)
+        gsum = [None, None]
+        for i, ps in enumerate(ctx.passes):
+            d_rgb, d_depth, d_w = gouts[3 * i], gouts[3 * i + 1], gouts[3 * i + 2]
+            R, K = ps["z"].shape
+            if d_rgb is None:
+                d_rgb = torch.zeros((R, 3), device=dev)
+            d_rgbs = ops.composite_backward(rays, ps["z"], ps["rgbs"], cfg["white_bkgd"], d_rgb.contiguous().float(),
+                                            None if d_depth is None else d_depth.contiguous().float(),
+                                            None if d_w is None else d_w.contiguous().float())
+            # through the output activations (models.py:260-265): sigmoid on rgb, relu on sigma
+            s = ps["rgbs"][..., :3]
+            g_out = torch.cat([d_rgbs[..., :3] * s * (1 - s),
+                               d_rgbs[..., 3:] * (ps["rgbs"][..., 3:] > 0).float()], dim=-1).reshape(-1, 4).contiguous()
+            mlp = net.mlp_coarse if (ps["coarse"] or shared) else net.mlp_fine
+            state = dict(mlp.named_parameters())
+            grads, d_zlat = _mlp_grads(state, mlp.packed_bwd(net.precision), ps["dumps"], g_out, scene.NS)
+            slot = 0 if (ps["coarse"] or shared) else 1
+            gsum[slot] = grads if gsum[slot] is None else {k: gsum[slot][k] + v for k, v in grads.items()}
+            if need_latent:
+                ops.latent_scatter(scene, rays, ps["z"], d_zlat, d_lat)
+        out = [None, None, d_lat.permute(0, 3, 1, 2).contiguous() if need_latent else None]
+        n_each = len(PARAM_NAMES)
+        for slot in range(ctx.n_params // n_each):
+            g = gsum[slot]
+            out += [None if g is None else g[n] for n in PARAM_NAMES]
+        return tuple(out)
+
+
+def render_autograd(renderer, net, rays, noise, want_weights):
+    """Differentiable twin of the one-call inference path; returns {coarse:{...}, fine:{...}} of
+    flat tensors like ops.render_forward."""
+    Kf = renderer.n_fine if renderer.using_fine else 0
+    cfg = dict(net=net, noise=noise, n_coarse=renderer.n_coarse, n_fine=Kf,
+               n_fine_depth=min(renderer.n_fine_depth, Kf), depth_std=renderer.depth_std,
+               white_bkgd=bool(renderer.white_bkgd), lindisp=bool(renderer.lindisp))
+    latent = net.encoder.latent
+    if net.stop_encoder_grad:
+        latent = latent.detach()
+    mlps = [net.mlp_coarse] + ([net.mlp_fine] if net.mlp_fine is not None else [])
+    params = []
+    for m in mlps:
+        named = dict(m.named_parameters())
+        params += [named[n] for n in PARAM_NAMES]
+    outs = _RenderFunction.apply(cfg, rays, latent, *params)
+    res = {"coarse": {"rgb": outs[0], "depth": outs[1], "weights": outs[2]}}
+    if Kf > 0:
+        res["fine"] = {"rgb": outs[3], "depth": outs[4], "weights": outs[5]}
+    if not want_weights:
+        for v in res.values():
+            v.pop("weights")
+    return res

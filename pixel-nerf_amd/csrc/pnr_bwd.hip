@@ -1,0 +1,444 @@
+// pnr_bwd.hip -- backward of the hot path for training (BASELINE config 5), gfx950.
+//
+//   bwd_kernel            fused data-gradient chain of one ResnetFC: same tile geometry as the
+//                         forward kernel (persistent 512-thread workgroup, 64-point tiles, wave w
+//                         owns features 64w..64w+63, gradient of the residual stream resident in
+//                         fp32 accumulators), driven by a TRANSPOSED weight stream
+//                         (lin_out^T, fc_1[b]^T, fc_0[b]^T, b = 4..0).  relu masks come from the
+//                         forward's 16-bit activation dumps; every layer's output gradient dY is
+//                         written as 16-bit rows for the weight-gradient GEMMs dW = dY^T X.
+//   composite_bwd_kernel  backward of the alpha compositing (nerf.py:223-249), wavefront per ray.
+//   latent_scatter_kernel d(interpolated latent) -> d(feature grid): bilinear scatter-add.
+//
+// Sample positions are treated as constants: the reference's only position gradient is the one
+// through the n_fine_depth samples (nerf.py:292), a 0.2-1.4 % effect that is not
+// propagated yet.
+#include <hip/hip_runtime.h>
+
+#include "pnr_common.h"
+#include "pnr_device.h"
+#include "pnr_layout.h"
+
+namespace pnr {
+
+typedef Advance<BRS_HEAD_END, BRS_TOTAL, BRS_TOTAL> AdvanceBwd;
+
+// ---------------------------------------------------------------- transposed weight stream
+template <typename T>
+__global__ void pack_weights_bwd_kernel(PnrMlpWeights p, T *__restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= BWSTREAM_ELEMS_PER_WAVE * NW) return;
+    const int e = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    const int it = (idx >> 9) % IT;
+    const size_t rest = idx / (FRAG_ELEMS * IT);
+    const int rs = rest % BRS_TOTAL;
+    const int wv = rest / BRS_TOTAL;
+    int g = 0;
+    while (g + 1 < NBGEMM && rs >= bgemm_offset(g + 1)) ++g;
+    const int s = rs - bgemm_offset(g);
+    const int i = lane & 31, h = lane >> 5;
+    // A-operand row = output row of the transposed GEMM = INPUT feature of the layer
+    const int f_row = wv * SL + it * 32 + i;
+    float v = 0.f;
+    if (g == BG_OUT) {
+        const int k = s * 16 + h * 8 + e;  // natural order of the 4 network outputs, zero padded
+        if (k < D_OUT) v = p.lin_out_w[k * D_HID + f_row];
+    } else {
+        const int b = 4 - (g - 1) / 2;       // BG_FC1_4, BG_FC0_4, BG_FC1_3, ... -> block index
+        const bool fc1 = ((g - 1) & 1) == 0;
+        const float *w = fc1 ? p.fc1_w[b] : p.fc0_w[b];
+        // K index = OUTPUT feature of the layer, in the storage order of the gradient image
+        const int f_o = feat_of(s >> 1, s & 1, 8 * h + e);
+        v = w[f_o * D_HID + f_row];
+    }
+    out[idx] = (T)v;
+}
+
+// ---------------------------------------------------------------- fused data-gradient chain
+struct BwdParams {
+    const char *wstream;
+    const char *d_a[5], *d_n[5], *d_x5;  // forward dumps: relu masks
+    const float *g_out;                  // (P,4) dL/d(lin_out output)
+    float scale;
+    long long P;
+    int NS, ntiles;
+    char *g_fc1[5], *g_fc0[5], *g_x0;
+};
+
+// acc = (dump row element != 0) ? acc : 0 ; dump holds relu(.) as 16-bit in storage order
+template <typename P>
+__device__ __forceinline__ void apply_mask(f32x16 (&acc)[IT][JT], const char *dump_lane, const bool *valid) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            u32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+            if (valid[jt]) {
+                const char *d = dump_lane + (size_t)jt * 32 * (D_HID * 2) + it * 64;
+                lo = *reinterpret_cast<const u32x4 *>(d);
+                hi = *reinterpret_cast<const u32x4 *>(d + 16);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t word = r < 8 ? lo[r >> 1] : hi[(r - 8) >> 1];
+                const uint32_t bits = (r & 1) ? (word >> 16) : (word & 0xffffu);
+                acc[it][jt][r] = bits ? acc[it][jt][r] : 0.f;
+            }
+        }
+}
+
+// G += (dump != 0) ? t : 0
+template <typename P>
+__device__ __forceinline__ void masked_add(f32x16 (&G)[IT][JT], const f32x16 (&t)[IT][JT], const char *dump_lane,
+                                           const bool *valid) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            u32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+            if (valid[jt]) {
+                const char *d = dump_lane + (size_t)jt * 32 * (D_HID * 2) + it * 64;
+                lo = *reinterpret_cast<const u32x4 *>(d);
+                hi = *reinterpret_cast<const u32x4 *>(d + 16);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t word = r < 8 ? lo[r >> 1] : hi[(r - 8) >> 1];
+                const uint32_t bits = (r & 1) ? (word >> 16) : (word & 0xffffu);
+                G[it][jt][r] += bits ? t[it][jt][r] : 0.f;
+            }
+        }
+}
+
+template <typename P>
+__device__ __forceinline__ void dump_only(const f32x16 (&acc)[IT][JT], char *dump_lane, const bool *valid) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            if (!valid[jt]) continue;
+            const f32x16 &a = acc[it][jt];
+            char *d = dump_lane + (size_t)jt * 32 * (D_HID * 2) + it * 64;
+            *reinterpret_cast<typename P::T8 *>(d) = pack8<P, false>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+            *reinterpret_cast<typename P::T8 *>(d + 16) =
+                pack8<P, false>(a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
+        }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&a)[IT][JT]) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[it][jt][r] = 0.f;
+}
+
+// reverse of one residual block (resnetfc.py:55-62):  given G = dL/d(x + fc_1(relu(fc_0(relu(x))))),
+//   dY(fc_1) = G ;  d net = (fc_1^T G) . [net > 0] = dY(fc_0) ;  G += (fc_0^T d net) . [x > 0]
+template <typename P>
+__device__ __forceinline__ void bwd_block(f32x16 (&G)[IT][JT], char *smem, int b, Ring<P> &R, int NS, const BwdParams &q,
+                                          size_t off, const bool *valid, uint32_t a_rd0, uint32_t a_rd1, uint32_t a_wr) {
+    __syncthreads();  // every wave is done reading the gradient image (previous GEMM)
+    write_act<P, false, true>(G, smem, a_wr, q.g_fc1[b] + off, valid);
+    __syncthreads();
+    f32x16 t[IT][JT];
+    zero_acc(t);
+    gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
+    apply_mask<P>(t, q.d_n[b] + off, valid);
+    __syncthreads();
+    write_act<P, false, true>(t, smem, a_wr, q.g_fc0[b] + off, valid);
+    __syncthreads();
+    zero_acc(t);
+    gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
+    masked_add<P>(G, t, q.d_a[b] + off, valid);
+}
+
+template <int PREC, bool MV>
+__global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q) {
+    typedef Prec<PREC> P;
+    typedef typename P::T T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+    const int NS = MV ? q.NS : 1;
+    const uint32_t a_rd0 = LDS_A + pl * ROW_ACT + h * 16, a_rd1 = a_rd0 + 32 * ROW_ACT;
+    const uint32_t in_rd0 = LDS_IN + pl * ROW_IN + h * 16, in_rd1 = in_rd0 + 32 * ROW_IN;
+    const uint32_t a_wr = LDS_A + pl * ROW_ACT + (wv * IT) * 64 + h * 32;
+
+    Ring<P> R;
+    R.wave_base = q.wstream + (size_t)wv * (BRS_TOTAL * IT * 1024) + lane * 16;
+    R.pf_view = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) R.r[j][it] = gload8<P>(R.wave_base + j * (IT * 1024) + it * 1024);
+    R.pf_rs = 4;
+
+    for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
+        bool valid[JT];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) valid[jt] = (long long)tile * MT + jt * 32 + pl < q.P;
+        const size_t off_pooled = (((size_t)tile * MT + pl) * D_HID + (wv * IT) * 32 + h * 16) * 2;
+
+        __syncthreads();  // previous tile: readers of the staging rows / gradient image are done
+        {   // stage scale * g_out as 16-bit operand rows [point][64] (4 real values, zero padded)
+            const int row = tid >> 3, chunk = tid & 7;
+            const long long g = (long long)tile * MT + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (chunk == 0 && g < q.P) v = *reinterpret_cast<const f32x4 *>(q.g_out + g * 4) * q.scale;
+            if (tid < MT * 8)
+                *reinterpret_cast<typename P::T8 *>(smem + LDS_IN + row * ROW_IN + chunk * 16) =
+                    pack8<P, false>(v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        f32x16 G[IT][JT];
+        zero_acc(G);
+        gemm<P, AdvanceBwd>(G, smem, in_rd0, in_rd1, KS_IN / 4, R, NS);  // lin_out^T g_out
+        apply_mask<P>(G, q.d_x5 + off_pooled, valid);                     // . [x5 > 0]
+#pragma unroll 1
+        for (int b = N_BLOCKS - 1; b >= COMBINE_LAYER; --b)
+            bwd_block<P>(G, smem, b, R, NS, q, off_pooled, valid, a_rd0, a_rd1, a_wr);
+        f32x16 Gp[MV ? IT : 1][MV ? JT : 1];
+        if constexpr (MV) {
+            // backward of the view mean (util.py:461-466): every view receives G / NS
+            const float inv = 1.f / (float)NS;
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) Gp[it][jt] = G[it][jt] * inv;
+        }
+#pragma unroll 1
+        for (int view = 0; view < NS; ++view) {
+            const size_t off_view = off_pooled + (size_t)view * (size_t)q.P * (D_HID * 2);
+            if constexpr (MV) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) G[it][jt] = Gp[it][jt];
+            }
+#pragma unroll 1
+            for (int b = COMBINE_LAYER - 1; b >= 0; --b)
+                bwd_block<P>(G, smem, b, R, NS, q, off_view, valid, a_rd0, a_rd1, a_wr);
+            dump_only<P>(G, q.g_x0 + off_view, valid);  // dY of lin_in and lin_z[0] (and of lin_z[b]: g_fc1[b-1])
+        }
+    }
+}
+
+// ---------------------------------------------------------------- compositing backward
+constexpr int CW = 4;  // wavefronts per block
+
+template <typename T> __device__ __forceinline__ T wsum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wscan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}
+__device__ __forceinline__ float wscan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// w_i = a_i T_i, T_i = prod_{j<i} (1 - a_j + 1e-10), a_i = 1 - exp(-delta_i relu(sigma_i))
+// g_i = dL/dw_i = d_rgb.c_i + d_depth z_i + d_w_i - [white] sum(d_rgb)
+// dL/da_i = g_i T_i - (sum_{j>i} g_j w_j) / (1 - a_i + 1e-10)
+template <int PASS>
+__device__ __forceinline__ float composite_bwd_pass(const float *zr, const float4 *cr, const float *dwr, int K, float far,
+                                                    float3 drgb, float ddepth, float gwhite, int lane, float total,
+                                                    float4 *dout) {
+    float carry = 1.f, run = 0.f, acc = 0.f;
+    for (int c0 = 0; c0 < K; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < K;
+        float zi = 0.f, alpha = 0.f, delta = 0.f, ex = 1.f;
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            zi = zr[i];
+            delta = ((i + 1 < K) ? zr[i + 1] : far) - zi;
+            cs = cr[i];
+            ex = expf(-delta * fmaxf(cs.w, 0.f));
+            alpha = 1.f - ex;
+        }
+        const float tf = valid ? (1.f - alpha + 1e-10f) : 1.f;
+        const float incl = wscan_mul(tf, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;
+        const float w = alpha * T;
+        float g = 0.f;
+        if (valid) g = drgb.x * cs.x + drgb.y * cs.y + drgb.z * cs.z + ddepth * zi + (dwr ? dwr[i] : 0.f) - gwhite;
+        const float gw = valid ? g * w : 0.f;
+        if (PASS == 0) {
+            acc += gw;
+        } else {
+            const float pre = wscan_add(gw, lane) + run;   // sum_{j<=i} g_j w_j
+            const float suffix = total - pre;              // sum_{j>i}
+            if (valid) {
+                const float dalpha = g * T - suffix / tf;
+                const float dsigma = cs.w > 0.f ? dalpha * delta * ex : 0.f;
+                dout[i] = make_float4(w * drgb.x, w * drgb.y, w * drgb.z, dsigma);
+            }
+            run = __shfl(pre, 63, 64);
+        }
+        carry = carry * __shfl(incl, 63, 64);
+    }
+    return PASS == 0 ? wsum(acc) : 0.f;
+}
+
+__global__ void __launch_bounds__(CW * 64)
+composite_bwd_kernel(const float *__restrict__ rays, const float *__restrict__ z, const float4 *__restrict__ rgbs, int R,
+                     int K, int white_bkgd, const float *__restrict__ d_rgb, const float *__restrict__ d_depth,
+                     const float *__restrict__ d_w, float4 *__restrict__ d_rgbs) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * CW + wv;
+    if (r >= R) return;
+    const float far = rays[(size_t)r * 8 + 7];
+    const float3 drgb = make_float3(d_rgb[(size_t)r * 3], d_rgb[(size_t)r * 3 + 1], d_rgb[(size_t)r * 3 + 2]);
+    const float ddepth = d_depth ? d_depth[r] : 0.f;
+    const float gwhite = white_bkgd ? (drgb.x + drgb.y + drgb.z) : 0.f;  // rgb += 1 - sum w
+    const float *zr = z + (size_t)r * K;
+    const float4 *cr = rgbs + (size_t)r * K;
+    const float *dwr = d_w ? d_w + (size_t)r * K : nullptr;
+    const float total = composite_bwd_pass<0>(zr, cr, dwr, K, far, drgb, ddepth, gwhite, lane, 0.f, nullptr);
+    composite_bwd_pass<1>(zr, cr, dwr, K, far, drgb, ddepth, gwhite, lane, total, d_rgbs + (size_t)r * K);
+}
+
+// ---------------------------------------------------------------- latent scatter-add
+// one wavefront per (view, point): lane handles channels 8*lane..+7 of the 4 bilinear corners
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(CW * 64)
+latent_scatter_kernel(const EvalParams q, const float *__restrict__ d_zlat, float *__restrict__ d_latent) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * CW + wv;  // view * P + point
+    if (idx >= q.P * q.NS) return;
+    const int view = (int)(idx / q.P);
+    const int g = (int)(idx % q.P);
+    const int r = g / q.K;
+    const float *ray = q.rays + (size_t)r * 8;
+    const float zz = q.z[g];
+    const float X = ray[0] + zz * ray[3], Y = ray[1] + zz * ray[4], Z = ray[2] + zz * ray[5];
+    const int obj = r / q.per_obj;
+    const float *pose = q.poses + (size_t)(obj * q.NS + view) * 12;
+    const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
+    const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
+    const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
+    const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, true);
+    const float *src = d_zlat + (size_t)idx * C_LAT + lane * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(src), b = *reinterpret_cast<const f32x4 *>(src + 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float w = pr.w[c];
+        if (w == 0.f) continue;
+        float *dst = d_latent + pr.off[c] + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(dst + e, w * a[e]);
+            atomicAdd(dst + 4 + e, w * b[e]);
+        }
+    }
+}
+#pragma clang fp contract(fast)
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" int pnr_storage_perm(int32_t *perm512) {
+    if (!perm512) return pnr_fail(PNR_E_INVALID, "pnr_storage_perm: null argument");
+    for (int e = 0; e < D_HID; ++e) perm512[e] = feat_of(e / 32, (e % 32) / 16, e % 16);
+    return PNR_OK;
+}
+
+extern "C" size_t pnr_packed_mlp_bwd_bytes(void) { return BPACKED_BYTES; }
+
+extern "C" int pnr_pack_mlp_bwd(const PnrMlpWeights *w, int precision, void *packed_bwd, void *stream) {
+    if (!w || !packed_bwd) return pnr_fail(PNR_E_INVALID, "pnr_pack_mlp_bwd: null argument");
+    const size_t n = BWSTREAM_ELEMS_PER_WAVE * NW;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (precision == PNR_PREC_F16)
+        hipLaunchKernelGGL(pack_weights_bwd_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *w, (_Float16 *)packed_bwd);
+    else if (precision == PNR_PREC_BF16)
+        hipLaunchKernelGGL(pack_weights_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *w, (__bf16 *)packed_bwd);
+    else
+        return pnr_fail(PNR_E_INVALID, "pnr_pack_mlp_bwd: unknown precision");
+    return pnr_check_launch("pnr_pack_mlp_bwd");
+}
+
+static int bwd_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const PnrTrainDumps *fwd, const float *g_out,
+                                float grad_scale, long long P, int NS, const PnrBackwardDumps *out, void *stream) {
+    if (!packed_bwd || !fwd || !g_out || !out || P <= 0 || NS <= 0 || !(grad_scale > 0.f))
+        return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: bad argument");
+    if (P > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: too many points");
+    BwdParams q = {};
+    q.wstream = (const char *)packed_bwd;
+    q.g_out = g_out; q.scale = grad_scale; q.P = P; q.NS = NS; q.ntiles = (int)((P + MT - 1) / MT);
+    q.d_x5 = (const char *)fwd->d_x5; q.g_x0 = (char *)out->g_x0;
+    if (!q.d_x5 || !q.g_x0) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: null dump");
+    for (int b = 0; b < 5; ++b) {
+        q.d_a[b] = (const char *)fwd->d_a[b]; q.d_n[b] = (const char *)fwd->d_n[b];
+        q.g_fc1[b] = (char *)out->g_fc1[b]; q.g_fc0[b] = (char *)out->g_fc0[b];
+        if (!q.d_a[b] || !q.d_n[b] || !q.g_fc1[b] || !q.g_fc0[b]) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: null dump");
+    }
+    const bool mv = NS > 1;
+    const int grid = q.ntiles < bwd_num_cus() ? q.ntiles : bwd_num_cus();
+    void (*k)(const BwdParams);
+    if (precision == PNR_PREC_F16) k = mv ? bwd_kernel<PNR_PREC_F16, true> : bwd_kernel<PNR_PREC_F16, false>;
+    else if (precision == PNR_PREC_BF16) k = mv ? bwd_kernel<PNR_PREC_BF16, true> : bwd_kernel<PNR_PREC_BF16, false>;
+    else return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: unknown precision");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(bwd_kernel)");
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), LDS_TOTAL, (hipStream_t)stream, q);
+    return pnr_check_launch("bwd_kernel");
+}
+
+extern "C" int pnr_composite_backward(const float *rays, const float *z, const float *rgbsigma, int R, int K, int white_bkgd,
+                                      const float *d_rgb, const float *d_depth, const float *d_weights, float *d_rgbsigma,
+                                      void *stream) {
+    if (R < 0 || K <= 0) return pnr_fail(PNR_E_INVALID, "pnr_composite_backward: bad sizes");
+    if (R == 0) return PNR_OK;
+    if (!rays || !z || !rgbsigma || !d_rgb || !d_rgbsigma) return pnr_fail(PNR_E_INVALID, "pnr_composite_backward: null argument");
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + CW - 1) / CW), dim3(CW * 64), 0, (hipStream_t)stream, rays, z,
+                       (const float4 *)rgbsigma, R, K, white_bkgd, d_rgb, d_depth, d_weights, (float4 *)d_rgbsigma);
+    return pnr_check_launch("pnr_composite_backward");
+}
+
+extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const float *z, int R, int rays_per_obj, int K,
+                                  const float *d_zlat, float *d_latent_nhwc, void *stream) {
+    if (!s || !rays || !z || !d_zlat || !d_latent_nhwc || R <= 0 || K <= 0 || rays_per_obj <= 0)
+        return pnr_fail(PNR_E_INVALID, "pnr_latent_scatter: bad argument");
+    if ((long long)rays_per_obj * s->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_latent_scatter: R != SB * rays_per_obj");
+    EvalParams q = {};
+    q.latent = s->latent_nhwc; q.poses = s->poses; q.focal = s->focal; q.c = s->c;
+    q.SB = s->SB; q.NS = s->NS; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
+    q.img_w = s->img_w; q.img_h = s->img_h;
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
+    const long long n = q.P * q.NS;
+    hipLaunchKernelGGL(latent_scatter_kernel, dim3((unsigned)((n + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream, q,
+                       d_zlat, d_latent_nhwc);
+    return pnr_check_launch("pnr_latent_scatter");
+}

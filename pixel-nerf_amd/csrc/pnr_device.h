@@ -1,0 +1,283 @@
+// pnr_device.h -- device-side building blocks shared by the forward (pnr_mlp.hip) and backward
+// (pnr_bwd.hip) fused network kernels: MFMA traits, 16-bit packing, the weight prefetch ring,
+// the tile GEMM, activation-image writes.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pnr_common.h"
+#include "pnr_layout.h"
+
+namespace pnr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int PREC> struct Prec;
+template <> struct Prec<PNR_PREC_F16> {
+    typedef _Float16 T;
+    typedef f16x8 T8;
+    typedef f16x2 T2;
+    static __device__ __forceinline__ f32x16 mfma(T8 a, T8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Prec<PNR_PREC_BF16> {
+    typedef __bf16 T;
+    typedef bf16x8 T8;
+    typedef bf16x2 T2;
+    static __device__ __forceinline__ f32x16 mfma(T8 a, T8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+struct EvalParams {
+    // scene (PnrScene)
+    const float *latent, *poses, *focal, *c;
+    int SB, NS, Hl, Wl, n_focal, n_c;
+    float img_w, img_h;
+    // packed network
+    const char *wstream;
+    const float *bias, *bout;
+    // points: variant A (rays + z) or B (xyz + viewdirs)
+    const float *rays, *z, *xyz, *viewdirs;
+    int K;             // samples per ray (A)
+    int per_obj;       // rays per object (A) or points per object (B)
+    long long P;       // total points
+    int ntiles;
+    float *out;        // (P,4)
+    float *dbg;        // optional debug dump of the final residual stream x (P,512), may be null
+    unsigned long long *tim;  // phase-timing accumulators (TIMING instantiation only)
+    // TRAIN instantiation: 16-bit row-major dumps of every linear layer's input operand
+    // (rows = view*P + point for the per-view layers, point for the pooled ones)
+    char *d_in;    // (NS*P, 64)   positional code + view direction (natural order, zero padded)
+    char *d_z;     // (NS*P, 512)  interpolated latent (natural channel order)
+    char *d_a[5];  // relu(x) in front of blocks[b].fc_0, storage order; b<3: (NS*P,512), else (P,512)
+    char *d_n[5];  // relu(net) in front of blocks[b].fc_1, same shapes
+    char *d_x5;    // (P,512) relu(x) in front of lin_out
+};
+
+// phase ids of the TIMING instantiation (wave 0 of workgroup 0, s_memtime ticks)
+enum Phase { PH_SYNC_TOP = 0, PH_GEOMETRY, PH_GATHER, PH_GEMM_IN_Z0, PH_BAR1, PH_WRITE_X, PH_BAR2, PH_GEMM_FC0, PH_BAR3,
+             PH_WRITE_NET, PH_BAR4, PH_GEMM_FC1_Z, PH_LIN_OUT, PH_BAR_OUT, PH_FINAL, NPHASE };
+#define PNR_T(ph)                                                         \
+    do {                                                                  \
+        if constexpr (TIMING) {                                           \
+            if ((tid & 63) == 0 && blockIdx.x == 0) {                     \
+                const unsigned long long t_ = __builtin_readcyclecounter(); \
+                atomicAdd(&tim[(tid >> 6) * NPHASE + ph], t_ - tlast);    \
+                tlast = t_;                                               \
+            }                                                             \
+        }                                                                 \
+    } while (0)
+
+__device__ __forceinline__ uint32_t pack2(float a, float b, _Float16) {
+    f32x2 v = {a, b};
+    f16x2 h = __builtin_convertvector(v, f16x2);
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b, __bf16) {
+    f32x2 v = {a, b};
+    bf16x2 h = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+// 8 fp32 -> 8 x 16-bit, optional relu
+template <typename P, bool RELU>
+__device__ __forceinline__ typename P::T8 pack8(float v0, float v1, float v2, float v3, float v4, float v5,
+                                                float v6, float v7) {
+    if (RELU) {
+        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        v4 = fmaxf(v4, 0.f); v5 = fmaxf(v5, 0.f); v6 = fmaxf(v6, 0.f); v7 = fmaxf(v7, 0.f);
+    }
+    typename P::T t = (typename P::T)0;
+    u32x4 u = {pack2(v0, v1, t), pack2(v2, v3, t), pack2(v4, v5, t), pack2(v6, v7, t)};
+    return __builtin_bit_cast(typename P::T8, u);
+}
+
+// ---------------------------------------------------------------- weight prefetch ring
+// ring slot j holds the IT fragments of stream position (consumed position + j); every consumed
+// slot is immediately refilled with position +4.  The prefetch cursor follows the consumption
+// order [per-view segment] x NS, [tail segment], and wraps to the start for the next tile.
+template <typename P> struct Ring {
+    typename P::T8 r[4][IT];
+    const char *wave_base;  // this wave's stream + lane*16
+    int pf_rs;              // ring step the next refill (slot 0) will fetch
+    int pf_view;
+};
+
+template <typename P> __device__ __forceinline__ typename P::T8 gload8(const char *p) {
+    return *reinterpret_cast<const typename P::T8 *>(p);
+}
+template <typename P> __device__ __forceinline__ typename P::T8 lds8(const char *smem, uint32_t a) {
+    return *reinterpret_cast<const typename P::T8 *>(smem + a);
+}
+
+// Prefetch-cursor policy: the stream segment [LOOP_LO, LOOP_HI) is consumed once per source view
+// (NS times), everything else once per tile; at TOTAL the cursor wraps to 0 for the next tile.
+//   forward : [0, RS_VIEW_END) x NS, then the pooled tail          -> Advance<0, RS_VIEW_END, RS_TOTAL>
+//   backward: pooled head once, then [BRS_HEAD_END, BRS_TOTAL) x NS -> Advance<BRS_HEAD_END, BRS_TOTAL, BRS_TOTAL>
+template <int LOOP_LO, int LOOP_HI, int TOTAL> struct Advance {
+    template <typename P> static __device__ __forceinline__ void step4(Ring<P> &R, int NS) {
+        int rs = R.pf_rs + 4, v = R.pf_view;
+        if (rs == LOOP_HI && v + 1 < NS) {
+            v += 1; rs = LOOP_LO;
+        } else if (rs == TOTAL) {
+            rs = 0; v = 0;
+        }
+        R.pf_rs = rs; R.pf_view = v;
+    }
+};
+typedef Advance<0, RS_VIEW_END, RS_TOTAL> AdvanceFwd;
+
+// acc[it][jt] += W-fragments (ring) x B-fragments (LDS rows baddr0/baddr1, 32 B per k-step),
+// nbody*4 k-steps.
+template <typename P, typename ADV = AdvanceFwd>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT], const char *smem, uint32_t baddr0, uint32_t baddr1,
+                                     int nbody, Ring<P> &R, int NS) {
+    typename P::T8 b[2][JT];
+    b[0][0] = lds8<P>(smem, baddr0);
+    b[0][1] = lds8<P>(smem, baddr1);
+#pragma unroll 1
+    for (int body = 0; body < nbody; ++body) {
+
+#ifdef PNR_EXP_FAKE_W  // experiment: refill from a fixed 8 KiB window (no L2 streaming); results are wrong
+        const char *pf = R.wave_base + (size_t)(R.pf_rs & 0) * (IT * 1024);
+#else
+        const char *pf = R.wave_base + (size_t)R.pf_rs * (IT * 1024);
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cur = j & 1;
+            // intended step order: LDS reads for step+1 | 4 MFMAs of this step | refill this ring
+            // slot (step+4).  hipcc re-orders this (it batches the 8 refills behind the last MFMA
+            // of the body); pinning the order with sched_barrier (-DPNR_PIN_SCHEDULE) gives the
+            // textbook stream but measured 2-3 % SLOWER (profiles/r01_gemm_experiments.md), so
+            // the compiler's schedule is the default.
+            b[cur ^ 1][0] = lds8<P>(smem, baddr0 + (j + 1) * 32);
+            b[cur ^ 1][1] = lds8<P>(smem, baddr1 + (j + 1) * 32);
+#ifdef PNR_PIN_SCHEDULE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            typename P::T8 a[IT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) a[it] = R.r[j][it];
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = P::mfma(a[it], b[cur][jt], acc[it][jt]);
+#ifdef PNR_PIN_SCHEDULE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef PNR_EXP_NO_WLOAD  // experiment: never refill the ring (no weight traffic at all); results are wrong
+#pragma unroll
+            for (int it = 0; it < IT; ++it) R.r[j][it] = gload8<P>(pf + j * (IT * 1024) + it * 1024);
+#endif
+#ifdef PNR_PIN_SCHEDULE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        baddr0 += 128;
+        baddr1 += 128;
+        ADV::step4(R, NS);
+    }
+}
+
+// [relu](acc) -> 16-bit -> activation image.  Lane (p,h) writes registers 0..15 of feature tile
+// T = wave*IT+it as 32 contiguous bytes at element offset 32T + 16h of its point row ("storage
+// order").  DUMP additionally stores the same 32 bytes to a row-major (rows,512) 16-bit array in
+// HBM (training: operands of the weight-gradient GEMMs and relu masks of the backward chain);
+// dump_lane = array + ((first row of the tile + p)*512 + 32*wave*IT + 16h) elements, valid[jt]
+// guards rows beyond the last point.
+template <typename P, bool RELU = true, bool DUMP = false>
+__device__ __forceinline__ void write_act(const f32x16 (&acc)[IT][JT], char *smem, uint32_t waddr,
+                                          char *dump_lane = nullptr, const bool *valid = nullptr) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const f32x16 &a = acc[it][jt];
+            const uint32_t ad = waddr + jt * 32 * ROW_ACT + it * 64;
+            const typename P::T8 lo = pack8<P, RELU>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+            const typename P::T8 hi = pack8<P, RELU>(a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
+            *reinterpret_cast<typename P::T8 *>(smem + ad) = lo;
+            *reinterpret_cast<typename P::T8 *>(smem + ad + 16) = hi;
+            if (DUMP) {
+                if (valid[jt]) {
+                    char *d = dump_lane + (size_t)jt * 32 * (D_HID * 2) + it * 64;
+                    *reinterpret_cast<typename P::T8 *>(d) = lo;
+                    *reinterpret_cast<typename P::T8 *>(d + 16) = hi;
+                }
+            }
+        }
+}
+
+template <bool INIT>
+__device__ __forceinline__ void add_bias(f32x16 (&acc)[IT][JT], const float *bias_lane, int slot) {
+    // bias_lane = bias + wave*BIAS_FLOATS_PER_WAVE + h*16 ; slot stride NW*BIAS_FLOATS_PER_WAVE
+    const float *b = bias_lane + (size_t)slot * (NW * BIAS_FLOATS_PER_WAVE);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        f32x4 q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const f32x4 *>(b + it * 32 + i * 4);
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (INIT) acc[it][jt][r] = q[r >> 2][r & 3];
+                else acc[it][jt][r] += q[r >> 2][r & 3];
+            }
+    }
+}
+
+
+// ---------------------------------------------------------------- projection + bilinear setup
+// Camera-space point and pinhole projection (models.py:165,206-212), SpatialEncoder.index
+// scaling (encoder.py:96-99,161-163) and grid_sample(bilinear, border, align_corners=True)
+// corner offsets / weights, in the reference's fp32 op order (no FMA contraction).
+// xr = R x (rotated point); off[] are element offsets into the NHWC grid.
+struct Proj {
+    uint32_t off[4];  // nw, ne, sw, se
+    float w[4];
+};
+#pragma clang fp contract(off)
+__device__ __forceinline__ Proj project_point(const EvalParams &q, const float *pose, int obj, int view, float xr0,
+                                              float xr1, float xr2, bool valid) {
+    const float xc0 = xr0 + pose[3], xc1 = xr1 + pose[7], xc2 = xr2 + pose[11];
+    const float *fo = q.focal + (q.n_focal > 1 ? obj * 2 : 0);
+    const float *cc = q.c + (q.n_c > 1 ? obj * 2 : 0);
+    float u = -xc0 / xc2; u = u * fo[0]; u = u + cc[0];
+    float v = -xc1 / xc2; v = v * fo[1]; v = v + cc[1];
+    const float Wl = (float)q.Wl, Hl = (float)q.Hl;
+    const float lsx = Wl / (Wl - 1.f) * 2.f, lsy = Hl / (Hl - 1.f) * 2.f;
+    const float gx = u * (lsx / q.img_w) - 1.f, gy = v * (lsy / q.img_h) - 1.f;
+    float ix = ((gx + 1.f) / 2.f) * (Wl - 1.f), iy = ((gy + 1.f) / 2.f) * (Hl - 1.f);
+    ix = fminf(Wl - 1.f, fmaxf(ix, 0.f));
+    iy = fminf(Hl - 1.f, fmaxf(iy, 0.f));
+    if (!(ix == ix) || !valid) ix = 0.f;  // NaN (point on the camera plane): keep reads in bounds
+    if (!(iy == iy) || !valid) iy = 0.f;
+    const float ix0 = floorf(ix), iy0 = floorf(iy);
+    const float ix1 = ix0 + 1.f, iy1 = iy0 + 1.f;
+    float w_nw = (ix1 - ix) * (iy1 - iy), w_ne = (ix - ix0) * (iy1 - iy);
+    float w_sw = (ix1 - ix) * (iy - iy0), w_se = (ix - ix0) * (iy - iy0);
+    const int x0 = (int)ix0, y0 = (int)iy0;
+    const int x1 = min(x0 + 1, q.Wl - 1), y1 = min(y0 + 1, q.Hl - 1);  // out-of-range corner has weight 0
+    if (x0 + 1 > q.Wl - 1) { w_ne = 0.f; w_se = 0.f; }
+    if (y0 + 1 > q.Hl - 1) { w_sw = 0.f; w_se = 0.f; }
+    if (!valid) { w_nw = w_ne = w_sw = w_se = 0.f; }
+    const uint32_t rowbase = (uint32_t)(obj * q.NS + view) * (uint32_t)(q.Hl * q.Wl);
+    Proj pr;
+    pr.off[0] = (rowbase + y0 * q.Wl + x0) * C_LAT; pr.off[1] = (rowbase + y0 * q.Wl + x1) * C_LAT;
+    pr.off[2] = (rowbase + y1 * q.Wl + x0) * C_LAT; pr.off[3] = (rowbase + y1 * q.Wl + x1) * C_LAT;
+    pr.w[0] = w_nw; pr.w[1] = w_ne; pr.w[2] = w_sw; pr.w[3] = w_se;
+    return pr;
+}
+#pragma clang fp contract(fast)
+
+}  // namespace pnr

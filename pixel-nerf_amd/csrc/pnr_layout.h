@@ -26,8 +26,11 @@ constexpr int D_OUT = 4;
 constexpr int N_BLOCKS = 5;
 constexpr int COMBINE_LAYER = 3;
 
-constexpr int NW = 8;             // waves per workgroup
-constexpr int NTHREADS = NW * 64; // 512
+#ifndef PNR_NW
+#define PNR_NW 8
+#endif
+constexpr int NW = PNR_NW;        // waves per workgroup (8: 2 per SIMD, 16: 4 per SIMD)
+constexpr int NTHREADS = NW * 64;
 constexpr int SL = D_HID / NW;    // hidden features per wave (64)
 constexpr int IT = SL / 32;       // feature tiles per wave (2)
 constexpr int MT = 64;            // points per tile
@@ -77,6 +80,18 @@ constexpr size_t PACKED_BYTES = BOUT_OFFSET_BYTES + 16;
 __host__ __device__ constexpr int feat_of(int T, int h, int r) {
     return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
 }
+
+// ---- backward chain: transposed weight stream, consumption order per tile ----
+//   head (pooled, once): lin_out^T (4 ring steps, k-step 0 real) | fc_1[4]^T fc_0[4]^T fc_1[3]^T fc_0[3]^T
+//   per source view    : fc_1[2]^T fc_0[2]^T fc_1[1]^T fc_0[1]^T fc_1[0]^T fc_0[0]^T
+enum BGemm { BG_OUT = 0, BG_FC1_4, BG_FC0_4, BG_FC1_3, BG_FC0_3, BG_FC1_2, BG_FC0_2, BG_FC1_1, BG_FC0_1, BG_FC1_0, BG_FC0_0, NBGEMM };
+__host__ __device__ constexpr int bgemm_offset(int g) { return g == 0 ? 0 : KS_IN + (g - 1) * KS_BIG; }
+constexpr int BRS_HEAD_END = bgemm_offset(BG_FC1_2);  // 132
+constexpr int BRS_TOTAL = bgemm_offset(NBGEMM);       // 324
+static_assert(BRS_HEAD_END % 4 == 0 && BRS_TOTAL % 4 == 0, "ring depth 4 needs aligned segments");
+constexpr size_t BWSTREAM_ELEMS_PER_WAVE = (size_t)BRS_TOTAL * IT * FRAG_ELEMS;
+constexpr size_t BPACKED_BYTES = BWSTREAM_ELEMS_PER_WAVE * NW * 2;
+constexpr int ROW_GOUT = 48;  // d(lin_out output) operand rows: 16 x 16-bit (4 real) + pad -> 3 slots/row
 
 // ---- LDS map of the fused kernel (bytes) ----
 constexpr int ROW_ACT = D_HID * 2 + 16;      // 1040 B per point row: 1024 B of 16-bit activations + one

@@ -18,208 +18,10 @@
 #include <vector>
 
 #include "pnr_common.h"
+#include "pnr_device.h"
 #include "pnr_layout.h"
 
 namespace pnr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-template <int PREC> struct Prec;
-template <> struct Prec<PNR_PREC_F16> {
-    typedef _Float16 T;
-    typedef f16x8 T8;
-    typedef f16x2 T2;
-    static __device__ __forceinline__ f32x16 mfma(T8 a, T8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct Prec<PNR_PREC_BF16> {
-    typedef __bf16 T;
-    typedef bf16x8 T8;
-    typedef bf16x2 T2;
-    static __device__ __forceinline__ f32x16 mfma(T8 a, T8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
-
-struct EvalParams {
-    // scene (PnrScene)
-    const float *latent, *poses, *focal, *c;
-    int SB, NS, Hl, Wl, n_focal, n_c;
-    float img_w, img_h;
-    // packed network
-    const char *wstream;
-    const float *bias, *bout;
-    // points: variant A (rays + z) or B (xyz + viewdirs)
-    const float *rays, *z, *xyz, *viewdirs;
-    int K;             // samples per ray (A)
-    int per_obj;       // rays per object (A) or points per object (B)
-    long long P;       // total points
-    int ntiles;
-    float *out;        // (P,4)
-    float *dbg;        // optional debug dump of the final residual stream x (P,512), may be null
-    unsigned long long *tim;  // phase-timing accumulators (TIMING instantiation only)
-};
-
-// phase ids of the TIMING instantiation (wave 0 of workgroup 0, s_memtime ticks)
-enum Phase { PH_SYNC_TOP = 0, PH_GEOMETRY, PH_GATHER, PH_GEMM_IN_Z0, PH_BAR1, PH_WRITE_X, PH_BAR2, PH_GEMM_FC0, PH_BAR3,
-             PH_WRITE_NET, PH_BAR4, PH_GEMM_FC1_Z, PH_LIN_OUT, PH_BAR_OUT, PH_FINAL, NPHASE };
-#define PNR_T(ph)                                                         \
-    do {                                                                  \
-        if constexpr (TIMING) {                                           \
-            if ((tid & 63) == 0 && blockIdx.x == 0) {                     \
-                const unsigned long long t_ = __builtin_readcyclecounter(); \
-                atomicAdd(&tim[(tid >> 6) * NPHASE + ph], t_ - tlast);    \
-                tlast = t_;                                               \
-            }                                                             \
-        }                                                                 \
-    } while (0)
-
-__device__ __forceinline__ uint32_t pack2(float a, float b, _Float16) {
-    f32x2 v = {a, b};
-    f16x2 h = __builtin_convertvector(v, f16x2);
-    return __builtin_bit_cast(uint32_t, h);
-}
-__device__ __forceinline__ uint32_t pack2(float a, float b, __bf16) {
-    f32x2 v = {a, b};
-    bf16x2 h = __builtin_convertvector(v, bf16x2);
-    return __builtin_bit_cast(uint32_t, h);
-}
-
-// 8 fp32 -> 8 x 16-bit, optional relu
-template <typename P, bool RELU>
-__device__ __forceinline__ typename P::T8 pack8(float v0, float v1, float v2, float v3, float v4, float v5,
-                                                float v6, float v7) {
-    if (RELU) {
-        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-        v4 = fmaxf(v4, 0.f); v5 = fmaxf(v5, 0.f); v6 = fmaxf(v6, 0.f); v7 = fmaxf(v7, 0.f);
-    }
-    typename P::T t = (typename P::T)0;
-    u32x4 u = {pack2(v0, v1, t), pack2(v2, v3, t), pack2(v4, v5, t), pack2(v6, v7, t)};
-    return __builtin_bit_cast(typename P::T8, u);
-}
-
-// ---------------------------------------------------------------- weight prefetch ring
-// ring slot j holds the IT fragments of stream position (consumed position + j); every consumed
-// slot is immediately refilled with position +4.  The prefetch cursor follows the consumption
-// order [per-view segment] x NS, [tail segment], and wraps to the start for the next tile.
-template <typename P> struct Ring {
-    typename P::T8 r[4][IT];
-    const char *wave_base;  // this wave's stream + lane*16
-    int pf_rs;              // ring step the next refill (slot 0) will fetch
-    int pf_view;
-};
-
-template <typename P> __device__ __forceinline__ typename P::T8 gload8(const char *p) {
-    return *reinterpret_cast<const typename P::T8 *>(p);
-}
-template <typename P> __device__ __forceinline__ typename P::T8 lds8(const char *smem, uint32_t a) {
-    return *reinterpret_cast<const typename P::T8 *>(smem + a);
-}
-
-template <typename P> __device__ __forceinline__ void ring_advance4(Ring<P> &R, int NS) {
-    int rs = R.pf_rs + 4, v = R.pf_view;
-    if (rs == RS_VIEW_END) {
-        if (v + 1 < NS) { v += 1; rs = 0; }
-    } else if (rs == RS_TOTAL) {
-        rs = 0; v = 0;
-    }
-    R.pf_rs = rs; R.pf_view = v;
-}
-
-// acc[it][jt] += W-fragments (ring) x B-fragments (LDS rows baddr0/baddr1, 32 B per k-step),
-// nbody*4 k-steps.
-template <typename P>
-__device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT], const char *smem, uint32_t baddr0, uint32_t baddr1,
-                                     int nbody, Ring<P> &R, int NS) {
-    typename P::T8 b[2][JT];
-    b[0][0] = lds8<P>(smem, baddr0);
-    b[0][1] = lds8<P>(smem, baddr1);
-#pragma unroll 1
-    for (int body = 0; body < nbody; ++body) {
-
-#ifdef PNR_EXP_FAKE_W  // experiment: refill from a fixed 8 KiB window (no L2 streaming); results are wrong
-        const char *pf = R.wave_base + (size_t)(R.pf_rs & 0) * (IT * 1024);
-#else
-        const char *pf = R.wave_base + (size_t)R.pf_rs * (IT * 1024);
-#endif
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cur = j & 1;
-            // intended step order: LDS reads for step+1 | 4 MFMAs of this step | refill this ring
-            // slot (step+4).  hipcc re-orders this (it batches the 8 refills behind the last MFMA
-            // of the body); pinning the order with sched_barrier (-DPNR_PIN_SCHEDULE) gives the
-            // textbook stream but measured 2-3 % SLOWER (profiles/r01_gemm_experiments.md), so
-            // the compiler's schedule is the default.
-            b[cur ^ 1][0] = lds8<P>(smem, baddr0 + (j + 1) * 32);
-            b[cur ^ 1][1] = lds8<P>(smem, baddr1 + (j + 1) * 32);
-#ifdef PNR_PIN_SCHEDULE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            const typename P::T8 a0 = R.r[j][0], a1 = R.r[j][1];
-            acc[0][0] = P::mfma(a0, b[cur][0], acc[0][0]);
-            acc[0][1] = P::mfma(a0, b[cur][1], acc[0][1]);
-            acc[1][0] = P::mfma(a1, b[cur][0], acc[1][0]);
-            acc[1][1] = P::mfma(a1, b[cur][1], acc[1][1]);
-#ifdef PNR_PIN_SCHEDULE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifndef PNR_EXP_NO_WLOAD  // experiment: never refill the ring (no weight traffic at all); results are wrong
-            R.r[j][0] = gload8<P>(pf + j * (IT * 1024));
-            R.r[j][1] = gload8<P>(pf + j * (IT * 1024) + 1024);
-#endif
-#ifdef PNR_PIN_SCHEDULE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-        baddr0 += 128;
-        baddr1 += 128;
-        ring_advance4(R, NS);
-    }
-}
-
-// relu(acc) -> 16-bit -> activation buffer.  Lane (p,h) writes registers 0..15 of feature tile
-// T = wave*IT+it as 32 contiguous bytes at element offset 32T + 16h of its point row.
-template <typename P>
-__device__ __forceinline__ void write_act(const f32x16 (&acc)[IT][JT], char *smem, uint32_t waddr) {
-#pragma unroll
-    for (int it = 0; it < IT; ++it)
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const f32x16 &a = acc[it][jt];
-            const uint32_t ad = waddr + jt * 32 * ROW_ACT + it * 64;
-            *reinterpret_cast<typename P::T8 *>(smem + ad) =
-                pack8<P, true>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
-            *reinterpret_cast<typename P::T8 *>(smem + ad + 16) =
-                pack8<P, true>(a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
-        }
-}
-
-template <bool INIT>
-__device__ __forceinline__ void add_bias(f32x16 (&acc)[IT][JT], const float *bias_lane, int slot) {
-    // bias_lane = bias + wave*BIAS_FLOATS_PER_WAVE + h*16 ; slot stride NW*BIAS_FLOATS_PER_WAVE
-    const float *b = bias_lane + (size_t)slot * (NW * BIAS_FLOATS_PER_WAVE);
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        f32x4 q[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const f32x4 *>(b + it * 32 + i * 4);
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (INIT) acc[it][jt][r] = q[r >> 2][r & 3];
-                else acc[it][jt][r] += q[r >> 2][r & 3];
-            }
-    }
-}
 
 // ---------------------------------------------------------------- feature phase (geometry)
 // Thread (p = tid&63, sub = tid>>6).  Follows the reference op order without FMA contraction
@@ -261,37 +63,12 @@ __device__ __forceinline__ void geometry(const EvalParams &q, char *smem, int ti
         const float dv2 = pose[8] * dx + pose[9] * dy + pose[10] * dz;
         in_row[0] = (T)(valid ? xr0 : 0.f); in_row[1] = (T)(valid ? xr1 : 0.f); in_row[2] = (T)(valid ? xr2 : 0.f);
         in_row[39] = (T)dv0; in_row[40] = (T)dv1; in_row[41] = (T)dv2;
-        // camera-space point and pinhole projection (models.py:165,206-212)
-        const float xc0 = xr0 + pose[3], xc1 = xr1 + pose[7], xc2 = xr2 + pose[11];
-        const float *fo = q.focal + (q.n_focal > 1 ? obj * 2 : 0);
-        const float *cc = q.c + (q.n_c > 1 ? obj * 2 : 0);
-        float u = -xc0 / xc2; u = u * fo[0]; u = u + cc[0];
-        float v = -xc1 / xc2; v = v * fo[1]; v = v + cc[1];
-        // SpatialEncoder.index (encoder.py:96-99,161-163) + grid_sample(bilinear, border,
-        // align_corners=True)
-        const float Wl = (float)q.Wl, Hl = (float)q.Hl;
-        const float lsx = Wl / (Wl - 1.f) * 2.f, lsy = Hl / (Hl - 1.f) * 2.f;
-        const float gx = u * (lsx / q.img_w) - 1.f, gy = v * (lsy / q.img_h) - 1.f;
-        float ix = ((gx + 1.f) / 2.f) * (Wl - 1.f), iy = ((gy + 1.f) / 2.f) * (Hl - 1.f);
-        ix = fminf(Wl - 1.f, fmaxf(ix, 0.f));
-        iy = fminf(Hl - 1.f, fmaxf(iy, 0.f));
-        if (!(ix == ix) || !valid) ix = 0.f;  // NaN (point on the camera plane): keep reads in bounds
-        if (!(iy == iy) || !valid) iy = 0.f;
-        const float ix0 = floorf(ix), iy0 = floorf(iy);
-        const float ix1 = ix0 + 1.f, iy1 = iy0 + 1.f;
-        float w_nw = (ix1 - ix) * (iy1 - iy), w_ne = (ix - ix0) * (iy1 - iy);
-        float w_sw = (ix1 - ix) * (iy - iy0), w_se = (ix - ix0) * (iy - iy0);
-        const int x0 = (int)ix0, y0 = (int)iy0;
-        const int x1 = min(x0 + 1, q.Wl - 1), y1 = min(y0 + 1, q.Hl - 1);  // out-of-range corner has weight 0
-        if (x0 + 1 > q.Wl - 1) { w_ne = 0.f; w_se = 0.f; }
-        if (y0 + 1 > q.Hl - 1) { w_sw = 0.f; w_se = 0.f; }
-        if (!valid) { w_nw = w_ne = w_sw = w_se = 0.f; }
-        const uint32_t rowbase = (uint32_t)(obj * q.NS + view) * (uint32_t)(q.Hl * q.Wl);
+        // camera-space point, pinhole projection, bilinear corner setup
+        const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, valid);
         uint32_t *mo = reinterpret_cast<uint32_t *>(smem + LDS_META + p * 32);
         float *mw = reinterpret_cast<float *>(smem + LDS_META + p * 32 + 16);
-        mo[0] = (rowbase + y0 * q.Wl + x0) * C_LAT; mo[1] = (rowbase + y0 * q.Wl + x1) * C_LAT;
-        mo[2] = (rowbase + y1 * q.Wl + x0) * C_LAT; mo[3] = (rowbase + y1 * q.Wl + x1) * C_LAT;
-        mw[0] = w_nw; mw[1] = w_ne; mw[2] = w_sw; mw[3] = w_se;
+        mo[0] = pr.off[0]; mo[1] = pr.off[1]; mo[2] = pr.off[2]; mo[3] = pr.off[3];
+        mw[0] = pr.w[0]; mw[1] = pr.w[1]; mw[2] = pr.w[2]; mw[3] = pr.w[3];
     } else if (sub <= 6) {
         // frequency k = sub-1: sin(f x), sin(f x + pi/2), f = 1.5 * 2^k (code.py:15,37-41)
         const float f = 1.5f * (float)(1 << (sub - 1));
@@ -309,8 +86,8 @@ __device__ __forceinline__ void geometry(const EvalParams &q, char *smem, int ti
 #pragma clang fp contract(fast)
 
 // bilinear lookup: wave handles points wave*8..+7; lane handles channels 8*lane..+7
-template <typename P>
-__device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, int lane) {
+template <typename P, bool TRAIN>
+__device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, int lane, int tile, int view) {
     const float *lat = q.latent + lane * 8;
 #pragma unroll 2
     for (int i = 0; i < MT / NW; i += 2) {
@@ -341,22 +118,29 @@ __device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, 
                 a += v[u][3][hh][ee] * w[u][3];
                 r[e] = a;
             }
-            *reinterpret_cast<typename P::T8 *>(smem + LDS_Z + p * ROW_ACT + lane * 16) =
-                pack8<P, false>(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+            const typename P::T8 zz = pack8<P, false>(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+            *reinterpret_cast<typename P::T8 *>(smem + LDS_Z + p * ROW_ACT + lane * 16) = zz;
+            if (TRAIN) {
+                const long long g = (long long)tile * MT + p;
+                if (g < q.P)
+                    *reinterpret_cast<typename P::T8 *>(q.d_z + (((long long)view * q.P + g) * C_LAT + lane * 8) * 2) = zz;
+            }
         }
     }
 }
 
 // one residual block (+ the lin_z of the next block when with_z):
 //   net = fc_0(relu(x)); x += fc_1(relu(net)) [+ lin_z[b+1](z)]       resnetfc.py:55-62,174-182
-template <typename P, bool TIMING>
+template <typename P, bool TIMING, bool TRAIN>
 __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b, bool with_z, Ring<P> &R,
                                           int NS, const float *bias_lane, uint32_t a_rd0, uint32_t a_rd1,
                                           uint32_t z_rd0, uint32_t z_rd1, uint32_t a_wr, int tid,
-                                          unsigned long long *tim, unsigned long long &tlast) {
+                                          unsigned long long *tim, unsigned long long &tlast,
+                                          const EvalParams &q, size_t dump_off, const bool *valid) {
+    // dump_off: byte offset of this lane's 32-byte slot in a (rows,512) 16-bit dump array
     __syncthreads();  // every wave is done reading LDS_A (previous fc_1)
     PNR_T(PH_BAR1);
-    write_act<P>(x, smem, a_wr);
+    write_act<P, true, TRAIN>(x, smem, a_wr, TRAIN ? q.d_a[b] + dump_off : nullptr, valid);
     PNR_T(PH_WRITE_X);
     __syncthreads();
     PNR_T(PH_BAR2);
@@ -367,7 +151,7 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b
         PNR_T(PH_GEMM_FC0);
         __syncthreads();  // every wave is done reading relu(x)
         PNR_T(PH_BAR3);
-        write_act<P>(net, smem, a_wr);
+        write_act<P, true, TRAIN>(net, smem, a_wr, TRAIN ? q.d_n[b] + dump_off : nullptr, valid);
         PNR_T(PH_WRITE_NET);
     }
     __syncthreads();
@@ -378,8 +162,8 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b
     PNR_T(PH_GEMM_FC1_Z);
 }
 
-template <int PREC, bool RAYS, bool MV, bool TIMING = false>
-__global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
+template <int PREC, bool RAYS, bool MV, bool TIMING = false, bool TRAIN = false>
+__global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams q) {
     typedef Prec<PREC> P;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -400,10 +184,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
     R.pf_rs = 0;
     R.pf_view = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        R.r[j][0] = gload8<P>(R.wave_base + j * (IT * 1024));
-        R.r[j][1] = gload8<P>(R.wave_base + j * (IT * 1024) + 1024);
-    }
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) R.r[j][it] = gload8<P>(R.wave_base + j * (IT * 1024) + it * 1024);
     R.pf_rs = 4;
     unsigned long long *tim = q.tim;
     unsigned long long tlast = TIMING ? __builtin_readcyclecounter() : 0ull;
@@ -411,14 +194,27 @@ __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
     for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
         f32x16 x[IT][JT];
         f32x16 xsum[MV ? IT : 1][MV ? JT : 1];
+        // training dumps: this lane's 32-byte slot in a (rows,512) array, row = [view*P +] point
+        bool valid[JT];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) valid[jt] = (long long)tile * MT + jt * 32 + pl < q.P;
+        const size_t dump_pooled = (((size_t)tile * MT + pl) * D_HID + (wv * IT) * 32 + h * 16) * 2;
 #pragma unroll 1
         for (int view = 0; view < NS; ++view) {
+            const size_t dump_view = dump_pooled + (size_t)view * (size_t)q.P * (D_HID * 2);
             __syncthreads();  // previous users of LDS_IN / LDS_META / LDS_Z are done
             PNR_T(PH_SYNC_TOP);
             geometry<P, RAYS>(q, smem, tile, view, tid);
             __syncthreads();
             PNR_T(PH_GEOMETRY);
-            gather<P>(q, smem, wv, lane);
+            if (TRAIN) {  // dump the lin_in operand rows (64 x 128 B) of this tile
+                const int row = tid >> 3, chunk = tid & 7;
+                const long long g = (long long)tile * MT + row;
+                if (tid < MT * 8 && g < q.P)
+                    *reinterpret_cast<u32x4 *>(q.d_in + (((long long)view * q.P + g) * D_IN_PAD + chunk * 8) * 2) =
+                        *reinterpret_cast<const u32x4 *>(smem + LDS_IN + row * ROW_IN + chunk * 16);
+            }
+            gather<P, TRAIN>(q, smem, wv, lane, tile, view);
             __syncthreads();
             PNR_T(PH_GATHER);
             add_bias<true>(x, bias_lane, B_IN_Z0);
@@ -427,8 +223,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
             PNR_T(PH_GEMM_IN_Z0);
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b)
-                res_block<P, TIMING>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr,
-                                     tid, tim, tlast);
+                res_block<P, TIMING, TRAIN>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
+                                            a_wr, tid, tim, tlast, q, dump_view, valid);
             if constexpr (MV) {
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
@@ -449,7 +245,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
         }
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b)
-            res_block<P, TIMING>(x, smem, b, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr, tid, tim, tlast);
+            res_block<P, TIMING, TRAIN>(x, smem, b, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr, tid, tim, tlast,
+                                        q, dump_pooled, valid);
 
         if (q.dbg) {
 #pragma unroll
@@ -471,24 +268,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) eval_kernel(const EvalParams q) {
                 for (int r = 0; r < 16; ++r) o[jt][r] = 0.f;
             const char *pf = R.wave_base + (size_t)R.pf_rs * (IT * 1024);
 #pragma unroll
-            for (int qk = 0; qk < 4; ++qk) {
+            for (int qk = 0; qk < 2 * IT; ++qk) {
                 const int xit = qk >> 1, rr = qk & 1;
-                const typename P::T8 a = R.r[qk >> 1][qk & 1];
+                const typename P::T8 a = R.r[qk / IT][qk % IT];
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
                     const f32x16 &v = x[xit][jt];
                     const typename P::T8 bq =
                         rr == 0 ? pack8<P, true>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
                                 : pack8<P, true>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
+                    if (TRAIN) {
+                        if (valid[jt])
+                            *reinterpret_cast<typename P::T8 *>(q.d_x5 + dump_pooled + (size_t)jt * 32 * (D_HID * 2) +
+                                                                xit * 64 + rr * 16) = bq;
+                    }
                     o[jt] = P::mfma(a, bq, o[jt]);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                R.r[j][0] = gload8<P>(pf + j * (IT * 1024));
-                R.r[j][1] = gload8<P>(pf + j * (IT * 1024) + 1024);
-            }
-            ring_advance4(R, NS);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) R.r[j][it] = gload8<P>(pf + j * (IT * 1024) + it * 1024);
+            AdvanceFwd::step4(R, NS);
             if (h == 0) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
@@ -522,6 +323,7 @@ template <int PREC, bool RAYS>
 static int launch(const EvalParams &q, bool mv, int grid, hipStream_t st) {
     hipError_t e;
     auto k = mv ? eval_kernel<PREC, RAYS, true> : eval_kernel<PREC, RAYS, false>;
+    if (RAYS && q.d_z) k = mv ? eval_kernel<PREC, true, true, false, true> : eval_kernel<PREC, true, false, false, true>;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_kernel)");
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -614,6 +416,23 @@ extern "C" int pnr_eval_ray_samples(const PnrScene *scene, const void *packed, i
     if (scene && (long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples: R != SB * rays_per_obj");
     pnr::EvalParams q = {};
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma; q.dbg = g_dbg_ptr;
+    return pnr::eval_common(scene, packed, precision, q, true, (hipStream_t)stream);
+}
+
+extern "C" int pnr_eval_ray_samples_train(const PnrScene *scene, const void *packed, int precision, const float *rays,
+                                          const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
+                                          const PnrTrainDumps *dumps, void *stream) {
+    if (R <= 0 || K <= 0 || rays_per_obj <= 0 || !rays || !z || !dumps)
+        return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_train: bad argument");
+    if (scene && (long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_train: R != SB * rays_per_obj");
+    if (!dumps->d_in || !dumps->d_z || !dumps->d_x5) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_train: null dump buffer");
+    pnr::EvalParams q = {};
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
+    q.d_in = (char *)dumps->d_in; q.d_z = (char *)dumps->d_z; q.d_x5 = (char *)dumps->d_x5;
+    for (int b = 0; b < 5; ++b) {
+        if (!dumps->d_a[b] || !dumps->d_n[b]) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_train: null dump buffer");
+        q.d_a[b] = (char *)dumps->d_a[b]; q.d_n[b] = (char *)dumps->d_n[b];
+    }
     return pnr::eval_common(scene, packed, precision, q, true, (hipStream_t)stream);
 }
 

@@ -63,10 +63,10 @@ __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
         const int k = feat_of(s >> 1, s & 1, 8 * h + e);
         v = src.w[f_out * D_HID + k];
     } else {
-        // lin_out: B operand = the wave's own accumulators; k-step q = 2*s + it covers
+        // lin_out: B operand = the wave's own accumulators; k-step q = IT*s + it covers
         // registers 8*(q&1)..+7 of the wave's feature tile (q>>1), for both lane halves.
         if (s < 2) {
-            const int q = 2 * s + it;
+            const int q = IT * s + it;
             const int k = feat_of(wv * IT + (q >> 1), h, 8 * (q & 1) + e);
             if (i < D_OUT) v = src.w[i * D_HID + k];
         }

@@ -71,6 +71,15 @@ class ResnetFC(nn.Module):
             self._packed[precision] = (fp, ops.pack_mlp(state, precision))
         return self._packed[precision][1]
 
+    def packed_bwd(self, precision="f16"):
+        """transposed weight streams for the backward data-gradient chain (training)."""
+        fp = self._fingerprint()
+        key = ("bwd", precision)
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != fp:
+            self._packed[key] = (fp, ops.pack_mlp(dict(self.state_dict()), precision, backward=True))
+        return self._packed[key][1]
+
     def forward(self, zx, combine_inner_dims=(1,), combine_index=None, dim_size=None):
         raise NotImplementedError(
             "ResnetFC.forward is fused into the HIP network kernel together with the feature lookup; "

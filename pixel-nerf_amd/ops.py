@@ -51,11 +51,7 @@ class PackedMLP:
         return ctypes.c_void_p(self.buf.data_ptr())
 
 
-def pack_mlp(state, precision="f16"):
-    """state: {reference ResnetFC state_dict key: float32 HIP tensor}
-    (src/model/resnetfc.py:66-130: lin_in, lin_out, blocks.N.fc_0/fc_1, lin_z.N)."""
-    lib = _lib.load()
-    prec = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+def _weights_struct(state):
     keep = {}
     for k in _MLP_KEYS:
         if k not in state:
@@ -74,10 +70,24 @@ def pack_mlp(state, precision="f16"):
         w.fc0_b[b] = keep[f"blocks.{b}.fc_0.bias"].data_ptr()
         w.fc1_w[b] = keep[f"blocks.{b}.fc_1.weight"].data_ptr()
         w.fc1_b[b] = keep[f"blocks.{b}.fc_1.bias"].data_ptr()
+    return w, keep
+
+
+def pack_mlp(state, precision="f16", backward=False):
+    """state: {reference ResnetFC state_dict key: float32 HIP tensor}
+    (src/model/resnetfc.py:66-130: lin_in, lin_out, blocks.N.fc_0/fc_1, lin_z.N).
+    backward=True packs the transposed streams of the data-gradient chain instead."""
+    lib = _lib.load()
+    prec = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+    w, keep = _weights_struct(state)
     dev = keep["lin_in.weight"].device
-    buf = torch.empty(lib.pnr_packed_mlp_bytes(), dtype=torch.uint8, device=dev)
+    nbytes = lib.pnr_packed_mlp_bwd_bytes() if backward else lib.pnr_packed_mlp_bytes()
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.pnr_pack_mlp(ctypes.byref(w), prec, _p(buf), _stream()), "pnr_pack_mlp")
+        if backward:
+            _lib.check(lib.pnr_pack_mlp_bwd(ctypes.byref(w), prec, _p(buf), _stream()), "pnr_pack_mlp_bwd")
+        else:
+            _lib.check(lib.pnr_pack_mlp(ctypes.byref(w), prec, _p(buf), _stream()), "pnr_pack_mlp")
     return PackedMLP(buf, prec)
 
 
@@ -302,3 +312,101 @@ def debug_phase_timing(scene, packed, rays, z):
     torch.cuda.synchronize()
     t = tim.cpu().reshape(8, len(PHASES))
     return {p: t[:, i].tolist() for i, p in enumerate(PHASES)}  # per wave
+
+
+# ------------------------------------------------------------------ training support
+
+
+def storage_perm(device=None):
+    """LongTensor perm (512): perm[e] = hidden feature stored at position e of a dump row."""
+    arr = (ctypes.c_int32 * 512)()
+    _lib.check(_lib.load().pnr_storage_perm(arr), "pnr_storage_perm")
+    return torch.tensor(list(arr), dtype=torch.long, device=device)
+
+
+class TrainDumps:
+    """16-bit dumps of every linear layer's input operand for P points x NS views."""
+
+    def __init__(self, P, NS, precision, device):
+        dt = torch.float16 if precision == _lib.PREC_F16 else torch.bfloat16
+        rv, rp = NS * P, P
+        self.P, self.NS, self.dtype = P, NS, dt
+        self.d_in = torch.empty((rv, 64), dtype=dt, device=device)
+        self.d_z = torch.empty((rv, 512), dtype=dt, device=device)
+        self.d_a = [torch.empty((rv if b < 3 else rp, 512), dtype=dt, device=device) for b in range(5)]
+        self.d_n = [torch.empty((rv if b < 3 else rp, 512), dtype=dt, device=device) for b in range(5)]
+        self.d_x5 = torch.empty((rp, 512), dtype=dt, device=device)
+        s = _lib.PnrTrainDumps()
+        s.d_in, s.d_z, s.d_x5 = self.d_in.data_ptr(), self.d_z.data_ptr(), self.d_x5.data_ptr()
+        for b in range(5):
+            s.d_a[b], s.d_n[b] = self.d_a[b].data_ptr(), self.d_n[b].data_ptr()
+        self.struct = s
+
+
+class BackwardDumps:
+    def __init__(self, fwd, device):
+        self.g_fc1 = [torch.empty_like(t) for t in fwd.d_n]
+        self.g_fc0 = [torch.empty_like(t) for t in fwd.d_a]
+        self.g_x0 = torch.empty_like(fwd.d_z)
+        s = _lib.PnrBackwardDumps()
+        s.g_x0 = self.g_x0.data_ptr()
+        for b in range(5):
+            s.g_fc1[b], s.g_fc0[b] = self.g_fc1[b].data_ptr(), self.g_fc0[b].data_ptr()
+        self.struct = s
+
+
+def eval_ray_samples_train(scene, packed, rays, z):
+    """eval_ray_samples + TrainDumps."""
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z = _f32(z, "z", (R, None))
+    K = z.shape[1]
+    dumps = TrainDumps(R * K, scene.NS, packed.precision, rays.device)
+    out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.pnr_eval_ray_samples_train(scene.ref, packed.ptr, packed.precision, _p(rays), _p(z), R,
+                                                  max(R // scene.SB, 1), K, _p(out), ctypes.byref(dumps.struct),
+                                                  _stream()), "pnr_eval_ray_samples_train")
+    return out, dumps
+
+
+def composite_backward(rays, z, rgbsigma, white_bkgd, d_rgb, d_depth=None, d_weights=None):
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z = _f32(z, "z", (R, None))
+    K = z.shape[1]
+    rgbsigma = _f32(rgbsigma, "rgbsigma", (R, K, 4))
+    d_rgb = _f32(d_rgb, "d_rgb", (R, 3))
+    d_depth = None if d_depth is None else _f32(d_depth, "d_depth", (R,))
+    d_weights = None if d_weights is None else _f32(d_weights, "d_weights", (R, K))
+    out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.pnr_composite_backward(_p(rays), _p(z), _p(rgbsigma), R, K, int(bool(white_bkgd)), _p(d_rgb),
+                                              _p(d_depth), _p(d_weights), _p(out), _stream()), "pnr_composite_backward")
+    return out
+
+
+def mlp_backward(packed_bwd, fwd_dumps, g_out, grad_scale):
+    lib = _lib.load()
+    g_out = _f32(g_out, "g_out", (fwd_dumps.P, 4))
+    out = BackwardDumps(fwd_dumps, g_out.device)
+    with torch.cuda.device(g_out.device):
+        _lib.check(lib.pnr_mlp_backward(packed_bwd.ptr, packed_bwd.precision, ctypes.byref(fwd_dumps.struct), _p(g_out),
+                                        float(grad_scale), fwd_dumps.P, fwd_dumps.NS, ctypes.byref(out.struct),
+                                        _stream()), "pnr_mlp_backward")
+    return out
+
+
+def latent_scatter(scene, rays, z, d_zlat, d_latent_nhwc):
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z = _f32(z, "z", (R, None))
+    K = z.shape[1]
+    d_zlat = _f32(d_zlat, "d_zlat", (scene.NS * R * K, 512))
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.pnr_latent_scatter(scene.ref, _p(rays), _p(z), R, max(R // scene.SB, 1), K, _p(d_zlat),
+                                          _p(d_latent_nhwc), _stream()), "pnr_latent_scatter")
+    return d_latent_nhwc

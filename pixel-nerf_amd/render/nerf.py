@@ -148,10 +148,17 @@ class NeRFRenderer(torch.nn.Module):
             if self.training and self.noise_std > 0.0:
                 raise NotImplementedError("noise_std > 0 (unused by every shipped config) is not fused")
             model._check_supported()
-            model._no_autograd()
-            res = ops.render_forward(model.scene(), model.packed(True), model.packed(False) if Kf > 0 else None,
-                                     rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
-                                     white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights)
+            needs_grad = torch.is_grad_enabled() and (
+                any(p.requires_grad for p in model.mlp_coarse.parameters())
+                or (model.mlp_fine is not None and any(p.requires_grad for p in model.mlp_fine.parameters()))
+                or (model.encoder.latent.requires_grad and not model.stop_encoder_grad))
+            if needs_grad:  # training: differentiable path (HIP forward with operand dumps + HIP backward)
+                from ..autograd import render_autograd
+                res = render_autograd(self, model, rays, noise, want_weights)
+            else:
+                res = ops.render_forward(model.scene(), model.packed(True), model.packed(False) if Kf > 0 else None,
+                                         rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
+                                         white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights)
             outputs = DotMap(coarse=self._format(res["coarse"], SB, want_weights))
             if Kf > 0:
                 outputs.fine = self._format(res["fine"], SB, want_weights)
