@@ -88,8 +88,8 @@ def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS):
 
 
 class _RenderFunction(torch.autograd.Function):
-    """inputs: cfg (python object), rays (R,8), latent (SB*NS,512,Hl,Wl), 26 coarse params,
-    26 fine params (or the coarse ones again when mlp_fine is None).
+    """inputs: cfg (python object), rays (R,8), latent (SB*NS,512,Hl,Wl), 30 coarse params,
+    30 fine params (or the coarse ones again when mlp_fine is None).
     outputs: rgb_c, depth_c, weights_c[, rgb_f, depth_f, weights_f]."""
 
     @staticmethod
