@@ -85,6 +85,19 @@ def cpu_baseline(scene, mlps, rays_sample, noise, threads=None):
     return rays_sample.shape[0] / dt, dt, out
 
 
+def pmc_traffic_per_launch():
+    """HBM-side bytes per fused-kernel launch from the committed rocprofv3 PMC passes of THIS
+    command (profiles/r01_bench_f16_pmc_eval_kernel.json: separate --pmc runs for FETCH_SIZE and
+    WRITE_SIZE, KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction; average
+    over the coarse and fine launches, like `achieved`).  None when the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_f16_pmc_eval_kernel.json")
+    try:
+        d = json.load(open(path))
+        return (2.0 * d["FETCH_SIZE"]["avg_per_launch"] + d["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
+    except Exception:
+        return None
+
+
 def eager_gpu_baseline(scene, mlps, rays, dev, n=16384):
     """The north_star's "reference single-GPU" comparison point: the same eager PyTorch fp32
     code path (the oracle restatement of the reference, with F.grid_sample like the reference
@@ -201,7 +214,12 @@ def main():
                        "rays_per_gpu_per_step": R, "n_coarse": 64, "n_fine": 128, "n_fine_depth": 16,
                        "source_views": NS, "api": "NeRFRenderer.bind_parallel(net, simple_output=True)(rays)"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.prec], "unit": "TFLOP/s",
-                         "frac": ach / PEAK_TFLOPS[args.prec], "traffic": None,
+                         "frac": ach / PEAK_TFLOPS[args.prec],
+                         "traffic": pmc_traffic_per_launch() if (args.prec == "f16" and R == 65536) else None,
+                         "traffic_note": "bytes per launch at the L2<->fabric interface (Infinity-Cache hits included): "
+                                         "2*FETCH_SIZE + WRITE_SIZE from profiles/r01_bench_f16_pmc_eval_kernel.json; "
+                                         "algorithmic HBM bytes per launch are ~0.18 GB (z in, rgb-sigma out, weights+grid once), "
+                                         "the excess is the weight stream's L2 misses served on-die",
                          "kernel": "pnr::eval_kernel (fused per-point network)", "launches": n_launch,
                          "avg_launch_ms": kern_ms / max(n_launch, 1),
                          "flop_per_ray": flop_per_ray, "kernel_time_frac_of_step": kern_ms * 1e-3 / elapsed},

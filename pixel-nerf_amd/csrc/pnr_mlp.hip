@@ -89,12 +89,14 @@ __device__ __forceinline__ void geometry(const EvalParams &q, char *smem, int ti
 template <typename P, bool TRAIN>
 __device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, int lane, int tile, int view) {
     const float *lat = q.latent + lane * 8;
-#pragma unroll 2
-    for (int i = 0; i < MT / NW; i += 2) {
-        f32x4 v[2][4][2];
-        f32x4 w[2];
+    constexpr int GB = 4;  // points per batch: one L2 round trip covers GB points (32 loads in flight)
+    static_assert((MT / NW) % GB == 0, "gather batch");
+#pragma unroll 1
+    for (int i = 0; i < MT / NW; i += GB) {
+        f32x4 v[GB][4][2];
+        f32x4 w[GB];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < GB; ++u) {
             const int p = wv * (MT / NW) + i + u;
             const u32x4 off = *reinterpret_cast<const u32x4 *>(smem + LDS_META + p * 32);
             w[u] = *reinterpret_cast<const f32x4 *>(smem + LDS_META + p * 32 + 16);
@@ -106,7 +108,7 @@ __device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, 
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < GB; ++u) {
             const int p = wv * (MT / NW) + i + u;
             float r[8];
 #pragma unroll
