@@ -89,11 +89,12 @@ int pnr_sample_coarse(const float *rays, const float *u1, int R, int Kc, int lin
 /* NeRFRenderer.sample_fine + sample_fine_depth + cat + sort, src/render/nerf.py:120-161 and
  * :285-295.  weights_c (R,Kc), depth_c (R), z_coarse (R,Kc); u2,u3 (R,Kimp) uniforms (:135,
  * :141), n4 (R,Kfd) normals (:158); Kimp = n_fine - n_fine_depth.  Either count may be 0
- * (the pointers are then ignored).  z_sorted (R, Kc+Kimp+Kfd) ascending. */
+ * (the pointers are then ignored).  z_sorted (R, Kc+Kimp+Kfd) ascending.  depth_ranks (may be
+ * NULL): (R,Kfd) position of every depth sample in z_sorted (training: the sort's permutation). */
 int pnr_sample_fine(const float *rays, const float *weights_c, const float *depth_c,
                     const float *z_coarse, const float *u2, const float *u3, const float *n4,
                     int R, int Kc, int Kimp, int Kfd, float depth_std, int lindisp,
-                    float *z_sorted, void *stream);
+                    float *z_sorted, int32_t *depth_ranks, void *stream);
 
 /* ---- the fused per-point network ---------------------------------------------------------
  * PixelNeRFNet.forward, src/model/models.py:146-266, including PositionalEncoding
@@ -150,11 +151,21 @@ size_t pnr_packed_mlp_bwd_bytes(void);
 int pnr_pack_mlp_bwd(const PnrMlpWeights *w /*host struct of device ptrs*/, int precision,
                      void *packed_bwd, void *stream);
 
-/* Backward of pnr_composite (src/render/nerf.py:223-249 under autograd; z treated as constant).
- * d_weights may be NULL.  d_rgbsigma (R,K,4) = dL/d(model output) AFTER sigmoid/relu. */
+/* Backward of pnr_composite (src/render/nerf.py:178-182,223-249 under autograd).
+ * d_depth / d_weights may be NULL.  d_rgbsigma (R,K,4) = dL/d(model output) AFTER sigmoid/relu;
+ * d_z (R,K) (may be NULL) = dL/dz through the deltas and depth = sum w z. */
 int pnr_composite_backward(const float *rays, const float *z, const float *rgbsigma, int R, int K,
                            int white_bkgd, const float *d_rgb, const float *d_depth,
-                           const float *d_weights, float *d_rgbsigma, void *stream);
+                           const float *d_weights, float *d_rgbsigma, float *d_z, void *stream);
+
+/* dL/dz of the sample positions through the network inputs (x = o + z d: positional code,
+ * models.py:169-182 / code.py:37-41, and projection + bilinear lookup, models.py:206-215 /
+ * encoder.py:96-109 with grid_sample's border-clip gradient).  d_in42 (rows_v,42) and d_zlat
+ * (rows_v,512) fp32 are dL/d(lin_in operand) and dL/d(interpolated latent); d_z (R,K) is
+ * accumulated (atomic adds; caller zero-initialises or passes the compositing d_z). */
+int pnr_position_backward(const PnrScene *scene /*host*/, const float *rays, const float *z, int R,
+                          int rays_per_obj, int K, const float *d_in42, const float *d_zlat,
+                          float *d_z, void *stream);
 
 /* Fused data-gradient chain of one ResnetFC (reverse of src/model/resnetfc.py:132-184).
  * g_out (P,4) = dL/d(lin_out output) (pre sigmoid/relu), grad_scale = power of two the chain is

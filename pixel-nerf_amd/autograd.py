@@ -10,11 +10,13 @@ backward : HIP kernels for everything that is not a plain GEMM --
            and library GEMMs (torch.matmul -> rocBLAS/hipBLASLt) for the weight gradients
            dW = dY^T X and the latent gradient sum_b dY_b W_z[b], which are plain dense GEMMs
            over the dumped operands.
+             pnr_position_backward    d(network inputs)           -> d(sample positions z)
 Gradients flow to every ResnetFC parameter of both networks and to `encoder.latent` (hence into
-the ResNet-34 through PyTorch autograd).  Sample positions are constants: the one position
-gradient of the reference (through the n_fine_depth samples, nerf.py:292) is not propagated
-(measured effect on the reference's own gradients: 0.2 % on MLP weights, 1.4 % on the latent,
-SURVEY.md §3.3).
+the ResNet-34 through PyTorch autograd), including the reference's one position-gradient path:
+fine loss -> positions of the n_fine_depth samples (compositing deltas/depth, positional code,
+projection + bilinear lookup) -> sort permutation -> clamp -> coarse depth (nerf.py:157-160,292)
+-> coarse network.  Coarse and importance samples carry no gradient in the reference either
+(rays are inputs, importance weights are detached, nerf.py:288).
 """
 import math
 
@@ -44,9 +46,9 @@ def _param_names():
 PARAM_NAMES = _param_names()
 
 
-def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS):
-    """All parameter gradients of one ResnetFC + d(interpolated latent) from one backward pass.
-    fwd: ops.TrainDumps of the forward; g_out (P,4) fp32 = dL/d(lin_out output)."""
+def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS, want_d_in=False):
+    """All parameter gradients of one ResnetFC + d(interpolated latent) [+ d(lin_in operand)] from
+    one backward pass.  fwd: ops.TrainDumps of the forward; g_out (P,4) fp32 = dL/d(lin_out output)."""
     dev = g_out.device
     perm, inv = _perms(dev)
     gmax = float(g_out.abs().max())
@@ -84,7 +86,10 @@ def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS):
     grads["lin_in.bias"] = (g0f.sum(0) * inv_s)[inv]
     grads["lin_out.weight"] = torch.matmul(g_out.t(), fwd.d_x5.float())[:, inv]
     grads["lin_out.bias"] = g_out.sum(0)
-    return grads, d_zlat.contiguous()
+    d_in = None
+    if want_d_in:  # dL/d(code | viewdir) = dY(lin_in) W_in   (rows_v, 42)
+        d_in = (torch.matmul(g0f, mlp_state["lin_in.weight"].detach()[perm]) * inv_s).contiguous()
+    return grads, d_zlat.contiguous(), d_in
 
 
 class _RenderFunction(torch.autograd.Function):
@@ -106,11 +111,12 @@ class _RenderFunction(torch.autograd.Function):
         passes.append(dict(z=z_c, rgbs=rgbs_c, dumps=dumps_c, coarse=True))
         outs = [rgb_c, depth_c, w_c]
         if Kf > 0:
-            z_f = ops.sample_fine(rays, w_c, depth_c, z_c, noise.get("u2"), noise.get("u3"),
-                                  noise.get("n4") if Kfd > 0 else None, cfg["depth_std"], cfg["lindisp"])
+            n4 = noise.get("n4") if Kfd > 0 else None
+            z_f, ranks = ops.sample_fine(rays, w_c, depth_c, z_c, noise.get("u2"), noise.get("u3"), n4,
+                                         cfg["depth_std"], cfg["lindisp"], want_ranks=True)
             rgbs_f, dumps_f = ops.eval_ray_samples_train(scene, pf, rays, z_f)
             w_f, rgb_f, depth_f = ops.composite(rays, z_f, rgbs_f, cfg["white_bkgd"], want_weights=True)
-            passes.append(dict(z=z_f, rgbs=rgbs_f, dumps=dumps_f, coarse=False))
+            passes.append(dict(z=z_f, rgbs=rgbs_f, dumps=dumps_f, coarse=False, ranks=ranks, n4=n4, depth_c=depth_c))
             outs += [rgb_f, depth_f, w_f]
         ctx.cfg, ctx.rays, ctx.scene, ctx.passes = cfg, rays, scene, passes
         ctx.latent_shape = latent.shape
@@ -127,25 +133,40 @@ class _RenderFunction(torch.autograd.Function):
                             dtype=torch.float32, device=dev) if need_latent else None
         shared = net.mlp_fine is None  # fine pass ran on the coarse network (models.py:242)
         gsum = [None, None]
-        for i, ps in enumerate(ctx.passes):
+        extra_depth = None  # dL/d(coarse depth) arriving through the fine pass's depth samples
+        for i in reversed(range(len(ctx.passes))):  # fine first: it feeds a depth gradient to coarse
+            ps = ctx.passes[i]
             d_rgb, d_depth, d_w = gouts[3 * i], gouts[3 * i + 1], gouts[3 * i + 2]
             R, K = ps["z"].shape
             if d_rgb is None:
                 d_rgb = torch.zeros((R, 3), device=dev)
-            d_rgbs = ops.composite_backward(rays, ps["z"], ps["rgbs"], cfg["white_bkgd"], d_rgb.contiguous().float(),
-                                            None if d_depth is None else d_depth.contiguous().float(),
-                                            None if d_w is None else d_w.contiguous().float())
+            if ps["coarse"] and extra_depth is not None:
+                d_depth = extra_depth if d_depth is None else d_depth + extra_depth
+            pos = (not ps["coarse"]) and ps.get("ranks") is not None  # depth samples exist
+            cb = ops.composite_backward(rays, ps["z"], ps["rgbs"], cfg["white_bkgd"], d_rgb.contiguous().float(),
+                                        None if d_depth is None else d_depth.contiguous().float(),
+                                        None if d_w is None else d_w.contiguous().float(), want_dz=pos)
+            d_rgbs, dz = cb if pos else (cb, None)
             # through the output activations (models.py:260-265): sigmoid on rgb, relu on sigma
             s = ps["rgbs"][..., :3]
             g_out = torch.cat([d_rgbs[..., :3] * s * (1 - s),
                                d_rgbs[..., 3:] * (ps["rgbs"][..., 3:] > 0).float()], dim=-1).reshape(-1, 4).contiguous()
             mlp = net.mlp_coarse if (ps["coarse"] or shared) else net.mlp_fine
             state = dict(mlp.named_parameters())
-            grads, d_zlat = _mlp_grads(state, mlp.packed_bwd(net.precision), ps["dumps"], g_out, scene.NS)
+            grads, d_zlat, d_in = _mlp_grads(state, mlp.packed_bwd(net.precision), ps["dumps"], g_out, scene.NS,
+                                             want_d_in=pos)
             slot = 0 if (ps["coarse"] or shared) else 1
             gsum[slot] = grads if gsum[slot] is None else {k: gsum[slot][k] + v for k, v in grads.items()}
             if need_latent:
                 ops.latent_scatter(scene, rays, ps["z"], d_zlat, d_lat)
+            if pos:
+                # dL/dz of every fine sample: compositing part (dz) + network-input part
+                ops.position_backward(scene, rays, ps["z"], d_in, d_zlat, dz)
+                # only the depth samples carry gradient: undo the sort, apply the clamp's mask
+                # z = max(min(depth + n*std, far), near)   (nerf.py:157-160)
+                zraw = ps["depth_c"].unsqueeze(1) + ps["n4"] * cfg["depth_std"]
+                live = ((zraw < rays[:, 7:8]) & (zraw > rays[:, 6:7])).float()
+                extra_depth = (dz.gather(1, ps["ranks"].long()) * live).sum(1)
         out = [None, None, d_lat.permute(0, 3, 1, 2).contiguous() if need_latent else None]
         n_each = len(PARAM_NAMES)
         for slot in range(ctx.n_params // n_each):

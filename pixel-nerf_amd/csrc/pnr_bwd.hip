@@ -8,11 +8,11 @@
 //                         forward's 16-bit activation dumps; every layer's output gradient dY is
 //                         written as 16-bit rows for the weight-gradient GEMMs dW = dY^T X.
 //   composite_bwd_kernel  backward of the alpha compositing (nerf.py:223-249), wavefront per ray.
+//                         also emits dL/dz through the deltas and depth = sum w z.
 //   latent_scatter_kernel d(interpolated latent) -> d(feature grid): bilinear scatter-add.
-//
-// Sample positions are treated as constants: the reference's only position gradient is the one
-// through the n_fine_depth samples (nerf.py:292), a 0.2-1.4 % effect that is not
-// propagated yet.
+//   position_bwd_kernel   dL/dz through the network inputs (positional code, projection, bilinear
+//                         coordinates): the reference's position gradient through the n_fine_depth
+//                         samples (nerf.py:292).
 #include <hip/hip_runtime.h>
 
 #include "pnr_common.h"
@@ -259,8 +259,8 @@ __device__ __forceinline__ float wscan_add(float v, int lane) {
 template <int PASS>
 __device__ __forceinline__ float composite_bwd_pass(const float *zr, const float4 *cr, const float *dwr, int K, float far,
                                                     float3 drgb, float ddepth, float gwhite, int lane, float total,
-                                                    float4 *dout) {
-    float carry = 1.f, run = 0.f, acc = 0.f;
+                                                    float4 *dout, float *dzout) {
+    float carry = 1.f, run = 0.f, acc = 0.f, ddelta_prev = 0.f;
     for (int c0 = 0; c0 < K; c0 += 64) {
         const int i = c0 + lane;
         const bool valid = i < K;
@@ -287,10 +287,20 @@ __device__ __forceinline__ float composite_bwd_pass(const float *zr, const float
         } else {
             const float pre = wscan_add(gw, lane) + run;   // sum_{j<=i} g_j w_j
             const float suffix = total - pre;              // sum_{j>i}
+            float ddelta = 0.f;
             if (valid) {
                 const float dalpha = g * T - suffix / tf;
                 const float dsigma = cs.w > 0.f ? dalpha * delta * ex : 0.f;
                 dout[i] = make_float4(w * drgb.x, w * drgb.y, w * drgb.z, dsigma);
+                ddelta = dalpha * fmaxf(cs.w, 0.f) * ex;  // d alpha_i / d delta_i = relu(sigma) exp(-delta relu(sigma))
+            }
+            if (dzout) {
+                // delta_i = z_{i+1} - z_i (last: far - z_i), depth = sum w z:
+                //   dL/dz_i = w_i d_depth - ddelta_i + ddelta_{i-1}
+                float up = __shfl_up(ddelta, 1, 64);
+                if (lane == 0) up = ddelta_prev;
+                if (valid) dzout[i] = w * ddepth - ddelta + up;
+                ddelta_prev = __shfl(ddelta, 63, 64);
             }
             run = __shfl(pre, 63, 64);
         }
@@ -302,7 +312,7 @@ __device__ __forceinline__ float composite_bwd_pass(const float *zr, const float
 __global__ void __launch_bounds__(CW * 64)
 composite_bwd_kernel(const float *__restrict__ rays, const float *__restrict__ z, const float4 *__restrict__ rgbs, int R,
                      int K, int white_bkgd, const float *__restrict__ d_rgb, const float *__restrict__ d_depth,
-                     const float *__restrict__ d_w, float4 *__restrict__ d_rgbs) {
+                     const float *__restrict__ d_w, float4 *__restrict__ d_rgbs, float *__restrict__ d_z) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * CW + wv;
     if (r >= R) return;
@@ -313,8 +323,9 @@ composite_bwd_kernel(const float *__restrict__ rays, const float *__restrict__ z
     const float *zr = z + (size_t)r * K;
     const float4 *cr = rgbs + (size_t)r * K;
     const float *dwr = d_w ? d_w + (size_t)r * K : nullptr;
-    const float total = composite_bwd_pass<0>(zr, cr, dwr, K, far, drgb, ddepth, gwhite, lane, 0.f, nullptr);
-    composite_bwd_pass<1>(zr, cr, dwr, K, far, drgb, ddepth, gwhite, lane, total, d_rgbs + (size_t)r * K);
+    const float total = composite_bwd_pass<0>(zr, cr, dwr, K, far, drgb, ddepth, gwhite, lane, 0.f, nullptr, nullptr);
+    composite_bwd_pass<1>(zr, cr, dwr, K, far, drgb, ddepth, gwhite, lane, total, d_rgbs + (size_t)r * K,
+                          d_z ? d_z + (size_t)r * K : nullptr);
 }
 
 // ---------------------------------------------------------------- latent scatter-add
@@ -349,6 +360,85 @@ latent_scatter_kernel(const EvalParams q, const float *__restrict__ d_zlat, floa
             atomicAdd(dst + e, w * a[e]);
             atomicAdd(dst + 4 + e, w * b[e]);
         }
+    }
+}
+
+// dL/dz through the network inputs; one wavefront per (view, point).
+__global__ void __launch_bounds__(CW * 64)
+position_bwd_kernel(const EvalParams q, const float *__restrict__ d_in42, const float *__restrict__ d_zlat,
+                    float *__restrict__ d_z) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * CW + wv;  // view * P + point
+    if (idx >= q.P * q.NS) return;
+    const int view = (int)(idx / q.P);
+    const int g = (int)(idx % q.P);
+    const int r = g / q.K;
+    const float *ray = q.rays + (size_t)r * 8;
+    const float zz = q.z[g];
+    const float X = ray[0] + zz * ray[3], Y = ray[1] + zz * ray[4], Z = ray[2] + zz * ray[5];
+    const int obj = r / q.per_obj;
+    const float *pose = q.poses + (size_t)(obj * q.NS + view) * 12;
+    const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
+    const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
+    const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
+    const float xc0 = xr0 + pose[3], xc1 = xr1 + pose[7], xc2 = xr2 + pose[11];
+    const float *fo = q.focal + (q.n_focal > 1 ? obj * 2 : 0);
+    const float *cc = q.c + (q.n_c > 1 ? obj * 2 : 0);
+    const float u = -xc0 / xc2 * fo[0] + cc[0], v = -xc1 / xc2 * fo[1] + cc[1];
+    const float Wl = (float)q.Wl, Hl = (float)q.Hl;
+    const float sx = Wl / (Wl - 1.f) * 2.f / q.img_w, sy = Hl / (Hl - 1.f) * 2.f / q.img_h;
+    float ix = ((u * sx - 1.f + 1.f) / 2.f) * (Wl - 1.f), iy = ((v * sy - 1.f + 1.f) / 2.f) * (Hl - 1.f);
+    // grid_sample border padding: clip_coordinates_set_grad -> gradient 0 outside (0, size-1)
+    const bool gx_on = ix > 0.f && ix < Wl - 1.f, gy_on = iy > 0.f && iy < Hl - 1.f;
+    ix = fminf(Wl - 1.f, fmaxf(ix, 0.f));
+    iy = fminf(Hl - 1.f, fmaxf(iy, 0.f));
+    float six = 0.f, siy = 0.f;
+    if ((gx_on || gy_on) && ix == ix && iy == iy) {
+        const float ix0 = floorf(ix), iy0 = floorf(iy);
+        const int x0 = (int)ix0, y0 = (int)iy0;
+        const int x1 = min(x0 + 1, q.Wl - 1), y1 = min(y0 + 1, q.Hl - 1);
+        const float ax = ix - ix0, ay = iy - iy0;  // fractional parts
+        const size_t rowbase = (size_t)(obj * q.NS + view) * (size_t)(q.Hl * q.Wl);
+        const float *nw = q.latent + (rowbase + (size_t)y0 * q.Wl + x0) * C_LAT + lane * 8;
+        const float *ne = q.latent + (rowbase + (size_t)y0 * q.Wl + x1) * C_LAT + lane * 8;
+        const float *sw = q.latent + (rowbase + (size_t)y1 * q.Wl + x0) * C_LAT + lane * 8;
+        const float *se = q.latent + (rowbase + (size_t)y1 * q.Wl + x1) * C_LAT + lane * 8;
+        const float *dz = d_zlat + (size_t)idx * C_LAT + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = nw[e], b = ne[e], c = sw[e], d = se[e], gq = dz[e];
+            six += gq * ((1.f - ay) * (b - a) + ay * (d - c));   // d zlat / d ix
+            siy += gq * ((1.f - ax) * (c - a) + ax * (d - b));   // d zlat / d iy
+        }
+    }
+    six = wsum(six);
+    siy = wsum(siy);
+    if (lane == 0) {
+        const float du = gx_on ? six * (Wl - 1.f) * 0.5f * sx : 0.f;
+        const float dv = gy_on ? siy * (Hl - 1.f) * 0.5f * sy : 0.f;
+        // u = -xc0/xc2 fx + cx ; v = -xc1/xc2 fy + cy   (fy already negated in `focal`)
+        float g0 = -fo[0] / xc2 * du;
+        float g1 = -fo[1] / xc2 * dv;
+        float g2 = (xc0 * fo[0] * du + xc1 * fo[1] * dv) / (xc2 * xc2);
+        // positional code: [x, sin(f_k x), sin(f_k x + pi/2)] , f_k = 1.5 * 2^k  (code.py:37-41)
+        const float *gi = d_in42 + (size_t)idx * D_IN;
+        const float xr[3] = {xr0, xr1, xr2};
+        float gc[3] = {gi[0], gi[1], gi[2]};
+        const float HALF_PI = 1.57079637050628662109375f;
+        for (int k = 0; k < 6; ++k) {
+            const float f = 1.5f * (float)(1 << k);
+            for (int c = 0; c < 3; ++c) {
+                const float a = xr[c] * f;
+                gc[c] += f * (cosf(a) * gi[3 + 6 * k + c] + cosf(a + HALF_PI) * gi[3 + 6 * k + 3 + c]);
+            }
+        }
+        g0 += gc[0]; g1 += gc[1]; g2 += gc[2];
+        // x_world gradient = R^T g ; dz = ray_dir . that
+        const float wx = pose[0] * g0 + pose[4] * g1 + pose[8] * g2;
+        const float wy = pose[1] * g0 + pose[5] * g1 + pose[9] * g2;
+        const float wz = pose[2] * g0 + pose[6] * g1 + pose[10] * g2;
+        const float val = ray[3] * wx + ray[4] * wy + ray[5] * wz;
+        if (val == val) atomicAdd(d_z + g, val);
     }
 }
 #pragma clang fp contract(fast)
@@ -418,13 +508,29 @@ extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const Pnr
 
 extern "C" int pnr_composite_backward(const float *rays, const float *z, const float *rgbsigma, int R, int K, int white_bkgd,
                                       const float *d_rgb, const float *d_depth, const float *d_weights, float *d_rgbsigma,
-                                      void *stream) {
+                                      float *d_z, void *stream) {
     if (R < 0 || K <= 0) return pnr_fail(PNR_E_INVALID, "pnr_composite_backward: bad sizes");
     if (R == 0) return PNR_OK;
     if (!rays || !z || !rgbsigma || !d_rgb || !d_rgbsigma) return pnr_fail(PNR_E_INVALID, "pnr_composite_backward: null argument");
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + CW - 1) / CW), dim3(CW * 64), 0, (hipStream_t)stream, rays, z,
-                       (const float4 *)rgbsigma, R, K, white_bkgd, d_rgb, d_depth, d_weights, (float4 *)d_rgbsigma);
+                       (const float4 *)rgbsigma, R, K, white_bkgd, d_rgb, d_depth, d_weights, (float4 *)d_rgbsigma, d_z);
     return pnr_check_launch("pnr_composite_backward");
+}
+
+extern "C" int pnr_position_backward(const PnrScene *s, const float *rays, const float *z, int R, int rays_per_obj, int K,
+                                     const float *d_in42, const float *d_zlat, float *d_z, void *stream) {
+    if (!s || !rays || !z || !d_in42 || !d_zlat || !d_z || R <= 0 || K <= 0 || rays_per_obj <= 0)
+        return pnr_fail(PNR_E_INVALID, "pnr_position_backward: bad argument");
+    if ((long long)rays_per_obj * s->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_position_backward: R != SB * rays_per_obj");
+    EvalParams q = {};
+    q.latent = s->latent_nhwc; q.poses = s->poses; q.focal = s->focal; q.c = s->c;
+    q.SB = s->SB; q.NS = s->NS; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
+    q.img_w = s->img_w; q.img_h = s->img_h;
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
+    const long long n = q.P * q.NS;
+    hipLaunchKernelGGL(position_bwd_kernel, dim3((unsigned)((n + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream, q,
+                       d_in42, d_zlat, d_z);
+    return pnr_check_launch("pnr_position_backward");
 }
 
 extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const float *z, int R, int rays_per_obj, int K,

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64)
 sample_fine_kernel(const float *__restrict__ rays, const float *__restrict__ wc, const float *__restrict__ depth_c,
                    const float *__restrict__ zc, const float *__restrict__ u2, const float *__restrict__ u3,
                    const float *__restrict__ n4, int R, int Kc, int Kimp, int Kfd, float depth_std, int lindisp,
-                   float *__restrict__ zout) {
+                   float *__restrict__ zout, int *__restrict__ depth_ranks) {
     __shared__ float s_cdf[WAVES_PER_BLOCK][MAX_KC + 1];
     __shared__ float s_z[WAVES_PER_BLOCK][MAX_KTOT];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -127,6 +127,7 @@ sample_fine_kernel(const float *__restrict__ rays, const float *__restrict__ wc,
             rank += (o < v || (o == v && j < e)) ? 1 : 0;
         }
         zout[(size_t)r * Ktot + rank] = v;
+        if (depth_ranks && e >= Kc + Kimp) depth_ranks[(size_t)r * Kfd + (e - Kc - Kimp)] = rank;
     }
 }
 
@@ -216,7 +217,7 @@ extern "C" int pnr_sample_coarse(const float *rays, const float *u1, int R, int 
 
 extern "C" int pnr_sample_fine(const float *rays, const float *weights_c, const float *depth_c, const float *z_coarse,
                                const float *u2, const float *u3, const float *n4, int R, int Kc, int Kimp, int Kfd,
-                               float depth_std, int lindisp, float *z_sorted, void *stream) {
+                               float depth_std, int lindisp, float *z_sorted, int32_t *depth_ranks, void *stream) {
     if (R < 0 || Kc <= 0 || Kimp < 0 || Kfd < 0) return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: bad sizes");
     if (Kc > MAX_KC || Kc + Kimp + Kfd > MAX_KTOT)
         return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: supports n_coarse <= 256 and n_coarse + n_fine <= 512");
@@ -225,7 +226,7 @@ extern "C" int pnr_sample_fine(const float *rays, const float *weights_c, const 
         return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: null argument");
     hipLaunchKernelGGL(sample_fine_kernel, dim3((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(WAVES_PER_BLOCK * 64),
                        0, (hipStream_t)stream, rays, weights_c, depth_c, z_coarse, u2, u3, n4, R, Kc, Kimp, Kfd,
-                       depth_std, lindisp, z_sorted);
+                       depth_std, lindisp, z_sorted, depth_ranks);
     return pnr_check_launch("pnr_sample_fine");
 }
 
@@ -285,7 +286,7 @@ extern "C" int pnr_render_forward(const PnrScene *scene, const void *packed_coar
     if ((rc = pnr_composite(rays, z_c, rgbs_c, R, Kc, white_bkgd, w_c, rgb_c, depth_c, stream))) return rc;
     if (Kf > 0) {
         const void *pf = packed_fine ? packed_fine : packed_coarse;  // models.py:242
-        if ((rc = pnr_sample_fine(rays, w_c, depth_c, z_c, u2, u3, n4, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, stream))) return rc;
+        if ((rc = pnr_sample_fine(rays, w_c, depth_c, z_c, u2, u3, n4, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, nullptr, stream))) return rc;
         if ((rc = pnr_eval_ray_samples(scene, pf, precision, rays, z_f, R, rays_per_obj, Kc + Kf, rgbs_f, stream))) return rc;
         if ((rc = pnr_composite(rays, z_f, rgbs_f, R, Kc + Kf, white_bkgd, weights_f, rgb_f, depth_f, stream))) return rc;
     }

@@ -150,9 +150,10 @@ def sample_coarse(rays, u1, lindisp=False):
     return z
 
 
-def sample_fine(rays, weights_c, depth_c, z_coarse, u2, u3, n4, depth_std=0.01, lindisp=False):
+def sample_fine(rays, weights_c, depth_c, z_coarse, u2, u3, n4, depth_std=0.01, lindisp=False, want_ranks=False):
     """-> z_sorted (R, Kc + Kimp + Kfd).  u2/u3 may be None (no importance samples), n4 may be
-    None (no depth samples)."""
+    None (no depth samples).  want_ranks: also return (R,Kfd) int32 positions of the depth samples
+    in z_sorted."""
     lib = _lib.load()
     rays = _f32(rays, "rays", (None, 8))
     R = rays.shape[0]
@@ -166,12 +167,13 @@ def sample_fine(rays, weights_c, depth_c, z_coarse, u2, u3, n4, depth_std=0.01, 
     if Kfd:
         depth_c, n4 = _f32(depth_c, "depth_c", (R,)), _f32(n4, "n4", (R, Kfd))
     z = torch.empty((R, Kc + Kimp + Kfd), dtype=torch.float32, device=rays.device)
+    ranks = torch.empty((R, Kfd), dtype=torch.int32, device=rays.device) if (want_ranks and Kfd) else None
     with torch.cuda.device(rays.device):
         _lib.check(lib.pnr_sample_fine(_p(rays), _p(weights_c) if Kimp else None, _p(depth_c) if Kfd else None,
                                        _p(z_coarse), _p(u2) if Kimp else None, _p(u3) if Kimp else None,
                                        _p(n4) if Kfd else None, R, Kc, Kimp, Kfd, float(depth_std),
-                                       int(lindisp), _p(z), _stream()), "pnr_sample_fine")
-    return z
+                                       int(lindisp), _p(z), _p(ranks), _stream()), "pnr_sample_fine")
+    return (z, ranks) if want_ranks else z
 
 
 def eval_ray_samples(scene, packed, rays, z):
@@ -371,7 +373,7 @@ def eval_ray_samples_train(scene, packed, rays, z):
     return out, dumps
 
 
-def composite_backward(rays, z, rgbsigma, white_bkgd, d_rgb, d_depth=None, d_weights=None):
+def composite_backward(rays, z, rgbsigma, white_bkgd, d_rgb, d_depth=None, d_weights=None, want_dz=False):
     lib = _lib.load()
     rays = _f32(rays, "rays", (None, 8))
     R = rays.shape[0]
@@ -382,10 +384,29 @@ def composite_backward(rays, z, rgbsigma, white_bkgd, d_rgb, d_depth=None, d_wei
     d_depth = None if d_depth is None else _f32(d_depth, "d_depth", (R,))
     d_weights = None if d_weights is None else _f32(d_weights, "d_weights", (R, K))
     out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
+    dz = torch.empty((R, K), dtype=torch.float32, device=rays.device) if want_dz else None
     with torch.cuda.device(rays.device):
         _lib.check(lib.pnr_composite_backward(_p(rays), _p(z), _p(rgbsigma), R, K, int(bool(white_bkgd)), _p(d_rgb),
-                                              _p(d_depth), _p(d_weights), _p(out), _stream()), "pnr_composite_backward")
-    return out
+                                              _p(d_depth), _p(d_weights), _p(out), _p(dz), _stream()),
+                   "pnr_composite_backward")
+    return (out, dz) if want_dz else out
+
+
+def position_backward(scene, rays, z, d_in42, d_zlat, d_z):
+    """accumulate dL/dz through the network inputs into d_z (R,K)."""
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z = _f32(z, "z", (R, None))
+    K = z.shape[1]
+    rows = scene.NS * R * K
+    d_in42 = _f32(d_in42, "d_in42", (rows, 42))
+    d_zlat = _f32(d_zlat, "d_zlat", (rows, 512))
+    d_z = _f32(d_z, "d_z", (R, K))
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.pnr_position_backward(scene.ref, _p(rays), _p(z), R, max(R // scene.SB, 1), K, _p(d_in42),
+                                             _p(d_zlat), _p(d_z), _stream()), "pnr_position_backward")
+    return d_z
 
 
 def mlp_backward(packed_bwd, fwd_dumps, g_out, grad_scale):

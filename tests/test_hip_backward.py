@@ -4,10 +4,10 @@ GPU tests (-m gpu) of the training path (BASELINE config 5): gradients from the 
 library GEMMs for dW) against torch autograd through the CPU oracle.
 
 Reference semantics: train/train.py:199-215 back-propagates MSE(coarse rgb) + MSE(fine rgb)
-through NeRFRenderer.forward into both ResnetFCs and encoder.latent.  Sample positions are
-treated as constants by the HIP backward, so the comparison oracle detaches the coarse depth that
-seeds the n_fine_depth samples (oracle.render(detach_depth=True)); the size of that omitted
-term is reported by tools/gpu_grad_check.py (profiles/r01_grad_parity_table.txt).
+through NeRFRenderer.forward into both ResnetFCs and encoder.latent, including the position
+gradient through the n_fine_depth samples (nerf.py:292: the coarse depth is NOT detached).  The
+comparison is against the oracle with exactly those semantics; tools/gpu_grad_check.py also
+prints how large that position term is (profiles/r01_grad_parity_table.txt).
 
 Tolerances (16-bit MFMA operands, fp32 accumulation, fp32 library GEMMs for dW):
   f16 : per-tensor relative L2 error <= 3e-2, cosine >= 0.9995

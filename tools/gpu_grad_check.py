@@ -63,16 +63,16 @@ def compare(name, prec="f16", verbose=True):
     worst = 0.0
     rows = []
     for k in go:
-        a, b, c = gh[k].double(), go[k].double(), gfull[k].double()
+        a, b, c = gh[k].double(), gfull[k].double(), go[k].double()  # hip, reference semantics, depth-detached
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
-        rel_full = float((b - c).norm() / (c.norm() + 1e-30))
+        rel_full = float((b - c).norm() / (b.norm() + 1e-30))
         rows.append((k, float(b.norm()), rel, cos, rel_full))
         worst = max(worst, rel)
     if verbose:
         print(f"== {name} {prec}: loss oracle {lo:.6f} hip {lh:.6f}")
         for k, n, rel, cos, rf in rows:
-            print(f"  {k:28s} |g| {n:10.3e}  rel.err {rel:9.2e}  cos {cos:.6f}   (oracle detached-vs-full depth: {rf:8.2e})")
+            print(f"  {k:28s} |g| {n:10.3e}  rel.err {rel:9.2e}  cos {cos:.6f}   (size of the depth-sample position term: {rf:8.2e})")
     return rows, (lo, lh)
 
 
