@@ -7,9 +7,9 @@ backward : HIP kernels for everything that is not a plain GEMM --
              pnr_composite_backward   d(rgb, depth, weights)      -> d(per-point rgb sigma)
              pnr_mlp_backward         fused data-gradient chain   -> per-layer output gradients dY
              pnr_latent_scatter       d(interpolated latent)      -> d(feature grid)
-           and library GEMMs (torch.matmul -> rocBLAS/hipBLASLt) for the weight gradients
-           dW = dY^T X and the latent gradient sum_b dY_b W_z[b], which are plain dense GEMMs
-           over the dumped operands.
+             pnr_weight_grad          dW = dY^T X, db = sum dY    from the 16-bit dumps (MFMA, fp32 acc)
+           and library GEMMs (torch.matmul) only for the three plain products that remain:
+           d z_lat = sum_b dY_b W_z[b], d(code) = dY W_in, and the tiny lin_in / lin_out weights.
              pnr_position_backward    d(network inputs)           -> d(sample positions z)
 Gradients flow to every ResnetFC parameter of both networks and to `encoder.latent` (hence into
 the ResNet-34 through PyTorch autograd), including the reference's one position-gradient path:
@@ -59,26 +59,26 @@ def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS, want_d_in=False):
     bd = ops.mlp_backward(packed_bwd, fwd, g_out, scale)
     inv_s = 1.0 / scale
 
-    def dW(dY, X):  # (rows, n_out) , (rows, n_in) 16-bit -> fp32 (n_out, n_in)
-        return torch.matmul(dY.float().t(), X.float())
-
+    prec = packed_bwd.precision
     grads = {}
-    # storage order -> feature order on the 512-wide dims
+    # weight gradients of the 512x512 linears: HIP MFMA kernel straight from the 16-bit dumps
+    # (fp32 accumulation); storage order -> feature order on the 512-wide dims afterwards
     for b in range(5):
-        g0 = dW(bd.g_fc0[b], fwd.d_a[b]) * inv_s
+        g0, b0 = ops.weight_grad(bd.g_fc0[b], fwd.d_a[b], prec, inv_s)
         grads[f"blocks.{b}.fc_0.weight"] = g0[inv][:, inv]
-        grads[f"blocks.{b}.fc_0.bias"] = (bd.g_fc0[b].float().sum(0) * inv_s)[inv]
-        g1 = dW(bd.g_fc1[b], fwd.d_n[b]) * inv_s
+        grads[f"blocks.{b}.fc_0.bias"] = b0[inv]
+        g1, b1 = ops.weight_grad(bd.g_fc1[b], fwd.d_n[b], prec, inv_s)
         grads[f"blocks.{b}.fc_1.weight"] = g1[inv][:, inv]
-        grads[f"blocks.{b}.fc_1.bias"] = (bd.g_fc1[b].float().sum(0) * inv_s)[inv]
+        grads[f"blocks.{b}.fc_1.bias"] = b1[inv]
     d_zlat = None
     for b in range(3):
         gz = bd.g_x0 if b == 0 else bd.g_fc1[b - 1]  # dL/d(residual stream entering block b), per view
-        gzf = gz.float()
-        grads[f"lin_z.{b}.weight"] = (torch.matmul(gzf.t(), fwd.d_z.float()) * inv_s)[inv]
-        grads[f"lin_z.{b}.bias"] = (gzf.sum(0) * inv_s)[inv]
-        # d z_lat += dY W_z[b]  (W in feature order; dY columns are in storage order)
-        term = torch.matmul(gzf, mlp_state[f"lin_z.{b}.weight"].detach()[perm])
+        gw, gb = ops.weight_grad(gz, fwd.d_z, prec, inv_s)
+        grads[f"lin_z.{b}.weight"] = gw[inv]
+        grads[f"lin_z.{b}.bias"] = gb[inv]
+        # d z_lat += dY W_z[b]  (W in feature order; dY columns are in storage order): a plain
+        # (rows,512)x(512,512) library GEMM on the 16-bit operands (fp32 accumulation inside)
+        term = torch.matmul(gz, mlp_state[f"lin_z.{b}.weight"].detach()[perm].to(gz.dtype)).float()
         d_zlat = term if d_zlat is None else d_zlat + term
     d_zlat = d_zlat * inv_s
     g0f = bd.g_x0.float()

@@ -228,6 +228,87 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
     }
 }
 
+// ---------------------------------------------------------------- weight-gradient GEMM
+// dW[o][k] += sum_r dY[r][o] X[r][k]   over 16-bit row-major dumps (rows, ldy) / (rows, ldx), fp32 out.
+// The reduction index r is the slow dimension of both operands, so each 16-row slab is staged in
+// LDS and the MFMA fragments are read column-wise (8 x 16-bit per lane).  Block = 4 waves = one
+// 64x64 tile of dW, blockIdx.z = slice of the rows (split-K): every slice writes its own partial
+// (part[z][512][512], bpart[z][512]) with plain stores and dw_reduce_kernel sums the slices in a
+// fixed order -> bit-reproducible, no atomics.  bpart = bias gradient sum_r dY[r][o].
+template <int PREC>
+__global__ void __launch_bounds__(256)
+dw_kernel(const typename Prec<PREC>::T *__restrict__ dY, const typename Prec<PREC>::T *__restrict__ X, long long rows,
+          int ldy, int ldx, int rows_per_block, float *__restrict__ part, float *__restrict__ bpart) {
+    typedef Prec<PREC> P;
+    typedef typename P::T T;
+    constexpr int LD = 64 + 2;  // +2 elements: consecutive slab rows start on different banks
+    __shared__ T sY[16][LD], sX[16][LD];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int o0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const long long r_begin = (long long)blockIdx.z * rows_per_block;
+    const long long r_end = r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows;
+    const int wo = (w >> 1) * 32, wk = (w & 1) * 32;
+    const int i = lane & 31, kh = lane >> 5;
+    // staging role: threads 0..127 copy the dY slab, 128..255 the X slab; 8 threads x 8 elements per row
+    const bool isx = t >= 128;
+    const int srow = (t & 127) >> 3, scol = (t & 7) * 8;
+    const T *src = isx ? X + k0 + scol : dY + o0 + scol;
+    const int ld = isx ? ldx : ldy;
+    f32x16 acc;
+    float bsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (long long r0 = r_begin; r0 < r_end; r0 += 16) {
+        u32x4 v = {0, 0, 0, 0};
+        if (r0 + srow < r_end) v = *reinterpret_cast<const u32x4 *>(src + (r0 + srow) * ld);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&(isx ? sX : sY)[srow][scol]);
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        __syncthreads();
+        T a[8], b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[e] = sY[8 * kh + e][wo + i];
+            b[e] = sX[8 * kh + e][wk + i];
+        }
+        typename P::T8 af, bf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { af[e] = a[e]; bf[e] = b[e]; }
+        acc = P::mfma(af, bf, acc);
+        if (blockIdx.x == 0 && (w & 1) == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum += (float)a[e];
+        }
+        __syncthreads();
+    }
+    // D layout: column j = lane&31 -> k, row (r&3)+8(r>>2)+4kh -> o
+    float *pz = part + (size_t)blockIdx.z * (D_HID * D_HID);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int orow = o0 + wo + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        pz[(size_t)orow * D_HID + k0 + wk + i] = acc[r];
+    }
+    if (blockIdx.x == 0 && (w & 1) == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);  // both k-halves of the slab
+        if (kh == 0) bpart[(size_t)blockIdx.z * D_HID + o0 + wo + i] = bsum;
+    }
+}
+
+// dW = scale * sum_z part[z], db = scale * sum_z bpart[z]  (fixed summation order)
+__global__ void dw_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bpart, int nz, float scale,
+                                 float *__restrict__ dW, float *__restrict__ db) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < D_HID * D_HID) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z) s += part[(size_t)z * (D_HID * D_HID) + idx];
+        dW[idx] = s * scale;
+    }
+    if (db && idx < D_HID) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z) s += bpart[(size_t)z * D_HID + idx];
+        db[idx] = s * scale;
+    }
+}
+
 // ---------------------------------------------------------------- compositing backward
 constexpr int CW = 4;  // wavefronts per block
 
@@ -504,6 +585,35 @@ extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const Pnr
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(bwd_kernel)");
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), LDS_TOTAL, (hipStream_t)stream, q);
     return pnr_check_launch("bwd_kernel");
+}
+
+constexpr int DW_MAX_SPLIT = 16;
+extern "C" size_t pnr_weight_grad_workspace_bytes(void) { return (size_t)DW_MAX_SPLIT * (D_HID * D_HID + D_HID) * sizeof(float); }
+
+extern "C" int pnr_weight_grad(const void *dY, const void *X, long long rows, int precision, float out_scale, float *dW,
+                               float *db, void *workspace, void *stream) {
+    if (!dY || !X || !dW || !workspace || rows <= 0) return pnr_fail(PNR_E_INVALID, "pnr_weight_grad: bad argument");
+    // ~2-4 blocks per CU: 64 output tiles x nsplit row slices
+    int nsplit = (int)((rows + 4095) / 4096);
+    if (nsplit > DW_MAX_SPLIT) nsplit = DW_MAX_SPLIT;
+    if (nsplit < 1) nsplit = 1;
+    long long per = (rows + nsplit - 1) / nsplit;
+    per = (per + 15) / 16 * 16;
+    const int nz = (int)((rows + per - 1) / per);
+    float *part = (float *)workspace;
+    float *bpart = part + (size_t)DW_MAX_SPLIT * D_HID * D_HID;
+    dim3 grid(D_HID / 64, D_HID / 64, (unsigned)nz);
+    hipStream_t st = (hipStream_t)stream;
+    if (precision == PNR_PREC_F16)
+        hipLaunchKernelGGL(dw_kernel<PNR_PREC_F16>, grid, dim3(256), 0, st, (const _Float16 *)dY, (const _Float16 *)X, rows,
+                           D_HID, D_HID, (int)per, part, bpart);
+    else if (precision == PNR_PREC_BF16)
+        hipLaunchKernelGGL(dw_kernel<PNR_PREC_BF16>, grid, dim3(256), 0, st, (const __bf16 *)dY, (const __bf16 *)X, rows,
+                           D_HID, D_HID, (int)per, part, bpart);
+    else
+        return pnr_fail(PNR_E_INVALID, "pnr_weight_grad: unknown precision");
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(D_HID * D_HID / 256), dim3(256), 0, st, part, bpart, nz, out_scale, dW, db);
+    return pnr_check_launch("pnr_weight_grad");
 }
 
 extern "C" int pnr_composite_backward(const float *rays, const float *z, const float *rgbsigma, int R, int K, int white_bkgd,

@@ -431,3 +431,24 @@ def latent_scatter(scene, rays, z, d_zlat, d_latent_nhwc):
         _lib.check(lib.pnr_latent_scatter(scene.ref, _p(rays), _p(z), R, max(R // scene.SB, 1), K, _p(d_zlat),
                                           _p(d_latent_nhwc), _stream()), "pnr_latent_scatter")
     return d_latent_nhwc
+
+
+def weight_grad(dY, X, precision, out_scale=1.0, want_bias=True):
+    """dW (512,512) = out_scale * dY^T X and db (512) = out_scale * sum_rows dY from 16-bit dumps
+    (rows,512); fp32 results in the operands' row/column order."""
+    lib = _lib.load()
+    rows = dY.shape[0]
+    assert dY.shape == (rows, 512) and X.shape == (rows, 512) and dY.dtype == X.dtype and dY.is_cuda
+    dY, X = dY.contiguous(), X.contiguous()
+    dW = torch.empty((512, 512), dtype=torch.float32, device=dY.device)
+    db = torch.empty((512,), dtype=torch.float32, device=dY.device) if want_bias else None
+    key = str(dY.device)
+    if key not in _wg_workspace:
+        _wg_workspace[key] = torch.empty(lib.pnr_weight_grad_workspace_bytes(), dtype=torch.uint8, device=dY.device)
+    with torch.cuda.device(dY.device):
+        _lib.check(lib.pnr_weight_grad(_p(dY), _p(X), rows, int(precision), float(out_scale), _p(dW), _p(db),
+                                       _p(_wg_workspace[key]), _stream()), "pnr_weight_grad")
+    return dW, db
+
+
+_wg_workspace = {}

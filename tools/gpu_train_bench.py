@@ -23,7 +23,7 @@ def main():
     rays = synthetic.target_rays(meta, n_rays=128).to(dev)  # (4,128,8)
     gt = torch.rand(4, 128, 3, device=dev)
     mc, mf = synthetic.make_mlp_params(11), synthetic.make_mlp_params(12)
-    for prec in ("f16", "bf16"):
+    for prec in ("f16", "bf16", "f16"):
         net = make_model(default_model_conf(), precision=prec).to(dev).train()
         net.mlp_coarse.load_state_dict(mc)
         net.mlp_fine.load_state_dict(mf)
@@ -48,10 +48,10 @@ def main():
             opt.step()
             return loss
 
-        for _ in range(3):
+        for _ in range(8):
             step()
         torch.cuda.synchronize()
-        n = 10
+        n = 20
         t0 = time.perf_counter()
         for _ in range(n):
             loss = step()
