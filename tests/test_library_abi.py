@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol(lib, repo_root):
 
 
 def test_struct_layouts_match_header():
-    # PnrScene: 4 pointers, 6 int32, 2 floats; PnrMlpWeights: 30 pointers
+    # PnrScene: 4 pointers, 6 int32, 2 floats; PnrMlpWeights: 30 pointers; dumps: 13 / 11 pointers
+    assert ctypes.sizeof(_lib.PnrTrainDumps) == 13 * 8 and ctypes.sizeof(_lib.PnrBackwardDumps) == 11 * 8
     assert ctypes.sizeof(_lib.PnrScene) == 4 * 8 + 6 * 4 + 2 * 4
     assert ctypes.sizeof(_lib.PnrMlpWeights) == 30 * 8
 
@@ -42,6 +43,10 @@ def test_host_only_entry_points(lib):
     # packed stream: 8 waves x 424 ring steps x 2 fragments x 1 KiB + biases + b_out
     assert lib.pnr_packed_mlp_bytes() == 8 * 424 * 2 * 1024 + 11 * 8 * 64 * 4 + 16
     assert lib.pnr_render_workspace_bytes(0, 64, 128) == 0
+    assert lib.pnr_packed_mlp_bwd_bytes() == 8 * 324 * 2 * 1024
+    assert lib.pnr_weight_grad_workspace_bytes() == 16 * (512 * 512 + 512) * 4
+    perm = (ctypes.c_int32 * 512)()
+    assert lib.pnr_storage_perm(perm) == 0 and sorted(perm) == list(range(512)) and perm[16] == 4 and perm[1] == 1
     r, kc, kf = 100, 64, 128
     fl = lambda n: (n + 63) // 64 * 64
     expect = 4 * (fl(r * kc) + fl(r * kc * 4) + fl(r * kc) + fl(r * (kc + kf)) + fl(r * (kc + kf) * 4))
@@ -52,10 +57,15 @@ def test_argument_validation_without_gpu(lib):
     # invalid arguments are rejected on the host before any HIP call
     assert lib.pnr_sample_coarse(None, None, 4, 0, 0, None, None) == -1
     assert b"bad sizes" in lib.pnr_last_error()
-    assert lib.pnr_sample_fine(None, None, None, None, None, None, None, 4, 300, 0, 0, 0.01, 0, None, None) == -1
+    assert lib.pnr_sample_fine(None, None, None, None, None, None, None, 4, 300, 0, 0, 0.01, 0, None, None, None) == -1
     assert b"n_coarse <= 256" in lib.pnr_last_error()
     assert lib.pnr_composite(None, None, None, 3, 8, 0, None, None, None, None) == -1
     assert lib.pnr_pack_mlp(None, 0, None, None) == -1
+    assert lib.pnr_pack_mlp_bwd(None, 0, None, None) == -1
+    assert lib.pnr_composite_backward(None, None, None, 3, 8, 0, None, None, None, None, None, None) == -1
+    assert lib.pnr_mlp_backward(None, 0, None, None, 1.0, 10, 1, None, None) == -1
+    assert lib.pnr_weight_grad(None, None, 10, 0, 1.0, None, None, None, None) == -1
+    assert lib.pnr_position_backward(None, None, None, 1, 1, 1, None, None, None, None) == -1
     # empty batches are a successful no-op (reference: empty output, nerf.py:23-27)
     assert lib.pnr_sample_coarse(None, None, 0, 8, 0, None, None) == 0
     assert lib.pnr_composite(None, None, None, 0, 8, 0, None, None, None, None) == 0
