@@ -125,3 +125,48 @@ def test_training_step_updates_and_is_deterministic(dev):
     lat.grad = None
     ((rd.fine.rgb - gt) ** 2).mean().backward()
     assert lat.grad is None
+
+
+def test_training_converges_on_a_fixed_batch(dev):
+    """Normalised gradient descent on one fixed ray batch with frozen noise (a smooth deterministic
+    loss): each step is sized to predict a 10 % decrease (eta = 0.1 L / |g|^2), so the loss must
+    fall monotonically if -- and only if -- the HIP gradients (both MLPs + encoder.latent) point
+    downhill with the right scale."""
+    from pixelnerf_amd.model import make_model
+    from pixelnerf_amd.render import NeRFRenderer
+    from pixelnerf_amd.util import DotMap
+    from pixelnerf_amd.util.conf import default_model_conf
+    from helpers import mlp_params
+    g, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
+    net = make_model(default_model_conf()).to(dev).train()
+    net.mlp_coarse.load_state_dict(mlp_params(11))
+    net.mlp_fine.load_state_dict(mlp_params(12))
+    lat = scene["latent"].to(dev).clone().requires_grad_(True)
+    ls = torch.tensor([32.0, 32.0], device=dev)
+    net.encoder.latent_scaling = ls / (ls - 1) * 2.0
+    net.poses, net.image_shape = scene["poses"].to(dev), scene["image_shape"].to(dev)
+    net.focal, net.c = scene["focal"].to(dev), scene["c"].to(dev)
+    net.num_objs, net.num_views_per_obj = scene["SB"], scene["NS"]
+    rend = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).to(dev)
+    render_par = rend.bind_parallel(net, None, simple_output=False).train()
+    params = list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters()) + [lat]
+    gt = torch.rand(4, 32, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) * 0.5 + 0.25
+    r = rays.to(dev)
+    losses = []
+    for it in range(9):
+        net.encoder.latent = lat  # leaf with grad, standing in for the encoder output
+        torch.manual_seed(123)    # frozen noise -> the same sample positions every step
+        rd = DotMap(render_par(r, want_weights=True))
+        loss = ((rd.coarse.rgb - gt) ** 2).mean() + ((rd.fine.rgb - gt) ** 2).mean()
+        for p_ in params:
+            p_.grad = None
+        loss.backward()
+        losses.append(loss.item())
+        g2 = sum(float((p_.grad.double() ** 2).sum()) for p_ in params)
+        assert g2 > 0 and all(torch.isfinite(p_.grad).all() for p_ in params)
+        eta = 0.1 * loss.item() / g2
+        with torch.no_grad():
+            for p_ in params:
+                p_.add_(p_.grad, alpha=-eta)  # in-place: bumps _version -> weights are re-packed
+    assert all(b < a for a, b in zip(losses, losses[1:])), losses
+    assert losses[-1] < 0.6 * losses[0], losses
