@@ -159,8 +159,13 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT], const char *smem, ui
             // of the body); pinning the order with sched_barrier (-DPNR_PIN_SCHEDULE) gives the
             // textbook stream but measured 2-3 % SLOWER (profiles/r01_gemm_experiments.md), so
             // the compiler's schedule is the default.
+#ifndef PNR_EXP_NO_BLOAD  // experiment: B fragments stay what the first read returned; results are wrong
             b[cur ^ 1][0] = lds8<P>(smem, baddr0 + (j + 1) * 32);
             b[cur ^ 1][1] = lds8<P>(smem, baddr1 + (j + 1) * 32);
+#else
+            b[cur ^ 1][0] = b[cur][0];
+            b[cur ^ 1][1] = b[cur][1];
+#endif
 #ifdef PNR_PIN_SCHEDULE
             __builtin_amdgcn_sched_barrier(0);
 #endif
