@@ -257,6 +257,27 @@ def test_empty_and_ragged_inputs(ops, dev):
         assert np.abs(got[..., :3].numpy() - ref[3][..., :3].numpy()).max() <= PREC_TOL["f16"]["rgb_max"]
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_object_boundary_inside_a_tile(ops, dev, prec):
+    """SB=2 x NS=2 with 5 rays x 7 samples per object: 35 points per object, so the object (pose /
+    feature-grid) switch happens in the middle of the first 64-point tile, for both variants."""
+    from pixelnerf_amd import synthetic
+    scene, meta = scene_for("mv_mini")
+    sc = dscene(ops, dev, "mv_mini")
+    pk = packed(ops, dev, 12, prec)
+    rays = synthetic.target_rays(meta, n_rays=5)  # (2, 5, 8)
+    r = rays.reshape(-1, 8)
+    u = torch.rand(10, 7, generator=torch.Generator().manual_seed(8))
+    z = O.sample_coarse(r, u, 7)
+    ref = O.composite(scene, mlp_params(12), r, z, 2, True)[3]  # (10, 7, 4)
+    got = ops.eval_ray_samples(sc, pk, r.to(dev), z.to(dev)).cpu()
+    assert np.abs(got[..., :3].numpy() - ref[..., :3].numpy()).max() <= PREC_TOL[prec]["rgb_max"]
+    pts = (r[:, None, :3] + z.unsqueeze(2) * r[:, None, 3:6]).reshape(2, -1, 3)
+    vd = r[:, None, 3:6].expand(-1, 7, -1).reshape(2, -1, 3)
+    got_b = ops.eval_points(sc, pk, pts.contiguous().to(dev), vd.contiguous().to(dev)).reshape(10, 7, 4)
+    assert torch.equal(got_b.cpu(), got)
+
+
 def test_errors_are_loud(ops, dev):
     from pixelnerf_amd import _lib
     sc = dscene(ops, dev, "sn64")
