@@ -86,10 +86,10 @@ __device__ __forceinline__ void geometry(const EvalParams &q, char *smem, int ti
 #pragma clang fp contract(fast)
 
 // bilinear lookup: wave handles points wave*8..+7; lane handles channels 8*lane..+7
-template <typename P, bool TRAIN>
+template <typename P, bool TRAIN, int GB>
 __device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, int lane, int tile, int view) {
     const float *lat = q.latent + lane * 8;
-    constexpr int GB = 4;  // points per batch: one L2 round trip covers GB points (32 loads in flight)
+    // GB = points per batch (8 x 16-byte loads in flight per point); 4 when registers allow
     static_assert((MT / NW) % GB == 0, "gather batch");
 #pragma unroll 1
     for (int i = 0; i < MT / NW; i += GB) {
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                     *reinterpret_cast<u32x4 *>(q.d_in + (((long long)view * q.P + g) * D_IN_PAD + chunk * 8) * 2) =
                         *reinterpret_cast<const u32x4 *>(smem + LDS_IN + row * ROW_IN + chunk * 16);
             }
-            gather<P, TRAIN>(q, smem, wv, lane, tile, view);
+            gather<P, TRAIN, MV ? 2 : 4>(q, smem, wv, lane, tile, view);  // multi-view also holds the view sum
             __syncthreads();
             PNR_T(PH_GATHER);
             add_bias<true>(x, bias_lane, B_IN_Z0);
