@@ -231,65 +231,109 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
 // ---------------------------------------------------------------- weight-gradient GEMM
 // dW[o][k] += sum_r dY[r][o] X[r][k]   over 16-bit row-major dumps (rows, ldy) / (rows, ldx), fp32 out.
 // The reduction index r is the slow dimension of both operands, so each 16-row slab is staged in
-// LDS and the MFMA fragments are read column-wise (8 x 16-bit per lane).  Block = 4 waves = one
-// 64x64 tile of dW, blockIdx.z = slice of the rows (split-K): every slice writes its own partial
+// LDS (transposed) and read back as MFMA fragments.  Block = 4 waves = one 128x128 tile of dW,
+// blockIdx.z = slice of the rows (split-K): every slice writes its own partial
 // (part[z][512][512], bpart[z][512]) with plain stores and dw_reduce_kernel sums the slices in a
 // fixed order -> bit-reproducible, no atomics.  bpart = bias gradient sum_r dY[r][o].
 template <int PREC>
 __global__ void __launch_bounds__(256)
 dw_kernel(const typename Prec<PREC>::T *__restrict__ dY, const typename Prec<PREC>::T *__restrict__ X, long long rows,
           int ldy, int ldx, int rows_per_block, float *__restrict__ part, float *__restrict__ bpart) {
+    // Block = 4 waves = one 128x128 tile of dW; wave = 64x64 = 2x2 MFMA tiles.  Slabs of 32 rows are
+    // staged TRANSPOSED in LDS (sT[col][row], 80-byte rows -> conflict-free ds_read_b128), so one
+    // fragment (8 consecutive rows of one column) is a single 16-byte LDS read.
     typedef Prec<PREC> P;
     typedef typename P::T T;
-    constexpr int LD = 64 + 2;  // +2 elements: consecutive slab rows start on different banks
-    __shared__ T sY[16][LD], sX[16][LD];
+    constexpr int SR = 32, LD = SR + 8;  // rows per slab, padded transposed row (16-byte multiple)
+    __shared__ __attribute__((aligned(16))) T sY[128][LD];
+    __shared__ __attribute__((aligned(16))) T sX[128][LD];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int o0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int o0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
     const long long r_begin = (long long)blockIdx.z * rows_per_block;
     const long long r_end = r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows;
-    const int wo = (w >> 1) * 32, wk = (w & 1) * 32;
+    const int wo = (w >> 1) * 64, wk = (w & 1) * 64;
     const int i = lane & 31, kh = lane >> 5;
-    // staging role: threads 0..127 copy the dY slab, 128..255 the X slab; 8 threads x 8 elements per row
-    const bool isx = t >= 128;
-    const int srow = (t & 127) >> 3, scol = (t & 7) * 8;
-    const T *src = isx ? X + k0 + scol : dY + o0 + scol;
-    const int ld = isx ? ldx : ldy;
-    f32x16 acc;
-    float bsum = 0.f;
+    // staging: slab = 32 rows x 128 columns per operand = 512 chunks of 8 columns; 2 chunks per thread
+    f32x16 acc[2][2];
+    float bsum[2] = {0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (long long r0 = r_begin; r0 < r_end; r0 += 16) {
-        u32x4 v = {0, 0, 0, 0};
-        if (r0 + srow < r_end) v = *reinterpret_cast<const u32x4 *>(src + (r0 + srow) * ld);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&(isx ? sX : sY)[srow][scol]);
-        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
-        __syncthreads();
-        T a[8], b[8];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            a[e] = sY[8 * kh + e][wo + i];
-            b[e] = sX[8 * kh + e][wk + i];
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // register-staged software pipeline: the global loads of slab s+1 are in flight while slab s is
+    // being multiplied out of LDS
+    u32x4 vy[2], vx[2];
+    auto load_slab = [&](long long r0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // neighbouring lanes take neighbouring ROWS of the same 8-column chunk: the transposing
+            // 2-byte LDS writes then land on consecutive addresses (no bank conflicts)
+            const int chunk = t + u * 256;            // 0..511
+            const int srow = chunk & 31, scol = (chunk >> 5) * 8;
+            vy[u] = u32x4{0, 0, 0, 0};
+            vx[u] = u32x4{0, 0, 0, 0};
+            if (r0 + srow < r_end) {
+                vy[u] = *reinterpret_cast<const u32x4 *>(dY + (r0 + srow) * ldy + o0 + scol);
+                vx[u] = *reinterpret_cast<const u32x4 *>(X + (r0 + srow) * ldx + k0 + scol);
+            }
         }
-        typename P::T8 af, bf;
+    };
+    load_slab(r_begin);
+    for (long long r0 = r_begin; r0 < r_end; r0 += SR) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { af[e] = a[e]; bf[e] = b[e]; }
-        acc = P::mfma(af, bf, acc);
-        if (blockIdx.x == 0 && (w & 1) == 0) {
+        for (int u = 0; u < 2; ++u) {
+            const int chunk = t + u * 256;
+            const int srow = chunk & 31, scol = (chunk >> 5) * 8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bsum += (float)a[e];
+            for (int e = 0; e < 8; ++e) {
+                const uint16_t hy = (uint16_t)((e & 1) ? (vy[u][e >> 1] >> 16) : (vy[u][e >> 1] & 0xffffu));
+                const uint16_t hx = (uint16_t)((e & 1) ? (vx[u][e >> 1] >> 16) : (vx[u][e >> 1] & 0xffffu));
+                reinterpret_cast<uint16_t *>(&sY[scol + e][0])[srow] = hy;
+                reinterpret_cast<uint16_t *>(&sX[scol + e][0])[srow] = hx;
+            }
+        }
+        __syncthreads();
+        if (r0 + SR < r_end) load_slab(r0 + SR);
+#pragma unroll
+        for (int ks = 0; ks < SR / 16; ++ks) {
+            typename P::T8 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                af[a] = *reinterpret_cast<const typename P::T8 *>(&sY[wo + a * 32 + i][ks * 16 + kh * 8]);
+                bf[a] = *reinterpret_cast<const typename P::T8 *>(&sX[wk + a * 32 + i][ks * 16 + kh * 8]);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = P::mfma(af[a], bf[b], acc[a][b]);
+            if (blockIdx.x == 0 && (w & 1) == 0) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[a] += (float)af[a][e];
+            }
         }
         __syncthreads();
     }
     // D layout: column j = lane&31 -> k, row (r&3)+8(r>>2)+4kh -> o
     float *pz = part + (size_t)blockIdx.z * (D_HID * D_HID);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int orow = o0 + wo + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        pz[(size_t)orow * D_HID + k0 + wk + i] = acc[r];
-    }
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orow = o0 + wo + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                pz[(size_t)orow * D_HID + k0 + wk + b * 32 + i] = acc[a][b][r];
+            }
     if (blockIdx.x == 0 && (w & 1) == 0) {
-        bsum += __shfl_xor(bsum, 32, 64);  // both k-halves of the slab
-        if (kh == 0) bpart[(size_t)blockIdx.z * D_HID + o0 + wo + i] = bsum;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);  // both row halves of every k-step
+            if (kh == 0) bpart[(size_t)blockIdx.z * D_HID + o0 + wo + a * 32 + i] = v;
+        }
     }
 }
 
@@ -410,38 +454,72 @@ composite_bwd_kernel(const float *__restrict__ rays, const float *__restrict__ z
 }
 
 // ---------------------------------------------------------------- latent scatter-add
-// one wavefront per (view, point): lane handles channels 8*lane..+7 of the 4 bilinear corners
+// One wavefront per (view, run of SCATTER_RUN consecutive points); lane handles channels 8*lane..+7.
+// Consecutive samples of a ray mostly fall into the same grid cell, so each of the 4 bilinear
+// corners keeps a register accumulator that is flushed with atomics only when its texel changes
+// (run-length merging: ~5x fewer atomics on the 32x32 sn64 grid).
+constexpr int SCATTER_RUN = 16;
 #pragma clang fp contract(off)
 __global__ void __launch_bounds__(CW * 64)
 latent_scatter_kernel(const EvalParams q, const float *__restrict__ d_zlat, float *__restrict__ d_latent) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * CW + wv;  // view * P + point
-    if (idx >= q.P * q.NS) return;
-    const int view = (int)(idx / q.P);
-    const int g = (int)(idx % q.P);
-    const int r = g / q.K;
-    const float *ray = q.rays + (size_t)r * 8;
-    const float zz = q.z[g];
-    const float X = ray[0] + zz * ray[3], Y = ray[1] + zz * ray[4], Z = ray[2] + zz * ray[5];
-    const int obj = r / q.per_obj;
-    const float *pose = q.poses + (size_t)(obj * q.NS + view) * 12;
-    const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
-    const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
-    const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
-    const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, true);
-    const float *src = d_zlat + (size_t)idx * C_LAT + lane * 8;
-    const f32x4 a = *reinterpret_cast<const f32x4 *>(src), b = *reinterpret_cast<const f32x4 *>(src + 4);
+    const long long runs_per_view = (q.P + SCATTER_RUN - 1) / SCATTER_RUN;
+    const long long run = (long long)blockIdx.x * CW + wv;
+    if (run >= runs_per_view * q.NS) return;
+    const int view = (int)(run / runs_per_view);
+    const long long g0 = (run % runs_per_view) * SCATTER_RUN;
+    float acc[4][8];
+    uint32_t cur[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float w = pr.w[c];
-        if (w == 0.f) continue;
-        float *dst = d_latent + pr.off[c] + lane * 8;
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            atomicAdd(dst + e, w * a[e]);
-            atomicAdd(dst + 4 + e, w * b[e]);
+        for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+    for (int j = 0; j < SCATTER_RUN; ++j) {
+        const long long gl = g0 + j;
+        if (gl >= q.P) break;
+        const int g = (int)gl;
+        const int r = g / q.K;
+        const float *ray = q.rays + (size_t)r * 8;
+        const float zz = q.z[g];
+        const float X = ray[0] + zz * ray[3], Y = ray[1] + zz * ray[4], Z = ray[2] + zz * ray[5];
+        const int obj = r / q.per_obj;
+        const float *pose = q.poses + (size_t)(obj * q.NS + view) * 12;
+        const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
+        const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
+        const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
+        const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, true);
+        const float *src = d_zlat + ((size_t)view * q.P + g) * C_LAT + lane * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(src), b = *reinterpret_cast<const f32x4 *>(src + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t off = __builtin_amdgcn_readfirstlane(pr.off[c]);  // identical in every lane
+            if (off != cur[c]) {
+                if (cur[c] != 0xffffffffu) {
+                    float *dst = d_latent + cur[c] + lane * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (acc[c][e] != 0.f) atomicAdd(dst + e, acc[c][e]);
+                        acc[c][e] = 0.f;
+                    }
+                }
+                cur[c] = off;
+            }
+            const float w = pr.w[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[c][e] += w * a[e];
+                acc[c][4 + e] += w * b[e];
+            }
         }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (cur[c] != 0xffffffffu) {
+            float *dst = d_latent + cur[c] + lane * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (acc[c][e] != 0.f) atomicAdd(dst + e, acc[c][e]);
+        }
 }
 
 // dL/dz through the network inputs; one wavefront per (view, point).
@@ -587,22 +665,22 @@ extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const Pnr
     return pnr_check_launch("bwd_kernel");
 }
 
-constexpr int DW_MAX_SPLIT = 16;
+constexpr int DW_MAX_SPLIT = 32;
 extern "C" size_t pnr_weight_grad_workspace_bytes(void) { return (size_t)DW_MAX_SPLIT * (D_HID * D_HID + D_HID) * sizeof(float); }
 
 extern "C" int pnr_weight_grad(const void *dY, const void *X, long long rows, int precision, float out_scale, float *dW,
                                float *db, void *workspace, void *stream) {
     if (!dY || !X || !dW || !workspace || rows <= 0) return pnr_fail(PNR_E_INVALID, "pnr_weight_grad: bad argument");
-    // ~2-4 blocks per CU: 64 output tiles x nsplit row slices
-    int nsplit = (int)((rows + 4095) / 4096);
+    // 16 output tiles of 128x128 x nsplit row slices (= up to 512 blocks, two per CU)
+    int nsplit = (int)((rows + 1023) / 1024);
     if (nsplit > DW_MAX_SPLIT) nsplit = DW_MAX_SPLIT;
     if (nsplit < 1) nsplit = 1;
     long long per = (rows + nsplit - 1) / nsplit;
-    per = (per + 15) / 16 * 16;
+    per = (per + 31) / 32 * 32;
     const int nz = (int)((rows + per - 1) / per);
     float *part = (float *)workspace;
     float *bpart = part + (size_t)DW_MAX_SPLIT * D_HID * D_HID;
-    dim3 grid(D_HID / 64, D_HID / 64, (unsigned)nz);
+    dim3 grid(D_HID / 128, D_HID / 128, (unsigned)nz);
     hipStream_t st = (hipStream_t)stream;
     if (precision == PNR_PREC_F16)
         hipLaunchKernelGGL(dw_kernel<PNR_PREC_F16>, grid, dim3(256), 0, st, (const _Float16 *)dY, (const _Float16 *)X, rows,
@@ -653,7 +731,7 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
     q.SB = s->SB; q.NS = s->NS; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
     q.img_w = s->img_w; q.img_h = s->img_h;
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
-    const long long n = q.P * q.NS;
+    const long long n = ((q.P + SCATTER_RUN - 1) / SCATTER_RUN) * q.NS;  // wavefronts
     hipLaunchKernelGGL(latent_scatter_kernel, dim3((unsigned)((n + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream, q,
                        d_zlat, d_latent_nhwc);
     return pnr_check_launch("pnr_latent_scatter");

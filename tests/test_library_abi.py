@@ -44,7 +44,7 @@ def test_host_only_entry_points(lib):
     assert lib.pnr_packed_mlp_bytes() == 8 * 424 * 2 * 1024 + 11 * 8 * 64 * 4 + 16
     assert lib.pnr_render_workspace_bytes(0, 64, 128) == 0
     assert lib.pnr_packed_mlp_bwd_bytes() == 8 * 324 * 2 * 1024
-    assert lib.pnr_weight_grad_workspace_bytes() == 16 * (512 * 512 + 512) * 4
+    assert lib.pnr_weight_grad_workspace_bytes() == 32 * (512 * 512 + 512) * 4
     perm = (ctypes.c_int32 * 512)()
     assert lib.pnr_storage_perm(perm) == 0 and sorted(perm) == list(range(512)) and perm[16] == 4 and perm[1] == 1
     r, kc, kf = 100, 64, 128
