@@ -152,11 +152,14 @@ int pnr_pack_mlp_bwd(const PnrMlpWeights *w /*host struct of device ptrs*/, int 
                      void *packed_bwd, void *stream);
 
 /* Backward of pnr_composite (src/render/nerf.py:178-182,223-249 under autograd).
- * d_depth / d_weights may be NULL.  d_rgbsigma (R,K,4) = dL/d(model output) AFTER sigmoid/relu;
+ * d_depth / d_weights may be NULL.  d_rgbsigma (R,K,4) = dL/d(model output) after sigmoid/relu,
+ * or, with pre_activation != 0, dL/d(lin_out output) (through rgb = sigmoid(.), sigma = relu(.),
+ * src/model/models.py:260-263) -- the g_out that pnr_mlp_backward consumes;
  * d_z (R,K) (may be NULL) = dL/dz through the deltas and depth = sum w z. */
 int pnr_composite_backward(const float *rays, const float *z, const float *rgbsigma, int R, int K,
                            int white_bkgd, const float *d_rgb, const float *d_depth,
-                           const float *d_weights, float *d_rgbsigma, float *d_z, void *stream);
+                           const float *d_weights, float *d_rgbsigma, float *d_z,
+                           int pre_activation, void *stream);
 
 /* dL/dz of the sample positions through the network inputs (x = o + z d: positional code,
  * models.py:169-182 / code.py:37-41, and projection + bilinear lookup, models.py:206-215 /

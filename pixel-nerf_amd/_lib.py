@@ -68,7 +68,7 @@ PROTOTYPES = {
     "pnr_storage_perm": (_I, [ctypes.POINTER(ctypes.c_int32)]),
     "pnr_packed_mlp_bwd_bytes": (_SZ, []),
     "pnr_pack_mlp_bwd": (_I, [ctypes.POINTER(PnrMlpWeights), _I, _P, _P]),
-    "pnr_composite_backward": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "pnr_composite_backward": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "pnr_position_backward": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "pnr_mlp_backward": (_I, [_P, _I, ctypes.POINTER(PnrTrainDumps), _P, _F, ctypes.c_longlong, _I,
                               ctypes.POINTER(PnrBackwardDumps), _P]),

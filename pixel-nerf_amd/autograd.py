@@ -145,12 +145,10 @@ class _RenderFunction(torch.autograd.Function):
             pos = (not ps["coarse"]) and ps.get("ranks") is not None  # depth samples exist
             cb = ops.composite_backward(rays, ps["z"], ps["rgbs"], cfg["white_bkgd"], d_rgb.contiguous().float(),
                                         None if d_depth is None else d_depth.contiguous().float(),
-                                        None if d_w is None else d_w.contiguous().float(), want_dz=pos)
-            d_rgbs, dz = cb if pos else (cb, None)
-            # through the output activations (models.py:260-265): sigmoid on rgb, relu on sigma
-            s = ps["rgbs"][..., :3]
-            g_out = torch.cat([d_rgbs[..., :3] * s * (1 - s),
-                               d_rgbs[..., 3:] * (ps["rgbs"][..., 3:] > 0).float()], dim=-1).reshape(-1, 4).contiguous()
+                                        None if d_w is None else d_w.contiguous().float(), want_dz=pos,
+                                        pre_activation=True)  # also through sigmoid / relu (models.py:260-265)
+            d_pre, dz = cb if pos else (cb, None)
+            g_out = d_pre.reshape(-1, 4)
             mlp = net.mlp_coarse if (ps["coarse"] or shared) else net.mlp_fine
             state = dict(mlp.named_parameters())
             grads, d_zlat, d_in = _mlp_grads(state, mlp.packed_bwd(net.precision), ps["dumps"], g_out, scene.NS,

@@ -384,7 +384,7 @@ __device__ __forceinline__ float wscan_add(float v, int lane) {
 template <int PASS>
 __device__ __forceinline__ float composite_bwd_pass(const float *zr, const float4 *cr, const float *dwr, int K, float far,
                                                     float3 drgb, float ddepth, float gwhite, int lane, float total,
-                                                    float4 *dout, float *dzout) {
+                                                    float4 *dout, float *dzout, bool preact) {
     float carry = 1.f, run = 0.f, acc = 0.f, ddelta_prev = 0.f;
     for (int c0 = 0; c0 < K; c0 += 64) {
         const int i = c0 + lane;
@@ -416,7 +416,11 @@ __device__ __forceinline__ float composite_bwd_pass(const float *zr, const float
             if (valid) {
                 const float dalpha = g * T - suffix / tf;
                 const float dsigma = cs.w > 0.f ? dalpha * delta * ex : 0.f;
-                dout[i] = make_float4(w * drgb.x, w * drgb.y, w * drgb.z, dsigma);
+                float4 go = make_float4(w * drgb.x, w * drgb.y, w * drgb.z, dsigma);
+                if (preact) {  // through rgb = sigmoid(.), sigma = relu(.) (models.py:260-263): relu' already applied
+                    go.x *= cs.x * (1.f - cs.x); go.y *= cs.y * (1.f - cs.y); go.z *= cs.z * (1.f - cs.z);
+                }
+                dout[i] = go;
                 ddelta = dalpha * fmaxf(cs.w, 0.f) * ex;  // d alpha_i / d delta_i = relu(sigma) exp(-delta relu(sigma))
             }
             if (dzout) {
@@ -437,7 +441,7 @@ __device__ __forceinline__ float composite_bwd_pass(const float *zr, const float
 __global__ void __launch_bounds__(CW * 64)
 composite_bwd_kernel(const float *__restrict__ rays, const float *__restrict__ z, const float4 *__restrict__ rgbs, int R,
                      int K, int white_bkgd, const float *__restrict__ d_rgb, const float *__restrict__ d_depth,
-                     const float *__restrict__ d_w, float4 *__restrict__ d_rgbs, float *__restrict__ d_z) {
+                     const float *__restrict__ d_w, float4 *__restrict__ d_rgbs, float *__restrict__ d_z, int preact) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * CW + wv;
     if (r >= R) return;
@@ -448,9 +452,9 @@ composite_bwd_kernel(const float *__restrict__ rays, const float *__restrict__ z
     const float *zr = z + (size_t)r * K;
     const float4 *cr = rgbs + (size_t)r * K;
     const float *dwr = d_w ? d_w + (size_t)r * K : nullptr;
-    const float total = composite_bwd_pass<0>(zr, cr, dwr, K, far, drgb, ddepth, gwhite, lane, 0.f, nullptr, nullptr);
+    const float total = composite_bwd_pass<0>(zr, cr, dwr, K, far, drgb, ddepth, gwhite, lane, 0.f, nullptr, nullptr, false);
     composite_bwd_pass<1>(zr, cr, dwr, K, far, drgb, ddepth, gwhite, lane, total, d_rgbs + (size_t)r * K,
-                          d_z ? d_z + (size_t)r * K : nullptr);
+                          d_z ? d_z + (size_t)r * K : nullptr, preact != 0);
 }
 
 // ---------------------------------------------------------------- latent scatter-add
@@ -696,12 +700,13 @@ extern "C" int pnr_weight_grad(const void *dY, const void *X, long long rows, in
 
 extern "C" int pnr_composite_backward(const float *rays, const float *z, const float *rgbsigma, int R, int K, int white_bkgd,
                                       const float *d_rgb, const float *d_depth, const float *d_weights, float *d_rgbsigma,
-                                      float *d_z, void *stream) {
+                                      float *d_z, int pre_activation, void *stream) {
     if (R < 0 || K <= 0) return pnr_fail(PNR_E_INVALID, "pnr_composite_backward: bad sizes");
     if (R == 0) return PNR_OK;
     if (!rays || !z || !rgbsigma || !d_rgb || !d_rgbsigma) return pnr_fail(PNR_E_INVALID, "pnr_composite_backward: null argument");
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + CW - 1) / CW), dim3(CW * 64), 0, (hipStream_t)stream, rays, z,
-                       (const float4 *)rgbsigma, R, K, white_bkgd, d_rgb, d_depth, d_weights, (float4 *)d_rgbsigma, d_z);
+                       (const float4 *)rgbsigma, R, K, white_bkgd, d_rgb, d_depth, d_weights, (float4 *)d_rgbsigma, d_z,
+                       pre_activation);
     return pnr_check_launch("pnr_composite_backward");
 }
 

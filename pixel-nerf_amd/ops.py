@@ -373,7 +373,10 @@ def eval_ray_samples_train(scene, packed, rays, z):
     return out, dumps
 
 
-def composite_backward(rays, z, rgbsigma, white_bkgd, d_rgb, d_depth=None, d_weights=None, want_dz=False):
+def composite_backward(rays, z, rgbsigma, white_bkgd, d_rgb, d_depth=None, d_weights=None, want_dz=False,
+                       pre_activation=False):
+    """-> dL/d(rgb sigma) per point (R,K,4) [after the output activations, or in front of them with
+    pre_activation=True] and optionally dL/dz (R,K)."""
     lib = _lib.load()
     rays = _f32(rays, "rays", (None, 8))
     R = rays.shape[0]
@@ -387,8 +390,8 @@ def composite_backward(rays, z, rgbsigma, white_bkgd, d_rgb, d_depth=None, d_wei
     dz = torch.empty((R, K), dtype=torch.float32, device=rays.device) if want_dz else None
     with torch.cuda.device(rays.device):
         _lib.check(lib.pnr_composite_backward(_p(rays), _p(z), _p(rgbsigma), R, K, int(bool(white_bkgd)), _p(d_rgb),
-                                              _p(d_depth), _p(d_weights), _p(out), _p(dz), _stream()),
-                   "pnr_composite_backward")
+                                              _p(d_depth), _p(d_weights), _p(out), _p(dz), int(bool(pre_activation)),
+                                              _stream()), "pnr_composite_backward")
     return (out, dz) if want_dz else out
 
 
