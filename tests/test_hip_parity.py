@@ -232,6 +232,16 @@ def test_full_size_properties(ops, dev):
         assert (d >= -1e-5).all() and (d <= meta["z_far"] + 1e-4).all()
         # white background: rgb = sum w c + 1 - sum w with c in (0,1)
         assert (out[p]["rgb"] >= -1e-5).all() and (out[p]["rgb"] <= 1 + 1e-4).all()
+    # race screen: 16-48 tiles per persistent workgroup, LDS images reused tile after tile, weight
+    # ring wrapping across tiles -- a second run must be bit-identical
+    out2 = ops.render_forward(sc, pc, pf, rays, 64, 128, 16, nz, white_bkgd=True, want_weights=True)
+    for p in ("coarse", "fine"):
+        assert torch.equal(out[p]["weights"], out2[p]["weights"]) and torch.equal(out[p]["rgb"], out2[p]["rgb"])
+    # and the image must not depend on how the rays are batched (tile/workgroup assignment changes)
+    idx = torch.randperm(R, generator=torch.Generator().manual_seed(2)).to(dev)
+    out3 = ops.render_forward(sc, pc, pf, rays[idx].contiguous(), 64, 128, 16,
+                              {k: v[idx].contiguous() for k, v in nz.items()}, white_bkgd=True)
+    assert torch.equal(out3["fine"]["rgb"], out["fine"]["rgb"][idx])
 
 
 # ------------------------------------------------------------------ edge cases / errors
