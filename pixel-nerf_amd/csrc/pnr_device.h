@@ -23,6 +23,7 @@ template <> struct Prec<PNR_PREC_F16> {
     typedef _Float16 T;
     typedef f16x8 T8;
     typedef f16x2 T2;
+    static constexpr float kMaxFinite = 65504.f;
     static __device__ __forceinline__ f32x16 mfma(T8 a, T8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
@@ -31,6 +32,7 @@ template <> struct Prec<PNR_PREC_BF16> {
     typedef __bf16 T;
     typedef bf16x8 T8;
     typedef bf16x2 T2;
+    static constexpr float kMaxFinite = 3.3895313892515355e38f;  // largest finite bf16
     static __device__ __forceinline__ f32x16 mfma(T8 a, T8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
@@ -92,8 +94,13 @@ template <typename P, bool RELU>
 __device__ __forceinline__ typename P::T8 pack8(float v0, float v1, float v2, float v3, float v4, float v5,
                                                 float v6, float v7) {
     if (RELU) {
-        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-        v4 = fmaxf(v4, 0.f); v5 = fmaxf(v5, 0.f); v6 = fmaxf(v6, 0.f); v7 = fmaxf(v7, 0.f);
+        // relu fused with saturation to the operand type's largest finite value: one v_med3_f32 per
+        // element, and an fp16 activation can never become inf (65504 for f16; bf16 has fp32's range)
+        const float hi = P::kMaxFinite;
+        v0 = __builtin_amdgcn_fmed3f(v0, 0.f, hi); v1 = __builtin_amdgcn_fmed3f(v1, 0.f, hi);
+        v2 = __builtin_amdgcn_fmed3f(v2, 0.f, hi); v3 = __builtin_amdgcn_fmed3f(v3, 0.f, hi);
+        v4 = __builtin_amdgcn_fmed3f(v4, 0.f, hi); v5 = __builtin_amdgcn_fmed3f(v5, 0.f, hi);
+        v6 = __builtin_amdgcn_fmed3f(v6, 0.f, hi); v7 = __builtin_amdgcn_fmed3f(v7, 0.f, hi);
     }
     typename P::T t = (typename P::T)0;
     u32x4 u = {pack2(v0, v1, t), pack2(v2, v3, t), pack2(v4, v5, t), pack2(v6, v7, t)};

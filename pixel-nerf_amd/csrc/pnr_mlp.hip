@@ -206,6 +206,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             const size_t dump_view = dump_pooled + (size_t)view * (size_t)q.P * (D_HID * 2);
             __syncthreads();  // previous users of LDS_IN / LDS_META / LDS_Z are done
             PNR_T(PH_SYNC_TOP);
+#ifdef PNR_EXP_NO_FEATURE  // experiment: feature phase only for the first tile (stale LDS afterwards; wrong results)
+            if (tile == (int)blockIdx.x) {
+#endif
             geometry<P, RAYS>(q, smem, tile, view, tid);
             __syncthreads();
             PNR_T(PH_GEOMETRY);
@@ -217,6 +220,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                         *reinterpret_cast<const u32x4 *>(smem + LDS_IN + row * ROW_IN + chunk * 16);
             }
             gather<P, TRAIN, MV ? 2 : 4>(q, smem, wv, lane, tile, view);  // multi-view also holds the view sum
+#ifdef PNR_EXP_NO_FEATURE
+            }
+#endif
             __syncthreads();
             PNR_T(PH_GATHER);
             add_bias<true>(x, bias_lane, B_IN_Z0);

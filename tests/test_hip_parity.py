@@ -301,3 +301,15 @@ def test_errors_are_loud(ops, dev):
     with pytest.raises(_lib.PixelNerfHipError):  # n_coarse beyond the sampler's static limit
         ops.sample_fine(torch.zeros(2, 8, device=dev), torch.zeros(2, 300, device=dev), torch.zeros(2, device=dev),
                         torch.zeros(2, 300, device=dev), torch.zeros(2, 4, device=dev), torch.zeros(2, 4, device=dev), None)
+
+
+def test_f16_activations_saturate_instead_of_overflowing(ops, dev):
+    """Scale the first layers so that hidden activations exceed the fp16 range (65504): the fused
+    relu+saturate keeps every output finite (an un-clamped fp16 conversion would give inf -> NaN)."""
+    sc = dscene(ops, dev, "sn64")
+    p = {k: v.clone() for k, v in mlp_params(11).items()}
+    p["lin_z.0.weight"] *= 1e6  # hidden stream ~1e6, far beyond 65504
+    pk = ops.pack_mlp({k: v.to(dev) for k, v in p.items()}, "f16")
+    g = load_golden("stages")
+    out = ops.eval_points(sc, pk, torch.from_numpy(g["sn64_xyz"]).to(dev), torch.from_numpy(g["sn64_viewdirs"]).to(dev))
+    assert torch.isfinite(out).all()
