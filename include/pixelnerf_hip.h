@@ -180,11 +180,12 @@ int pnr_mlp_backward(const void *packed_bwd, int precision, const PnrTrainDumps 
 /* Weight gradient of one 512x512 linear from the 16-bit dumps: dW (512,512) fp32 = out_scale *
  * dY^T X, db (512) fp32 = out_scale * column sums of dY (db may be NULL); dY, X (rows,512) 16-bit
  * row-major at `precision`.  Split over row slices with a fixed-order reduction (bit-reproducible);
- * workspace: pnr_weight_grad_workspace_bytes().  Row/column order of the result follows the
- * operands' (storage order where the dumps are in storage order). */
+ * workspace: pnr_weight_grad_workspace_bytes().  rows_storage_order / cols_storage_order: dY / X
+ * columns are in storage order (pnr_storage_perm); dW and db are always written in feature order. */
 size_t pnr_weight_grad_workspace_bytes(void);
 int pnr_weight_grad(const void *dY, const void *X, long long rows, int precision, float out_scale,
-                    float *dW, float *db, void *workspace, void *stream);
+                    int rows_storage_order, int cols_storage_order, float *dW, float *db,
+                    void *workspace, void *stream);
 
 /* d(encoder.latent) += bilinear scatter of d_zlat (rows_v,512) fp32 (natural channel order) to
  * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (atomic adds; caller zero-initialises). */

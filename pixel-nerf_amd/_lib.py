@@ -73,7 +73,7 @@ PROTOTYPES = {
     "pnr_mlp_backward": (_I, [_P, _I, ctypes.POINTER(PnrTrainDumps), _P, _F, ctypes.c_longlong, _I,
                               ctypes.POINTER(PnrBackwardDumps), _P]),
     "pnr_weight_grad_workspace_bytes": (_SZ, []),
-    "pnr_weight_grad": (_I, [_P, _P, ctypes.c_longlong, _I, _F, _P, _P, _P, _P]),
+    "pnr_weight_grad": (_I, [_P, _P, ctypes.c_longlong, _I, _F, _I, _I, _P, _P, _P, _P]),
     "pnr_latent_scatter": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _P]),
     "pnr_composite": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "pnr_render_workspace_bytes": (_SZ, [_I, _I, _I]),

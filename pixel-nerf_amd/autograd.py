@@ -62,20 +62,17 @@ def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS, want_d_in=False):
     prec = packed_bwd.precision
     grads = {}
     # weight gradients of the 512x512 linears: HIP MFMA kernel straight from the 16-bit dumps
-    # (fp32 accumulation); storage order -> feature order on the 512-wide dims afterwards
+    # (fp32 accumulation); the kernel's reduction step writes them in feature order
     for b in range(5):
-        g0, b0 = ops.weight_grad(bd.g_fc0[b], fwd.d_a[b], prec, inv_s)
-        grads[f"blocks.{b}.fc_0.weight"] = g0[inv][:, inv]
-        grads[f"blocks.{b}.fc_0.bias"] = b0[inv]
-        g1, b1 = ops.weight_grad(bd.g_fc1[b], fwd.d_n[b], prec, inv_s)
-        grads[f"blocks.{b}.fc_1.weight"] = g1[inv][:, inv]
-        grads[f"blocks.{b}.fc_1.bias"] = b1[inv]
+        grads[f"blocks.{b}.fc_0.weight"], grads[f"blocks.{b}.fc_0.bias"] = ops.weight_grad(
+            bd.g_fc0[b], fwd.d_a[b], prec, inv_s, rows_st=True, cols_st=True)
+        grads[f"blocks.{b}.fc_1.weight"], grads[f"blocks.{b}.fc_1.bias"] = ops.weight_grad(
+            bd.g_fc1[b], fwd.d_n[b], prec, inv_s, rows_st=True, cols_st=True)
     d_zlat = None
     for b in range(3):
         gz = bd.g_x0 if b == 0 else bd.g_fc1[b - 1]  # dL/d(residual stream entering block b), per view
-        gw, gb = ops.weight_grad(gz, fwd.d_z, prec, inv_s)
-        grads[f"lin_z.{b}.weight"] = gw[inv]
-        grads[f"lin_z.{b}.bias"] = gb[inv]
+        grads[f"lin_z.{b}.weight"], grads[f"lin_z.{b}.bias"] = ops.weight_grad(
+            gz, fwd.d_z, prec, inv_s, rows_st=True, cols_st=False)  # latent channels are in natural order
         # d z_lat += dY W_z[b]  (W in feature order; dY columns are in storage order): a plain
         # (rows,512)x(512,512) library GEMM on the 16-bit operands (fp32 accumulation inside)
         term = torch.matmul(gz, mlp_state[f"lin_z.{b}.weight"].detach()[perm].to(gz.dtype)).float()

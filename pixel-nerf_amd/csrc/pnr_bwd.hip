@@ -337,19 +337,24 @@ dw_kernel(const typename Prec<PREC>::T *__restrict__ dY, const typename Prec<PRE
     }
 }
 
-// dW = scale * sum_z part[z], db = scale * sum_z bpart[z]  (fixed summation order)
+// dW = scale * sum_z part[z], db = scale * sum_z bpart[z]  (fixed summation order).  rows_st / cols_st:
+// the operand that indexes the rows (dY) / columns (X) of dW was dumped in storage order; the result is
+// written in feature order (row e -> feature feat_of(e/32, (e%32)/16, e%16)).
 __global__ void dw_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bpart, int nz, float scale,
-                                 float *__restrict__ dW, float *__restrict__ db) {
+                                 int rows_st, int cols_st, float *__restrict__ dW, float *__restrict__ db) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < D_HID * D_HID) {
         float s = 0.f;
         for (int z = 0; z < nz; ++z) s += part[(size_t)z * (D_HID * D_HID) + idx];
-        dW[idx] = s * scale;
+        int r = idx / D_HID, c = idx % D_HID;
+        if (rows_st) r = feat_of(r >> 5, (r >> 4) & 1, r & 15);
+        if (cols_st) c = feat_of(c >> 5, (c >> 4) & 1, c & 15);
+        dW[r * D_HID + c] = s * scale;
     }
     if (db && idx < D_HID) {
         float s = 0.f;
         for (int z = 0; z < nz; ++z) s += bpart[(size_t)z * D_HID + idx];
-        db[idx] = s * scale;
+        db[rows_st ? feat_of(idx >> 5, (idx >> 4) & 1, idx & 15) : idx] = s * scale;
     }
 }
 
@@ -672,8 +677,9 @@ extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const Pnr
 constexpr int DW_MAX_SPLIT = 32;
 extern "C" size_t pnr_weight_grad_workspace_bytes(void) { return (size_t)DW_MAX_SPLIT * (D_HID * D_HID + D_HID) * sizeof(float); }
 
-extern "C" int pnr_weight_grad(const void *dY, const void *X, long long rows, int precision, float out_scale, float *dW,
-                               float *db, void *workspace, void *stream) {
+extern "C" int pnr_weight_grad(const void *dY, const void *X, long long rows, int precision, float out_scale,
+                               int rows_storage_order, int cols_storage_order, float *dW, float *db, void *workspace,
+                               void *stream) {
     if (!dY || !X || !dW || !workspace || rows <= 0) return pnr_fail(PNR_E_INVALID, "pnr_weight_grad: bad argument");
     // 16 output tiles of 128x128 x nsplit row slices (= up to 512 blocks, two per CU)
     int nsplit = (int)((rows + 1023) / 1024);
@@ -694,7 +700,8 @@ extern "C" int pnr_weight_grad(const void *dY, const void *X, long long rows, in
                            D_HID, D_HID, (int)per, part, bpart);
     else
         return pnr_fail(PNR_E_INVALID, "pnr_weight_grad: unknown precision");
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(D_HID * D_HID / 256), dim3(256), 0, st, part, bpart, nz, out_scale, dW, db);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(D_HID * D_HID / 256), dim3(256), 0, st, part, bpart, nz, out_scale,
+                       rows_storage_order, cols_storage_order, dW, db);
     return pnr_check_launch("pnr_weight_grad");
 }
 

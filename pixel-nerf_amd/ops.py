@@ -436,9 +436,9 @@ def latent_scatter(scene, rays, z, d_zlat, d_latent_nhwc):
     return d_latent_nhwc
 
 
-def weight_grad(dY, X, precision, out_scale=1.0, want_bias=True):
+def weight_grad(dY, X, precision, out_scale=1.0, want_bias=True, rows_st=False, cols_st=False):
     """dW (512,512) = out_scale * dY^T X and db (512) = out_scale * sum_rows dY from 16-bit dumps
-    (rows,512); fp32 results in the operands' row/column order."""
+    (rows,512).  rows_st / cols_st: dY / X are in storage order; results are in feature order."""
     lib = _lib.load()
     rows = dY.shape[0]
     assert dY.shape == (rows, 512) and X.shape == (rows, 512) and dY.dtype == X.dtype and dY.is_cuda
@@ -449,8 +449,9 @@ def weight_grad(dY, X, precision, out_scale=1.0, want_bias=True):
     if key not in _wg_workspace:
         _wg_workspace[key] = torch.empty(lib.pnr_weight_grad_workspace_bytes(), dtype=torch.uint8, device=dY.device)
     with torch.cuda.device(dY.device):
-        _lib.check(lib.pnr_weight_grad(_p(dY), _p(X), rows, int(precision), float(out_scale), _p(dW), _p(db),
-                                       _p(_wg_workspace[key]), _stream()), "pnr_weight_grad")
+        _lib.check(lib.pnr_weight_grad(_p(dY), _p(X), rows, int(precision), float(out_scale), int(bool(rows_st)),
+                                       int(bool(cols_st)), _p(dW), _p(db), _p(_wg_workspace[key]), _stream()),
+                   "pnr_weight_grad")
     return dW, db
 
 
