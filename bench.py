@@ -22,7 +22,9 @@ The JSON line also carries
   cpu_baseline : the CPU oracle (restatement of the reference, kind "port") timed on this
                  host's cores on a bounded sample of the same workload, rank 0 / N=1 only;
   psnr_db      : PSNR of the HIP render vs that CPU render on the sample (identical rays,
-                 weights, grid and noise) -- the "matched PSNR" of the metric.
+                 weights, grid and noise) -- the "matched PSNR" of the metric;
+  psnr_db_full_size_vs_f32_hip : PSNR of one full step (all R rays) vs the exact-fp32 HIP path
+                 (precision "f32", ~1e-6 from the reference), outside the timed region.
 """
 import argparse
 import json
@@ -133,6 +135,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=0, help="CPU-baseline sample size (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true")
+    ap.add_argument("--no-f32-check", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: functional test on one GPU)")
     args = ap.parse_args()
 
@@ -253,6 +256,22 @@ def main():
                                    "sample": "%d rays of the same workload (64+128, same weights/grid), %.1f s, "
                                              "oracle/pnr_oracle.py (torch CPU fp32 restatement of the reference)" % (n, dt)}
             res["speedup_vs_cpu_baseline"] = rays_per_s / rate
+        if world == 1 and not args.no_f32_check:
+            # full-size cross-check on the GPU: all R rays of the step through the exact-fp32 HIP path
+            # (precision "f32", agrees with the reference to ~1e-6) with the same noise
+            from oracle import pnr_oracle as O
+            noise = {k: v.to(dev) for k, v in synthetic.make_noise(R, 64, 128, 16, seed=101).items()}
+            with torch.no_grad():
+                fast = renderer(net, rays[None], _noise=noise)
+                net.precision = "f32"
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                exact = renderer(net, rays[None], _noise=noise)
+                torch.cuda.synchronize()
+                dt32 = time.perf_counter() - t1
+                net.precision = args.prec
+            res["psnr_db_full_size_vs_f32_hip"] = O.psnr(fast.fine.rgb.cpu(), exact.fine.rgb.cpu())
+            res["f32_hip_path_rays_per_s"] = R / dt32
         if world == 1 and not args.no_eager_baseline:
             res["torch_eager_gpu_baseline"] = eager_gpu_baseline(scene, mlps, rays, dev)
             res["speedup_vs_torch_eager_gpu"] = rays_per_s / res["torch_eager_gpu_baseline"]["value"]

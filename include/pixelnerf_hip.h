@@ -36,6 +36,7 @@ extern "C" {
 /* arithmetic of the 512-wide linear layers (operands of the MFMA; accumulation is fp32) */
 #define PNR_PREC_F16 0       /* fp16 operands, v_mfma_f32_32x32x16_f16  */
 #define PNR_PREC_BF16 1      /* bf16 operands, v_mfma_f32_32x32x16_bf16 */
+#define PNR_PREC_F32 2       /* exact fp32 validation path (pnr_eval_*_f32 only), v_mfma_f32_32x32x2_f32 */
 
 /* Encoded-scene state: exactly what PixelNeRFNet.encode() leaves in module buffers
  * (src/model/models.py:111-141, src/model/encoder.py:160-163), except that the feature grid
@@ -111,6 +112,21 @@ int pnr_eval_ray_samples(const PnrScene *scene /*host*/, const void *packed, int
 int pnr_eval_points(const PnrScene *scene /*host*/, const void *packed, int precision,
                     const float *xyz, const float *viewdirs, int B, float *rgbsigma,
                     void *stream);
+
+/* ---- exact-fp32 evaluation (validation grade) --------------------------------------------------
+ * Same contract as pnr_eval_ray_samples / pnr_eval_points (PixelNeRFNet.forward, models.py:161-265)
+ * with every operand in fp32: unfused, one GEMM launch per nn.Linear on the fp32 MFMA, activations
+ * in HBM.  Takes the raw nn.Linear tensors (no repack).  Results track the reference's fp32 path
+ * to rounding level; throughput is ~1/20 of the 16-bit fused kernel.  The points are processed in
+ * chunks sized by the workspace: pnr_eval_f32_workspace_bytes(NS, chunk_points) bytes hold one
+ * chunk of chunk_points points (>= 64). */
+size_t pnr_eval_f32_workspace_bytes(int NS, long long chunk_points);
+int pnr_eval_ray_samples_f32(const PnrScene *scene /*host*/, const PnrMlpWeights *w /*host*/,
+                             const float *rays, const float *z, int R, int rays_per_obj, int K,
+                             float *rgbsigma, void *workspace, size_t workspace_bytes, void *stream);
+int pnr_eval_points_f32(const PnrScene *scene /*host*/, const PnrMlpWeights *w /*host*/,
+                        const float *xyz, const float *viewdirs, int B, float *rgbsigma,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- training (autograd) support -------------------------------------------------------------
  * The reference trains through this path with plain autograd (train/train.py:199-215): MSE on

@@ -40,15 +40,33 @@ def _f32(t, name, shape=None):
 
 
 class PackedMLP:
-    """A ResnetFC's parameters repacked into the fused kernel's fragment stream."""
+    """A ResnetFC's parameters repacked into the fused kernel's fragment stream.
+    precision "f32" (exact validation path) keeps the raw nn.Linear tensors instead."""
 
-    def __init__(self, buf, precision):
+    def __init__(self, buf, precision, weights=None):
         self.buf = buf
         self.precision = precision
+        self.weights = weights  # f32 only: (PnrMlpWeights, {key: tensor} keeping the storage alive)
 
     @property
     def ptr(self):
+        if self.buf is None:
+            raise _lib.PixelNerfHipError("this entry point has no fp32 instantiation (precision='f32' covers "
+                                         "inference through eval_ray_samples / eval_points / render_forward)")
         return ctypes.c_void_p(self.buf.data_ptr())
+
+    @property
+    def wref(self):
+        return ctypes.byref(self.weights[0])
+
+
+F32_CHUNK_POINTS = 1 << 17  # points per chunk of the fp32 path (workspace ~1.4 GB x NS)
+
+
+def _f32_workspace(lib, scene, P):
+    chunk = max(64, min(int(P), F32_CHUNK_POINTS // scene.NS))
+    nbytes = lib.pnr_eval_f32_workspace_bytes(scene.NS, chunk)
+    return torch.empty(nbytes, dtype=torch.uint8, device=scene.device), nbytes
 
 
 def _weights_struct(state):
@@ -80,6 +98,10 @@ def pack_mlp(state, precision="f16", backward=False):
     lib = _lib.load()
     prec = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
     w, keep = _weights_struct(state)
+    if prec == _lib.PREC_F32:
+        if backward:
+            raise _lib.PixelNerfHipError("precision='f32' has no backward path")
+        return PackedMLP(None, prec, weights=(w, keep))
     dev = keep["lin_in.weight"].device
     nbytes = lib.pnr_packed_mlp_bwd_bytes() if backward else lib.pnr_packed_mlp_bytes()
     buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -186,6 +208,12 @@ def eval_ray_samples(scene, packed, rays, z):
     if R % scene.SB != 0:
         raise ValueError("number of rays must be a multiple of the number of objects")
     out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
+    if packed.precision == _lib.PREC_F32:
+        ws, nbytes = _f32_workspace(lib, scene, R * K)
+        with torch.cuda.device(rays.device):
+            _lib.check(lib.pnr_eval_ray_samples_f32(scene.ref, packed.wref, _p(rays), _p(z), R, max(R // scene.SB, 1), K,
+                                                    _p(out), _p(ws), nbytes, _stream()), "pnr_eval_ray_samples_f32")
+        return out
     with torch.cuda.device(rays.device):
         _lib.check(lib.pnr_eval_ray_samples(scene.ref, packed.ptr, packed.precision, _p(rays), _p(z), R,
                                             max(R // scene.SB, 1), K, _p(out), _stream()),
@@ -200,6 +228,12 @@ def eval_points(scene, packed, xyz, viewdirs):
     B = xyz.shape[1]
     viewdirs = _f32(viewdirs, "viewdirs", (scene.SB, B, 3))
     out = torch.empty((scene.SB, B, 4), dtype=torch.float32, device=xyz.device)
+    if packed.precision == _lib.PREC_F32:
+        ws, nbytes = _f32_workspace(lib, scene, scene.SB * B)
+        with torch.cuda.device(xyz.device):
+            _lib.check(lib.pnr_eval_points_f32(scene.ref, packed.wref, _p(xyz), _p(viewdirs), B, _p(out), _p(ws), nbytes,
+                                               _stream()), "pnr_eval_points_f32")
+        return out
     with torch.cuda.device(xyz.device):
         _lib.check(lib.pnr_eval_points(scene.ref, packed.ptr, packed.precision, _p(xyz), _p(viewdirs), B,
                                        _p(out), _stream()), "pnr_eval_points")
@@ -242,6 +276,23 @@ def render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_
         u2, u3 = _f32(noise["u2"], "u2", (R, Kimp)), _f32(noise["u3"], "u3", (R, Kimp))
     if Kf > 0 and Kfd > 0:
         n4 = _f32(noise["n4"], "n4", (R, Kfd))
+    if packed_fine is not None and packed_fine.precision != packed_coarse.precision:
+        raise ValueError("coarse and fine networks must be packed at the same precision")
+    if packed_coarse.precision == _lib.PREC_F32:
+        # exact-fp32 validation path: the same stages, one C call each
+        z_c = sample_coarse(rays, u1, lindisp)
+        w_c, rgb_c, depth_c = composite(rays, z_c, eval_ray_samples(scene, packed_coarse, rays, z_c), white_bkgd, True)
+        ret = {"coarse": {"rgb": rgb_c, "depth": depth_c}}
+        if want_weights:
+            ret["coarse"]["weights"] = w_c
+        if Kf > 0:
+            z_f = sample_fine(rays, w_c, depth_c, z_c, u2, u3, n4, depth_std, lindisp)
+            fine = packed_fine if packed_fine is not None else packed_coarse
+            w_f, rgb_f, depth_f = composite(rays, z_f, eval_ray_samples(scene, fine, rays, z_f), white_bkgd, want_weights)
+            ret["fine"] = {"rgb": rgb_f, "depth": depth_f}
+            if want_weights:
+                ret["fine"]["weights"] = w_f
+        return ret
 
     def outs(K):
         return (torch.empty((R, 3), dtype=torch.float32, device=dev),
@@ -251,8 +302,6 @@ def render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_
     rgb_c, depth_c, w_c = outs(Kc)
     rgb_f, depth_f, w_f = outs(Kc + Kf) if Kf > 0 else (None, None, None)
     ws = torch.empty(max(lib.pnr_render_workspace_bytes(R, Kc, Kf), 16), dtype=torch.uint8, device=dev)
-    if packed_fine is not None and packed_fine.precision != packed_coarse.precision:
-        raise ValueError("coarse and fine networks must be packed at the same precision")
     with torch.cuda.device(dev):
         _lib.check(lib.pnr_render_forward(
             scene.ref, packed_coarse.ptr, packed_fine.ptr if packed_fine is not None else None,

@@ -1,0 +1,135 @@
+"""
+GPU parity tests (-m gpu) of the exact-fp32 validation path (precision="f32",
+pixel-nerf_amd/csrc/pnr_f32.hip): every operand fp32, linears on v_mfma_f32_32x32x2_f32.
+
+Stated tolerances against the reference's own fp32 outputs (tests/golden, identical rays, weights,
+feature grid and noise) -- only summation order and libm differ:
+  * per point : |rgb| err <= 2e-5, sigma err <= 1e-4 * max(1, sigma)      (measured 2.5e-6 / 4.8e-6)
+  * renders   : coarse rgb <= 2e-5, depth <= 1e-4*(far-near); the fine pass within the same bounds
+                except for a <= 2 % allowance of rays whose importance samples flipped a cdf bin
+                at rounding level (helpers.assert_close_frac); PSNR >= 85 dB  (measured 109-142 dB).
+It also serves as the on-GPU yardstick for the 16-bit fused kernel at sizes the CPU oracle cannot
+reach in test time.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import RENDER_SCENARIOS, assert_close_frac, golden_setup, load_golden, mlp_params, scene_for
+from oracle import pnr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pixelnerf_amd import ops as _ops
+    return _ops
+
+
+def dscene(ops, dev, name):
+    s, _ = scene_for(name)
+    return ops.make_scene(s["latent"].to(dev), s["poses"].to(dev), s["focal"].to(dev), s["c"].to(dev),
+                          s["image_shape"], s["NS"])
+
+
+def packed(ops, dev, seed, prec="f32"):
+    return ops.pack_mlp({k: v.to(dev) for k, v in mlp_params(seed).items()}, prec)
+
+
+@pytest.mark.parametrize("scene_name", ["sn64", "dtu_mini", "mv_mini"])
+def test_f32_eval_points_matches_reference(ops, dev, scene_name):
+    g = load_golden("stages")
+    sc = dscene(ops, dev, scene_name)
+    xyz = torch.from_numpy(g[f"{scene_name}_xyz"]).to(dev)
+    vd = torch.from_numpy(g[f"{scene_name}_viewdirs"]).to(dev)
+    for which, seed in (("coarse", 11), ("fine", 12)):
+        out = ops.eval_points(sc, packed(ops, dev, seed), xyz, vd).cpu().numpy()
+        ref = g[f"{scene_name}_out_{which}"]
+        assert np.isfinite(out).all()
+        e_rgb = np.abs(out[..., :3] - ref[..., :3]).max()
+        e_s = (np.abs(out[..., 3] - ref[..., 3]) / np.maximum(1.0, ref[..., 3])).max()
+        assert e_rgb <= 2e-5, f"rgb max err {e_rgb:.3e}"
+        assert e_s <= 1e-4, f"sigma rel err {e_s:.3e}"
+
+
+@pytest.mark.parametrize("name", RENDER_SCENARIOS)
+def test_f32_render_matches_reference(ops, dev, name):
+    g, scene, meta, mc, mf, rays, noise = golden_setup(name)
+    Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])
+    sc = dscene(ops, dev, str(g["scene"]))
+    pc = packed(ops, dev, int(g["mlp_seed_coarse"]))
+    pf = packed(ops, dev, int(g["mlp_seed_fine"])) if mf is not None else None
+    r = rays.reshape(-1, 8).to(dev)
+    out = ops.render_forward(sc, pc, pf, r, Kc, Kf, Kfd, {k: v.to(dev) for k, v in noise.items()},
+                             depth_std=float(g["depth_std"]), white_bkgd=bool(g["white_bkgd"]),
+                             lindisp=bool(g["lindisp"]), want_weights=True)
+    span = float(meta["z_far"] - meta["z_near"])
+    assert ("fine" in out) == (Kf > 0)
+    for p in ["coarse"] + (["fine"] if Kf > 0 else []):
+        K = Kc if p == "coarse" else Kc + Kf
+        flips = 0.0 if p == "coarse" else 2e-2  # the goldens hold 96..256 rays: one flipped ray is ~1 %
+        rgb, depth, w = out[p]["rgb"].cpu(), out[p]["depth"].cpu().numpy(), out[p]["weights"].cpu().numpy()
+        assert_close_frac(rgb.numpy(), g[f"{p}_rgb"].reshape(-1, 3), 2e-5, max_frac=flips, loose_atol=0.05, what=f"{p} rgb")
+        assert_close_frac(depth, g[f"{p}_depth"].reshape(-1), 1e-4 * span, max_frac=flips, loose_atol=0.05 * span,
+                          what=f"{p} depth")
+        if p == "coarse":
+            np.testing.assert_allclose(w, g["coarse_weights"].reshape(-1, K), rtol=0, atol=2e-5)
+        ps = O.psnr(rgb, torch.from_numpy(g[f"{p}_rgb"]).reshape(-1, 3))
+        assert ps >= 85.0, f"{p} PSNR {ps:.1f} dB"
+
+
+def test_f32_chunking_is_invisible(ops, dev, monkeypatch):
+    """The fp32 path walks the points in workspace-sized chunks; any chunk size gives the same bits."""
+    g, scene, meta, mc, mf, rays, noise = golden_setup("mv_mini_lindisp")
+    sc = dscene(ops, dev, "mv_mini")
+    pk = packed(ops, dev, 12)
+    r = rays.reshape(-1, 8).to(dev)
+    z = torch.from_numpy(g["fine_z"]).to(dev)
+    whole = ops.eval_ray_samples(sc, pk, r, z)
+    monkeypatch.setattr(ops, "F32_CHUNK_POINTS", 2 * 192)  # NS=2 -> 192-point chunks, ragged tail
+    parts = ops.eval_ray_samples(sc, pk, r, z)
+    assert torch.equal(whole, parts)
+    # variant B agrees with variant A
+    SB = rays.shape[0]
+    pts = (r[:, None, :3] + z.unsqueeze(2) * r[:, None, 3:6]).reshape(SB, -1, 3)
+    vd = r[:, None, 3:6].expand(-1, z.shape[1], -1).reshape(SB, -1, 3)
+    b = ops.eval_points(sc, pk, pts.contiguous(), vd.contiguous()).reshape(whole.shape)
+    assert torch.equal(whole, b)
+
+
+@pytest.mark.parametrize("prec,floor_db", [("f16", 52.0), ("bf16", 36.0)])
+def test_fused_kernel_against_f32_path_at_full_size(ops, dev, prec, floor_db):
+    """The shipped eval configuration (SRN 128x128 view, 64 + 128 samples, 16 of them depth samples) on
+    16384 rays: the 16-bit fused kernel vs the exact-fp32 path, both on the GPU."""
+    from pixelnerf_amd import synthetic
+    s, meta = scene_for("srn_car")
+    sc = dscene(ops, dev, "srn_car")
+    rays = synthetic.target_rays(meta, n_rays=16384).reshape(-1, 8).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    R = rays.shape[0]
+    noise = {"u1": torch.rand(R, 64, generator=gen), "u2": torch.rand(R, 112, generator=gen),
+             "u3": torch.rand(R, 112, generator=gen), "n4": torch.randn(R, 16, generator=gen)}
+    noise = {k: v.to(dev) for k, v in noise.items()}
+    outs = {}
+    for p in ("f32", prec):
+        outs[p] = ops.render_forward(sc, packed(ops, dev, 11, p), packed(ops, dev, 12, p), rays, 64, 128, 16, noise,
+                                     white_bkgd=True)
+    for which in ("coarse", "fine"):
+        ps = O.psnr(outs[prec][which]["rgb"].cpu(), outs["f32"][which]["rgb"].cpu())
+        assert ps >= floor_db, f"{prec} {which} PSNR vs f32 path {ps:.1f} dB"
+
+
+def test_f32_has_no_training_path(ops, dev):
+    from pixelnerf_amd import _lib
+    with pytest.raises(_lib.PixelNerfHipError):
+        ops.pack_mlp({k: v.to(dev) for k, v in mlp_params(11).items()}, "f32", backward=True)
+    sc = dscene(ops, dev, "sn64")
+    with pytest.raises(_lib.PixelNerfHipError):
+        ops.eval_ray_samples_train(sc, packed(ops, dev, 11), torch.zeros(64, 8, device=dev), torch.ones(64, 8, device=dev))
