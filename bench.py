@@ -158,9 +158,10 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from pixelnerf_amd import ops, synthetic
+    from pixelnerf_amd import _lib, ops, synthetic
     from pixelnerf_amd.dist import broadcast_encoded
 
+    _lib.ensure_built()  # normally a no-op: the .so built by __graft_entry__.build() travels with the tree
     scene, meta, net, renderer, mlps = build(dev, args.prec)
     R = args.rays
     rays = make_rays(meta, R, rank).to(dev)

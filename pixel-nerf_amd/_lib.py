@@ -116,13 +116,33 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd).replace(tmp, LIB_PATH))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise PixelNerfHipError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)  # atomic: a process that already mapped the old file keeps it
     return LIB_PATH
+
+
+def ensure_built():
+    """Build the library if it is missing or older than its sources, safely under concurrent
+    callers (the ranks of a torch.distributed.run launch): one builds under an exclusive file
+    lock, the others wait and find it done.  For entry scripts (bench.py, smoke, the test
+    session); load() itself never builds."""
+    import fcntl
+    if not _needs_build():
+        return LIB_PATH
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return build_library(force=False)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def load():
