@@ -155,6 +155,8 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT], const char *smem, ui
 
 #ifdef PNR_EXP_FAKE_W  // experiment: refill from a fixed 8 KiB window (no L2 streaming); results are wrong
         const char *pf = R.wave_base + (size_t)(R.pf_rs & 0) * (IT * 1024);
+#elif defined(PNR_EXP_WRAP_W)  // experiment: the stream wraps inside its first PNR_EXP_WRAP_W ring steps (L2-resident); wrong results
+        const char *pf = R.wave_base + (size_t)(R.pf_rs % PNR_EXP_WRAP_W) * (IT * 1024);
 #else
         const char *pf = R.wave_base + (size_t)R.pf_rs * (IT * 1024);
 #endif
