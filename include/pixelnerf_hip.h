@@ -235,6 +235,54 @@ int pnr_render_forward(const PnrScene *scene /*host*/, const void *packed_coarse
 int pnr_gen_rays(const float *poses, int NV, int W, int H, float fx, float fy, float cx, float cy,
                  float z_near, float z_far, float *rays, void *stream);
 
+/* ---- next-row helpers (continued): render whole target views ----------
+ * util.gen_rays + NeRFRenderer.forward in ONE call (what eval/eval.py:247-279 and
+ * eval/gen_video.py do per object: build all rays of the target views on the host, copy, render):
+ * poses_c2w (NV,4,4) device, views grouped per object (NV = SB * views_per_object); the rays of all
+ * NV*H*W pixels are generated into the workspace; outputs / noise are laid out as in
+ * pnr_render_forward with R = NV*H*W. */
+size_t pnr_render_views_workspace_bytes(int NV, int W, int H, int Kc, int Kf);
+int pnr_render_views(const PnrScene *scene /*host*/, const void *packed_coarse, const void *packed_fine,
+                     int precision, const float *poses_c2w, int NV, int W, int H, float fx, float fy,
+                     float cx, float cy, float z_near, float z_far, int Kc, int Kf, int Kfd,
+                     float depth_std, int white_bkgd, int lindisp, const float *u1, const float *u2,
+                     const float *u3, const float *n4, float *rgb_c, float *depth_c, float *weights_c,
+                     float *rgb_f, float *depth_f, float *weights_f, void *workspace, void *stream);
+
+/* ---- next-row helpers: encoder output formatting --------------------
+ * src/model/encoder.py:150-163: F.interpolate(bilinear, align_corners=True) of every ResNet stage
+ * to stage 0's size + channel concat.  stages: HOST array of n_stages device pointers, stage s is
+ * (NV, channels[s], heights[s], widths[s]) NCHW fp32; channels multiples of 32.  Writes the grid
+ * channel-last (NV, H0, W0, sum channels) -- the layout PnrScene.latent_nhwc wants -- and, if
+ * latent_nchw != NULL, the reference's NCHW `latent` tensor as well, in one pass. */
+int pnr_pyramid_to_latent(const float *const *stages, const int *channels, const int *heights,
+                          const int *widths, int n_stages, int NV, float *latent_nhwc,
+                          float *latent_nchw, void *stream);
+
+/* ---- next-row helpers: eval epilogue on device ----------------------
+ * eval/eval.py:283-290,327-329 and util.psnr (src/util/util.py:474-481): rgb (n_views,pixels,3) ->
+ * clamp to [0,1] [-> uint8 = trunc(x*255)]; depth -> (d - z_near)/(z_far - z_near); per-view sum
+ * of squared errors against gt_rgb (same shape, [0,1]) in fp64 (PSNR_v = -10 log10(sse_v /
+ * (3*pixels))).  Every output pointer may be NULL. */
+int pnr_eval_epilogue(const float *rgb, const float *depth, int n_views, int pixels_per_view,
+                      float z_near, float z_far, const float *gt_rgb, unsigned char *rgb_u8,
+                      float *rgb_clamped, float *depth_norm, double *sq_err_sum, void *stream);
+
+/* ---- next-row helpers: training-ray selection on device ---------------
+ * train/train.py:143-182 with util.bbox_sample (src/util/util.py:220-235): for each of SB objects
+ * pick B pixels among its NV views and emit their rays and ground-truth colours (image*0.5+0.5)
+ * directly -- the reference builds all NV*H*W rays per object to index 128 of them.
+ * poses (SB,NV,4,4) camera-to-world; images (SB,NV,3,H,W) in [-1,1]; focal (SB,2) = (fx,fy);
+ * c (SB,2) or NULL (image centre).  Random draws are inputs, in the reference's order:
+ *   bboxes != NULL: bboxes (SB,NV,4) float [x0,y0,x1,y1]; ids (SB,B) int64 = randint(0,NV);
+ *                   ux, uy (SB,B) = rand;   x = long(ux*(x1+1-x0)+x0), y likewise;
+ *   bboxes == NULL: ids (SB,B) int64 = randint(0,NV*H*W) flat pixel indices; ux, uy ignored.
+ * Out: rays (SB,B,8), rgb_gt (SB,B,3). */
+int pnr_sample_training_rays(const float *poses, const float *images, const float *focal,
+                             const float *c, const float *bboxes, const long long *ids,
+                             const float *ux, const float *uy, int SB, int NV, int W, int H, int B,
+                             float z_near, float z_far, float *rays, float *rgb_gt, void *stream);
+
 /* Timing hook for bench.py: seconds spent in the fused network kernel launches issued on
  * `stream` since the last reset, measured with HIP events recorded around each launch on
  * that stream (call only after the stream has been synchronised). */

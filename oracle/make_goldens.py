@@ -238,6 +238,64 @@ def stage_goldens():
     return rec
 
 
+class _Const(torch.nn.Module):
+    """Trunk stand-in: returns a fixed tensor whatever it is fed (the torchvision backbone is a stub here)."""
+
+    def __init__(self, t=None):
+        super().__init__()
+        self.t = t
+
+    def forward(self, x):
+        return x if self.t is None else self.t
+
+
+def neighbour_goldens():
+    """Fixtures for the rows next to the hot path, from the reference's own code:
+    * SpatialEncoder.forward's output formatting (src/model/encoder.py:150-163) run on seeded ResNet-stage
+      tensors (the trunk modules are replaced by constants; only interpolate + cat + latent_scaling run);
+    * util.gen_rays (src/util/util.py:238-276) with fx != fy and an off-centre principal point;
+    * util.psnr (src/util/util.py:474-481)."""
+    import util as ref_util
+    from model.encoder import SpatialEncoder
+
+    rec = {}
+    for name in ("pool", "nopool"):  # the full-size "dtu" pyramid is a property/bench case, not a fixture
+        NV, shapes = synthetic.PYRAMIDS[name]
+        stages = synthetic.pyramid_stages(name)
+        enc = SpatialEncoder(backbone="resnet34", pretrained=False, num_layers=4, use_first_pool=(name == "pool"))
+        m = enc.model
+        m.conv1, m.bn1, m.relu = _Const(stages[0]), _Const(), _Const()
+        m.maxpool = _Const()
+        m.layer1, m.layer2, m.layer3 = _Const(stages[1]), _Const(stages[2]), _Const(stages[3])
+        with torch.no_grad():
+            lat = enc(torch.zeros(NV, 3, 8, 8))
+        rec[f"pyr_{name}_latent"] = lat.numpy()
+        rec[f"pyr_{name}_scaling"] = enc.latent_scaling.numpy()
+
+    rs = np.random.RandomState(77)
+    poses = torch.stack([torch.as_tensor(synthetic.pose_spherical(t, p, 2.2)) for t, p in ((10.0, -20.0), (130.0, -35.0), (250.0, 5.0))])
+    focal = torch.tensor([41.5, 39.25])
+    c = torch.tensor([10.75, 6.5])
+    rec["rays_poses"] = poses.numpy()
+    rec["rays_focal"], rec["rays_c"] = focal.numpy(), c.numpy()
+    rec["rays_out"] = ref_util.gen_rays(poses, 20, 15, focal, 0.8, 1.8, c=c).numpy()
+
+    # util.bbox_sample draws randint, rand, rand in this order: replay them as explicit inputs
+    bboxes = torch.tensor([[3.0, 2.0, 17.0, 12.0], [0.0, 0.0, 19.0, 14.0], [8.0, 5.0, 8.0, 5.0]])
+    torch.manual_seed(31)
+    rec["bbox_pix"] = ref_util.bbox_sample(bboxes, 500).numpy()
+    torch.manual_seed(31)
+    rec["bbox_ids"] = torch.randint(0, 3, (500,)).numpy()
+    rec["bbox_ux"], rec["bbox_uy"] = torch.rand(500).numpy(), torch.rand(500).numpy()
+    rec["bbox_boxes"] = bboxes.numpy()
+
+    pred = torch.from_numpy(rs.uniform(-0.2, 1.2, (3, 300, 3)).astype(np.float32))
+    gt = torch.from_numpy(rs.uniform(0.0, 1.0, (3, 300, 3)).astype(np.float32))
+    rec["psnr_pred"], rec["psnr_gt"] = pred.numpy(), gt.numpy()
+    rec["psnr_out"] = np.array([ref_util.psnr(pred[i].clamp(0, 1), gt[i]) for i in range(3)], np.float64)
+    return rec
+
+
 def state_dict_manifest():
     """Names and shapes of the reference net's state_dict (encoder.* excluded: the torchvision
     backbone is a stub here) and of the renderer's -- the checkpoint-compatibility contract
@@ -259,14 +317,14 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "manifest"])
+    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "neighbours", "manifest"])
     for name in names:
         if name == "manifest":
             path = os.path.join(outdir, "state_dict_manifest.txt")
             open(path, "w").write("\n".join(state_dict_manifest()) + "\n")
             print("wrote", path)
             continue
-        rec = stage_goldens() if name == "stages" else run_scenario(name)
+        rec = stage_goldens() if name == "stages" else neighbour_goldens() if name == "neighbours" else run_scenario(name)
         path = os.path.join(outdir, name + ".npz")
         np.savez_compressed(path, **rec)
         print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))

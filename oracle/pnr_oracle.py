@@ -24,7 +24,9 @@ repository root).  All random draws are explicit inputs, in the reference's draw
 """
 import math
 
+import numpy as np
 import torch
+import torch.nn.functional as F
 
 # --------------------------------------------------------------------------------------
 # model side
@@ -305,3 +307,55 @@ def psnr(pred, target):
     if mse == 0:
         return float("inf")
     return -10 * math.log10(mse)
+
+
+# ---------------------------------------------------------------- neighbours of the path
+
+
+def encoder_format(stages, upsample_interp="bilinear"):
+    """src/model/encoder.py:150-163: every stage upsampled to stage 0's size (align_corners=True) and
+    concatenated on channels -> (latent NCHW, latent_scaling)."""
+    sz = stages[0].shape[-2:]
+    lat = torch.cat([F.interpolate(t, sz, mode=upsample_interp, align_corners=True) for t in stages], dim=1)
+    ls = torch.tensor([lat.shape[-1], lat.shape[-2]], dtype=torch.float32)
+    return lat, ls / (ls - 1) * 2.0
+
+
+def eval_epilogue(rgb, depth, z_near, z_far, gt=None):
+    """eval/eval.py:283-290 (depth normalisation, clamp), :302 (uint8 = trunc(x*255)), :327-329
+    (skimage compare_psnr, data_range=1: fp64 mean squared error) -- numpy restatement."""
+    rgb = np.clip(np.asarray(rgb, np.float32), 0.0, 1.0)
+    out = {"rgb": rgb, "rgb_u8": (rgb * 255).astype(np.uint8),
+           "depth_norm": (np.asarray(depth, np.float32) - np.float32(z_near)) / (np.float32(z_far) - np.float32(z_near))}
+    if gt is not None:
+        d = rgb.astype(np.float64) - np.asarray(gt, np.float32).astype(np.float64)
+        mse = (d * d).reshape(rgb.shape[0], -1).mean(axis=1)
+        out["psnr"] = 10.0 * np.log10(1.0 / mse)
+    return out
+
+
+def bbox_pixels(bboxes, image_ids, ux, uy):
+    """src/util/util.py:220-235 with the draws (randint, rand, rand) made explicit -> (n,3) [image, y, x]."""
+    pb = bboxes[image_ids]
+    x = (ux * (pb[:, 2] + 1 - pb[:, 0]) + pb[:, 0]).long()
+    y = (uy * (pb[:, 3] + 1 - pb[:, 1]) + pb[:, 1]).long()
+    return torch.stack((image_ids, y, x), dim=-1)
+
+
+def sample_training_rays(gen_rays, poses, images, focal, z_near, z_far, ids, c=None, bboxes=None, ux=None, uy=None):
+    """train/train.py:143-182: per object, the full (NV,H,W,8) ray map (`gen_rays` = a restatement of
+    util.gen_rays) and the (NV,H,W,3) colour map indexed at the drawn pixels."""
+    SB, NV = poses.shape[:2]
+    H, W = images.shape[-2:]
+    all_rays, all_gt = [], []
+    for o in range(SB):
+        cam_rays = gen_rays(poses[o], W, H, focal[o], z_near, z_far, c=None if c is None else c[o])
+        rgb_all = (images[o] * 0.5 + 0.5).permute(0, 2, 3, 1).contiguous().reshape(-1, 3)
+        if bboxes is not None:
+            pix = bbox_pixels(bboxes[o], ids[o], ux[o], uy[o])
+            pix_inds = pix[..., 0] * H * W + pix[..., 1] * W + pix[..., 2]
+        else:
+            pix_inds = ids[o]
+        all_gt.append(rgb_all[pix_inds])
+        all_rays.append(cam_rays.reshape(-1, 8)[pix_inds])
+    return torch.stack(all_rays), torch.stack(all_gt)

@@ -12,7 +12,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelnerf_hip.so")  # override: A/B experiments
-SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_bwd.hip", "pnr_f32.hip"]
+SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_bwd.hip", "pnr_f32.hip", "pnr_encode.hip"]
 HEADERS = ["pnr_common.h", "pnr_layout.h", "pnr_device.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
 
 PREC_F16, PREC_BF16, PREC_F32 = 0, 1, 2
@@ -63,6 +63,13 @@ PROTOTYPES = {
     "pnr_sample_fine": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P]),
     "pnr_eval_ray_samples": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _I, _I, _P, _P]),
     "pnr_eval_points": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _P, _P]),
+    "pnr_render_views_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "pnr_render_views": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F,
+                              _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pnr_pyramid_to_latent": (_I, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                   ctypes.POINTER(ctypes.c_int), _I, _I, _P, _P, _P]),
+    "pnr_sample_training_rays": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "pnr_eval_epilogue": (_I, [_P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "pnr_eval_f32_workspace_bytes": (_SZ, [_I, ctypes.c_longlong]),
     "pnr_eval_ray_samples_f32": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _I, _I, _P,
                                       _P, _SZ, _P]),

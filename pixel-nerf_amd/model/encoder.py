@@ -102,15 +102,26 @@ class SpatialEncoder(nn.Module):
             x = self.model.layer4(x)
             latents.append(x)
         self.latents = latents
+        if (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and self.upsample_interp == "bilinear"
+                and all(t.shape[1] % 32 == 0 for t in latents)):
+            # inference: one HIP pass writes the NHWC grid the fused kernel reads AND the reference's NCHW tensor
+            nhwc, self.latent = ops.pyramid_to_latent(latents, want_nchw=True)
+            self._nhwc = ((self.latent.data_ptr(), self.latent._version, tuple(self.latent.shape)), nhwc)
+            self._set_scaling()
+            return self.latent
         align_corners = None if self.index_interp == "nearest " else True
         latent_sz = latents[0].shape[-2:]
         for i in range(len(latents)):
             latents[i] = F.interpolate(latents[i], latent_sz, mode=self.upsample_interp, align_corners=align_corners)
         self.latent = torch.cat(latents, dim=1)
+        self._set_scaling()
+        return self.latent
+
+    def _set_scaling(self):
+        """encoder.py:161-163."""
         self.latent_scaling[0] = self.latent.shape[-1]
         self.latent_scaling[1] = self.latent.shape[-2]
         self.latent_scaling = self.latent_scaling / (self.latent_scaling - 1) * 2.0
-        return self.latent
 
     def latent_nhwc(self):
         """Channel-last copy of `latent` for the fused kernel (one bilinear corner = one

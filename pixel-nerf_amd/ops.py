@@ -333,6 +333,139 @@ def gen_rays(poses, width, height, focal, z_near, z_far, c=None):
     return rays
 
 
+def render_views(scene, packed_coarse, packed_fine, poses_c2w, width, height, focal, z_near, z_far, n_coarse, n_fine,
+                 n_fine_depth, noise, c=None, depth_std=0.01, white_bkgd=False, lindisp=False, want_weights=False):
+    """util.gen_rays + NeRFRenderer.forward in one C call (eval/eval.py:247-279): poses_c2w (NV,4,4),
+    views grouped per object; every pixel of every view is rendered.  Returns the same nested dict as
+    render_forward with R = NV*H*W rows (reshape to (NV,H,W,...))."""
+    lib = _lib.load()
+    poses = _f32(poses_c2w, "poses_c2w", (None, 4, 4))
+    NV, W, H = poses.shape[0], int(width), int(height)
+    R, dev = NV * W * H, poses.device
+    if packed_coarse.precision == _lib.PREC_F32:
+        rays = gen_rays(poses, W, H, focal, z_near, z_far, c).reshape(-1, 8)
+        return render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_fine_depth, noise, depth_std,
+                              white_bkgd, lindisp, want_weights)
+    Kc, Kf, Kfd = int(n_coarse), int(n_fine), int(n_fine_depth)
+    Kimp = Kf - Kfd
+    if Kf > 0 and Kimp < 0:
+        raise ValueError("n_fine_depth must not exceed n_fine")
+    if NV % scene.SB != 0:
+        raise ValueError("number of views must be a multiple of the number of objects")
+    fx, fy = (float(focal), float(focal)) if not hasattr(focal, "__len__") else (float(focal[0]), float(focal[-1]))
+    cx, cy = (W * 0.5, H * 0.5) if c is None else (float(c[0]), float(c[1]))
+    u1 = _f32(noise["u1"], "u1", (R, Kc))
+    u2 = u3 = n4 = None
+    if Kf > 0 and Kimp > 0:
+        u2, u3 = _f32(noise["u2"], "u2", (R, Kimp)), _f32(noise["u3"], "u3", (R, Kimp))
+    if Kf > 0 and Kfd > 0:
+        n4 = _f32(noise["n4"], "n4", (R, Kfd))
+    if packed_fine is not None and packed_fine.precision != packed_coarse.precision:
+        raise ValueError("coarse and fine networks must be packed at the same precision")
+
+    def outs(K):
+        return (torch.empty((R, 3), dtype=torch.float32, device=dev),
+                torch.empty((R,), dtype=torch.float32, device=dev),
+                torch.empty((R, K), dtype=torch.float32, device=dev) if want_weights else None)
+
+    rgb_c, depth_c, w_c = outs(Kc)
+    rgb_f, depth_f, w_f = outs(Kc + Kf) if Kf > 0 else (None, None, None)
+    ws = torch.empty(max(lib.pnr_render_views_workspace_bytes(NV, W, H, Kc, Kf), 16), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_render_views(
+            scene.ref, packed_coarse.ptr, packed_fine.ptr if packed_fine is not None else None, packed_coarse.precision,
+            _p(poses), NV, W, H, fx, fy, cx, cy, float(z_near), float(z_far), Kc, Kf, Kfd, float(depth_std),
+            int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4),
+            _p(rgb_c), _p(depth_c), _p(w_c), _p(rgb_f), _p(depth_f), _p(w_f), _p(ws), _stream()), "pnr_render_views")
+    ret = {"coarse": {"rgb": rgb_c, "depth": depth_c}}
+    if want_weights:
+        ret["coarse"]["weights"] = w_c
+    if Kf > 0:
+        ret["fine"] = {"rgb": rgb_f, "depth": depth_f}
+        if want_weights:
+            ret["fine"]["weights"] = w_f
+    return ret
+
+
+def pyramid_to_latent(stages, want_nchw=True):
+    """Encoder output formatting (src/model/encoder.py:150-163): stages = list of (NV,C_s,H_s,W_s) float32
+    HIP tensors (ResNet stage outputs).  -> (latent_nhwc (NV,H0,W0,sum C), latent_nchw (NV,sum C,H0,W0) | None):
+    bilinear(align_corners=True) upsample to stage 0's size + channel concat, in one pass."""
+    lib = _lib.load()
+    stages = [_f32(t, f"stages[{i}]", (None, None, None, None)) for i, t in enumerate(stages)]
+    n = len(stages)
+    NV = stages[0].shape[0]
+    if any(t.shape[0] != NV for t in stages):
+        raise ValueError("all stages must have the same batch size")
+    H0, W0 = stages[0].shape[2:]
+    Ctot = sum(t.shape[1] for t in stages)
+    dev = stages[0].device
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in stages])
+    ch = (ctypes.c_int * n)(*[t.shape[1] for t in stages])
+    hs = (ctypes.c_int * n)(*[t.shape[2] for t in stages])
+    wd = (ctypes.c_int * n)(*[t.shape[3] for t in stages])
+    nhwc = torch.empty((NV, H0, W0, Ctot), dtype=torch.float32, device=dev)
+    nchw = torch.empty((NV, Ctot, H0, W0), dtype=torch.float32, device=dev) if want_nchw else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_pyramid_to_latent(ptrs, ch, hs, wd, n, NV, _p(nhwc), _p(nchw), _stream()),
+                   "pnr_pyramid_to_latent")
+    return nhwc, nchw
+
+
+def sample_training_rays(poses, images, focal, z_near, z_far, ids, c=None, bboxes=None, ux=None, uy=None):
+    """train/train.py:143-182 on device.  poses (SB,NV,4,4), images (SB,NV,3,H,W) in [-1,1], focal (SB,2),
+    c (SB,2)|None; ids (SB,B) int64: view ids (with bboxes (SB,NV,4) + ux, uy (SB,B)) or flat pixel indices.
+    -> rays (SB,B,8), rgb_gt (SB,B,3)."""
+    lib = _lib.load()
+    poses = _f32(poses, "poses", (None, None, 4, 4))
+    SB, NV = poses.shape[:2]
+    images = _f32(images, "images", (SB, NV, 3, None, None))
+    H, W = images.shape[-2:]
+    focal = _f32(focal, "focal", (SB, 2))
+    c = None if c is None else _f32(c, "c", (SB, 2))
+    if ids.dtype != torch.int64 or not ids.is_cuda or ids.dim() != 2 or ids.shape[0] != SB:
+        raise TypeError("ids: expected an int64 HIP tensor of shape (SB,B)")
+    ids = ids.contiguous()
+    B = ids.shape[1]
+    if bboxes is not None:
+        bboxes = _f32(bboxes, "bboxes", (SB, NV, 4))
+        ux, uy = _f32(ux, "ux", (SB, B)), _f32(uy, "uy", (SB, B))
+    dev = poses.device
+    rays = torch.empty((SB, B, 8), dtype=torch.float32, device=dev)
+    gt = torch.empty((SB, B, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_sample_training_rays(_p(poses), _p(images), _p(focal), _p(c), _p(bboxes), _p(ids), _p(ux), _p(uy),
+                                                SB, NV, W, H, B, float(z_near), float(z_far), _p(rays), _p(gt), _stream()),
+                   "pnr_sample_training_rays")
+    return rays, gt
+
+
+def eval_epilogue(rgb, depth=None, z_near=0.0, z_far=1.0, gt_rgb=None, want_u8=True):
+    """eval/eval.py:283-290,327-329 on device.  rgb (NV,P,3) [+ depth (NV,P)] [+ gt_rgb (NV,P,3) in [0,1]] ->
+    dict(rgb (clamped), rgb_u8, depth_norm, sse (NV,) float64, psnr (NV,) float64)."""
+    lib = _lib.load()
+    rgb = _f32(rgb, "rgb", (None, None, 3))
+    NV, P = rgb.shape[:2]
+    dev = rgb.device
+    depth = None if depth is None else _f32(depth, "depth", (NV, P))
+    gt = None if gt_rgb is None else _f32(gt_rgb, "gt_rgb", (NV, P, 3))
+    out = {"rgb": torch.empty_like(rgb)}
+    u8 = torch.empty((NV, P, 3), dtype=torch.uint8, device=dev) if want_u8 else None
+    dn = torch.empty((NV, P), dtype=torch.float32, device=dev) if depth is not None else None
+    sse = torch.empty((NV,), dtype=torch.float64, device=dev) if gt is not None else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_eval_epilogue(_p(rgb), _p(depth), NV, P, float(z_near), float(z_far), _p(gt), _p(u8),
+                                         _p(out["rgb"]), _p(dn), _p(sse), _stream()), "pnr_eval_epilogue")
+    if want_u8:
+        out["rgb_u8"] = u8
+    if dn is not None:
+        out["depth_norm"] = dn
+    if sse is not None:
+        out["sse"] = sse
+        out["psnr"] = -10.0 * torch.log10(sse / (3 * P))
+    return out
+
+
 def profile_enable(on=True):
     _lib.check(_lib.load().pnr_profile_enable(int(bool(on))), "pnr_profile_enable")
 

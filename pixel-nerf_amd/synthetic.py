@@ -216,3 +216,20 @@ def make_noise(R, n_coarse, n_fine, n_fine_depth, seed=1234):
         if n_fine_depth > 0:
             noise["n4"] = torch.from_numpy(rs.randn(R, n_fine_depth).astype(np.float32))
     return noise
+
+
+PYRAMIDS = {
+    # name: (NV, [(C, H, W) per ResNet stage])  -- encoder output-formatting fixtures
+    "pool": (2, [(64, 9, 11), (64, 5, 6), (128, 3, 3), (256, 2, 2)]),       # conv1 s2 + maxpool (srn/dtu style), odd sizes
+    "nopool": (1, [(64, 12, 12), (64, 12, 12), (128, 6, 6), (256, 3, 3)]),  # use_first_pool=False (sn64): stage 1 = stage 0 size
+    # full-size shapes of BASELINE config (4): DTU 300x400 image, 3 source views
+    "dtu": (3, [(64, 150, 200), (64, 75, 100), (128, 38, 50), (256, 19, 25)]),
+}
+
+
+def pyramid_stages(name, seed=4242):
+    """Seeded stand-ins for the ResNet-34 stage outputs that SpatialEncoder.forward upsamples and
+    concatenates (src/model/encoder.py:128-160)."""
+    NV, shapes = PYRAMIDS[name]
+    rs = np.random.RandomState(seed)
+    return [torch.from_numpy(rs.randn(NV, c, h, w).astype(np.float32)) for c, h, w in shapes]

@@ -110,3 +110,40 @@ def test_render_end_to_end_matches_reference(name):
         assert_close_frac(out["fine"]["depth"].numpy(), g["fine_depth"], 5e-5 * span,
                           max_frac=2e-2, loose_atol=2e-2 * span, what="fine depth")
         assert O.psnr(out["fine"]["rgb"], torch.from_numpy(g["fine_rgb"])) > 70.0
+
+
+# ------------------------------------------------------------------ neighbours of the path
+
+
+@pytest.mark.parametrize("name", ["pool", "nopool"])
+def test_encoder_format_matches_reference(name):
+    """Restated encoder output formatting vs SpatialEncoder.forward of the reference run on the same
+    seeded stage tensors (oracle/make_goldens.py::neighbour_goldens)."""
+    from pixelnerf_amd import synthetic
+    g = load_golden("neighbours")
+    lat, scaling = O.encoder_format(synthetic.pyramid_stages(name))
+    np.testing.assert_array_equal(lat.numpy(), g[f"pyr_{name}_latent"])
+    np.testing.assert_array_equal(scaling.numpy(), g[f"pyr_{name}_scaling"])
+
+
+def test_gen_rays_restatement_matches_reference():
+    from pixelnerf_amd import synthetic
+    g = load_golden("neighbours")
+    rays = synthetic.gen_rays(torch.from_numpy(g["rays_poses"]), 20, 15, torch.from_numpy(g["rays_focal"]), 0.8, 1.8,
+                              c=torch.from_numpy(g["rays_c"]))
+    np.testing.assert_allclose(rays.numpy(), g["rays_out"], rtol=0, atol=1e-6)
+
+
+def test_eval_epilogue_psnr_matches_reference_util_psnr():
+    """util.psnr (fp32 mean) vs the skimage-style fp64 restatement: same value to ~1e-5 dB."""
+    g = load_golden("neighbours")
+    out = O.eval_epilogue(g["psnr_pred"], np.zeros((3, 300), np.float32), 0.0, 1.0, gt=g["psnr_gt"])
+    np.testing.assert_allclose(out["psnr"], g["psnr_out"], rtol=0, atol=1e-4)
+    assert out["rgb_u8"].dtype == np.uint8 and out["rgb"].min() >= 0.0 and out["rgb"].max() <= 1.0
+
+
+def test_bbox_pixels_matches_reference_bbox_sample():
+    g = load_golden("neighbours")
+    pix = O.bbox_pixels(torch.from_numpy(g["bbox_boxes"]), torch.from_numpy(g["bbox_ids"]), torch.from_numpy(g["bbox_ux"]),
+                        torch.from_numpy(g["bbox_uy"]))
+    np.testing.assert_array_equal(pix.numpy(), g["bbox_pix"])
