@@ -252,7 +252,7 @@ int pnr_render_views(const PnrScene *scene /*host*/, const void *packed_coarse, 
 /* ---- next-row helpers: encoder output formatting --------------------
  * src/model/encoder.py:150-163: F.interpolate(bilinear, align_corners=True) of every ResNet stage
  * to stage 0's size + channel concat.  stages: HOST array of n_stages device pointers, stage s is
- * (NV, channels[s], heights[s], widths[s]) NCHW fp32; channels multiples of 32.  Writes the grid
+ * (NV, channels[s], heights[s], widths[s]) NCHW fp32; channels multiples of 64.  Writes the grid
  * channel-last (NV, H0, W0, sum channels) -- the layout PnrScene.latent_nhwc wants -- and, if
  * latent_nchw != NULL, the reference's NCHW `latent` tensor as well, in one pass. */
 int pnr_pyramid_to_latent(const float *const *stages, const int *channels, const int *heights,

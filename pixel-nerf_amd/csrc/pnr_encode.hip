@@ -10,8 +10,8 @@
 // well -- no separate interpolate / cat / transpose passes over up to 176 MiB.
 //
 // HBM-bound: algorithmic bytes = pyramid read once + 4*512 B per output pixel per written layout.
-// 32-channel x 32-pixel tiles; interpolation with lanes along x (coalesced source rows and NCHW
-// stores), transposed through LDS, stored with lanes along channels (coalesced NHWC rows).
+// 64-channel x 32-pixel x 4-row tiles; interpolation with lanes along x (coalesced source rows and NCHW
+// stores), transposed through LDS, stored with lanes along channels (16-byte NHWC stores).
 #include <hip/hip_runtime.h>
 
 #include "pnr_common.h"
@@ -19,6 +19,7 @@
 namespace pnr {
 
 constexpr int MAX_STAGES = 5;  // encoder.py:68 num_layers <= 5
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 struct Pyramid {
     const float *src[MAX_STAGES];
@@ -27,45 +28,61 @@ struct Pyramid {
     int n;
 };
 
+constexpr int FT_C = 64;  // channels per tile
+constexpr int FT_X = 32;  // pixels (along x) per tile
+constexpr int FT_Y = 4;   // rows per workgroup
+
 // ATen upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1); i0 = (int)src;
 // i1 = i0 + (i0 < in-1); l1 = src - i0; l0 = 1 - l1;
 // val = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)     (no FMA contraction)
+// Workgroup = 256 threads: FT_C channels x FT_X pixels x FT_Y rows.  Phase 1 (lanes along x): interpolate,
+// store NCHW, park in LDS; phase 2 (lanes along channels): 16-byte NHWC stores, 256 B contiguous per pixel.
 __global__ void __launch_bounds__(256)
 pyramid_to_latent_kernel(const Pyramid p, int NV, int H0, int W0, float *__restrict__ nhwc, float *__restrict__ nchw) {
 #pragma clang fp contract(off)
-    __shared__ float tile[32][33];
-    const int tx = threadIdx.x, ty = threadIdx.y;  // (32, 8)
+    __shared__ float tile[FT_C][FT_X + 1];
+    const int t = threadIdx.x;
+    const int tx = t & 31, ty = t >> 5;  // phase 1: x, channel group (8)
     const int Ctot = p.c_begin[p.n];
-    const int ctiles = Ctot / 32;
-    const int n = blockIdx.z / ctiles, c0 = (blockIdx.z % ctiles) * 32;
-    const int y = blockIdx.y, x0 = blockIdx.x * 32;
+    const int ctiles = Ctot / FT_C;
+    const int n = blockIdx.z / ctiles, c0 = (blockIdx.z % ctiles) * FT_C;
+    const int x0 = blockIdx.x * FT_X;
     int s = 0;
     while (s + 1 < p.n && c0 >= p.c_begin[s + 1]) ++s;
     const int Hs = p.H[s], Ws = p.W[s], Cs = p.c_begin[s + 1] - p.c_begin[s];
     const float sy = H0 > 1 ? (float)(Hs - 1) / (float)(H0 - 1) : 0.f;
     const float sx = W0 > 1 ? (float)(Ws - 1) / (float)(W0 - 1) : 0.f;
-    const float fy = sy * (float)y;
-    const int y0 = (int)fy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
-    const float h1 = fy - (float)y0, h0 = 1.f - h1;
     const int x = x0 + tx;
-    if (x < W0) {
-        const float fx = sx * (float)x;
-        const int xa = (int)fx, xb = xa + (xa < Ws - 1 ? 1 : 0);
-        const float w1 = fx - (float)xa, w0 = 1.f - w1;
+    const float fx = sx * (float)x;
+    const int xa = min((int)fx, Ws - 1), xb = xa + (xa < Ws - 1 ? 1 : 0);
+    const float w1 = fx - (float)xa, w0 = 1.f - w1;
+    const int xx2 = t >> 4, c4 = (t & 15) * 4;  // phase 2: pixel (16 per pass), 4 channels
+    for (int yy = 0; yy < FT_Y; ++yy) {
+        const int y = blockIdx.y * FT_Y + yy;
+        if (y >= H0) break;
+        const float fy = sy * (float)y;
+        const int y0 = (int)fy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
+        const float h1 = fy - (float)y0, h0 = 1.f - h1;
+        if (x < W0) {
 #pragma unroll
-        for (int cc = ty; cc < 32; cc += 8) {
-            const int c = c0 + cc;
-            const float *plane = p.src[s] + ((size_t)n * Cs + (c - p.c_begin[s])) * Hs * Ws;
-            const float *r0 = plane + (size_t)y0 * Ws, *r1 = plane + (size_t)y1 * Ws;
-            const float v = h0 * (w0 * r0[xa] + w1 * r0[xb]) + h1 * (w0 * r1[xa] + w1 * r1[xb]);
-            tile[cc][tx] = v;
-            if (nchw) nchw[(((size_t)n * Ctot + c) * H0 + y) * W0 + x] = v;
+            for (int cc = ty; cc < FT_C; cc += 8) {
+                const int c = c0 + cc;
+                const float *plane = p.src[s] + ((size_t)n * Cs + (c - p.c_begin[s])) * Hs * Ws;
+                const float *r0 = plane + (size_t)y0 * Ws, *r1 = plane + (size_t)y1 * Ws;
+                const float v = h0 * (w0 * r0[xa] + w1 * r0[xb]) + h1 * (w0 * r1[xa] + w1 * r1[xb]);
+                tile[cc][tx] = v;
+                if (nchw) nchw[(((size_t)n * Ctot + c) * H0 + y) * W0 + x] = v;
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll
-    for (int xx = ty; xx < 32; xx += 8)
-        if (x0 + xx < W0) nhwc[(((size_t)n * H0 + y) * W0 + x0 + xx) * Ctot + c0 + tx] = tile[tx][xx];
+        for (int xx = xx2; xx < FT_X; xx += 16)
+            if (x0 + xx < W0) {
+                const f32x4_t v = {tile[c4][xx], tile[c4 + 1][xx], tile[c4 + 2][xx], tile[c4 + 3][xx]};
+                *reinterpret_cast<f32x4_t *>(nhwc + (((size_t)n * H0 + y) * W0 + x0 + xx) * Ctot + c0 + c4) = v;
+            }
+        __syncthreads();
+    }
 }
 
 // eval/eval.py:283-290,327-329 + util.psnr (util.py:474-481): one workgroup per view.  rgb -> clamp[0,1]
@@ -208,17 +225,17 @@ extern "C" int pnr_pyramid_to_latent(const float *const *stages, const int *chan
     p.n = n_stages;
     int c = 0;
     for (int s = 0; s < n_stages; ++s) {
-        if (!stages[s] || channels[s] <= 0 || channels[s] % 32 != 0 || heights[s] <= 0 || widths[s] <= 0)
-            return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: stage channels must be positive multiples of 32, sizes positive");
+        if (!stages[s] || channels[s] <= 0 || channels[s] % pnr::FT_C != 0 || heights[s] <= 0 || widths[s] <= 0)
+            return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: stage channels must be positive multiples of 64, sizes positive");
         p.src[s] = stages[s]; p.c_begin[s] = c; p.H[s] = heights[s]; p.W[s] = widths[s];
         c += channels[s];
     }
     p.c_begin[n_stages] = c;
     if (NV == 0) return PNR_OK;
     const int H0 = heights[0], W0 = widths[0];
-    if (H0 > 65535 || (long long)NV * (c / 32) > 65535) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: grid too large");
-    dim3 grid((W0 + 31) / 32, H0, NV * (c / 32));
-    hipLaunchKernelGGL(pnr::pyramid_to_latent_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, p, NV, H0, W0, latent_nhwc,
+    if ((long long)NV * (c / pnr::FT_C) > 65535) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: grid too large");
+    dim3 grid((W0 + pnr::FT_X - 1) / pnr::FT_X, (H0 + pnr::FT_Y - 1) / pnr::FT_Y, NV * (c / pnr::FT_C));
+    hipLaunchKernelGGL(pnr::pyramid_to_latent_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, NV, H0, W0, latent_nhwc,
                        latent_nchw);
     return pnr_check_launch("pnr_pyramid_to_latent");
 }
