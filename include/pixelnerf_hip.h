@@ -203,8 +203,30 @@ int pnr_weight_grad(const void *dY, const void *X, long long rows, int precision
                     int rows_storage_order, int cols_storage_order, float *dW, float *db,
                     void *workspace, void *stream);
 
+/* The same for up to 16 linears in ONE launch pair (all 13 512x512 layers of a ResnetFC): fewer, fuller
+ * launches and 4-8x fewer split slices to reduce.  jobs: host array.
+ * workspace: pnr_weight_grad_batched_workspace_bytes(n_jobs, largest rows of the jobs). */
+typedef struct PnrWeightGradJob {
+    const void *dY, *X;          /* (rows,512) 16-bit row-major dumps                  */
+    long long rows;
+    int rows_storage_order, cols_storage_order;
+    float *dW, *db;              /* (512,dw_cols), (512) fp32 outputs; db may be NULL */
+    int x_cols;                  /* columns (= row stride) of X: 0 -> 512; 64 for the lin_in operand (natural order) */
+    int dw_cols;                 /* columns (= row stride) of dW written: 0 -> x_cols; 42 for lin_in                 */
+} PnrWeightGradJob;
+size_t pnr_weight_grad_batched_workspace_bytes(int n_jobs, long long max_rows);
+int pnr_weight_grad_batched(const PnrWeightGradJob *jobs /*host*/, int n_jobs, int precision,
+                            float out_scale, void *workspace, void *stream);
+
+/* lin_out (4 x 512): dW = g_out^T x5, db = column sums of g_out; g_out (P,4) fp32 = dL/d(lin_out output),
+ * x5 (P,512) 16-bit dump (storage order); dW written in feature order.  Fixed-order reduction. */
+size_t pnr_lin_out_grad_workspace_bytes(void);
+int pnr_lin_out_grad(const float *g_out, const void *x5, long long P, int precision, float *dW,
+                     float *db, void *workspace, void *stream);
+
 /* d(encoder.latent) += bilinear scatter of d_zlat (rows_v,512) fp32 (natural channel order) to
- * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (atomic adds; caller zero-initialises). */
+ * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (caller zero-initialises; accumulates).  Grids of up to 4608
+ * texels per image are accumulated in LDS slabs (no global atomics), larger ones with global atomics. */
 int pnr_latent_scatter(const PnrScene *scene /*host*/, const float *rays, const float *z, int R,
                        int rays_per_obj, int K, const float *d_zlat, float *d_latent_nhwc, void *stream);
 

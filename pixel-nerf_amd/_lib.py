@@ -41,6 +41,12 @@ class PnrMlpWeights(ctypes.Structure):
     ]
 
 
+class PnrWeightGradJob(ctypes.Structure):
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("rows", ctypes.c_longlong),
+                ("rows_storage_order", ctypes.c_int), ("cols_storage_order", ctypes.c_int),
+                ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("x_cols", ctypes.c_int), ("dw_cols", ctypes.c_int)]
+
+
 class PnrTrainDumps(ctypes.Structure):
     _fields_ = [("d_in", ctypes.c_void_p), ("d_z", ctypes.c_void_p), ("d_a", ctypes.c_void_p * 5),
                 ("d_n", ctypes.c_void_p * 5), ("d_x5", ctypes.c_void_p)]
@@ -85,6 +91,10 @@ PROTOTYPES = {
                               ctypes.POINTER(PnrBackwardDumps), _P]),
     "pnr_weight_grad_workspace_bytes": (_SZ, []),
     "pnr_weight_grad": (_I, [_P, _P, ctypes.c_longlong, _I, _F, _I, _I, _P, _P, _P, _P]),
+    "pnr_lin_out_grad_workspace_bytes": (_SZ, []),
+    "pnr_lin_out_grad": (_I, [_P, _P, ctypes.c_longlong, _I, _P, _P, _P, _P]),
+    "pnr_weight_grad_batched_workspace_bytes": (_SZ, [_I, ctypes.c_longlong]),
+    "pnr_weight_grad_batched": (_I, [ctypes.POINTER(PnrWeightGradJob), _I, _I, _F, _P, _P]),
     "pnr_latent_scatter": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _P]),
     "pnr_composite": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "pnr_render_workspace_bytes": (_SZ, [_I, _I, _I]),

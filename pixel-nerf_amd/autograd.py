@@ -63,29 +63,31 @@ def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS, want_d_in=False):
     grads = {}
     # weight gradients of the 512x512 linears: HIP MFMA kernel straight from the 16-bit dumps
     # (fp32 accumulation); the kernel's reduction step writes them in feature order
+    jobs, names = [], []
     for b in range(5):
-        grads[f"blocks.{b}.fc_0.weight"], grads[f"blocks.{b}.fc_0.bias"] = ops.weight_grad(
-            bd.g_fc0[b], fwd.d_a[b], prec, inv_s, rows_st=True, cols_st=True)
-        grads[f"blocks.{b}.fc_1.weight"], grads[f"blocks.{b}.fc_1.bias"] = ops.weight_grad(
-            bd.g_fc1[b], fwd.d_n[b], prec, inv_s, rows_st=True, cols_st=True)
+        jobs += [(bd.g_fc0[b], fwd.d_a[b], True, True), (bd.g_fc1[b], fwd.d_n[b], True, True)]
+        names += [f"blocks.{b}.fc_0", f"blocks.{b}.fc_1"]
+    gzs = [bd.g_x0 if b == 0 else bd.g_fc1[b - 1] for b in range(3)]  # dL/d(residual stream entering block b), per view
+    for b in range(3):
+        jobs.append((gzs[b], fwd.d_z, True, False))  # latent channels are in natural order
+        names.append(f"lin_z.{b}")
+    jobs.append((bd.g_x0, fwd.d_in, True, False, 64, 42))  # lin_in: operand (rows,64) = code | viewdir | 0-pad
+    names.append("lin_in")
+    for name, (dW, db) in zip(names, ops.weight_grad_batched(jobs, prec, inv_s)):  # one launch for all 14 linears
+        grads[name + ".weight"], grads[name + ".bias"] = dW, db
     d_zlat = None
     for b in range(3):
-        gz = bd.g_x0 if b == 0 else bd.g_fc1[b - 1]  # dL/d(residual stream entering block b), per view
-        grads[f"lin_z.{b}.weight"], grads[f"lin_z.{b}.bias"] = ops.weight_grad(
-            gz, fwd.d_z, prec, inv_s, rows_st=True, cols_st=False)  # latent channels are in natural order
+        gz = gzs[b]
         # d z_lat += dY W_z[b]  (W in feature order; dY columns are in storage order): a plain
         # (rows,512)x(512,512) library GEMM on the 16-bit operands (fp32 accumulation inside)
         term = torch.matmul(gz, mlp_state[f"lin_z.{b}.weight"].detach()[perm].to(gz.dtype)).float()
         d_zlat = term if d_zlat is None else d_zlat + term
     d_zlat = d_zlat * inv_s
-    g0f = bd.g_x0.float()
-    grads["lin_in.weight"] = (torch.matmul(g0f.t(), fwd.d_in.float()[:, :42]) * inv_s)[inv]
-    grads["lin_in.bias"] = (g0f.sum(0) * inv_s)[inv]
-    grads["lin_out.weight"] = torch.matmul(g_out.t(), fwd.d_x5.float())[:, inv]
-    grads["lin_out.bias"] = g_out.sum(0)
+    grads["lin_out.weight"], grads["lin_out.bias"] = ops.lin_out_grad(g_out, fwd.d_x5, prec)
     d_in = None
-    if want_d_in:  # dL/d(code | viewdir) = dY(lin_in) W_in   (rows_v, 42)
-        d_in = (torch.matmul(g0f, mlp_state["lin_in.weight"].detach()[perm]) * inv_s).contiguous()
+    if want_d_in:  # dL/d(code | viewdir) = dY(lin_in) W_in   (rows_v, 42): 16-bit library GEMM like the lin_z terms
+        w_in = mlp_state["lin_in.weight"].detach()[perm].to(bd.g_x0.dtype)
+        d_in = (torch.matmul(bd.g_x0, w_in).float() * inv_s).contiguous()
     return grads, d_zlat.contiguous(), d_in
 
 

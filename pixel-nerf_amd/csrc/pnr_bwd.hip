@@ -229,31 +229,61 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
 }
 
 // ---------------------------------------------------------------- weight-gradient GEMM
-// dW[o][k] += sum_r dY[r][o] X[r][k]   over 16-bit row-major dumps (rows, ldy) / (rows, ldx), fp32 out.
-// The reduction index r is the slow dimension of both operands, so each 16-row slab is staged in
-// LDS (transposed) and read back as MFMA fragments.  Block = 4 waves = one 128x128 tile of dW,
-// blockIdx.z = slice of the rows (split-K): every slice writes its own partial
-// (part[z][512][512], bpart[z][512]) with plain stores and dw_reduce_kernel sums the slices in a
-// fixed order -> bit-reproducible, no atomics.  bpart = bias gradient sum_r dY[r][o].
+// dW[o][k] = sum_r dY[r][o] X[r][k]   over 16-bit row-major dumps (rows,512) / (rows,512), fp32 out.
+// The reduction index r is the slow dimension of both operands.  Slabs of 32 rows are staged in LDS AS
+// THEY LIE IN MEMORY (row-major, 16-byte global loads -> 16-byte LDS writes) and the MFMA fragments
+// (8 consecutive rows of one column) come out of gfx950's transposing LDS read ds_read_b64_tr_b16:
+// per 16-lane group a [4 rows][16 columns] block, lane c receives column c.  Row stride 320 B puts the
+// 4 rows of a block and the two blocks of a 32-lane half on disjoint banks.
+// Block = 4 waves = one 128x128 tile of dW (wave = 64x64 = 2x2 MFMA tiles); blockIdx.y = slice of the
+// rows (split-K), blockIdx.z = job: all linears of a network go in ONE launch.  Every slice writes its own
+// partial (part[job][z][512][512], bpart[job][z][512]) with plain stores and dw_reduce_kernel sums them in
+// a fixed order -> bit-reproducible, no atomics.  bpart = bias gradient sum_r dY[r][o].
+constexpr int DW_MAX_JOBS = 16;
+struct DwJobs {
+    const void *dY[DW_MAX_JOBS], *X[DW_MAX_JOBS];
+    float *dW[DW_MAX_JOBS], *db[DW_MAX_JOBS];
+    long long rows[DW_MAX_JOBS];
+    short nx[DW_MAX_JOBS];   // columns of X (= its row stride): 512, or 64 for the lin_in operand
+    short ncw[DW_MAX_JOBS];  // columns of dW written (= its row stride): 512, or 42 for lin_in
+    unsigned char rows_st[DW_MAX_JOBS], cols_st[DW_MAX_JOBS];
+    int nsplit;
+};
+
+template <typename T8>
+__device__ __forceinline__ T8 tr_frag(const char *smem_row_col) {
+    // two transposing reads: rows +0..3 and +4..7 (row stride 320 B) of this lane's column
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s4 *lds_s4;
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(smem_row_col));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(smem_row_col + 4 * 320));
+    const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(T8, v);
+}
+
 template <int PREC>
 __global__ void __launch_bounds__(256)
-dw_kernel(const typename Prec<PREC>::T *__restrict__ dY, const typename Prec<PREC>::T *__restrict__ X, long long rows,
-          int ldy, int ldx, int rows_per_block, float *__restrict__ part, float *__restrict__ bpart) {
-    // Block = 4 waves = one 128x128 tile of dW; wave = 64x64 = 2x2 MFMA tiles.  Slabs of 32 rows are
-    // staged TRANSPOSED in LDS (sT[col][row], 80-byte rows -> conflict-free ds_read_b128), so one
-    // fragment (8 consecutive rows of one column) is a single 16-byte LDS read.
+dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart) {
     typedef Prec<PREC> P;
     typedef typename P::T T;
-    constexpr int SR = 32, LD = SR + 8;  // rows per slab, padded transposed row (16-byte multiple)
-    __shared__ __attribute__((aligned(16))) T sY[128][LD];
-    __shared__ __attribute__((aligned(16))) T sX[128][LD];
+    constexpr int SR = 32, LDB = 320;  // rows per slab, LDS row stride in bytes (128 columns + 64 B pad)
+    __shared__ __attribute__((aligned(16))) char sY[SR * LDB];
+    __shared__ __attribute__((aligned(16))) char sX[SR * LDB];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int o0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
-    const long long r_begin = (long long)blockIdx.z * rows_per_block;
-    const long long r_end = r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows;
+    const int job = blockIdx.z;
+    const T *dY = reinterpret_cast<const T *>(jobs.dY[job]);
+    const T *X = reinterpret_cast<const T *>(jobs.X[job]);
+    const long long rows = jobs.rows[job];
+    const int nx = jobs.nx[job];
+    long long per = (rows + jobs.nsplit - 1) / jobs.nsplit;
+    per = (per + SR - 1) / SR * SR;
+    const int o0 = (blockIdx.x >> 2) * 128, k0 = (blockIdx.x & 3) * 128;
+    if (k0 >= nx) return;  // narrow X (lin_in): only the first column tile exists
+    const long long r_begin = (long long)blockIdx.y * per;
+    const long long r_end = r_begin + per < rows ? r_begin + per : rows;
     const int wo = (w >> 1) * 64, wk = (w & 1) * 64;
     const int i = lane & 31, kh = lane >> 5;
-    // staging: slab = 32 rows x 128 columns per operand = 512 chunks of 8 columns; 2 chunks per thread
     f32x16 acc[2][2];
     float bsum[2] = {0.f, 0.f};
 #pragma unroll
@@ -263,36 +293,32 @@ dw_kernel(const typename Prec<PREC>::T *__restrict__ dY, const typename Prec<PRE
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     // register-staged software pipeline: the global loads of slab s+1 are in flight while slab s is
-    // being multiplied out of LDS
+    // being multiplied out of LDS.  slab = 32 rows x 16 chunks of 8 columns per operand; 2 chunks per thread
     u32x4 vy[2], vx[2];
     auto load_slab = [&](long long r0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            // neighbouring lanes take neighbouring ROWS of the same 8-column chunk: the transposing
-            // 2-byte LDS writes then land on consecutive addresses (no bank conflicts)
-            const int chunk = t + u * 256;            // 0..511
-            const int srow = chunk & 31, scol = (chunk >> 5) * 8;
+            const int chunk = t + u * 256;  // consecutive lanes -> consecutive 16-byte chunks of a row
+            const int srow = chunk >> 4, scol = (chunk & 15) * 8;
             vy[u] = u32x4{0, 0, 0, 0};
             vx[u] = u32x4{0, 0, 0, 0};
             if (r0 + srow < r_end) {
-                vy[u] = *reinterpret_cast<const u32x4 *>(dY + (r0 + srow) * ldy + o0 + scol);
-                vx[u] = *reinterpret_cast<const u32x4 *>(X + (r0 + srow) * ldx + k0 + scol);
+                vy[u] = *reinterpret_cast<const u32x4 *>(dY + (r0 + srow) * D_HID + o0 + scol);
+                if (k0 + scol < nx) vx[u] = *reinterpret_cast<const u32x4 *>(X + (r0 + srow) * nx + k0 + scol);
             }
         }
     };
-    load_slab(r_begin);
+    // this lane's corner of the [4][16] transpose blocks: row 8kh + (c16>>2), column 16*((lane>>4)&1) + 4*(c16&3)
+    const int c16 = lane & 15;
+    const int frag_off = (8 * kh + (c16 >> 2)) * LDB + (16 * ((lane >> 4) & 1) + 4 * (c16 & 3)) * 2;
+    if (r_begin < r_end) load_slab(r_begin);
     for (long long r0 = r_begin; r0 < r_end; r0 += SR) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int chunk = t + u * 256;
-            const int srow = chunk & 31, scol = (chunk >> 5) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint16_t hy = (uint16_t)((e & 1) ? (vy[u][e >> 1] >> 16) : (vy[u][e >> 1] & 0xffffu));
-                const uint16_t hx = (uint16_t)((e & 1) ? (vx[u][e >> 1] >> 16) : (vx[u][e >> 1] & 0xffffu));
-                reinterpret_cast<uint16_t *>(&sY[scol + e][0])[srow] = hy;
-                reinterpret_cast<uint16_t *>(&sX[scol + e][0])[srow] = hx;
-            }
+            const int srow = chunk >> 4, scol = (chunk & 15) * 8;
+            *reinterpret_cast<u32x4 *>(sY + srow * LDB + scol * 2) = vy[u];
+            *reinterpret_cast<u32x4 *>(sX + srow * LDB + scol * 2) = vx[u];
         }
         __syncthreads();
         if (r0 + SR < r_end) load_slab(r0 + SR);
@@ -301,14 +327,14 @@ dw_kernel(const typename Prec<PREC>::T *__restrict__ dY, const typename Prec<PRE
             typename P::T8 af[2], bf[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                af[a] = *reinterpret_cast<const typename P::T8 *>(&sY[wo + a * 32 + i][ks * 16 + kh * 8]);
-                bf[a] = *reinterpret_cast<const typename P::T8 *>(&sX[wk + a * 32 + i][ks * 16 + kh * 8]);
+                af[a] = tr_frag<typename P::T8>(sY + ks * 16 * LDB + (wo + a * 32) * 2 + frag_off);
+                bf[a] = tr_frag<typename P::T8>(sX + ks * 16 * LDB + (wk + a * 32) * 2 + frag_off);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = P::mfma(af[a], bf[b], acc[a][b]);
-            if (blockIdx.x == 0 && (w & 1) == 0) {
+            if ((blockIdx.x & 3) == 0 && (w & 1) == 0) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -318,7 +344,7 @@ dw_kernel(const typename Prec<PREC>::T *__restrict__ dY, const typename Prec<PRE
         __syncthreads();
     }
     // D layout: column j = lane&31 -> k, row (r&3)+8(r>>2)+4kh -> o
-    float *pz = part + (size_t)blockIdx.z * (D_HID * D_HID);
+    float *pz = part + ((size_t)job * jobs.nsplit + blockIdx.y) * (D_HID * D_HID);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -328,33 +354,38 @@ dw_kernel(const typename Prec<PREC>::T *__restrict__ dY, const typename Prec<PRE
                 const int orow = o0 + wo + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 pz[(size_t)orow * D_HID + k0 + wk + b * 32 + i] = acc[a][b][r];
             }
-    if (blockIdx.x == 0 && (w & 1) == 0) {
+    if ((blockIdx.x & 3) == 0 && (w & 1) == 0) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);  // both row halves of every k-step
-            if (kh == 0) bpart[(size_t)blockIdx.z * D_HID + o0 + wo + a * 32 + i] = v;
+            if (kh == 0) bpart[((size_t)job * jobs.nsplit + blockIdx.y) * D_HID + o0 + wo + a * 32 + i] = v;
         }
     }
 }
 
-// dW = scale * sum_z part[z], db = scale * sum_z bpart[z]  (fixed summation order).  rows_st / cols_st:
-// the operand that indexes the rows (dY) / columns (X) of dW was dumped in storage order; the result is
-// written in feature order (row e -> feature feat_of(e/32, (e%32)/16, e%16)).
-__global__ void dw_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bpart, int nz, float scale,
-                                 int rows_st, int cols_st, float *__restrict__ dW, float *__restrict__ db) {
+// dW = scale * sum_z part[job][z], db = scale * sum_z bpart[job][z]  (fixed summation order); blockIdx.y = job.
+// rows_st / cols_st: the operand that indexes the rows (dY) / columns (X) of dW was dumped in storage order;
+// the result is written in feature order (row e -> feature feat_of(e/32, (e%32)/16, e%16)).
+__global__ void dw_reduce_kernel(const DwJobs jobs, const float *__restrict__ part, const float *__restrict__ bpart,
+                                 float scale) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < D_HID * D_HID) {
+    const int job = blockIdx.y, nz = jobs.nsplit;
+    const float *pj = part + (size_t)job * nz * (D_HID * D_HID);
+    const float *bj = bpart + (size_t)job * nz * D_HID;
+    const bool rows_st = jobs.rows_st[job], cols_st = jobs.cols_st[job];
+    if (idx < D_HID * D_HID && (idx % D_HID) < ((jobs.nx[job] + 127) / 128) * 128) {
         float s = 0.f;
-        for (int z = 0; z < nz; ++z) s += part[(size_t)z * (D_HID * D_HID) + idx];
+        for (int z = 0; z < nz; ++z) s += pj[(size_t)z * (D_HID * D_HID) + idx];
         int r = idx / D_HID, c = idx % D_HID;
         if (rows_st) r = feat_of(r >> 5, (r >> 4) & 1, r & 15);
         if (cols_st) c = feat_of(c >> 5, (c >> 4) & 1, c & 15);
-        dW[r * D_HID + c] = s * scale;
+        const int ncw = jobs.ncw[job];
+        if (c < ncw) jobs.dW[job][r * ncw + c] = s * scale;
     }
-    if (db && idx < D_HID) {
+    if (jobs.db[job] && idx < D_HID) {
         float s = 0.f;
-        for (int z = 0; z < nz; ++z) s += bpart[(size_t)z * D_HID + idx];
-        db[rows_st ? feat_of(idx >> 5, (idx >> 4) & 1, idx & 15) : idx] = s * scale;
+        for (int z = 0; z < nz; ++z) s += bj[(size_t)z * D_HID + idx];
+        jobs.db[job][rows_st ? feat_of(idx >> 5, (idx >> 4) & 1, idx & 15) : idx] = s * scale;
     }
 }
 
@@ -531,6 +562,79 @@ latent_scatter_kernel(const EvalParams q, const float *__restrict__ d_zlat, floa
         }
 }
 
+// Small grids (Hl*Wl <= SLAB_MAX_TEXELS, e.g. the 32x32 / 64x64 grids of sn64 / SRN): dozens of samples hit
+// every texel, so global atomics serialise on a few thousand addresses.  Instead one workgroup owns an
+// (image, 8-channel slice) slab of the gradient grid in LDS: it walks all points of that image's object,
+// accumulates the four bilinear corners with LDS atomics, and adds the slab to HBM once (one global atomic
+// per non-zero slab element; up to 4 workgroups share an (image, slice) by splitting the points).  Points
+// are projected in batches of 256 (one per thread), corner texels / weights parked in LDS.
+constexpr int SLAB_CS = 8;                // channels per slab
+constexpr int SLAB_MAX_TEXELS = 4608;     // 4608 * 8 floats = 144 KiB of LDS
+__global__ void __launch_bounds__(256)
+latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat, float *__restrict__ d_latent) {
+    extern __shared__ float slab[];  // [Hl*Wl][SLAB_CS] then 256 x (4 texels, 4 weights)
+    const int t = threadIdx.x;
+    const int texels = q.Hl * q.Wl;
+    int *m_tex = reinterpret_cast<int *>(slab + (size_t)texels * SLAB_CS);
+    float *m_w = reinterpret_cast<float *>(m_tex + 256 * 4);
+    const int nslices = C_LAT / SLAB_CS;
+    const int img = blockIdx.x / nslices, cs = blockIdx.x % nslices;  // img = obj * NS + view
+    const int obj = img / q.NS, view = img % q.NS;
+    for (int i = t; i < texels * SLAB_CS; i += 256) slab[i] = 0.f;
+    const long long pts = (long long)q.per_obj * q.K;  // points of this object
+    const long long g_begin = (long long)obj * pts;
+    // blockIdx.y = slice of the object's points (multiples of 256): more workgroups per CU hide the load latency
+    long long per = (pts + gridDim.y - 1) / gridDim.y;
+    per = (per + 255) / 256 * 256;
+    const long long p_begin = (long long)blockIdx.y * per, p_end = p_begin + per < pts ? p_begin + per : pts;
+    const uint32_t rowbase = (uint32_t)img * (uint32_t)texels;
+    const float *pose = q.poses + (size_t)img * 12;
+    const int ch = t & (SLAB_CS - 1), pi = t / SLAB_CS;  // channel, point lane (32 points per pass)
+    __syncthreads();
+    for (long long b0 = p_begin; b0 < p_end; b0 += 256) {
+        // all 8 gradient loads of this thread for the batch go out first, the projection runs under them
+        float v[256 / (256 / SLAB_CS)];
+#pragma unroll
+        for (int j = 0; j < SLAB_CS; ++j) {
+            const long long pnt = b0 + pi + j * (256 / SLAB_CS);
+            v[j] = pnt < p_end ? d_zlat[((size_t)view * q.P + (size_t)(g_begin + pnt)) * C_LAT + cs * SLAB_CS + ch] : 0.f;
+        }
+        if (b0 + t < p_end) {
+            const int g = (int)(g_begin + b0 + t);
+            const int r = g / q.K;
+            const float *ray = q.rays + (size_t)r * 8;
+            const float zz = q.z[g];
+            const float X = ray[0] + zz * ray[3], Y = ray[1] + zz * ray[4], Z = ray[2] + zz * ray[5];
+            const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
+            const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
+            const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
+            const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, true);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                m_tex[t * 4 + c] = (int)(pr.off[c] / C_LAT - rowbase);
+                m_w[t * 4 + c] = pr.w[c];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SLAB_CS; ++j) {
+            const int i = pi + j * (256 / SLAB_CS);
+            if (b0 + i < p_end && v[j] != 0.f) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float w = m_w[i * 4 + c];
+                    if (w != 0.f) atomicAdd(&slab[m_tex[i * 4 + c] * SLAB_CS + ch], w * v[j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < texels * SLAB_CS; i += 256) {
+        const float sv = slab[i];
+        if (sv != 0.f) atomicAdd(d_latent + ((size_t)rowbase + i / SLAB_CS) * C_LAT + cs * SLAB_CS + (i % SLAB_CS), sv);
+    }
+}
+
 // dL/dz through the network inputs; one wavefront per (view, point).
 __global__ void __launch_bounds__(CW * 64)
 position_bwd_kernel(const EvalParams q, const float *__restrict__ d_in42, const float *__restrict__ d_zlat,
@@ -674,35 +778,121 @@ extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const Pnr
     return pnr_check_launch("bwd_kernel");
 }
 
+// lin_out (4 x 512): dW[o][k] = sum_r g[r][o] x5[r][k], db[o] = sum_r g[r][o]; g fp32 (P,4), x5 16-bit (P,512)
+// in storage order.  Row slices -> partials -> fixed-order reduce (written in feature order).
+constexpr int LO_BLOCKS = 256;
+template <typename T>
+__global__ void __launch_bounds__(256)
+lin_out_grad_kernel(const float *__restrict__ g, const T *__restrict__ x5, long long P, float *__restrict__ part) {
+    const int t = threadIdx.x;
+    const long long per = (P + LO_BLOCKS - 1) / LO_BLOCKS;
+    const long long r0 = (long long)blockIdx.x * per, r1 = r0 + per < P ? r0 + per : P;
+    float acc[4][2] = {}, bs[4] = {};
+    for (long long r = r0; r < r1; ++r) {
+        const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + r * 4);
+        const uint32_t xw = *reinterpret_cast<const uint32_t *>(x5 + r * D_HID + 2 * t);
+        const float xa = (float)__builtin_bit_cast(T, (uint16_t)(xw & 0xffffu)), xb = (float)__builtin_bit_cast(T, (uint16_t)(xw >> 16));
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            acc[o][0] += gv[o] * xa; acc[o][1] += gv[o] * xb;
+            bs[o] += gv[o];
+        }
+    }
+    float *pz = part + (size_t)blockIdx.x * (4 * D_HID + 4);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        pz[o * D_HID + 2 * t] = acc[o][0];
+        pz[o * D_HID + 2 * t + 1] = acc[o][1];
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) pz[4 * D_HID + o] = bs[o];
+    }
+}
+__global__ void lin_out_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * D_HID + 4) return;
+    float s = 0.f;
+    for (int z = 0; z < LO_BLOCKS; ++z) s += part[(size_t)z * (4 * D_HID + 4) + idx];
+    if (idx < 4 * D_HID) {
+        const int o = idx / D_HID, e = idx % D_HID;
+        dW[o * D_HID + feat_of(e >> 5, (e >> 4) & 1, e & 15)] = s;
+    } else if (db) {
+        db[idx - 4 * D_HID] = s;
+    }
+}
+
+extern "C" size_t pnr_lin_out_grad_workspace_bytes(void) { return (size_t)LO_BLOCKS * (4 * D_HID + 4) * sizeof(float); }
+
+extern "C" int pnr_lin_out_grad(const float *g_out, const void *x5, long long P, int precision, float *dW, float *db,
+                                void *workspace, void *stream) {
+    if (!g_out || !x5 || !dW || !workspace || P <= 0) return pnr_fail(PNR_E_INVALID, "pnr_lin_out_grad: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    if (precision == PNR_PREC_F16)
+        hipLaunchKernelGGL(lin_out_grad_kernel<_Float16>, dim3(LO_BLOCKS), dim3(256), 0, st, g_out, (const _Float16 *)x5, P, part);
+    else if (precision == PNR_PREC_BF16)
+        hipLaunchKernelGGL(lin_out_grad_kernel<__bf16>, dim3(LO_BLOCKS), dim3(256), 0, st, g_out, (const __bf16 *)x5, P, part);
+    else
+        return pnr_fail(PNR_E_INVALID, "pnr_lin_out_grad: unknown precision");
+    hipLaunchKernelGGL(lin_out_reduce_kernel, dim3((4 * D_HID + 4 + 255) / 256), dim3(256), 0, st, part, dW, db);
+    return pnr_check_launch("pnr_lin_out_grad");
+}
+
 constexpr int DW_MAX_SPLIT = 32;
+static int dw_nsplit(int n_jobs, long long max_rows) {
+    // >= ~768 workgroups (3 per CU) from 16 tiles x jobs x slices; slices of at least 256 rows
+    int nsplit = (768 + 16 * n_jobs - 1) / (16 * n_jobs);
+    const long long cap = (max_rows + 255) / 256;
+    if (nsplit > cap) nsplit = (int)cap;
+    if (nsplit > DW_MAX_SPLIT) nsplit = DW_MAX_SPLIT;
+    return nsplit < 1 ? 1 : nsplit;
+}
+
+extern "C" size_t pnr_weight_grad_batched_workspace_bytes(int n_jobs, long long max_rows) {
+    if (n_jobs < 1 || n_jobs > DW_MAX_JOBS || max_rows < 1) return 0;
+    return (size_t)n_jobs * dw_nsplit(n_jobs, max_rows) * (D_HID * D_HID + D_HID) * sizeof(float);
+}
 extern "C" size_t pnr_weight_grad_workspace_bytes(void) { return (size_t)DW_MAX_SPLIT * (D_HID * D_HID + D_HID) * sizeof(float); }
+
+extern "C" int pnr_weight_grad_batched(const PnrWeightGradJob *jobs, int n_jobs, int precision, float out_scale,
+                                       void *workspace, void *stream) {
+    if (!jobs || !workspace || n_jobs < 1 || n_jobs > DW_MAX_JOBS)
+        return pnr_fail(PNR_E_INVALID, "pnr_weight_grad_batched: 1..16 jobs and a workspace are required");
+    DwJobs J = {};
+    long long max_rows = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!jobs[j].dY || !jobs[j].X || !jobs[j].dW || jobs[j].rows <= 0)
+            return pnr_fail(PNR_E_INVALID, "pnr_weight_grad_batched: bad job");
+        J.dY[j] = jobs[j].dY; J.X[j] = jobs[j].X; J.dW[j] = jobs[j].dW; J.db[j] = jobs[j].db; J.rows[j] = jobs[j].rows;
+        J.rows_st[j] = jobs[j].rows_storage_order ? 1 : 0; J.cols_st[j] = jobs[j].cols_storage_order ? 1 : 0;
+        const int nx = jobs[j].x_cols ? jobs[j].x_cols : D_HID, ncw = jobs[j].dw_cols ? jobs[j].dw_cols : nx;
+        if (nx < 8 || nx > D_HID || nx % 8 != 0 || ncw < 1 || ncw > nx || (nx != D_HID && jobs[j].cols_storage_order))
+            return pnr_fail(PNR_E_INVALID, "pnr_weight_grad_batched: x_cols must be a multiple of 8 in [8,512], dw_cols <= x_cols");
+        J.nx[j] = (short)nx; J.ncw[j] = (short)ncw;
+        if (jobs[j].rows > max_rows) max_rows = jobs[j].rows;
+    }
+    J.nsplit = dw_nsplit(n_jobs, max_rows);
+    float *part = (float *)workspace;
+    float *bpart = part + (size_t)n_jobs * J.nsplit * D_HID * D_HID;
+    dim3 grid(16, (unsigned)J.nsplit, (unsigned)n_jobs);
+    hipStream_t st = (hipStream_t)stream;
+    if (precision == PNR_PREC_F16)
+        hipLaunchKernelGGL(dw_kernel<PNR_PREC_F16>, grid, dim3(256), 0, st, J, part, bpart);
+    else if (precision == PNR_PREC_BF16)
+        hipLaunchKernelGGL(dw_kernel<PNR_PREC_BF16>, grid, dim3(256), 0, st, J, part, bpart);
+    else
+        return pnr_fail(PNR_E_INVALID, "pnr_weight_grad_batched: unknown precision");
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(D_HID * D_HID / 256, (unsigned)n_jobs), dim3(256), 0, st, J, part, bpart, out_scale);
+    return pnr_check_launch("pnr_weight_grad_batched");
+}
 
 extern "C" int pnr_weight_grad(const void *dY, const void *X, long long rows, int precision, float out_scale,
                                int rows_storage_order, int cols_storage_order, float *dW, float *db, void *workspace,
                                void *stream) {
     if (!dY || !X || !dW || !workspace || rows <= 0) return pnr_fail(PNR_E_INVALID, "pnr_weight_grad: bad argument");
-    // 16 output tiles of 128x128 x nsplit row slices (= up to 512 blocks, two per CU)
-    int nsplit = (int)((rows + 1023) / 1024);
-    if (nsplit > DW_MAX_SPLIT) nsplit = DW_MAX_SPLIT;
-    if (nsplit < 1) nsplit = 1;
-    long long per = (rows + nsplit - 1) / nsplit;
-    per = (per + 31) / 32 * 32;
-    const int nz = (int)((rows + per - 1) / per);
-    float *part = (float *)workspace;
-    float *bpart = part + (size_t)DW_MAX_SPLIT * D_HID * D_HID;
-    dim3 grid(D_HID / 128, D_HID / 128, (unsigned)nz);
-    hipStream_t st = (hipStream_t)stream;
-    if (precision == PNR_PREC_F16)
-        hipLaunchKernelGGL(dw_kernel<PNR_PREC_F16>, grid, dim3(256), 0, st, (const _Float16 *)dY, (const _Float16 *)X, rows,
-                           D_HID, D_HID, (int)per, part, bpart);
-    else if (precision == PNR_PREC_BF16)
-        hipLaunchKernelGGL(dw_kernel<PNR_PREC_BF16>, grid, dim3(256), 0, st, (const __bf16 *)dY, (const __bf16 *)X, rows,
-                           D_HID, D_HID, (int)per, part, bpart);
-    else
-        return pnr_fail(PNR_E_INVALID, "pnr_weight_grad: unknown precision");
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(D_HID * D_HID / 256), dim3(256), 0, st, part, bpart, nz, out_scale,
-                       rows_storage_order, cols_storage_order, dW, db);
-    return pnr_check_launch("pnr_weight_grad");
+    PnrWeightGradJob job = {dY, X, rows, rows_storage_order, cols_storage_order, dW, db, 0, 0};
+    return pnr_weight_grad_batched(&job, 1, precision, out_scale, workspace, stream);
 }
 
 extern "C" int pnr_composite_backward(const float *rays, const float *z, const float *rgbsigma, int R, int K, int white_bkgd,
@@ -743,6 +933,22 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
     q.SB = s->SB; q.NS = s->NS; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
     q.img_w = s->img_w; q.img_h = s->img_h;
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
+    if (q.Hl * q.Wl <= SLAB_MAX_TEXELS) {  // small grid: LDS slabs, no global atomics
+        const size_t lds = (size_t)q.Hl * q.Wl * SLAB_CS * sizeof(float) + 256 * 8 * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(latent_scatter_slab_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_MAX_TEXELS * SLAB_CS * 4 + 8192);
+            if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(latent_scatter_slab_kernel)");
+            attr_set = true;
+        }
+        const long long pts = (long long)rays_per_obj * K;
+        int psplit = (int)((pts + 4095) / 4096);  // >= 16 batches of 256 points per workgroup
+        if (psplit > 4) psplit = 4;
+        hipLaunchKernelGGL(latent_scatter_slab_kernel, dim3((unsigned)(q.SB * q.NS * (C_LAT / SLAB_CS)), psplit), dim3(256), lds,
+                           (hipStream_t)stream, q, d_zlat, d_latent_nhwc);
+        return pnr_check_launch("pnr_latent_scatter");
+    }
     const long long n = ((q.P + SCATTER_RUN - 1) / SCATTER_RUN) * q.NS;  // wavefronts
     hipLaunchKernelGGL(latent_scatter_kernel, dim3((unsigned)((n + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream, q,
                        d_zlat, d_latent_nhwc);

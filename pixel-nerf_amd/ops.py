@@ -637,4 +637,59 @@ def weight_grad(dY, X, precision, out_scale=1.0, want_bias=True, rows_st=False, 
     return dW, db
 
 
+def weight_grad_batched(jobs, precision, out_scale=1.0):
+    """jobs: list of (dY, X, rows_st, cols_st[, x_cols, dw_cols]) with dY (rows,512), X (rows,x_cols=512) 16-bit
+    dumps -> list of (dW (512,dw_cols), db (512)), all computed by ONE pnr_weight_grad_batched call (<= 16 jobs)."""
+    lib = _lib.load()
+    n = len(jobs)
+    dev = jobs[0][0].device
+    arr = (_lib.PnrWeightGradJob * n)()
+    outs, keep = [], []
+    max_rows = 0
+    if n > 16:
+        raise _lib.PixelNerfHipError("weight_grad_batched: at most 16 jobs per call")
+    for j, job in enumerate(jobs):
+        dY, X, rows_st, cols_st = job[:4]
+        x_cols, dw_cols = (job[4], job[5]) if len(job) > 4 else (512, 512)
+        rows = dY.shape[0]
+        assert dY.shape == (rows, 512) and X.shape == (rows, x_cols) and dY.dtype == X.dtype and dY.is_cuda
+        dY, X = dY.contiguous(), X.contiguous()
+        dW = torch.empty((512, dw_cols), dtype=torch.float32, device=dev)
+        db = torch.empty((512,), dtype=torch.float32, device=dev)
+        keep.append((dY, X))
+        outs.append((dW, db))
+        arr[j].dY, arr[j].X, arr[j].rows = dY.data_ptr(), X.data_ptr(), rows
+        arr[j].rows_storage_order, arr[j].cols_storage_order = int(bool(rows_st)), int(bool(cols_st))
+        arr[j].dW, arr[j].db = dW.data_ptr(), db.data_ptr()
+        arr[j].x_cols, arr[j].dw_cols = x_cols, dw_cols
+        max_rows = max(max_rows, rows)
+    need = lib.pnr_weight_grad_batched_workspace_bytes(n, max_rows)
+    key = ("batched", str(dev))
+    if key not in _wg_workspace or _wg_workspace[key].numel() < need:
+        _wg_workspace[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_weight_grad_batched(arr, n, int(precision), float(out_scale), _p(_wg_workspace[key]), _stream()),
+                   "pnr_weight_grad_batched")
+    return outs
+
+
+def lin_out_grad(g_out, x5, precision):
+    """lin_out: dW (4,512) = g_out^T x5 (feature order), db (4) = column sums; g_out (P,4) fp32, x5 (P,512) dump."""
+    lib = _lib.load()
+    g_out = _f32(g_out, "g_out", (None, 4))
+    P = g_out.shape[0]
+    assert x5.shape == (P, 512) and x5.is_cuda
+    x5 = x5.contiguous()
+    dev = g_out.device
+    dW = torch.empty((4, 512), dtype=torch.float32, device=dev)
+    db = torch.empty((4,), dtype=torch.float32, device=dev)
+    key = ("lin_out", str(dev))
+    if key not in _wg_workspace:
+        _wg_workspace[key] = torch.empty(lib.pnr_lin_out_grad_workspace_bytes(), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_lin_out_grad(_p(g_out), _p(x5), P, int(precision), _p(dW), _p(db), _p(_wg_workspace[key]), _stream()),
+                   "pnr_lin_out_grad")
+    return dW, db
+
+
 _wg_workspace = {}

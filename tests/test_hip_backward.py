@@ -170,3 +170,105 @@ def test_training_converges_on_a_fixed_batch(dev):
                 p_.add_(p_.grad, alpha=-eta)  # in-place: bumps _version -> weights are re-packed
     assert all(b < a for a, b in zip(losses, losses[1:])), losses
     assert losses[-1] < 0.6 * losses[0], losses
+
+
+@pytest.mark.parametrize("Hl,Wl", [(16, 16), (72, 80)])  # LDS-slab kernel / global-atomic kernel (5760 texels)
+def test_latent_scatter_matches_autograd(dev, Hl, Wl):
+    """d(interpolated latent) -> d(feature grid) for SB=2 x NS=2, against autograd through the oracle's lookup
+    (encoder.py:80-109).  fp32 on both sides; atomics reorder sums: 1e-5 relative."""
+    from helpers import scene_for
+    from pixelnerf_amd import ops, synthetic
+    scene, meta = scene_for("mv_mini")
+    scene = dict(scene)
+    gen = torch.Generator().manual_seed(21)
+    scene["latent"] = torch.randn(4, 512, Hl, Wl, generator=gen)
+    SB, NS = scene["SB"], scene["NS"]
+    rays = synthetic.target_rays(meta, n_rays=24)  # (2, 24, 8)
+    r = rays.reshape(-1, 8)
+    K = 10
+    z = O.sample_coarse(r, torch.rand(r.shape[0], K, generator=gen), K)
+    B = 24 * K
+    P = SB * B
+    d_zlat = torch.randn(NS * P, 512, generator=gen)
+    d_zlat[5] = 0.0
+    # reference: the oracle's projection + lookup, differentiated w.r.t. the grid
+    lat = scene["latent"].clone().requires_grad_(True)
+    xyz = (r[:, None, :3] + z.unsqueeze(2) * r[:, None, 3:6]).reshape(SB, B, 3)
+    xyz_r = O.repeat_interleave(xyz, NS)
+    poses = scene["poses"]
+    xyz_cam = torch.matmul(poses[:, None, :3, :3], xyz_r.unsqueeze(-1))[..., 0] + poses[:, None, :3, 3]
+    uv = -xyz_cam[:, :, :2] / xyz_cam[:, :, 2:]
+    uv = uv * scene["focal"].unsqueeze(1) + scene["c"].unsqueeze(1)
+    feats = O.index_latent(lat, uv, scene["image_shape"])  # (SB*NS, 512, B)
+    g = d_zlat.reshape(NS, SB, B, 512).permute(1, 0, 3, 2).reshape(SB * NS, 512, B)  # row obj*NS+view
+    (feats * g).sum().backward()
+    sc = ops.make_scene(scene["latent"].to(dev), scene["poses"].to(dev), scene["focal"].to(dev), scene["c"].to(dev),
+                        scene["image_shape"], NS)
+    out = torch.zeros(4, Hl, Wl, 512, device=dev)
+    ops.latent_scatter(sc, r.to(dev), z.to(dev), d_zlat.to(dev), out)
+    ops.latent_scatter(sc, r.to(dev), z.to(dev), d_zlat.to(dev), out)  # accumulates into the buffer
+    got = out.permute(0, 3, 1, 2).cpu() / 2
+    ref = lat.grad
+    assert (got - ref).norm() <= 1e-5 * ref.norm()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("prec,dt", [("f16", torch.float16), ("bf16", torch.bfloat16)])
+def test_weight_grad_kernel_single_and_batched(dev, prec, dt):
+    """dW = dY^T X / db = column sums from 16-bit row-major dumps (transposing LDS reads, split rows, fixed-order
+    reduce) against an fp32 matmul of the same 16-bit values: products are exact in fp32, only the summation
+    order differs -> 2e-6 relative.  Ragged row counts, storage-order -> feature-order mapping, several jobs
+    with different row counts in one launch, bit-reproducibility."""
+    from pixelnerf_amd import _lib, ops
+    gen = torch.Generator().manual_seed(4)
+    perm = ops.storage_perm(dev).long()  # storage position e -> feature
+    p = _lib.PRECISIONS[prec]
+
+    def ref(dY, X, rs, cs, scale):
+        dW = (dY.float().t() @ X.float()) * scale
+        db = dY.float().sum(0) * scale
+        if rs:
+            o = torch.empty_like(dW); o[perm] = dW; dW = o
+            b = torch.empty_like(db); b[perm] = db; db = b
+        if cs:
+            o = torch.empty_like(dW); o[:, perm] = dW; dW = o
+        return dW, db
+
+    jobs = []
+    for rows, rs, cs in ((1000, True, True), (37, False, False), (4096 + 5, True, False), (640, False, True)):
+        dY = (torch.randn(rows, 512, generator=gen) * 0.5).to(dt).to(dev)
+        X = torch.randn(rows, 512, generator=gen).to(dt).to(dev)
+        jobs.append((dY, X, rs, cs))
+    outs = ops.weight_grad_batched(jobs, p, 0.25)
+    again = ops.weight_grad_batched(jobs, p, 0.25)
+    for (dY, X, rs, cs), (dW, db), (dW2, db2) in zip(jobs, outs, again):
+        rW, rb = ref(dY, X, rs, cs, 0.25)
+        assert (dW - rW).norm() <= 2e-6 * rW.norm() and (db - rb).norm() <= 2e-6 * rb.norm()
+        assert (dW - rW).abs().max() <= 1e-4 * rW.abs().max()
+        assert torch.equal(dW, dW2) and torch.equal(db, db2)
+        sW, sb = ops.weight_grad(dY, X, p, 0.25, rows_st=rs, cols_st=cs)  # single-job entry: same maths
+        assert (sW - rW).norm() <= 2e-6 * rW.norm() and (sb - rb).norm() <= 2e-6 * rb.norm()
+    with pytest.raises(_lib.PixelNerfHipError):
+        ops.weight_grad_batched(jobs * 5, p)  # more than 16 jobs
+    # the lin_in form: X is the (rows,64) code|viewdir operand in natural order, dW is (512,42)
+    rows = 3000
+    dY = (torch.randn(rows, 512, generator=gen) * 0.5).to(dt).to(dev)
+    X = torch.randn(rows, 64, generator=gen).to(dt).to(dev)
+    X[:, 42:] = 0
+    (dW, db), (dW_full, _) = ops.weight_grad_batched([(dY, X, True, False, 64, 42), jobs[0]], p, 2.0)
+    rW = torch.empty(512, 42, device=dev)
+    rW[perm] = (dY.float().t() @ X.float()[:, :42]) * 2.0
+    rb = torch.empty(512, device=dev)
+    rb[perm] = dY.float().sum(0) * 2.0
+    assert dW.shape == (512, 42) and (dW - rW).norm() <= 2e-6 * rW.norm() and (db - rb).norm() <= 2e-6 * rb.norm()
+    assert (dW_full - ref(*jobs[0], 2.0)[0]).norm() <= 2e-6 * dW_full.norm()
+    # lin_out: g (P,4) fp32 x dump (P,512) in storage order -> (4,512) in feature order
+    P = 5000
+    g = torch.randn(P, 4, generator=gen).to(dev)
+    x5 = torch.randn(P, 512, generator=gen).abs().to(dt).to(dev)
+    oW, ob = ops.lin_out_grad(g, x5, p)
+    r = torch.empty(4, 512, device=dev)
+    r[:, perm] = g.t() @ x5.float()
+    assert (oW - r).norm() <= 2e-6 * r.norm() and torch.allclose(ob, g.sum(0), rtol=1e-5, atol=1e-4)
+    oW2, ob2 = ops.lin_out_grad(g, x5, p)
+    assert torch.equal(oW, oW2) and torch.equal(ob, ob2)
