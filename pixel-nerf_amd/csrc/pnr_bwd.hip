@@ -233,9 +233,10 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
 // The reduction index r is the slow dimension of both operands.  Slabs of 32 rows are staged in LDS AS
 // THEY LIE IN MEMORY (row-major, 16-byte global loads -> 16-byte LDS writes) and the MFMA fragments
 // (8 consecutive rows of one column) come out of gfx950's transposing LDS read ds_read_b64_tr_b16:
-// per 16-lane group a [4 rows][16 columns] block, lane c receives column c.  Row stride 320 B puts the
+// per 16-lane group a [4 rows][16 columns] block, lane c receives column c.  Row stride 576 B puts the
 // 4 rows of a block and the two blocks of a 32-lane half on disjoint banks.
-// Block = 4 waves = one 128x128 tile of dW (wave = 64x64 = 2x2 MFMA tiles); blockIdx.y = slice of the
+// Block = 8 waves = one 256x256 tile of dW (wave = 64x128 = 2x4 MFMA tiles: every operand element is
+// fetched from L2 twice, not four times as with 128x128 tiles); blockIdx.y = slice of the
 // rows (split-K), blockIdx.z = job: all linears of a network go in ONE launch.  Every slice writes its own
 // partial (part[job][z][512][512], bpart[job][z][512]) with plain stores and dw_reduce_kernel sums them in
 // a fixed order -> bit-reproducible, no atomics.  bpart = bias gradient sum_r dY[r][o].
@@ -250,24 +251,24 @@ struct DwJobs {
     int nsplit;
 };
 
-template <typename T8>
+template <typename T8, int LDB>
 __device__ __forceinline__ T8 tr_frag(const char *smem_row_col) {
-    // two transposing reads: rows +0..3 and +4..7 (row stride 320 B) of this lane's column
+    // two transposing reads: rows +0..3 and +4..7 (row stride LDB bytes) of this lane's column
     typedef short s4 __attribute__((ext_vector_type(4)));
     typedef short s8 __attribute__((ext_vector_type(8)));
     typedef __attribute__((address_space(3))) s4 *lds_s4;
     const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(smem_row_col));
-    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(smem_row_col + 4 * 320));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(smem_row_col + 4 * LDB));
     const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(T8, v);
 }
 
 template <int PREC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart) {
     typedef Prec<PREC> P;
     typedef typename P::T T;
-    constexpr int SR = 32, LDB = 320;  // rows per slab, LDS row stride in bytes (128 columns + 64 B pad)
+    constexpr int SR = 32, LDB = 576;  // rows per slab, LDS row stride in bytes (256 columns + 64 B pad: 144 dwords = 16 mod 64)
     __shared__ __attribute__((aligned(16))) char sY[SR * LDB];
     __shared__ __attribute__((aligned(16))) char sX[SR * LDB];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -278,28 +279,28 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
     const int nx = jobs.nx[job];
     long long per = (rows + jobs.nsplit - 1) / jobs.nsplit;
     per = (per + SR - 1) / SR * SR;
-    const int o0 = (blockIdx.x >> 2) * 128, k0 = (blockIdx.x & 3) * 128;
+    const int o0 = (blockIdx.x >> 1) * 256, k0 = (blockIdx.x & 1) * 256;
     if (k0 >= nx) return;  // narrow X (lin_in): only the first column tile exists
     const long long r_begin = (long long)blockIdx.y * per;
     const long long r_end = r_begin + per < rows ? r_begin + per : rows;
-    const int wo = (w >> 1) * 64, wk = (w & 1) * 64;
+    const int wo = (w >> 1) * 64, wk = (w & 1) * 128;  // wave tile: 64 (o) x 128 (k) = 2 x 4 MFMA tiles
     const int i = lane & 31, kh = lane >> 5;
-    f32x16 acc[2][2];
+    f32x16 acc[2][4];
     float bsum[2] = {0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     // register-staged software pipeline: the global loads of slab s+1 are in flight while slab s is
-    // being multiplied out of LDS.  slab = 32 rows x 16 chunks of 8 columns per operand; 2 chunks per thread
+    // being multiplied out of LDS.  slab = 32 rows x 32 chunks of 8 columns per operand; 2 chunks per thread
     u32x4 vy[2], vx[2];
     auto load_slab = [&](long long r0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int chunk = t + u * 256;  // consecutive lanes -> consecutive 16-byte chunks of a row
-            const int srow = chunk >> 4, scol = (chunk & 15) * 8;
+            const int chunk = t + u * 512;  // consecutive lanes -> consecutive 16-byte chunks of a row
+            const int srow = chunk >> 5, scol = (chunk & 31) * 8;
             vy[u] = u32x4{0, 0, 0, 0};
             vx[u] = u32x4{0, 0, 0, 0};
             if (r0 + srow < r_end) {
@@ -315,8 +316,8 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
     for (long long r0 = r_begin; r0 < r_end; r0 += SR) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int chunk = t + u * 256;
-            const int srow = chunk >> 4, scol = (chunk & 15) * 8;
+            const int chunk = t + u * 512;
+            const int srow = chunk >> 5, scol = (chunk & 31) * 8;
             *reinterpret_cast<u32x4 *>(sY + srow * LDB + scol * 2) = vy[u];
             *reinterpret_cast<u32x4 *>(sX + srow * LDB + scol * 2) = vx[u];
         }
@@ -324,17 +325,16 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
         if (r0 + SR < r_end) load_slab(r0 + SR);
 #pragma unroll
         for (int ks = 0; ks < SR / 16; ++ks) {
-            typename P::T8 af[2], bf[2];
+            typename P::T8 af[2], bf[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                af[a] = tr_frag<typename P::T8>(sY + ks * 16 * LDB + (wo + a * 32) * 2 + frag_off);
-                bf[a] = tr_frag<typename P::T8>(sX + ks * 16 * LDB + (wk + a * 32) * 2 + frag_off);
-            }
+            for (int a = 0; a < 2; ++a) af[a] = tr_frag<typename P::T8, LDB>(sY + ks * 16 * LDB + (wo + a * 32) * 2 + frag_off);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[b] = tr_frag<typename P::T8, LDB>(sX + ks * 16 * LDB + (wk + b * 32) * 2 + frag_off);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = P::mfma(af[a], bf[b], acc[a][b]);
-            if ((blockIdx.x & 3) == 0 && (w & 1) == 0) {
+                for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(af[a], bf[b], acc[a][b]);
+            if ((blockIdx.x & 1) == 0 && (w & 1) == 0) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -348,13 +348,13 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int orow = o0 + wo + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 pz[(size_t)orow * D_HID + k0 + wk + b * 32 + i] = acc[a][b][r];
             }
-    if ((blockIdx.x & 3) == 0 && (w & 1) == 0) {
+    if ((blockIdx.x & 1) == 0 && (w & 1) == 0) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);  // both row halves of every k-step
@@ -373,7 +373,7 @@ __global__ void dw_reduce_kernel(const DwJobs jobs, const float *__restrict__ pa
     const float *pj = part + (size_t)job * nz * (D_HID * D_HID);
     const float *bj = bpart + (size_t)job * nz * D_HID;
     const bool rows_st = jobs.rows_st[job], cols_st = jobs.cols_st[job];
-    if (idx < D_HID * D_HID && (idx % D_HID) < ((jobs.nx[job] + 127) / 128) * 128) {
+    if (idx < D_HID * D_HID && (idx % D_HID) < ((jobs.nx[job] + 255) / 256) * 256) {
         float s = 0.f;
         for (int z = 0; z < nz; ++z) s += pj[(size_t)z * (D_HID * D_HID) + idx];
         int r = idx / D_HID, c = idx % D_HID;
@@ -589,14 +589,19 @@ latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat,
     const long long p_begin = (long long)blockIdx.y * per, p_end = p_begin + per < pts ? p_begin + per : pts;
     const uint32_t rowbase = (uint32_t)img * (uint32_t)texels;
     const float *pose = q.poses + (size_t)img * 12;
-    const int ch = t & (SLAB_CS - 1), pi = t / SLAB_CS;  // channel, point lane (32 points per pass)
+    // thread = (channel, run of 8 consecutive points).  Consecutive samples of a ray mostly share their grid cell:
+    // each corner keeps a register accumulator that is flushed to the slab (one LDS atomic) only when its texel
+    // changes, and lanes with the same channel work on different runs -- same-address LDS atomics, which
+    // serialise badly, become rare.
+    constexpr int RUN = 256 / (256 / SLAB_CS);  // 8 points per thread and batch
+    const int ch = t & (SLAB_CS - 1), run = t / SLAB_CS;
     __syncthreads();
     for (long long b0 = p_begin; b0 < p_end; b0 += 256) {
         // all 8 gradient loads of this thread for the batch go out first, the projection runs under them
-        float v[256 / (256 / SLAB_CS)];
+        float v[RUN];
 #pragma unroll
-        for (int j = 0; j < SLAB_CS; ++j) {
-            const long long pnt = b0 + pi + j * (256 / SLAB_CS);
+        for (int j = 0; j < RUN; ++j) {
+            const long long pnt = b0 + run * RUN + j;
             v[j] = pnt < p_end ? d_zlat[((size_t)view * q.P + (size_t)(g_begin + pnt)) * C_LAT + cs * SLAB_CS + ch] : 0.f;
         }
         if (b0 + t < p_end) {
@@ -616,17 +621,27 @@ latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat,
             }
         }
         __syncthreads();
+        int cur[4] = {-1, -1, -1, -1};
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < SLAB_CS; ++j) {
-            const int i = pi + j * (256 / SLAB_CS);
-            if (b0 + i < p_end && v[j] != 0.f) {
+        for (int j = 0; j < RUN; ++j) {
+            const int i = run * RUN + j;
+            if (b0 + i < p_end) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float w = m_w[i * 4 + c];
-                    if (w != 0.f) atomicAdd(&slab[m_tex[i * 4 + c] * SLAB_CS + ch], w * v[j]);
+                    const int tex = m_tex[i * 4 + c];
+                    if (tex != cur[c]) {
+                        if (acc[c] != 0.f) atomicAdd(&slab[cur[c] * SLAB_CS + ch], acc[c]);
+                        cur[c] = tex;
+                        acc[c] = 0.f;
+                    }
+                    acc[c] += m_w[i * 4 + c] * v[j];
                 }
             }
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (acc[c] != 0.f) atomicAdd(&slab[cur[c] * SLAB_CS + ch], acc[c]);
         __syncthreads();
     }
     for (int i = t; i < texels * SLAB_CS; i += 256) {
@@ -841,8 +856,8 @@ extern "C" int pnr_lin_out_grad(const float *g_out, const void *x5, long long P,
 
 constexpr int DW_MAX_SPLIT = 32;
 static int dw_nsplit(int n_jobs, long long max_rows) {
-    // >= ~768 workgroups (3 per CU) from 16 tiles x jobs x slices; slices of at least 256 rows
-    int nsplit = (768 + 16 * n_jobs - 1) / (16 * n_jobs);
+    // >= ~512 workgroups of 8 waves (2 per CU) from 4 tiles x jobs x slices; slices of at least 256 rows
+    int nsplit = (512 + 4 * n_jobs - 1) / (4 * n_jobs);
     const long long cap = (max_rows + 255) / 256;
     if (nsplit > cap) nsplit = (int)cap;
     if (nsplit > DW_MAX_SPLIT) nsplit = DW_MAX_SPLIT;
@@ -875,12 +890,12 @@ extern "C" int pnr_weight_grad_batched(const PnrWeightGradJob *jobs, int n_jobs,
     J.nsplit = dw_nsplit(n_jobs, max_rows);
     float *part = (float *)workspace;
     float *bpart = part + (size_t)n_jobs * J.nsplit * D_HID * D_HID;
-    dim3 grid(16, (unsigned)J.nsplit, (unsigned)n_jobs);
+    dim3 grid(4, (unsigned)J.nsplit, (unsigned)n_jobs);
     hipStream_t st = (hipStream_t)stream;
     if (precision == PNR_PREC_F16)
-        hipLaunchKernelGGL(dw_kernel<PNR_PREC_F16>, grid, dim3(256), 0, st, J, part, bpart);
+        hipLaunchKernelGGL(dw_kernel<PNR_PREC_F16>, grid, dim3(512), 0, st, J, part, bpart);
     else if (precision == PNR_PREC_BF16)
-        hipLaunchKernelGGL(dw_kernel<PNR_PREC_BF16>, grid, dim3(256), 0, st, J, part, bpart);
+        hipLaunchKernelGGL(dw_kernel<PNR_PREC_BF16>, grid, dim3(512), 0, st, J, part, bpart);
     else
         return pnr_fail(PNR_E_INVALID, "pnr_weight_grad_batched: unknown precision");
     hipLaunchKernelGGL(dw_reduce_kernel, dim3(D_HID * D_HID / 256, (unsigned)n_jobs), dim3(256), 0, st, J, part, bpart, out_scale);
