@@ -190,8 +190,13 @@ int pnr_position_backward(const PnrScene *scene /*host*/, const float *rays, con
  * g_out (P,4) = dL/d(lin_out output) (pre sigmoid/relu), grad_scale = power of two the chain is
  * run at (16-bit range management; every dump is scaled by it).  NS = views per object. */
 int pnr_mlp_backward(const void *packed_bwd, int precision, const PnrTrainDumps *fwd /*host*/,
-                     const float *g_out, float grad_scale, long long P, int NS,
-                     const PnrBackwardDumps *out /*host*/, void *stream);
+                     const float *g_out, float grad_scale, const float *grad_scale_dev /*nullable:
+                     device scalar that overrides grad_scale (no host sync to pick it)*/,
+                     long long P, int NS, const PnrBackwardDumps *out /*host*/, void *stream);
+
+/* Picks that scale on the device: scales[0] = 2^(6 - ceil(log2 max|g|)) (1 for g == 0), scales[1] =
+ * 1/scales[0]; both NaN when g holds a non-finite value (the gradients then come out NaN).  g: n floats. */
+int pnr_grad_scale(const float *g, long long n, float *scales /*device, 2 floats*/, void *stream);
 
 /* Weight gradient of one 512x512 linear from the 16-bit dumps: dW (512,512) fp32 = out_scale *
  * dY^T X, db (512) fp32 = out_scale * column sums of dY (db may be NULL); dY, X (rows,512) 16-bit
@@ -216,7 +221,8 @@ typedef struct PnrWeightGradJob {
 } PnrWeightGradJob;
 size_t pnr_weight_grad_batched_workspace_bytes(int n_jobs, long long max_rows);
 int pnr_weight_grad_batched(const PnrWeightGradJob *jobs /*host*/, int n_jobs, int precision,
-                            float out_scale, void *workspace, void *stream);
+                            float out_scale, const float *out_scale_dev /*nullable device scalar,
+                            multiplies out_scale*/, void *workspace, void *stream);
 
 /* lin_out (4 x 512): dW = g_out^T x5, db = column sums of g_out; g_out (P,4) fp32 = dL/d(lin_out output),
  * x5 (P,512) 16-bit dump (storage order); dW written in feature order.  Fixed-order reduction. */

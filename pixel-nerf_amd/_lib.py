@@ -87,14 +87,15 @@ PROTOTYPES = {
     "pnr_pack_mlp_bwd": (_I, [ctypes.POINTER(PnrMlpWeights), _I, _P, _P]),
     "pnr_composite_backward": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "pnr_position_backward": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _P, _P]),
-    "pnr_mlp_backward": (_I, [_P, _I, ctypes.POINTER(PnrTrainDumps), _P, _F, ctypes.c_longlong, _I,
+    "pnr_mlp_backward": (_I, [_P, _I, ctypes.POINTER(PnrTrainDumps), _P, _F, _P, ctypes.c_longlong, _I,
                               ctypes.POINTER(PnrBackwardDumps), _P]),
     "pnr_weight_grad_workspace_bytes": (_SZ, []),
     "pnr_weight_grad": (_I, [_P, _P, ctypes.c_longlong, _I, _F, _I, _I, _P, _P, _P, _P]),
     "pnr_lin_out_grad_workspace_bytes": (_SZ, []),
     "pnr_lin_out_grad": (_I, [_P, _P, ctypes.c_longlong, _I, _P, _P, _P, _P]),
     "pnr_weight_grad_batched_workspace_bytes": (_SZ, [_I, ctypes.c_longlong]),
-    "pnr_weight_grad_batched": (_I, [ctypes.POINTER(PnrWeightGradJob), _I, _I, _F, _P, _P]),
+    "pnr_weight_grad_batched": (_I, [ctypes.POINTER(PnrWeightGradJob), _I, _I, _F, _P, _P, _P]),
+    "pnr_grad_scale": (_I, [_P, ctypes.c_longlong, _P, _P]),
     "pnr_latent_scatter": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _P]),
     "pnr_composite": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "pnr_render_workspace_bytes": (_SZ, [_I, _I, _I]),

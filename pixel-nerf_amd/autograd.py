@@ -18,7 +18,6 @@ projection + bilinear lookup) -> sort permutation -> clamp -> coarse depth (nerf
 -> coarse network.  Coarse and importance samples carry no gradient in the reference either
 (rays are inputs, importance weights are detached, nerf.py:288).
 """
-import math
 
 import torch
 
@@ -51,13 +50,11 @@ def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS, want_d_in=False):
     one backward pass.  fwd: ops.TrainDumps of the forward; g_out (P,4) fp32 = dL/d(lin_out output)."""
     dev = g_out.device
     perm, inv = _perms(dev)
-    gmax = float(g_out.abs().max())
-    if not math.isfinite(gmax):
-        raise FloatingPointError("non-finite gradient entering the network backward")
-    # run the 16-bit chain at a power-of-two scale that puts max|g| near 2^6 (exact to undo)
-    scale = 1.0 if gmax == 0.0 else 2.0 ** (6 - math.ceil(math.log2(gmax)))
-    bd = ops.mlp_backward(packed_bwd, fwd, g_out, scale)
-    inv_s = 1.0 / scale
+    # run the 16-bit chain at a power-of-two scale that puts max|g| near 2^6 (exact to undo); the scale is picked
+    # on the device (no host sync in the middle of the backward); a non-finite g poisons it with NaN
+    sc = ops.grad_scale(g_out)
+    bd = ops.mlp_backward(packed_bwd, fwd, g_out, sc[0:1])
+    inv_s = sc[1:2]
 
     prec = packed_bwd.precision
     grads = {}
@@ -73,7 +70,7 @@ def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS, want_d_in=False):
         names.append(f"lin_z.{b}")
     jobs.append((bd.g_x0, fwd.d_in, True, False, 64, 42))  # lin_in: operand (rows,64) = code | viewdir | 0-pad
     names.append("lin_in")
-    for name, (dW, db) in zip(names, ops.weight_grad_batched(jobs, prec, inv_s)):  # one launch for all 14 linears
+    for name, (dW, db) in zip(names, ops.weight_grad_batched(jobs, prec, 1.0, out_scale_dev=inv_s)):  # one launch, 14 linears
         grads[name + ".weight"], grads[name + ".bias"] = dW, db
     d_zlat = None
     for b in range(3):

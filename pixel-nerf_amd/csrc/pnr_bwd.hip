@@ -61,6 +61,7 @@ struct BwdParams {
     const char *d_a[5], *d_n[5], *d_x5;  // forward dumps: relu masks
     const float *g_out;                  // (P,4) dL/d(lin_out output)
     float scale;
+    const float *scale_dev;  // when set, the chain runs at *scale_dev instead (scale picked on the device)
     long long P;
     int NS, ntiles;
     char *g_fc1[5], *g_fc0[5], *g_x0;
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
             const int row = tid >> 3, chunk = tid & 7;
             const long long g = (long long)tile * MT + row;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (chunk == 0 && g < q.P) v = *reinterpret_cast<const f32x4 *>(q.g_out + g * 4) * q.scale;
+            if (chunk == 0 && g < q.P) v = *reinterpret_cast<const f32x4 *>(q.g_out + g * 4) * (q.scale_dev ? *q.scale_dev : q.scale);
             if (tid < MT * 8)
                 *reinterpret_cast<typename P::T8 *>(smem + LDS_IN + row * ROW_IN + chunk * 16) =
                     pack8<P, false>(v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f);
@@ -367,9 +368,10 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
 // rows_st / cols_st: the operand that indexes the rows (dY) / columns (X) of dW was dumped in storage order;
 // the result is written in feature order (row e -> feature feat_of(e/32, (e%32)/16, e%16)).
 __global__ void dw_reduce_kernel(const DwJobs jobs, const float *__restrict__ part, const float *__restrict__ bpart,
-                                 float scale) {
+                                 float scale, const float *__restrict__ scale_dev) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int job = blockIdx.y, nz = jobs.nsplit;
+    if (scale_dev) scale *= *scale_dev;
     const float *pj = part + (size_t)job * nz * (D_HID * D_HID);
     const float *bj = bpart + (size_t)job * nz * D_HID;
     const bool rows_st = jobs.rows_st[job], cols_st = jobs.cols_st[job];
@@ -766,14 +768,47 @@ static int bwd_num_cus() {
     return n;
 }
 
+// scales[0] = 2^(6 - ceil(log2 max|g|)) (1 if g == 0), scales[1] = 1 / scales[0]; NaN if g holds a non-finite value
+__global__ void __launch_bounds__(1024) grad_scale_kernel(const float *__restrict__ g, long long n, float *__restrict__ scales) {
+    __shared__ float red[1024];
+    float m = 0.f;
+    bool bad = false;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        const float a = fabsf(g[i]);
+        bad |= !(a <= 3.0e38f);
+        m = fmaxf(m, a);
+    }
+    red[threadIdx.x] = bad ? __builtin_inff() : m;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mx = red[0];
+        float sc = 1.f;
+        if (!(mx <= 3.0e38f)) sc = __builtin_nanf("");
+        else if (mx > 0.f) sc = exp2f(6.f - ceilf(log2f(mx)));
+        scales[0] = sc;
+        scales[1] = 1.f / sc;
+    }
+}
+
+extern "C" int pnr_grad_scale(const float *g, long long n, float *scales, void *stream) {
+    if (!g || !scales || n <= 0) return pnr_fail(PNR_E_INVALID, "pnr_grad_scale: bad argument");
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, scales);
+    return pnr_check_launch("pnr_grad_scale");
+}
+
 extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const PnrTrainDumps *fwd, const float *g_out,
-                                float grad_scale, long long P, int NS, const PnrBackwardDumps *out, void *stream) {
-    if (!packed_bwd || !fwd || !g_out || !out || P <= 0 || NS <= 0 || !(grad_scale > 0.f))
+                                float grad_scale, const float *grad_scale_dev, long long P, int NS,
+                                const PnrBackwardDumps *out, void *stream) {
+    if (!packed_bwd || !fwd || !g_out || !out || P <= 0 || NS <= 0 || (!grad_scale_dev && !(grad_scale > 0.f)))
         return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: bad argument");
     if (P > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: too many points");
     BwdParams q = {};
     q.wstream = (const char *)packed_bwd;
-    q.g_out = g_out; q.scale = grad_scale; q.P = P; q.NS = NS; q.ntiles = (int)((P + MT - 1) / MT);
+    q.g_out = g_out; q.scale = grad_scale; q.scale_dev = grad_scale_dev; q.P = P; q.NS = NS; q.ntiles = (int)((P + MT - 1) / MT);
     q.d_x5 = (const char *)fwd->d_x5; q.g_x0 = (char *)out->g_x0;
     if (!q.d_x5 || !q.g_x0) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: null dump");
     for (int b = 0; b < 5; ++b) {
@@ -871,7 +906,7 @@ extern "C" size_t pnr_weight_grad_batched_workspace_bytes(int n_jobs, long long 
 extern "C" size_t pnr_weight_grad_workspace_bytes(void) { return (size_t)DW_MAX_SPLIT * (D_HID * D_HID + D_HID) * sizeof(float); }
 
 extern "C" int pnr_weight_grad_batched(const PnrWeightGradJob *jobs, int n_jobs, int precision, float out_scale,
-                                       void *workspace, void *stream) {
+                                       const float *out_scale_dev, void *workspace, void *stream) {
     if (!jobs || !workspace || n_jobs < 1 || n_jobs > DW_MAX_JOBS)
         return pnr_fail(PNR_E_INVALID, "pnr_weight_grad_batched: 1..16 jobs and a workspace are required");
     DwJobs J = {};
@@ -898,7 +933,7 @@ extern "C" int pnr_weight_grad_batched(const PnrWeightGradJob *jobs, int n_jobs,
         hipLaunchKernelGGL(dw_kernel<PNR_PREC_BF16>, grid, dim3(512), 0, st, J, part, bpart);
     else
         return pnr_fail(PNR_E_INVALID, "pnr_weight_grad_batched: unknown precision");
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(D_HID * D_HID / 256, (unsigned)n_jobs), dim3(256), 0, st, J, part, bpart, out_scale);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(D_HID * D_HID / 256, (unsigned)n_jobs), dim3(256), 0, st, J, part, bpart, out_scale, out_scale_dev);
     return pnr_check_launch("pnr_weight_grad_batched");
 }
 
@@ -907,7 +942,7 @@ extern "C" int pnr_weight_grad(const void *dY, const void *X, long long rows, in
                                void *stream) {
     if (!dY || !X || !dW || !workspace || rows <= 0) return pnr_fail(PNR_E_INVALID, "pnr_weight_grad: bad argument");
     PnrWeightGradJob job = {dY, X, rows, rows_storage_order, cols_storage_order, dW, db, 0, 0};
-    return pnr_weight_grad_batched(&job, 1, precision, out_scale, workspace, stream);
+    return pnr_weight_grad_batched(&job, 1, precision, out_scale, nullptr, workspace, stream);
 }
 
 extern "C" int pnr_composite_backward(const float *rays, const float *z, const float *rgbsigma, int R, int K, int white_bkgd,

@@ -594,14 +594,27 @@ def position_backward(scene, rays, z, d_in42, d_zlat, d_z):
     return d_z
 
 
+def grad_scale(g):
+    """-> device tensor (2,): [scale, 1/scale] with scale = 2^(6 - ceil(log2 max|g|)), picked without a host sync
+    (NaN when g holds a non-finite value)."""
+    lib = _lib.load()
+    g = _f32(g, "g")
+    out = torch.empty(2, dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(lib.pnr_grad_scale(_p(g), g.numel(), _p(out), _stream()), "pnr_grad_scale")
+    return out
+
+
 def mlp_backward(packed_bwd, fwd_dumps, g_out, grad_scale):
+    """grad_scale: python float, or a 1-element device tensor (e.g. ops.grad_scale(g_out)[0:1])."""
     lib = _lib.load()
     g_out = _f32(g_out, "g_out", (fwd_dumps.P, 4))
     out = BackwardDumps(fwd_dumps, g_out.device)
+    dev_scale = grad_scale if isinstance(grad_scale, torch.Tensor) else None
     with torch.cuda.device(g_out.device):
         _lib.check(lib.pnr_mlp_backward(packed_bwd.ptr, packed_bwd.precision, ctypes.byref(fwd_dumps.struct), _p(g_out),
-                                        float(grad_scale), fwd_dumps.P, fwd_dumps.NS, ctypes.byref(out.struct),
-                                        _stream()), "pnr_mlp_backward")
+                                        1.0 if dev_scale is not None else float(grad_scale), _p(dev_scale), fwd_dumps.P,
+                                        fwd_dumps.NS, ctypes.byref(out.struct), _stream()), "pnr_mlp_backward")
     return out
 
 
@@ -637,7 +650,7 @@ def weight_grad(dY, X, precision, out_scale=1.0, want_bias=True, rows_st=False, 
     return dW, db
 
 
-def weight_grad_batched(jobs, precision, out_scale=1.0):
+def weight_grad_batched(jobs, precision, out_scale=1.0, out_scale_dev=None):
     """jobs: list of (dY, X, rows_st, cols_st[, x_cols, dw_cols]) with dY (rows,512), X (rows,x_cols=512) 16-bit
     dumps -> list of (dW (512,dw_cols), db (512)), all computed by ONE pnr_weight_grad_batched call (<= 16 jobs)."""
     lib = _lib.load()
@@ -668,7 +681,8 @@ def weight_grad_batched(jobs, precision, out_scale=1.0):
     if key not in _wg_workspace or _wg_workspace[key].numel() < need:
         _wg_workspace[key] = torch.empty(need, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.pnr_weight_grad_batched(arr, n, int(precision), float(out_scale), _p(_wg_workspace[key]), _stream()),
+        _lib.check(lib.pnr_weight_grad_batched(arr, n, int(precision), float(out_scale), _p(out_scale_dev),
+                                               _p(_wg_workspace[key]), _stream()),
                    "pnr_weight_grad_batched")
     return outs
 

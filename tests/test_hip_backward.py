@@ -272,3 +272,34 @@ def test_weight_grad_kernel_single_and_batched(dev, prec, dt):
     assert (oW - r).norm() <= 2e-6 * r.norm() and torch.allclose(ob, g.sum(0), rtol=1e-5, atol=1e-4)
     oW2, ob2 = ops.lin_out_grad(g, x5, p)
     assert torch.equal(oW, oW2) and torch.equal(ob, ob2)
+
+
+def test_grad_scale_is_picked_on_device(dev):
+    """scale = 2^(6 - ceil(log2 max|g|)) without a host sync; zero gradient -> 1; non-finite -> NaN poison.
+    A device-side scale gives the same backward dumps as the same scale passed from the host."""
+    import math
+    from pixelnerf_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for mag in (3e-7, 0.02, 1.0, 64.0, 5000.0):
+        g = (torch.randn(1000, 4, generator=gen) * mag).to(dev)
+        sc = ops.grad_scale(g).cpu()
+        want = 2.0 ** (6 - math.ceil(math.log2(float(g.abs().max()))))
+        assert sc[0].item() == want and sc[1].item() == 1.0 / want
+    assert ops.grad_scale(torch.zeros(8, 4, device=dev)).cpu().tolist() == [1.0, 1.0]
+    bad = torch.ones(8, 4, device=dev)
+    bad[3, 1] = float("inf")
+    assert torch.isnan(ops.grad_scale(bad)).all()
+    # host float vs device scalar: identical launches
+    g_, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
+    sc_ = ops.make_scene(scene["latent"].to(dev), scene["poses"].to(dev), scene["focal"].to(dev), scene["c"].to(dev),
+                         scene["image_shape"], scene["NS"])
+    params = {k: v.to(dev) for k, v in mf.items()}
+    pk, pkb = ops.pack_mlp(params, "f16"), ops.pack_mlp(params, "f16", backward=True)
+    r = rays.reshape(-1, 8).to(dev)
+    z = torch.from_numpy(g_["coarse_z"]).to(dev)
+    _, dumps = ops.eval_ray_samples_train(sc_, pk, r, z)
+    g_out = torch.randn(r.shape[0] * z.shape[1], 4, generator=gen).to(dev) * 0.01
+    s = ops.grad_scale(g_out)
+    a = ops.mlp_backward(pkb, dumps, g_out, float(s[0].item()))
+    b = ops.mlp_backward(pkb, dumps, g_out, s[0:1])
+    assert torch.equal(a.g_x0, b.g_x0) and all(torch.equal(x, y) for x, y in zip(a.g_fc0, b.g_fc0))

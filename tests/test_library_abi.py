@@ -63,7 +63,8 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pnr_pack_mlp(None, 0, None, None) == -1
     assert lib.pnr_pack_mlp_bwd(None, 0, None, None) == -1
     assert lib.pnr_composite_backward(None, None, None, 3, 8, 0, None, None, None, None, None, 0, None) == -1
-    assert lib.pnr_mlp_backward(None, 0, None, None, 1.0, 10, 1, None, None) == -1
+    assert lib.pnr_mlp_backward(None, 0, None, None, 1.0, None, 10, 1, None, None) == -1
+    assert lib.pnr_grad_scale(None, 10, None, None) == -1
     assert lib.pnr_weight_grad(None, None, 10, 0, 1.0, 0, 0, None, None, None, None) == -1
     assert lib.pnr_position_backward(None, None, None, 1, 1, 1, None, None, None, None) == -1
     # empty batches are a successful no-op (reference: empty output, nerf.py:23-27)
