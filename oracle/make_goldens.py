@@ -296,6 +296,51 @@ def neighbour_goldens():
     return rec
 
 
+GRAD_SCENARIOS = ("train_64_32", "srn_mini_64_128")  # SB=4 x NS=1 (BASELINE config 5 shapes) and NS=2 pooling
+
+def gradient_goldens():
+    """Gradients of the UNMODIFIED reference (torch autograd through NeRFRenderer.forward, train/train.py:199-215:
+    MSE(coarse rgb) + MSE(fine rgb) against a seeded target) w.r.t. every ResnetFC parameter of both networks and
+    encoder.latent, on the golden scenarios' rays and noise.  Frozen per tensor: L2 norm + a seeded subsample."""
+    import render.nerf as ref_nerf
+
+    rec = {}
+    for name in GRAD_SCENARIOS:
+        scene_name, Kc, Kf, Kfd, n_rays, lindisp, use_fine = SCENARIOS[name]
+        scene, meta = synthetic.make_scene(scene_name, seed=SCENE_SEED)
+        rays = synthetic.target_rays(meta, n_rays=n_rays)
+        SB = rays.shape[0]
+        noise = synthetic.make_noise(SB * n_rays, Kc, Kf, Kfd)
+        queue = [("rand_like", noise["u1"]), ("rand", noise["u2"]), ("rand_like", noise["u3"]), ("randn_like", noise["n4"])]
+        net = build_reference_net(use_fine).train()
+        scene = dict(scene)
+        scene["latent"] = scene["latent"].clone().requires_grad_(True)
+        set_encode_state(net, scene)
+        renderer = ref_nerf.NeRFRenderer(n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, depth_std=0.01,
+                                         white_bkgd=meta["white_bkgd"], lindisp=lindisp, eval_batch_size=50000).train()
+        gt = torch.from_numpy(np.random.RandomState(77).uniform(0, 1, (SB, n_rays, 3)).astype(np.float32))
+        real_torch = ref_nerf.torch
+        ref_nerf.torch = _TorchProxy(queue)
+        try:
+            out = renderer(net, rays, want_weights=True)
+        finally:
+            ref_nerf.torch = real_torch
+        assert len(queue) == 0
+        loss = ((out.coarse.rgb - gt) ** 2).mean() + ((out.fine.rgb - gt) ** 2).mean()
+        loss.backward()
+        rec[f"{name}_loss"] = np.float64(loss.item())
+        rec[f"{name}_gt"] = gt.numpy()
+        tensors = [("latent", scene["latent"].grad)]
+        for which, mlp in (("coarse", net.mlp_coarse), ("fine", net.mlp_fine)):
+            tensors += [(f"{which}.{k}", p.grad) for k, p in mlp.named_parameters()]
+        for key, g in tensors:
+            flat = g.detach().reshape(-1).numpy()
+            idx = synthetic.grad_sample_index(flat.size, key)
+            rec[f"{name}_grad_{key}_norm"] = np.float64(np.linalg.norm(flat.astype(np.float64)))
+            rec[f"{name}_grad_{key}_sample"] = flat[idx].astype(np.float32)
+    return rec
+
+
 def state_dict_manifest():
     """Names and shapes of the reference net's state_dict (encoder.* excluded: the torchvision
     backbone is a stub here) and of the renderer's -- the checkpoint-compatibility contract
@@ -317,14 +362,15 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "neighbours", "manifest"])
+    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "neighbours", "gradients", "manifest"])
     for name in names:
         if name == "manifest":
             path = os.path.join(outdir, "state_dict_manifest.txt")
             open(path, "w").write("\n".join(state_dict_manifest()) + "\n")
             print("wrote", path)
             continue
-        rec = stage_goldens() if name == "stages" else neighbour_goldens() if name == "neighbours" else run_scenario(name)
+        rec = (stage_goldens() if name == "stages" else neighbour_goldens() if name == "neighbours"
+               else gradient_goldens() if name == "gradients" else run_scenario(name))
         path = os.path.join(outdir, name + ".npz")
         np.savez_compressed(path, **rec)
         print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))

@@ -233,3 +233,22 @@ def pyramid_stages(name, seed=4242):
     NV, shapes = PYRAMIDS[name]
     rs = np.random.RandomState(seed)
     return [torch.from_numpy(rs.randn(NV, c, h, w).astype(np.float32)) for c, h, w in shapes]
+
+
+GRAD_SAMPLES = 2048
+
+
+def _name_hash(s):
+    h = 0
+    for ch in s:
+        h = (h * 131 + ord(ch)) % (2 ** 31 - 1)
+    return h
+
+
+def grad_sample_index(numel, key):
+    """Seeded positions at which tests/golden/gradients.npz freezes a gradient tensor of the reference
+    (the whole tensor when it has at most GRAD_SAMPLES elements)."""
+    if numel <= GRAD_SAMPLES:
+        return np.arange(numel)
+    rs = np.random.RandomState(_name_hash(key))
+    return np.sort(rs.choice(numel, GRAD_SAMPLES, replace=False))

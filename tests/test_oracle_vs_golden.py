@@ -147,3 +147,38 @@ def test_bbox_pixels_matches_reference_bbox_sample():
     pix = O.bbox_pixels(torch.from_numpy(g["bbox_boxes"]), torch.from_numpy(g["bbox_ids"]), torch.from_numpy(g["bbox_ux"]),
                         torch.from_numpy(g["bbox_uy"]))
     np.testing.assert_array_equal(pix.numpy(), g["bbox_pix"])
+
+
+# ------------------------------------------------------------------ gradients (BASELINE config 5)
+
+
+@pytest.mark.parametrize("name", ["train_64_32", "srn_mini_64_128"])
+def test_oracle_autograd_matches_reference_autograd(name):
+    """torch autograd through the oracle vs the UNMODIFIED reference's own backward (tests/golden/gradients.npz:
+    per-tensor L2 norm + seeded subsample of every ResnetFC gradient of both networks and of encoder.latent,
+    including the position gradient through the depth samples, nerf.py:292).  fp32 on both sides, different
+    summation orders: norms within 1e-4, subsamples within 1e-3 relative (measured 1e-6 / 2e-4)."""
+    from pixelnerf_amd import synthetic
+    gg = load_golden("gradients")
+    g, scene, meta, mc, mf, rays, noise = golden_setup(name)
+    Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])
+    sc = dict(scene)
+    sc["latent"] = scene["latent"].clone().requires_grad_(True)
+    pc = {k: v.clone().requires_grad_(True) for k, v in mc.items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in mf.items()}
+    out = O.render(sc, pc, pf, rays, noise, Kc, Kf, Kfd, white_bkgd=bool(g["white_bkgd"]), lindisp=bool(g["lindisp"]))
+    gt = torch.from_numpy(gg[f"{name}_gt"])
+    loss = ((out["coarse"]["rgb"] - gt) ** 2).mean() + ((out["fine"]["rgb"] - gt) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - float(gg[f"{name}_loss"])) <= 1e-6
+    grads = {"latent": sc["latent"].grad, **{"coarse." + k: v.grad for k, v in pc.items()},
+             **{"fine." + k: v.grad for k, v in pf.items()}}
+    assert len(grads) == 61
+    for key, gr in grads.items():
+        flat = gr.reshape(-1).numpy()
+        ref_s = gg[f"{name}_grad_{key}_sample"]
+        ref_n = float(gg[f"{name}_grad_{key}_norm"])
+        got_s = flat[synthetic.grad_sample_index(flat.size, key)]
+        assert ref_n > 0, key
+        assert abs(np.linalg.norm(flat.astype(np.float64)) - ref_n) <= 1e-4 * ref_n, key
+        assert np.linalg.norm(got_s - ref_s) <= 1e-3 * np.linalg.norm(ref_s), key
