@@ -78,6 +78,34 @@ size_t pnr_packed_mlp_bytes(void);
 int pnr_pack_mlp(const PnrMlpWeights *w /*host struct of device ptrs*/, int precision,
                  void *packed, void *stream);
 
+/* ---- folded inference form -------------------------------------------------------------------
+ * lin_z[b] (resnetfc.py:175-180) acts on the bilinearly interpolated latent, and both are linear:
+ * lin_z[b](sum_c w_c grid[c]) = sum_c w_c (W_z[b] grid[c] + b_z[b]) because the bilinear weights sum to 1.
+ * pnr_fold_latent applies W_z[b] to every texel of the encoded grid once per scene and network (fp32 MFMA,
+ * 3 tables of (SB*NS,Hl,Wl,512) 16-bit, pnr_folded_tables_bytes), pnr_pack_mlp_folded packs the stream
+ * without the three lin_z GEMMs, and the *_folded entry points replace those GEMMs (22-28 % of the
+ * per-point FLOPs) by one bilinear lookup per table.  Same results to the stated tolerance; inference
+ * only.  Re-fold when the grid or the lin_z parameters change. */
+size_t pnr_folded_tables_bytes(const PnrScene *scene /*host*/);
+int pnr_fold_latent(const PnrScene *scene /*host*/, const PnrMlpWeights *w /*host*/, int precision,
+                    void *tables, void *stream);
+int pnr_pack_mlp_folded(const PnrMlpWeights *w /*host*/, int precision, void *packed /*pnr_packed_mlp_bytes()*/,
+                        void *stream);
+int pnr_eval_ray_samples_folded(const PnrScene *scene /*host*/, const void *packed_folded, const void *tables,
+                                int precision, const float *rays, const float *z, int R, int rays_per_obj,
+                                int K, float *rgbsigma, void *stream);
+int pnr_eval_points_folded(const PnrScene *scene /*host*/, const void *packed_folded, const void *tables,
+                           int precision, const float *xyz, const float *viewdirs, int B, float *rgbsigma,
+                           void *stream);
+int pnr_render_forward_folded(const PnrScene *scene /*host*/, const void *packed_coarse,
+                              const void *tables_coarse, const void *packed_fine /*nullable*/,
+                              const void *tables_fine, int precision, const float *rays, int R,
+                              int rays_per_obj, int Kc, int Kf, int Kfd, float depth_std, int white_bkgd,
+                              int lindisp, const float *u1, const float *u2, const float *u3,
+                              const float *n4, float *rgb_c, float *depth_c, float *weights_c,
+                              float *rgb_f, float *depth_f, float *weights_f, void *workspace,
+                              void *stream);
+
 /* encoder.latent NCHW -> NHWC (layout change for the lookup in src/model/encoder.py:80-109). */
 int pnr_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, void *stream);
 

@@ -80,6 +80,13 @@ PROTOTYPES = {
     "pnr_eval_ray_samples_f32": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _I, _I, _P,
                                       _P, _SZ, _P]),
     "pnr_eval_points_f32": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _P, _P, _SZ, _P]),
+    "pnr_folded_tables_bytes": (_SZ, [ctypes.POINTER(PnrScene)]),
+    "pnr_fold_latent": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _I, _P, _P]),
+    "pnr_pack_mlp_folded": (_I, [ctypes.POINTER(PnrMlpWeights), _I, _P, _P]),
+    "pnr_eval_ray_samples_folded": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _P, _I, _I, _I, _P, _P]),
+    "pnr_eval_points_folded": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _P, _I, _P, _P]),
+    "pnr_render_forward_folded": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I,
+                                       _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pnr_eval_ray_samples_train": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _I, _I, _P,
                                         ctypes.POINTER(PnrTrainDumps), _P]),
     "pnr_storage_perm": (_I, [ctypes.POINTER(ctypes.c_int32)]),

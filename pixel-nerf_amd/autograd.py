@@ -98,8 +98,8 @@ class _RenderFunction(torch.autograd.Function):
         net, noise = cfg["net"], cfg["noise"]
         Kc, Kf, Kfd = cfg["n_coarse"], cfg["n_fine"], cfg["n_fine_depth"]
         scene = net.scene()
-        pc = net.packed(True)
-        pf = net.packed(False) if Kf > 0 else None
+        pc = net.packed(True, folded=False)  # the training instantiation keeps the lin_z GEMMs (operands are dumped)
+        pf = net.packed(False, folded=False) if Kf > 0 else None
         passes = []
         z_c = ops.sample_coarse(rays, noise["u1"], cfg["lindisp"])
         rgbs_c, dumps_c = ops.eval_ray_samples_train(scene, pc, rays, z_c)

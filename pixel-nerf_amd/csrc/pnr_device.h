@@ -46,6 +46,9 @@ struct EvalParams {
     // packed network
     const char *wstream;
     const float *bias, *bout;
+    // folded inference: 3 per-texel tables (16-bit, NHWC like the grid, hidden features in storage order)
+    const char *tables;
+    long long table_stride;  // elements per table
     // points: variant A (rays + z) or B (xyz + viewdirs)
     const float *rays, *z, *xyz, *viewdirs;
     int K;             // samples per ray (A)

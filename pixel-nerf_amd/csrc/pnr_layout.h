@@ -57,6 +57,18 @@ constexpr int RS_VIEW_END = gemm_offset(G_FC0_3);  // 292: end of the per-view s
 constexpr int RS_TOTAL = gemm_offset(NGEMM);       // 424
 static_assert(RS_VIEW_END % 4 == 0 && RS_TOTAL % 4 == 0, "ring depth 4 needs aligned segments");
 
+// "folded" inference stream: lin_z[b](z) is linear in the interpolated latent, so W_z[b] is applied to the feature
+// grid once per scene (per-texel tables, pnr_fold_latent) and the three lin_z GEMMs leave the per-point stream.
+__host__ __device__ constexpr bool gemm_is_linz(int g) { return g == G_Z0 || g == G_Z1 || g == G_Z2; }
+__host__ __device__ constexpr int gemm_offset_fold(int g) {  // first ring step of GEMM g in the folded stream
+    int o = 0;
+    for (int i = 0; i < g; ++i) o += gemm_is_linz(i) ? 0 : gemm_ksteps(i);
+    return o;
+}
+constexpr int RS_VIEW_END_F = gemm_offset_fold(G_FC0_3);  // 196
+constexpr int RS_TOTAL_F = gemm_offset_fold(NGEMM);       // 328
+static_assert(RS_VIEW_END_F % 4 == 0 && RS_TOTAL_F % 4 == 0, "ring depth 4 needs aligned segments");
+
 constexpr int FRAG_ELEMS = 64 * 8;  // 64 lanes x 8 elements (1 KiB of 16-bit)
 constexpr size_t WSTREAM_ELEMS_PER_WAVE = (size_t)RS_TOTAL * IT * FRAG_ELEMS;
 constexpr size_t WSTREAM_BYTES = WSTREAM_ELEMS_PER_WAVE * NW * 2;  // 6,946,816 B
@@ -79,6 +91,10 @@ constexpr size_t PACKED_BYTES = BOUT_OFFSET_BYTES + 16;
 // hidden feature held by D-register r of half h in feature tile T (global tile index 0..15)
 __host__ __device__ constexpr int feat_of(int T, int h, int r) {
     return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+// inverse: position of hidden feature f in "storage order" (element 32T + 16h + r of an activation row)
+__host__ __device__ constexpr int slot_of(int f) {
+    return (f & ~31) + 16 * ((f >> 2) & 1) + (f & 3) + 4 * ((f & 31) >> 3);
 }
 
 // ---- backward chain: transposed weight stream, consumption order per tile ----

@@ -131,14 +131,71 @@ __device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, 
     }
 }
 
+
+// Folded form (inference): the same bilinear combination over a per-texel TABLE T_b = W_z[b] . grid + b_z[b]
+// (16-bit, hidden features in storage order, pnr_fold_latent) gives lin_z[b](z) directly; the rows go to the
+// LDS_Z image and every lane adds its own slots to the residual stream (add_from_z).
+template <typename P, int GB>
+__device__ __forceinline__ void gather_table(const EvalParams &q, char *smem, int wv, int lane, int b) {
+    const typename P::T *tab = reinterpret_cast<const typename P::T *>(q.tables) + (size_t)b * q.table_stride + lane * 8;
+    static_assert((MT / NW) % GB == 0, "gather batch");
+#pragma unroll 1
+    for (int i = 0; i < MT / NW; i += GB) {
+        typename P::T8 v[GB][4];
+        f32x4 w[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int p = wv * (MT / NW) + i + u;
+            const u32x4 off = *reinterpret_cast<const u32x4 *>(smem + LDS_META + p * 32);
+            w[u] = *reinterpret_cast<const f32x4 *>(smem + LDS_META + p * 32 + 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[u][c] = *reinterpret_cast<const typename P::T8 *>(tab + off[c]);
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int p = wv * (MT / NW) + i + u;
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = (float)v[u][0][e] * w[u][0];
+                a += (float)v[u][1][e] * w[u][1];
+                a += (float)v[u][2][e] * w[u][2];
+                a += (float)v[u][3][e] * w[u][3];
+                r[e] = a;
+            }
+            *reinterpret_cast<typename P::T8 *>(smem + LDS_Z + p * ROW_ACT + lane * 16) =
+                pack8<P, false>(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        }
+    }
+}
+
+// x += this lane's slots of the 16-bit rows in the LDS_Z image (storage order = the accumulator map)
+template <typename P>
+__device__ __forceinline__ void add_from_z(f32x16 (&x)[IT][JT], const char *smem, uint32_t z_slot) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const uint32_t ad = z_slot + jt * 32 * ROW_ACT + it * 64;
+            const typename P::T8 lo = *reinterpret_cast<const typename P::T8 *>(smem + ad);
+            const typename P::T8 hi = *reinterpret_cast<const typename P::T8 *>(smem + ad + 16);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                x[it][jt][r] += (float)lo[r];
+                x[it][jt][8 + r] += (float)hi[r];
+            }
+        }
+}
+
 // one residual block (+ the lin_z of the next block when with_z):
 //   net = fc_0(relu(x)); x += fc_1(relu(net)) [+ lin_z[b+1](z)]       resnetfc.py:55-62,174-182
-template <typename P, bool TIMING, bool TRAIN>
+template <typename P, bool TIMING, bool TRAIN, bool FOLD>
 __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b, bool with_z, Ring<P> &R,
                                           int NS, const float *bias_lane, uint32_t a_rd0, uint32_t a_rd1,
                                           uint32_t z_rd0, uint32_t z_rd1, uint32_t a_wr, int tid,
                                           unsigned long long *tim, unsigned long long &tlast,
-                                          const EvalParams &q, size_t dump_off, const bool *valid) {
+                                          const EvalParams &q, size_t dump_off, const bool *valid, int wv, int lane) {
+    typedef Advance<0, FOLD ? RS_VIEW_END_F : RS_VIEW_END, FOLD ? RS_TOTAL_F : RS_TOTAL> ADV;
     // dump_off: byte offset of this lane's 32-byte slot in a (rows,512) 16-bit dump array
     __syncthreads();  // every wave is done reading LDS_A (previous fc_1)
     PNR_T(PH_BAR1);
@@ -149,7 +206,7 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b
     {
         f32x16 net[IT][JT];
         add_bias<true>(net, bias_lane, 1 + 2 * b);
-        gemm<P>(net, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
+        gemm<P, ADV>(net, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
         PNR_T(PH_GEMM_FC0);
         __syncthreads();  // every wave is done reading relu(x)
         PNR_T(PH_BAR3);
@@ -159,14 +216,24 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b
     __syncthreads();
     PNR_T(PH_BAR4);
     add_bias<false>(x, bias_lane, 2 + 2 * b);
-    gemm<P>(x, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
-    if (with_z) gemm<P>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);
+    gemm<P, ADV>(x, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
+    if (with_z) {
+        if constexpr (FOLD) {  // lin_z[b+1](z) = bilinear lookup in table b+1 (LDS_Z is free: its last readers ran before fc_0)
+            gather_table<P, 2>(q, smem, wv, lane, b + 1);  // the residual stream is live here: smaller batches
+            __syncthreads();
+            add_from_z<P>(x, smem, a_wr - LDS_A + LDS_Z);
+        } else {
+            gemm<P, ADV>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);
+        }
+    }
     PNR_T(PH_GEMM_FC1_Z);
 }
 
-template <int PREC, bool RAYS, bool MV, bool TIMING = false, bool TRAIN = false>
+template <int PREC, bool RAYS, bool MV, bool TIMING = false, bool TRAIN = false, bool FOLD = false>
 __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams q) {
     typedef Prec<PREC> P;
+    typedef Advance<0, FOLD ? RS_VIEW_END_F : RS_VIEW_END, FOLD ? RS_TOTAL_F : RS_TOTAL> ADV;
+    static_assert(!(FOLD && TRAIN), "the training instantiation keeps the lin_z GEMMs (their operands are dumped)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -182,7 +249,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
     const float *bias_lane = q.bias + wv * BIAS_FLOATS_PER_WAVE + h * 16;
 
     Ring<P> R;
-    R.wave_base = q.wstream + (size_t)wv * (RS_TOTAL * IT * 1024) + lane * 16;
+    R.wave_base = q.wstream + (size_t)wv * ((FOLD ? RS_TOTAL_F : RS_TOTAL) * IT * 1024) + lane * 16;
     R.pf_rs = 0;
     R.pf_view = 0;
 #pragma unroll
@@ -219,20 +286,22 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                     *reinterpret_cast<u32x4 *>(q.d_in + (((long long)view * q.P + g) * D_IN_PAD + chunk * 8) * 2) =
                         *reinterpret_cast<const u32x4 *>(smem + LDS_IN + row * ROW_IN + chunk * 16);
             }
-            gather<P, TRAIN, MV ? 2 : 4>(q, smem, wv, lane, tile, view);  // multi-view also holds the view sum
+            if constexpr (FOLD) gather_table<P, MV ? 2 : 4>(q, smem, wv, lane, 0);
+            else gather<P, TRAIN, MV ? 2 : 4>(q, smem, wv, lane, tile, view);  // multi-view also holds the view sum
 #ifdef PNR_EXP_NO_FEATURE
             }
 #endif
             __syncthreads();
             PNR_T(PH_GATHER);
             add_bias<true>(x, bias_lane, B_IN_Z0);
-            gemm<P>(x, smem, in_rd0, in_rd1, KS_IN / 4, R, NS);      // lin_in     resnetfc.py:147
-            gemm<P>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);       // lin_z[0]   resnetfc.py:175-180
+            gemm<P, ADV>(x, smem, in_rd0, in_rd1, KS_IN / 4, R, NS);      // lin_in     resnetfc.py:147
+            if constexpr (FOLD) add_from_z<P>(x, smem, a_wr - LDS_A + LDS_Z);  // lin_z[0] via table 0
+            else gemm<P, ADV>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);  // lin_z[0]   resnetfc.py:175-180
             PNR_T(PH_GEMM_IN_Z0);
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b)
-                res_block<P, TIMING, TRAIN>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                            a_wr, tid, tim, tlast, q, dump_view, valid);
+                res_block<P, TIMING, TRAIN, FOLD>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
+                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane);
             if constexpr (MV) {
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
@@ -253,8 +322,8 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
         }
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b)
-            res_block<P, TIMING, TRAIN>(x, smem, b, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr, tid, tim, tlast,
-                                        q, dump_pooled, valid);
+            res_block<P, TIMING, TRAIN, FOLD>(x, smem, b, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr, tid, tim, tlast,
+                                              q, dump_pooled, valid, wv, lane);
 
         if (q.dbg) {
 #pragma unroll
@@ -297,7 +366,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int it = 0; it < IT; ++it) R.r[j][it] = gload8<P>(pf + j * (IT * 1024) + it * 1024);
-            AdvanceFwd::step4(R, NS);
+            ADV::step4(R, NS);
             if (h == 0) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
@@ -332,6 +401,7 @@ static int launch(const EvalParams &q, bool mv, int grid, hipStream_t st) {
     hipError_t e;
     auto k = mv ? eval_kernel<PREC, RAYS, true> : eval_kernel<PREC, RAYS, false>;
     if (RAYS && q.d_z) k = mv ? eval_kernel<PREC, true, true, false, true> : eval_kernel<PREC, true, false, false, true>;
+    else if (q.tables) k = mv ? eval_kernel<PREC, RAYS, true, false, false, true> : eval_kernel<PREC, RAYS, false, false, false, true>;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_kernel)");
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -358,8 +428,12 @@ static int num_cus() {
     return n;
 }
 
-static int eval_common(const PnrScene *s, const void *packed, int precision, EvalParams &q, bool rays, hipStream_t st) {
+static int eval_common(const PnrScene *s, const void *packed, int precision, EvalParams &q, bool rays, hipStream_t st,
+                       const void *tables = nullptr) {
     if (!s || !packed || !q.out) return pnr_fail(PNR_E_INVALID, "pnr_eval: null argument");
+    q.tables = (const char *)tables;  // non-null: `packed` is a folded stream (pnr_pack_mlp_folded)
+    if (tables && q.d_z) return pnr_fail(PNR_E_INVALID, "pnr_eval: the training instantiation is not folded");
+    q.table_stride = (long long)s->SB * s->NS * s->Hl * s->Wl * C_LAT;
     if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_eval: bad scene shape");
     if (!(s->n_focal == 1 || s->n_focal == s->SB) || !(s->n_c == 1 || s->n_c == s->SB))
         return pnr_fail(PNR_E_INVALID, "pnr_eval: focal / c must have 1 or SB rows");
@@ -417,14 +491,27 @@ static float *g_dbg_ptr = nullptr;
 // test hook (not part of the public header): dump the final residual stream of the next launches
 extern "C" int pnr_debug_set_x_dump(float *ptr) { g_dbg_ptr = ptr; return PNR_OK; }
 
-extern "C" int pnr_eval_ray_samples(const PnrScene *scene, const void *packed, int precision, const float *rays,
-                                    const float *z, int R, int rays_per_obj, int K, float *rgbsigma, void *stream) {
+static int eval_ray_samples_impl(const PnrScene *scene, const void *packed, const void *tables, int precision,
+                                 const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
+                                 void *stream) {
     if (R < 0 || K <= 0 || rays_per_obj <= 0) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples: bad sizes");
     if (R > 0 && (!rays || !z)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples: null rays/z");
     if (scene && (long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples: R != SB * rays_per_obj");
     pnr::EvalParams q = {};
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma; q.dbg = g_dbg_ptr;
-    return pnr::eval_common(scene, packed, precision, q, true, (hipStream_t)stream);
+    return pnr::eval_common(scene, packed, precision, q, true, (hipStream_t)stream, tables);
+}
+
+extern "C" int pnr_eval_ray_samples(const PnrScene *scene, const void *packed, int precision, const float *rays,
+                                    const float *z, int R, int rays_per_obj, int K, float *rgbsigma, void *stream) {
+    return eval_ray_samples_impl(scene, packed, nullptr, precision, rays, z, R, rays_per_obj, K, rgbsigma, stream);
+}
+
+extern "C" int pnr_eval_ray_samples_folded(const PnrScene *scene, const void *packed_folded, const void *tables,
+                                           int precision, const float *rays, const float *z, int R, int rays_per_obj,
+                                           int K, float *rgbsigma, void *stream) {
+    if (!tables) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_folded: null tables");
+    return eval_ray_samples_impl(scene, packed_folded, tables, precision, rays, z, R, rays_per_obj, K, rgbsigma, stream);
 }
 
 extern "C" int pnr_eval_ray_samples_train(const PnrScene *scene, const void *packed, int precision, const float *rays,
@@ -444,14 +531,25 @@ extern "C" int pnr_eval_ray_samples_train(const PnrScene *scene, const void *pac
     return pnr::eval_common(scene, packed, precision, q, true, (hipStream_t)stream);
 }
 
-extern "C" int pnr_eval_points(const PnrScene *scene, const void *packed, int precision, const float *xyz,
-                               const float *viewdirs, int B, float *rgbsigma, void *stream) {
+static int eval_points_impl(const PnrScene *scene, const void *packed, const void *tables, int precision, const float *xyz,
+                            const float *viewdirs, int B, float *rgbsigma, void *stream) {
     if (B < 0) return pnr_fail(PNR_E_INVALID, "pnr_eval_points: bad sizes");
     if (B > 0 && (!xyz || !viewdirs)) return pnr_fail(PNR_E_INVALID, "pnr_eval_points: null xyz/viewdirs");
     pnr::EvalParams q = {};
     q.xyz = xyz; q.viewdirs = viewdirs; q.K = 1; q.per_obj = B > 0 ? B : 1;
     q.P = scene ? (long long)scene->SB * B : 0; q.out = rgbsigma; q.dbg = g_dbg_ptr;
-    return pnr::eval_common(scene, packed, precision, q, false, (hipStream_t)stream);
+    return pnr::eval_common(scene, packed, precision, q, false, (hipStream_t)stream, tables);
+}
+
+extern "C" int pnr_eval_points(const PnrScene *scene, const void *packed, int precision, const float *xyz,
+                               const float *viewdirs, int B, float *rgbsigma, void *stream) {
+    return eval_points_impl(scene, packed, nullptr, precision, xyz, viewdirs, B, rgbsigma, stream);
+}
+
+extern "C" int pnr_eval_points_folded(const PnrScene *scene, const void *packed_folded, const void *tables, int precision,
+                                      const float *xyz, const float *viewdirs, int B, float *rgbsigma, void *stream) {
+    if (!tables) return pnr_fail(PNR_E_INVALID, "pnr_eval_points_folded: null tables");
+    return eval_points_impl(scene, packed_folded, tables, precision, xyz, viewdirs, B, rgbsigma, stream);
 }
 
 extern "C" int pnr_profile_enable(int on) {

@@ -34,19 +34,27 @@ __device__ inline GemmSrc gemm_source(const PnrMlpWeights &p, int g) {
     }
 }
 
-template <typename T>
+// FOLD: the stream without the three lin_z GEMMs (they are folded into per-texel tables, pnr_fold_latent)
+template <typename T, bool FOLD>
 __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
+    constexpr int TOTAL = FOLD ? RS_TOTAL_F : RS_TOTAL;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= WSTREAM_ELEMS_PER_WAVE * NW) return;
+    if (idx >= (size_t)TOTAL * IT * FRAG_ELEMS * NW) return;
     const int e = idx & 7;
     const int lane = (idx >> 3) & 63;
     const int it = (idx >> 9) % IT;
     const size_t rest = idx / (FRAG_ELEMS * IT);
-    const int rs = rest % RS_TOTAL;
-    const int wv = rest / RS_TOTAL;
-    int g = 0;
-    while (g + 1 < NGEMM && rs >= gemm_offset(g + 1)) ++g;
-    const int s = rs - gemm_offset(g);
+    const int rs = rest % TOTAL;
+    const int wv = rest / TOTAL;
+    int g = 0, s = 0;
+    if (FOLD) {
+        for (int i = 0; i < NGEMM; ++i)
+            if (!gemm_is_linz(i) && rs >= gemm_offset_fold(i)) g = i;
+        s = rs - gemm_offset_fold(g);
+    } else {
+        while (g + 1 < NGEMM && rs >= gemm_offset(g + 1)) ++g;
+        s = rs - gemm_offset(g);
+    }
     const int i = lane & 31, h = lane >> 5;
     const int f_out = wv * SL + it * 32 + i;
     const GemmSrc src = gemm_source(p, g);
@@ -74,6 +82,7 @@ __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
     out[idx] = (T)v;
 }
 
+template <bool FOLD>
 __global__ void pack_bias_kernel(PnrMlpWeights p, float *__restrict__ bias, float *__restrict__ bout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < D_OUT) bout[idx] = p.lin_out_b[idx];
@@ -84,11 +93,11 @@ __global__ void pack_bias_kernel(PnrMlpWeights p, float *__restrict__ bias, floa
     const int f = feat_of(wv * IT + it, h, r);
     float v = 0.f;
     switch (slot) {
-        case B_IN_Z0: v = p.lin_in_b[f] + p.lin_z_b[0][f]; break;
+        case B_IN_Z0: v = p.lin_in_b[f] + (FOLD ? 0.f : p.lin_z_b[0][f]); break;  // folded: the tables carry lin_z's bias
         case B_FC0_0: v = p.fc0_b[0][f]; break;
-        case B_FC1_0_Z1: v = p.fc1_b[0][f] + p.lin_z_b[1][f]; break;
+        case B_FC1_0_Z1: v = p.fc1_b[0][f] + (FOLD ? 0.f : p.lin_z_b[1][f]); break;
         case B_FC0_1: v = p.fc0_b[1][f]; break;
-        case B_FC1_1_Z2: v = p.fc1_b[1][f] + p.lin_z_b[2][f]; break;
+        case B_FC1_1_Z2: v = p.fc1_b[1][f] + (FOLD ? 0.f : p.lin_z_b[2][f]); break;
         case B_FC0_2: v = p.fc0_b[2][f]; break;
         case B_FC1_2: v = p.fc1_b[2][f]; break;
         case B_FC0_3: v = p.fc0_b[3][f]; break;
@@ -118,27 +127,103 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, float *__restr
     }
 }
 
+// Folding lin_z into the feature grid (inference): table[b][texel][slot_of(n)] = sum_k W_z[b][n][k] grid[texel][k] + b_z[b][n],
+// fp32 on v_mfma_f32_32x32x2_f32 (exact products, fp32 sums), stored 16-bit saturated, hidden features in storage
+// order.  lin_z[b](bilinear(grid)) == bilinear(table[b]) by linearity (the bilinear weights sum to 1), so the
+// per-point stream loses three of its 13.4 GEMMs.  Block = 4 waves = 64 texels x 64 features, K staged 32 at a time.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+template <typename T>
+__global__ void __launch_bounds__(256)
+fold_kernel(const float *__restrict__ grid, const float *__restrict__ W, const float *__restrict__ bias, T *__restrict__ table,
+            long long M, float max_finite) {
+    __shared__ float sX[64][33], sW[64][33];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const long long m0 = (long long)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+    const int i = lane & 31, kh = lane >> 5;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < C_LAT; k0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = t + u * 256, row = e >> 5, col = e & 31;
+            sX[row][col] = (m0 + row < M) ? grid[(m0 + row) * C_LAT + k0 + col] : 0.f;
+            sW[row][col] = W[(size_t)(n0 + row) * C_LAT + k0 + col];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[wm + i][2 * kk + kh], sW[wn + i][2 * kk + kh], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int n = n0 + wn + i;  // D layout: column = lane&31 -> feature, row (r&3)+8(r>>2)+4kh -> texel
+    const float bn = bias[n];
+    const int slot = slot_of(n);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (m < M) table[m * D_HID + slot] = (T)__builtin_amdgcn_fmed3f(acc[r] + bn, -max_finite, max_finite);
+    }
+}
+
 }  // namespace pnr
+
+extern "C" size_t pnr_folded_tables_bytes(const PnrScene *s) {
+    if (!s || s->SB <= 0 || s->NS <= 0 || s->Hl <= 0 || s->Wl <= 0) return 0;
+    return (size_t)pnr::COMBINE_LAYER * s->SB * s->NS * s->Hl * s->Wl * pnr::D_HID * 2;
+}
+
+extern "C" int pnr_fold_latent(const PnrScene *s, const PnrMlpWeights *w, int precision, void *tables, void *stream) {
+    using namespace pnr;
+    if (!s || !w || !tables || !s->latent_nhwc) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: null argument");
+    if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: bad scene shape");
+    const long long M = (long long)s->SB * s->NS * s->Hl * s->Wl;
+    if ((M + 63) / 64 > 0x7fffffffLL) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: grid too large");
+    dim3 grid((unsigned)((M + 63) / 64), D_HID / 64);
+    for (int b = 0; b < COMBINE_LAYER; ++b) {
+        if (!w->lin_z_w[b] || !w->lin_z_b[b]) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: null lin_z parameters");
+        if (precision == PNR_PREC_F16)
+            hipLaunchKernelGGL(fold_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, w->lin_z_w[b],
+                               w->lin_z_b[b], (_Float16 *)tables + (size_t)b * M * D_HID, M, 65504.0f);
+        else if (precision == PNR_PREC_BF16)
+            hipLaunchKernelGGL(fold_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, w->lin_z_w[b],
+                               w->lin_z_b[b], (__bf16 *)tables + (size_t)b * M * D_HID, M, 3.3895314e38f);
+        else
+            return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: unknown precision");
+    }
+    return pnr_check_launch("pnr_fold_latent");
+}
 
 extern "C" size_t pnr_packed_mlp_bytes(void) { return pnr::PACKED_BYTES; }
 
-extern "C" int pnr_pack_mlp(const PnrMlpWeights *w, int precision, void *packed, void *stream) {
+template <bool FOLD>
+static int pack_mlp_impl(const PnrMlpWeights *w, int precision, void *packed, void *stream) {
     using namespace pnr;
     if (!w || !packed) return pnr_fail(PNR_E_INVALID, "pnr_pack_mlp: null argument");
     hipStream_t st = (hipStream_t)stream;
-    const size_t n = WSTREAM_ELEMS_PER_WAVE * NW;
+    const size_t n = (size_t)(FOLD ? RS_TOTAL_F : RS_TOTAL) * IT * FRAG_ELEMS * NW;
     const int threads = 256;
     const unsigned blocks = (unsigned)((n + threads - 1) / threads);
     if (precision == PNR_PREC_F16)
-        hipLaunchKernelGGL(pack_weights_kernel<_Float16>, dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed);
+        hipLaunchKernelGGL((pack_weights_kernel<_Float16, FOLD>), dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed);
     else if (precision == PNR_PREC_BF16)
-        hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(blocks), dim3(threads), 0, st, *w, (__bf16 *)packed);
+        hipLaunchKernelGGL((pack_weights_kernel<__bf16, FOLD>), dim3(blocks), dim3(threads), 0, st, *w, (__bf16 *)packed);
     else
         return pnr_fail(PNR_E_INVALID, "pnr_pack_mlp: unknown precision");
     const int nb = NBIAS * NW * BIAS_FLOATS_PER_WAVE;
-    hipLaunchKernelGGL(pack_bias_kernel, dim3((nb + threads - 1) / threads), dim3(threads), 0, st, *w,
+    hipLaunchKernelGGL(pack_bias_kernel<FOLD>, dim3((nb + threads - 1) / threads), dim3(threads), 0, st, *w,
                        (float *)((char *)packed + BIAS_OFFSET_BYTES), (float *)((char *)packed + BOUT_OFFSET_BYTES));
     return pnr_check_launch("pnr_pack_mlp");
+}
+
+extern "C" int pnr_pack_mlp(const PnrMlpWeights *w, int precision, void *packed, void *stream) {
+    return pack_mlp_impl<false>(w, precision, packed, stream);
+}
+
+extern "C" int pnr_pack_mlp_folded(const PnrMlpWeights *w, int precision, void *packed, void *stream) {
+    return pack_mlp_impl<true>(w, precision, packed, stream);
 }
 
 extern "C" int pnr_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, void *stream) {

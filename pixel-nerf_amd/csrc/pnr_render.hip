@@ -262,8 +262,14 @@ extern "C" size_t pnr_render_workspace_bytes(int R, int Kc, int Kf) {
     return fl * sizeof(float);
 }
 
-extern "C" int pnr_render_forward(const PnrScene *scene, const void *packed_coarse, const void *packed_fine,
-                                  int precision, const float *rays, int R, int rays_per_obj, int Kc, int Kf, int Kfd,
+static int eval_any(const PnrScene *scene, const void *packed, const void *tables, int precision, const float *rays,
+                    const float *z, int R, int rays_per_obj, int K, float *rgbsigma, void *stream) {
+    return tables ? pnr_eval_ray_samples_folded(scene, packed, tables, precision, rays, z, R, rays_per_obj, K, rgbsigma, stream)
+                  : pnr_eval_ray_samples(scene, packed, precision, rays, z, R, rays_per_obj, K, rgbsigma, stream);
+}
+
+static int render_forward_impl(const PnrScene *scene, const void *packed_coarse, const void *tables_coarse,
+                               const void *packed_fine, const void *tables_fine, int precision, const float *rays, int R, int rays_per_obj, int Kc, int Kf, int Kfd,
                                   float depth_std, int white_bkgd, int lindisp, const float *u1, const float *u2,
                                   const float *u3, const float *n4, float *rgb_c, float *depth_c, float *weights_c,
                                   float *rgb_f, float *depth_f, float *weights_f, void *workspace, void *stream) {
@@ -282,13 +288,37 @@ extern "C" int pnr_render_forward(const PnrScene *scene, const void *packed_coar
     if (weights_c) w_c = weights_c;  // write straight into the caller's buffer
     int rc;
     if ((rc = pnr_sample_coarse(rays, u1, R, Kc, lindisp, z_c, stream))) return rc;
-    if ((rc = pnr_eval_ray_samples(scene, packed_coarse, precision, rays, z_c, R, rays_per_obj, Kc, rgbs_c, stream))) return rc;
+    if ((rc = eval_any(scene, packed_coarse, tables_coarse, precision, rays, z_c, R, rays_per_obj, Kc, rgbs_c, stream))) return rc;
     if ((rc = pnr_composite(rays, z_c, rgbs_c, R, Kc, white_bkgd, w_c, rgb_c, depth_c, stream))) return rc;
     if (Kf > 0) {
         const void *pf = packed_fine ? packed_fine : packed_coarse;  // models.py:242
+        const void *tf = packed_fine ? tables_fine : tables_coarse;
         if ((rc = pnr_sample_fine(rays, w_c, depth_c, z_c, u2, u3, n4, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, nullptr, stream))) return rc;
-        if ((rc = pnr_eval_ray_samples(scene, pf, precision, rays, z_f, R, rays_per_obj, Kc + Kf, rgbs_f, stream))) return rc;
+        if ((rc = eval_any(scene, pf, tf, precision, rays, z_f, R, rays_per_obj, Kc + Kf, rgbs_f, stream))) return rc;
         if ((rc = pnr_composite(rays, z_f, rgbs_f, R, Kc + Kf, white_bkgd, weights_f, rgb_f, depth_f, stream))) return rc;
     }
     return PNR_OK;
+}
+
+extern "C" int pnr_render_forward(const PnrScene *scene, const void *packed_coarse, const void *packed_fine,
+                                  int precision, const float *rays, int R, int rays_per_obj, int Kc, int Kf, int Kfd,
+                                  float depth_std, int white_bkgd, int lindisp, const float *u1, const float *u2,
+                                  const float *u3, const float *n4, float *rgb_c, float *depth_c, float *weights_c,
+                                  float *rgb_f, float *depth_f, float *weights_f, void *workspace, void *stream) {
+    return render_forward_impl(scene, packed_coarse, nullptr, packed_fine, nullptr, precision, rays, R, rays_per_obj, Kc, Kf,
+                               Kfd, depth_std, white_bkgd, lindisp, u1, u2, u3, n4, rgb_c, depth_c, weights_c, rgb_f, depth_f,
+                               weights_f, workspace, stream);
+}
+
+extern "C" int pnr_render_forward_folded(const PnrScene *scene, const void *packed_coarse, const void *tables_coarse,
+                                         const void *packed_fine, const void *tables_fine, int precision, const float *rays,
+                                         int R, int rays_per_obj, int Kc, int Kf, int Kfd, float depth_std, int white_bkgd,
+                                         int lindisp, const float *u1, const float *u2, const float *u3, const float *n4,
+                                         float *rgb_c, float *depth_c, float *weights_c, float *rgb_f, float *depth_f,
+                                         float *weights_f, void *workspace, void *stream) {
+    if (!tables_coarse || (packed_fine && !tables_fine))
+        return pnr_fail(PNR_E_INVALID, "pnr_render_forward_folded: every folded network needs its tables");
+    return render_forward_impl(scene, packed_coarse, tables_coarse, packed_fine, tables_fine, precision, rays, R, rays_per_obj,
+                               Kc, Kf, Kfd, depth_std, white_bkgd, lindisp, u1, u2, u3, n4, rgb_c, depth_c, weights_c, rgb_f,
+                               depth_f, weights_f, workspace, stream);
 }

@@ -24,11 +24,13 @@ from .model_util import make_encoder, make_mlp
 
 
 class PixelNeRFNet(torch.nn.Module):
-    def __init__(self, conf, stop_encoder_grad=False, precision="f16"):
+    def __init__(self, conf, stop_encoder_grad=False, precision="f16", fold=True):
         """:param conf PyHocon-like config subtree 'model' (util.Conf or a real ConfigTree)
         :param precision operand type of the 512-wide linears on the matrix cores: 'f16'
         (default; PSNR >= 52 dB vs the fp32 reference), 'bf16' (>= 36 dB), or 'f32' -- the exact,
-        unfused validation path (inference only, ~1/20 of the f16 rate, agrees to ~1e-5)."""
+        unfused validation path (inference only, ~1/20 of the f16 rate, agrees to ~1e-5).
+        :param fold inference applies lin_z[b] to the encoded grid once per scene (per-texel tables) instead of
+        once per sample -- the same function by linearity, 22-28 % fewer FLOPs per sample (ops.fold_latent)."""
         super().__init__()
         self.encoder = make_encoder(conf["encoder"])
         self.use_encoder = conf.get_bool("use_encoder", True)
@@ -64,7 +66,9 @@ class PixelNeRFNet(torch.nn.Module):
         self.num_objs = 0
         self.num_views_per_obj = 1
         self.precision = precision
+        self.fold = bool(fold)
         self._scene = None
+        self._tables = {}
 
     # ------------------------------------------------------------------ encode (PyTorch-ROCm)
     def encode(self, images, poses, focal, z_bounds=None, c=None):
@@ -135,10 +139,28 @@ class PixelNeRFNet(torch.nn.Module):
             self._scene = (key, sc)
         return self._scene[1]
 
-    def packed(self, coarse=True):
-        """models.py:242: the fine network falls back to the coarse one when mlp_fine is None."""
+    def _folding(self):
+        return self.fold and self.precision != "f32"
+
+    def packed(self, coarse=True, folded=None):
+        """models.py:242: the fine network falls back to the coarse one when mlp_fine is None.
+        folded: None = what inference uses (self.fold); the training path asks for the full stream."""
         mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
-        return mlp.packed(self.precision)
+        return mlp.packed(self.precision, folded=self._folding() if folded is None else folded)
+
+    def tables(self, coarse=True):
+        """lin_z folded into the current scene's grid for the coarse / fine network (None when fold is off);
+        rebuilt when encode() or the network's parameters change."""
+        if not self._folding():
+            return None
+        mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
+        sc = self.scene()
+        key = (id(sc), mlp._fingerprint(), self.precision)
+        slot = "coarse" if mlp is self.mlp_coarse else "fine"
+        hit = self._tables.get(slot)
+        if hit is None or hit[0] != key:
+            self._tables[slot] = (key, ops.fold_latent(sc, dict(mlp.state_dict()), self.precision), sc)
+        return self._tables[slot][1]
 
     def _no_autograd(self):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -158,7 +180,8 @@ class PixelNeRFNet(torch.nn.Module):
         sc = self.scene()
         if SB != sc.SB:
             raise ValueError(f"xyz has {SB} objects but encode() saw {sc.SB}")
-        return ops.eval_points(sc, self.packed(coarse), xyz.float(), viewdirs.reshape(SB, B, 3).float())
+        return ops.eval_points(sc, self.packed(coarse), xyz.float(), viewdirs.reshape(SB, B, 3).float(),
+                               tables=self.tables(coarse))
 
     # ------------------------------------------------------------------ checkpoints
     def load_weights(self, args, opt_init=False, strict=True, device=None):

@@ -59,17 +59,18 @@ class ResnetFC(nn.Module):
     def _fingerprint(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def packed(self, precision="f16"):
+    def packed(self, precision="f16", folded=False):
         if not self.supported():
             raise NotImplementedError(
                 "fused HIP network supports d_in=42, d_latent=512, d_hidden=512, n_blocks=5, "
                 "combine_layer=3, combine_type=average (conf/default_mv.conf); got a different ResnetFC")
         fp = self._fingerprint()
-        hit = self._packed.get(precision)
+        key = (precision, bool(folded))
+        hit = self._packed.get(key)
         if hit is None or hit[0] != fp:
             state = {k: v for k, v in self.state_dict().items()}
-            self._packed[precision] = (fp, ops.pack_mlp(state, precision))
-        return self._packed[precision][1]
+            self._packed[key] = (fp, ops.pack_mlp(state, precision, folded=folded))
+        return self._packed[key][1]
 
     def packed_bwd(self, precision="f16"):
         """transposed weight streams for the backward data-gradient chain (training)."""

@@ -43,10 +43,11 @@ class PackedMLP:
     """A ResnetFC's parameters repacked into the fused kernel's fragment stream.
     precision "f32" (exact validation path) keeps the raw nn.Linear tensors instead."""
 
-    def __init__(self, buf, precision, weights=None):
+    def __init__(self, buf, precision, weights=None, folded=False):
         self.buf = buf
         self.precision = precision
         self.weights = weights  # f32 only: (PnrMlpWeights, {key: tensor} keeping the storage alive)
+        self.folded = folded    # stream without the lin_z GEMMs: must be used with fold_latent() tables
 
     @property
     def ptr(self):
@@ -91,10 +92,11 @@ def _weights_struct(state):
     return w, keep
 
 
-def pack_mlp(state, precision="f16", backward=False):
+def pack_mlp(state, precision="f16", backward=False, folded=False):
     """state: {reference ResnetFC state_dict key: float32 HIP tensor}
     (src/model/resnetfc.py:66-130: lin_in, lin_out, blocks.N.fc_0/fc_1, lin_z.N).
-    backward=True packs the transposed streams of the data-gradient chain instead."""
+    backward=True packs the transposed streams of the data-gradient chain instead;
+    folded=True packs the inference stream without the lin_z GEMMs (use with fold_latent)."""
     lib = _lib.load()
     prec = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
     w, keep = _weights_struct(state)
@@ -103,14 +105,40 @@ def pack_mlp(state, precision="f16", backward=False):
             raise _lib.PixelNerfHipError("precision='f32' has no backward path")
         return PackedMLP(None, prec, weights=(w, keep))
     dev = keep["lin_in.weight"].device
+    if backward and folded:
+        raise ValueError("the backward streams have no folded form")
     nbytes = lib.pnr_packed_mlp_bwd_bytes() if backward else lib.pnr_packed_mlp_bytes()
     buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         if backward:
             _lib.check(lib.pnr_pack_mlp_bwd(ctypes.byref(w), prec, _p(buf), _stream()), "pnr_pack_mlp_bwd")
+        elif folded:
+            _lib.check(lib.pnr_pack_mlp_folded(ctypes.byref(w), prec, _p(buf), _stream()), "pnr_pack_mlp_folded")
         else:
             _lib.check(lib.pnr_pack_mlp(ctypes.byref(w), prec, _p(buf), _stream()), "pnr_pack_mlp")
-    return PackedMLP(buf, prec)
+    return PackedMLP(buf, prec, folded=folded)
+
+
+def fold_latent(scene, state, precision="f16"):
+    """Per-texel tables T_b = W_z[b] . grid + b_z[b] (b = 0..2) of one network for one encoded scene:
+    (3, SB*NS, Hl, Wl, 512) 16-bit, hidden features in storage order.  Re-run when the grid or lin_z change."""
+    lib = _lib.load()
+    prec = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+    if prec == _lib.PREC_F32:
+        raise _lib.PixelNerfHipError("precision='f32' has no folded form")
+    w, keep = _weights_struct(state)
+    NV, Hl, Wl, _ = scene.latent_nhwc.shape
+    dt = torch.float16 if prec == _lib.PREC_F16 else torch.bfloat16
+    tables = torch.empty((3, NV, Hl, Wl, 512), dtype=dt, device=scene.device)
+    assert tables.numel() * 2 == lib.pnr_folded_tables_bytes(scene.ref)
+    with torch.cuda.device(scene.device):
+        _lib.check(lib.pnr_fold_latent(scene.ref, ctypes.byref(w), prec, _p(tables), _stream()), "pnr_fold_latent")
+    return tables
+
+
+def _check_fold(packed, tables, what):
+    if packed.folded != (tables is not None):
+        raise _lib.PixelNerfHipError(f"{what}: a folded network stream needs its fold_latent() tables (and only it takes them)")
 
 
 class Scene:
@@ -198,8 +226,9 @@ def sample_fine(rays, weights_c, depth_c, z_coarse, u2, u3, n4, depth_std=0.01, 
     return (z, ranks) if want_ranks else z
 
 
-def eval_ray_samples(scene, packed, rays, z):
-    """rays (R,8), z (R,K) -> rgbsigma (R,K,4); R = SB * rays_per_obj."""
+def eval_ray_samples(scene, packed, rays, z, tables=None):
+    """rays (R,8), z (R,K) -> rgbsigma (R,K,4); R = SB * rays_per_obj.  tables: fold_latent() output when
+    `packed` is a folded stream."""
     lib = _lib.load()
     rays = _f32(rays, "rays", (None, 8))
     R = rays.shape[0]
@@ -214,14 +243,20 @@ def eval_ray_samples(scene, packed, rays, z):
             _lib.check(lib.pnr_eval_ray_samples_f32(scene.ref, packed.wref, _p(rays), _p(z), R, max(R // scene.SB, 1), K,
                                                     _p(out), _p(ws), nbytes, _stream()), "pnr_eval_ray_samples_f32")
         return out
+    _check_fold(packed, tables, "eval_ray_samples")
     with torch.cuda.device(rays.device):
-        _lib.check(lib.pnr_eval_ray_samples(scene.ref, packed.ptr, packed.precision, _p(rays), _p(z), R,
-                                            max(R // scene.SB, 1), K, _p(out), _stream()),
-                   "pnr_eval_ray_samples")
+        if tables is not None:
+            _lib.check(lib.pnr_eval_ray_samples_folded(scene.ref, packed.ptr, _p(tables), packed.precision, _p(rays), _p(z), R,
+                                                       max(R // scene.SB, 1), K, _p(out), _stream()),
+                       "pnr_eval_ray_samples_folded")
+        else:
+            _lib.check(lib.pnr_eval_ray_samples(scene.ref, packed.ptr, packed.precision, _p(rays), _p(z), R,
+                                                max(R // scene.SB, 1), K, _p(out), _stream()),
+                       "pnr_eval_ray_samples")
     return out
 
 
-def eval_points(scene, packed, xyz, viewdirs):
+def eval_points(scene, packed, xyz, viewdirs, tables=None):
     """xyz, viewdirs (SB,B,3) -> (SB,B,4)."""
     lib = _lib.load()
     xyz = _f32(xyz, "xyz", (scene.SB, None, 3))
@@ -234,9 +269,14 @@ def eval_points(scene, packed, xyz, viewdirs):
             _lib.check(lib.pnr_eval_points_f32(scene.ref, packed.wref, _p(xyz), _p(viewdirs), B, _p(out), _p(ws), nbytes,
                                                _stream()), "pnr_eval_points_f32")
         return out
+    _check_fold(packed, tables, "eval_points")
     with torch.cuda.device(xyz.device):
-        _lib.check(lib.pnr_eval_points(scene.ref, packed.ptr, packed.precision, _p(xyz), _p(viewdirs), B,
-                                       _p(out), _stream()), "pnr_eval_points")
+        if tables is not None:
+            _lib.check(lib.pnr_eval_points_folded(scene.ref, packed.ptr, _p(tables), packed.precision, _p(xyz), _p(viewdirs),
+                                                  B, _p(out), _stream()), "pnr_eval_points_folded")
+        else:
+            _lib.check(lib.pnr_eval_points(scene.ref, packed.ptr, packed.precision, _p(xyz), _p(viewdirs), B,
+                                           _p(out), _stream()), "pnr_eval_points")
     return out
 
 
@@ -258,9 +298,10 @@ def composite(rays, z, rgbsigma, white_bkgd=False, want_weights=True):
 
 
 def render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_fine_depth, noise,
-                   depth_std=0.01, white_bkgd=False, lindisp=False, want_weights=False):
+                   depth_std=0.01, white_bkgd=False, lindisp=False, want_weights=False, tables=None):
     """Whole NeRFRenderer.forward (nerf.py:251-303) for rays (R,8) in object-major order.
-    noise: dict(u1[,u2,u3][,n4]).  Returns {"coarse": {...}, "fine": {...}} of flat tensors."""
+    noise: dict(u1[,u2,u3][,n4]).  Returns {"coarse": {...}, "fine": {...}} of flat tensors.
+    tables: (tables_coarse, tables_fine|None) from fold_latent() when the networks are folded streams."""
     lib = _lib.load()
     rays = _f32(rays, "rays", (None, 8))
     R, dev = rays.shape[0], rays.device
@@ -302,13 +343,25 @@ def render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_
     rgb_c, depth_c, w_c = outs(Kc)
     rgb_f, depth_f, w_f = outs(Kc + Kf) if Kf > 0 else (None, None, None)
     ws = torch.empty(max(lib.pnr_render_workspace_bytes(R, Kc, Kf), 16), dtype=torch.uint8, device=dev)
+    tc, tf = tables if tables is not None else (None, None)
+    _check_fold(packed_coarse, tc, "render_forward")
+    if packed_fine is not None:
+        _check_fold(packed_fine, tf, "render_forward")
     with torch.cuda.device(dev):
-        _lib.check(lib.pnr_render_forward(
-            scene.ref, packed_coarse.ptr, packed_fine.ptr if packed_fine is not None else None,
-            packed_coarse.precision, _p(rays), R, max(R // scene.SB, 1), Kc, Kf, Kfd, float(depth_std),
-            int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4),
-            _p(rgb_c), _p(depth_c), _p(w_c), _p(rgb_f), _p(depth_f), _p(w_f), _p(ws), _stream()),
-            "pnr_render_forward")
+        if tc is not None:
+            _lib.check(lib.pnr_render_forward_folded(
+                scene.ref, packed_coarse.ptr, _p(tc), packed_fine.ptr if packed_fine is not None else None, _p(tf),
+                packed_coarse.precision, _p(rays), R, max(R // scene.SB, 1), Kc, Kf, Kfd, float(depth_std),
+                int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4),
+                _p(rgb_c), _p(depth_c), _p(w_c), _p(rgb_f), _p(depth_f), _p(w_f), _p(ws), _stream()),
+                "pnr_render_forward_folded")
+        else:
+            _lib.check(lib.pnr_render_forward(
+                scene.ref, packed_coarse.ptr, packed_fine.ptr if packed_fine is not None else None,
+                packed_coarse.precision, _p(rays), R, max(R // scene.SB, 1), Kc, Kf, Kfd, float(depth_std),
+                int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4),
+                _p(rgb_c), _p(depth_c), _p(w_c), _p(rgb_f), _p(depth_f), _p(w_f), _p(ws), _stream()),
+                "pnr_render_forward")
     ret = {"coarse": {"rgb": rgb_c, "depth": depth_c}}
     if want_weights:
         ret["coarse"]["weights"] = w_c

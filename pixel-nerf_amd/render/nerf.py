@@ -156,9 +156,11 @@ class NeRFRenderer(torch.nn.Module):
                 from ..autograd import render_autograd
                 res = render_autograd(self, model, rays, noise, want_weights)
             else:
+                tc = model.tables(True)
                 res = ops.render_forward(model.scene(), model.packed(True), model.packed(False) if Kf > 0 else None,
                                          rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
-                                         white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights)
+                                         white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights,
+                                         tables=None if tc is None else (tc, model.tables(False) if Kf > 0 else None))
             outputs = DotMap(coarse=self._format(res["coarse"], SB, want_weights))
             if Kf > 0:
                 outputs.fine = self._format(res["fine"], SB, want_weights)
