@@ -229,9 +229,10 @@ def main():
                          "frac": ach / PEAK_TFLOPS[args.prec],
                          "traffic": pmc_traffic_per_launch() if (args.prec == "f16" and R == 65536) else None,
                          "traffic_note": "bytes per launch at the L2<->fabric interface (Infinity-Cache hits included): "
-                                         "2*FETCH_SIZE + WRITE_SIZE from profiles/r01_bench_f16_pmc_eval_kernel.json; "
-                                         "algorithmic HBM bytes per launch are ~0.18 GB (z in, rgb-sigma out, weights+grid once), "
-                                         "the excess is the weight stream's L2 misses served on-die",
+                                         "2*FETCH_SIZE + WRITE_SIZE from profiles/r01_bench_f16_pmc_eval_kernel.json (tools/collect_pmc.sh); "
+                                         "algorithmic HBM bytes per launch are ~0.18 GB (z in, rgb-sigma out, weights+tables once); "
+                                         "the excess is the 5.4 MB weight stream (> 4 MB L2 per XCD) re-fetched from the Infinity Cache "
+                                         "once per tile pass and XCD -- measured to cost < 1 % (profiles/r01_gemm_experiments.md)",
                          "kernel": "pnr::eval_kernel (fused per-point network)", "launches": n_launch,
                          "avg_launch_ms": kern_ms / max(n_launch, 1),
                          "flop_per_ray": flop_per_ray, "kernel_time_frac_of_step": kern_ms * 1e-3 / elapsed,
