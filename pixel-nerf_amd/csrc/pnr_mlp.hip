@@ -219,9 +219,11 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b
     gemm<P, ADV>(x, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
     if (with_z) {
         if constexpr (FOLD) {  // lin_z[b+1](z) = bilinear lookup in table b+1 (LDS_Z is free: its last readers ran before fc_0)
+            PNR_T(PH_GEMM_FC1_Z);
             gather_table<P, 2>(q, smem, wv, lane, b + 1);  // the residual stream is live here: smaller batches
             __syncthreads();
             add_from_z<P>(x, smem, a_wr - LDS_A + LDS_Z);
+            PNR_T(PH_TABLE);
         } else {
             gemm<P, ADV>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);
         }
@@ -458,8 +460,9 @@ static int eval_common(const PnrScene *s, const void *packed, int precision, Eva
 
 // test/diagnostic hook (not in the public header): per-phase s_memtime totals of wave 0 of
 // workgroup 0 for one f16 single-view launch.  tim: NW*NPHASE device counters, zeroed by the caller.
-extern "C" int pnr_debug_phase_timing(const PnrScene *s, const void *packed, const float *rays, const float *z, int R,
-                                      int rays_per_obj, int K, unsigned long long *tim, void *stream) {
+extern "C" int pnr_debug_phase_timing(const PnrScene *s, const void *packed, const void *tables, const float *rays,
+                                      const float *z, int R, int rays_per_obj, int K, unsigned long long *tim,
+                                      void *stream) {
     using namespace pnr;
     if (!s || !packed || !rays || !z || !tim || s->NS != 1) return pnr_fail(PNR_E_INVALID, "pnr_debug_phase_timing: bad argument");
     EvalParams q = {};
@@ -471,6 +474,8 @@ extern "C" int pnr_debug_phase_timing(const PnrScene *s, const void *packed, con
     q.bias = (const float *)((const char *)packed + BIAS_OFFSET_BYTES);
     q.bout = (const float *)((const char *)packed + BOUT_OFFSET_BYTES);
     q.ntiles = (int)((q.P + MT - 1) / MT);
+    q.tables = (const char *)tables;  // non-null: folded stream
+    q.table_stride = (long long)s->SB * s->NS * s->Hl * s->Wl * C_LAT;
     static float *scratch_out = nullptr;
     static long long scratch_n = 0;
     if (scratch_n < q.P) {
@@ -479,7 +484,7 @@ extern "C" int pnr_debug_phase_timing(const PnrScene *s, const void *packed, con
         scratch_n = q.P;
     }
     q.out = scratch_out;
-    auto k = eval_kernel<PNR_PREC_F16, true, false, true>;
+    auto k = tables ? eval_kernel<PNR_PREC_F16, true, false, true, false, true> : eval_kernel<PNR_PREC_F16, true, false, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute");
     const int grid = q.ntiles < num_cus() ? q.ntiles : num_cus();

@@ -535,15 +535,16 @@ def debug_set_x_dump(t):
 
 
 PHASES = ["sync_top", "geometry", "gather", "gemm_in_z0", "bar1", "write_x", "bar2", "gemm_fc0", "bar3", "write_net",
-          "bar4", "gemm_fc1_z", "lin_out", "bar_out", "final"]
+          "bar4", "gemm_fc1_z", "lin_out", "bar_out", "final", "table"]
 
 
-def debug_phase_timing(scene, packed, rays, z):
+def debug_phase_timing(scene, packed, rays, z, tables=None):
     """diagnostic: {phase: [s_memtime ticks of wave 0..7]} of workgroup 0, one f16 single-view launch."""
     lib = _lib.load()
     rays, z = _f32(rays, "rays", (None, 8)), _f32(z, "z")
     tim = torch.zeros(8 * len(PHASES), dtype=torch.int64, device=rays.device)
-    _lib.check(lib.pnr_debug_phase_timing(scene.ref, packed.ptr, _p(rays), _p(z), rays.shape[0],
+    _check_fold(packed, tables, "debug_phase_timing")
+    _lib.check(lib.pnr_debug_phase_timing(scene.ref, packed.ptr, _p(tables), _p(rays), _p(z), rays.shape[0],
                                           max(rays.shape[0] // scene.SB, 1), z.shape[1], _p(tim), _stream()),
                "pnr_debug_phase_timing")
     torch.cuda.synchronize()

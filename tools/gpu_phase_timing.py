@@ -11,9 +11,13 @@ sc = ops.make_scene(scene["latent"].to(dev), scene["poses"].to(dev), scene["foca
 R, K = 16384, 192
 rays = synthetic.target_rays(meta).reshape(-1, 8).repeat(4, 1)[:R].contiguous().to(dev)
 z = torch.sort(ops.sample_coarse(rays, torch.rand(R, K, device=dev)), dim=-1)[0]
-pk = ops.pack_mlp({k: v.to(dev) for k, v in synthetic.make_mlp_params(11).items()}, "f16")
+state = {k: v.to(dev) for k, v in synthetic.make_mlp_params(11).items()}
+fold = "--no-fold" not in sys.argv
+pk = ops.pack_mlp(state, "f16", folded=fold)
+tab = ops.fold_latent(sc, state, "f16") if fold else None
+print("folded stream" if fold else "full stream (--no-fold)")
 for it in range(2):
-    t = ops.debug_phase_timing(sc, pk, rays, z)
+    t = ops.debug_phase_timing(sc, pk, rays, z, tables=tab)
 ntile = (R * K // 64 + 255) // 256
 tot = [sum(v[w] for v in t.values()) for w in range(8)]
 print(f"tiles by WG0: {ntile}; per-tile ticks per wave: " + " ".join(f"{x/ntile:8.0f}" for x in tot))
