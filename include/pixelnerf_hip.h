@@ -273,7 +273,9 @@ int pnr_composite(const float *rays, const float *z, const float *rgbsigma, int 
 /* ---- whole renderer forward --------------------------------------------------------------
  * NeRFRenderer.forward, src/render/nerf.py:251-303 (inference; no autograd).
  * Noise pointers follow the reference's draw order (u1 :111, u2 :135, u3 :141, n4 :158).
- * packed_fine == NULL falls back to the coarse network (models.py:242).
+ * packed_fine == NULL falls back to the coarse network (models.py:242); the fine pass then evaluates only the Kf
+ * new samples and merges them with the coarse pass's outputs at the Kc shared positions (same network, same
+ * points: bit-identical to evaluating all Kc+Kf).
  * Outputs: *_c (coarse), *_f (fine; ignored when Kf == 0); weights pointers may be NULL.
  * workspace: pnr_render_workspace_bytes(R,Kc,Kf) bytes of scratch. */
 size_t pnr_render_workspace_bytes(int R, int Kc, int Kf);

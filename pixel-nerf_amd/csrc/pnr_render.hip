@@ -70,7 +70,8 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64)
 sample_fine_kernel(const float *__restrict__ rays, const float *__restrict__ wc, const float *__restrict__ depth_c,
                    const float *__restrict__ zc, const float *__restrict__ u2, const float *__restrict__ u3,
                    const float *__restrict__ n4, int R, int Kc, int Kimp, int Kfd, float depth_std, int lindisp,
-                   float *__restrict__ zout, int *__restrict__ depth_ranks) {
+                   float *__restrict__ zout, int *__restrict__ depth_ranks, float *__restrict__ z_new,
+                   int *__restrict__ ranks_all) {
     __shared__ float s_cdf[WAVES_PER_BLOCK][MAX_KC + 1];
     __shared__ float s_z[WAVES_PER_BLOCK][MAX_KTOT];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -128,7 +129,23 @@ sample_fine_kernel(const float *__restrict__ rays, const float *__restrict__ wc,
         }
         zout[(size_t)r * Ktot + rank] = v;
         if (depth_ranks && e >= Kc + Kimp) depth_ranks[(size_t)r * Kfd + (e - Kc - Kimp)] = rank;
+        // optional: the new samples in draw order and every source element's sorted position (coarse-network reuse)
+        if (ranks_all) ranks_all[(size_t)r * Ktot + e] = rank;
+        if (z_new && e >= Kc) z_new[(size_t)r * (Kimp + Kfd) + (e - Kc)] = v;
     }
+}
+
+// fine pass on the coarse network (mlp_fine is None, models.py:242): the Kc coarse samples were already evaluated by
+// the same network at the same points -- a point's output does not depend on its neighbours -- so only the Kf new
+// samples are evaluated and the two result sets are merged into sorted order.
+__global__ void merge_rgbsigma_kernel(const float4 *__restrict__ rgbs_c, const float4 *__restrict__ rgbs_new,
+                                      const int *__restrict__ ranks_all, int R, int Kc, int Kf, float4 *__restrict__ rgbs_f) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Kt = Kc + Kf;
+    if (idx >= (long long)R * Kt) return;
+    const int r = (int)(idx / Kt), e = (int)(idx % Kt);
+    const float4 v = e < Kc ? rgbs_c[(size_t)r * Kc + e] : rgbs_new[(size_t)r * Kf + (e - Kc)];
+    rgbs_f[(size_t)r * Kt + ranks_all[idx]] = v;
 }
 
 // NeRFRenderer.composite, nerf.py:178-182 (deltas) and :223-249
@@ -215,9 +232,10 @@ extern "C" int pnr_sample_coarse(const float *rays, const float *u1, int R, int 
     return pnr_check_launch("pnr_sample_coarse");
 }
 
-extern "C" int pnr_sample_fine(const float *rays, const float *weights_c, const float *depth_c, const float *z_coarse,
-                               const float *u2, const float *u3, const float *n4, int R, int Kc, int Kimp, int Kfd,
-                               float depth_std, int lindisp, float *z_sorted, int32_t *depth_ranks, void *stream) {
+static int sample_fine_impl(const float *rays, const float *weights_c, const float *depth_c, const float *z_coarse,
+                            const float *u2, const float *u3, const float *n4, int R, int Kc, int Kimp, int Kfd,
+                            float depth_std, int lindisp, float *z_sorted, int32_t *depth_ranks, float *z_new,
+                            int32_t *ranks_all, void *stream) {
     if (R < 0 || Kc <= 0 || Kimp < 0 || Kfd < 0) return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: bad sizes");
     if (Kc > MAX_KC || Kc + Kimp + Kfd > MAX_KTOT)
         return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: supports n_coarse <= 256 and n_coarse + n_fine <= 512");
@@ -226,8 +244,15 @@ extern "C" int pnr_sample_fine(const float *rays, const float *weights_c, const 
         return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: null argument");
     hipLaunchKernelGGL(sample_fine_kernel, dim3((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(WAVES_PER_BLOCK * 64),
                        0, (hipStream_t)stream, rays, weights_c, depth_c, z_coarse, u2, u3, n4, R, Kc, Kimp, Kfd,
-                       depth_std, lindisp, z_sorted, depth_ranks);
+                       depth_std, lindisp, z_sorted, depth_ranks, z_new, ranks_all);
     return pnr_check_launch("pnr_sample_fine");
+}
+
+extern "C" int pnr_sample_fine(const float *rays, const float *weights_c, const float *depth_c, const float *z_coarse,
+                               const float *u2, const float *u3, const float *n4, int R, int Kc, int Kimp, int Kfd,
+                               float depth_std, int lindisp, float *z_sorted, int32_t *depth_ranks, void *stream) {
+    return sample_fine_impl(rays, weights_c, depth_c, z_coarse, u2, u3, n4, R, Kc, Kimp, Kfd, depth_std, lindisp, z_sorted,
+                            depth_ranks, nullptr, nullptr, stream);
 }
 
 extern "C" int pnr_composite(const float *rays, const float *z, const float *rgbsigma, int R, int K, int white_bkgd,
@@ -252,13 +277,14 @@ extern "C" int pnr_gen_rays(const float *poses, int NV, int W, int H, float fx, 
 }
 
 // workspace layout (floats): z_c [R*Kc] | rgbs_c [R*Kc*4] | w_c [R*Kc] | z_f [R*Kt] | rgbs_f [R*Kt*4]
+//                            | z_new [R*Kf] | rgbs_new [R*Kf*4] | ranks [R*Kt]   (coarse-network reuse, mlp_fine == NULL)
 static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 extern "C" size_t pnr_render_workspace_bytes(int R, int Kc, int Kf) {
     if (R <= 0 || Kc <= 0 || Kf < 0) return 0;
     const size_t r = (size_t)R, kc = (size_t)Kc, kt = (size_t)(Kc + Kf);
     size_t fl = align64(r * kc) + align64(r * kc * 4) + align64(r * kc);
-    if (Kf > 0) fl += align64(r * kt) + align64(r * kt * 4);
+    if (Kf > 0) fl += align64(r * kt) + align64(r * kt * 4) + align64(r * (kt - kc)) + align64(r * (kt - kc) * 4) + align64(r * kt);
     return fl * sizeof(float);
 }
 
@@ -284,17 +310,30 @@ static int render_forward_impl(const PnrScene *scene, const void *packed_coarse,
     float *rgbs_c = ws; ws += align64(r * kc * 4);
     float *w_c = ws; ws += align64(r * kc);
     float *z_f = ws; ws += align64(r * kt);
-    float *rgbs_f = ws;
+    float *rgbs_f = ws; ws += align64(r * kt * 4);
+    float *z_new = ws; ws += align64(r * (kt - kc));
+    float *rgbs_new = ws; ws += align64(r * (kt - kc) * 4);
+    int32_t *ranks = (int32_t *)ws;
     if (weights_c) w_c = weights_c;  // write straight into the caller's buffer
     int rc;
     if ((rc = pnr_sample_coarse(rays, u1, R, Kc, lindisp, z_c, stream))) return rc;
     if ((rc = eval_any(scene, packed_coarse, tables_coarse, precision, rays, z_c, R, rays_per_obj, Kc, rgbs_c, stream))) return rc;
     if ((rc = pnr_composite(rays, z_c, rgbs_c, R, Kc, white_bkgd, w_c, rgb_c, depth_c, stream))) return rc;
     if (Kf > 0) {
-        const void *pf = packed_fine ? packed_fine : packed_coarse;  // models.py:242
-        const void *tf = packed_fine ? tables_fine : tables_coarse;
-        if ((rc = pnr_sample_fine(rays, w_c, depth_c, z_c, u2, u3, n4, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, nullptr, stream))) return rc;
-        if ((rc = eval_any(scene, pf, tf, precision, rays, z_f, R, rays_per_obj, Kc + Kf, rgbs_f, stream))) return rc;
+        if (packed_fine) {
+            if ((rc = pnr_sample_fine(rays, w_c, depth_c, z_c, u2, u3, n4, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, nullptr, stream))) return rc;
+            if ((rc = eval_any(scene, packed_fine, tables_fine, precision, rays, z_f, R, rays_per_obj, Kc + Kf, rgbs_f, stream))) return rc;
+        } else {
+            // mlp_fine is None (models.py:242, eval/eval.py:140): the fine pass runs the coarse network on the merged
+            // samples, Kc of which it has just evaluated -- evaluate the Kf new ones only and merge in sorted order
+            if ((rc = sample_fine_impl(rays, w_c, depth_c, z_c, u2, u3, n4, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, nullptr,
+                                       z_new, ranks, stream))) return rc;
+            if ((rc = eval_any(scene, packed_coarse, tables_coarse, precision, rays, z_new, R, rays_per_obj, Kf, rgbs_new, stream))) return rc;
+            const long long n = (long long)R * (Kc + Kf);
+            hipLaunchKernelGGL(merge_rgbsigma_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const float4 *)rgbs_c, (const float4 *)rgbs_new, ranks, R, Kc, Kf, (float4 *)rgbs_f);
+            if ((rc = pnr_check_launch("merge_rgbsigma_kernel"))) return rc;
+        }
         if ((rc = pnr_composite(rays, z_f, rgbs_f, R, Kc + Kf, white_bkgd, weights_f, rgb_f, depth_f, stream))) return rc;
     }
     return PNR_OK;

@@ -313,3 +313,25 @@ def test_f16_activations_saturate_instead_of_overflowing(ops, dev):
     g = load_golden("stages")
     out = ops.eval_points(sc, pk, torch.from_numpy(g["sn64_xyz"]).to(dev), torch.from_numpy(g["sn64_viewdirs"]).to(dev))
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("fold", [False, True])
+def test_fine_pass_on_the_coarse_network_reuses_coarse_outputs(ops, dev, fold):
+    """mlp_fine is None (eval/eval.py:140, models.py:242): the fine pass runs the coarse network; render_forward then
+    evaluates only the new samples and merges.  Must be bit-identical to passing the same network explicitly as the
+    fine one (which evaluates all Kc+Kf samples)."""
+    from pixelnerf_amd import synthetic
+    s, meta = scene_for("mv_mini")
+    sc = dscene(ops, dev, "mv_mini")
+    state = {k: v.to(dev) for k, v in mlp_params(11).items()}
+    pk = ops.pack_mlp(state, "f16", folded=fold)
+    tab = ops.fold_latent(sc, state, "f16") if fold else None
+    rays = synthetic.target_rays(meta, n_rays=100).reshape(-1, 8).to(dev)
+    R = rays.shape[0]
+    noise = {k: v.to(dev) for k, v in synthetic.make_noise(R, 24, 40, 8, seed=2).items()}
+    kw = dict(white_bkgd=True, want_weights=True)
+    a = ops.render_forward(sc, pk, None, rays, 24, 40, 8, noise, tables=None if tab is None else (tab, None), **kw)
+    b = ops.render_forward(sc, pk, pk, rays, 24, 40, 8, noise, tables=None if tab is None else (tab, tab), **kw)
+    for p in ("coarse", "fine"):
+        for k in ("rgb", "depth", "weights"):
+            assert torch.equal(a[p][k], b[p][k]), (p, k)

@@ -49,7 +49,8 @@ def test_host_only_entry_points(lib):
     assert lib.pnr_storage_perm(perm) == 0 and sorted(perm) == list(range(512)) and perm[16] == 4 and perm[1] == 1
     r, kc, kf = 100, 64, 128
     fl = lambda n: (n + 63) // 64 * 64
-    expect = 4 * (fl(r * kc) + fl(r * kc * 4) + fl(r * kc) + fl(r * (kc + kf)) + fl(r * (kc + kf) * 4))
+    expect = 4 * (fl(r * kc) + fl(r * kc * 4) + fl(r * kc) + fl(r * (kc + kf)) + fl(r * (kc + kf) * 4)
+                  + fl(r * kf) + fl(r * kf * 4) + fl(r * (kc + kf)))  # + new samples / their outputs / ranks (coarse-network reuse)
     assert lib.pnr_render_workspace_bytes(r, kc, kf) == expect
 
 
