@@ -220,9 +220,11 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b
     if (with_z) {
         if constexpr (FOLD) {  // lin_z[b+1](z) = bilinear lookup in table b+1 (LDS_Z is free: its last readers ran before fc_0)
             PNR_T(PH_GEMM_FC1_Z);
+#ifndef PNR_EXP_NO_LOOKUP12  // experiment: upper bound of hiding the block-1/2 lookups entirely (wrong results)
             gather_table<P, 2>(q, smem, wv, lane, b + 1);  // the residual stream is live here: smaller batches
             __syncthreads();
             add_from_z<P>(x, smem, a_wr - LDS_A + LDS_Z);
+#endif
             PNR_T(PH_TABLE);
         } else {
             gemm<P, ADV>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);
