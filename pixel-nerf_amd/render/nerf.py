@@ -156,11 +156,14 @@ class NeRFRenderer(torch.nn.Module):
                 from ..autograd import render_autograd
                 res = render_autograd(self, model, rays, noise, want_weights)
             else:
+                # mlp_fine is None (eval/eval.py:140): pass no fine network, so the fine pass re-uses the coarse pass's
+                # outputs at the shared sample positions instead of evaluating them again
+                own_fine = Kf > 0 and getattr(model, "mlp_fine", None) is not None
                 tc = model.tables(True)
-                res = ops.render_forward(model.scene(), model.packed(True), model.packed(False) if Kf > 0 else None,
+                res = ops.render_forward(model.scene(), model.packed(True), model.packed(False) if own_fine else None,
                                          rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
                                          white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights,
-                                         tables=None if tc is None else (tc, model.tables(False) if Kf > 0 else None))
+                                         tables=None if tc is None else (tc, model.tables(False) if own_fine else None))
             outputs = DotMap(coarse=self._format(res["coarse"], SB, want_weights))
             if Kf > 0:
                 outputs.fine = self._format(res["fine"], SB, want_weights)
