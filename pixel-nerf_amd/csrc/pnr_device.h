@@ -24,6 +24,7 @@ template <> struct Prec<PNR_PREC_F16> {
     typedef f16x8 T8;
     typedef f16x2 T2;
     static constexpr float kMaxFinite = 65504.f;
+    static constexpr bool kIsF16 = true;
     static __device__ __forceinline__ f32x16 mfma(T8 a, T8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
@@ -33,6 +34,7 @@ template <> struct Prec<PNR_PREC_BF16> {
     typedef bf16x8 T8;
     typedef bf16x2 T2;
     static constexpr float kMaxFinite = 3.3895313892515355e38f;  // largest finite bf16
+    static constexpr bool kIsF16 = false;
     static __device__ __forceinline__ f32x16 mfma(T8 a, T8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
@@ -96,6 +98,18 @@ __device__ __forceinline__ uint32_t pack2(float a, float b, __bf16) {
 template <typename P, bool RELU>
 __device__ __forceinline__ typename P::T8 pack8(float v0, float v1, float v2, float v3, float v4, float v5,
                                                 float v6, float v7) {
+#ifdef PNR_F16_OVFL_RELU  // experiment: MODE.FP16_OVFL clamps overflowing f16 results, relu = v_pk_max_f16 after the convert
+    if constexpr (RELU && P::kIsF16) {
+        const f16x2 z = {(_Float16)0, (_Float16)0};
+        const f16x2 h0 = __builtin_elementwise_max(__builtin_convertvector((f32x2){v0, v1}, f16x2), z);
+        const f16x2 h1 = __builtin_elementwise_max(__builtin_convertvector((f32x2){v2, v3}, f16x2), z);
+        const f16x2 h2 = __builtin_elementwise_max(__builtin_convertvector((f32x2){v4, v5}, f16x2), z);
+        const f16x2 h3 = __builtin_elementwise_max(__builtin_convertvector((f32x2){v6, v7}, f16x2), z);
+        const u32x4 u = {__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1), __builtin_bit_cast(uint32_t, h2),
+                         __builtin_bit_cast(uint32_t, h3)};
+        return __builtin_bit_cast(typename P::T8, u);
+    }
+#endif
     if (RELU) {
         // relu fused with saturation to the operand type's largest finite value: one v_med3_f32 per
         // element, and an fp16 activation can never become inf (65504 for f16; bf16 has fp32's range)

@@ -154,6 +154,24 @@ __device__ __forceinline__ void gather_table(const EvalParams &q, char *smem, in
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
             const int p = wv * (MT / NW) + i + u;
+#ifdef PNR_F16_PK_LOOKUP  // experiment: packed f16 bilinear (v_pk_mul/fma_f16), overflow clamped by MODE.FP16_OVFL
+            if constexpr (P::kIsF16) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f16x2 acc2;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f16x2 wc = {(_Float16)w[u][c], (_Float16)w[u][c]};
+                        const f16x2 vc = {v[u][c][2 * k], v[u][c][2 * k + 1]};
+                        acc2 = c == 0 ? vc * wc : vc * wc + acc2;
+                    }
+                    o[k] = __builtin_bit_cast(uint32_t, acc2);
+                }
+                *reinterpret_cast<u32x4 *>(smem + LDS_Z + p * ROW_ACT + lane * 16) = o;
+                continue;
+            }
+#endif
             float r[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -252,6 +270,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
     const uint32_t a_wr = LDS_A + pl * ROW_ACT + (wv * IT) * 64 + h * 32;
     const float *bias_lane = q.bias + wv * BIAS_FLOATS_PER_WAVE + h * 16;
 
+#if defined(PNR_F16_OVFL_RELU) || defined(PNR_F16_OVFL_MODE)
+    if constexpr (P::kIsF16) __builtin_amdgcn_s_setreg(1473, 1);  // hwreg(HW_REG_MODE, 23, 1): FP16_OVFL
+#endif
     Ring<P> R;
     R.wave_base = q.wstream + (size_t)wv * ((FOLD ? RS_TOTAL_F : RS_TOTAL) * IT * 1024) + lane * 16;
     R.pf_rs = 0;
