@@ -44,7 +44,7 @@ PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0}  # dense MFMA peak, MI355X_MICROAR
 
 
 def build(dev, prec, scene_name="sn64"):
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     from pixelnerf_amd.model import make_model
     from pixelnerf_amd.render import NeRFRenderer
     from pixelnerf_amd.util.conf import default_model_conf
@@ -68,7 +68,7 @@ def build(dev, prec, scene_name="sn64"):
 
 def make_rays(meta, R, rank):
     """R rays: whole 64x64 target views on the sn64 camera circle (different views per rank)."""
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     n_img = (R + meta["W"] * meta["H"] - 1) // (meta["W"] * meta["H"])
     poses = torch.stack([synthetic.pose_spherical(75.0 + 360.0 * (i + rank * n_img) / (n_img * 8 + 1), -20.0,
                                                   meta["radius"]) for i in range(n_img)])
@@ -88,17 +88,34 @@ def cpu_baseline(scene, mlps, rays_sample, noise, threads=None):
     return rays_sample.shape[0] / dt, dt, out
 
 
+KERNEL_SOURCES = ["pnr_mlp.hip", "pnr_device.h", "pnr_layout.h"]
+PMC_PROFILE = os.path.join("profiles", "r02_bench_f16_pmc_eval_kernel.json")
+
+
+def kernel_source_sha16():
+    """Identity of the fused network kernel: hash of the sources it is compiled from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "pixel-nerf_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic_per_launch():
-    """HBM-side bytes per fused-kernel launch from the committed rocprofv3 PMC passes of THIS
-    command (profiles/r01_bench_f16_pmc_eval_kernel.json: separate --pmc runs for FETCH_SIZE and
-    WRITE_SIZE, KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction; average
-    over the coarse and fine launches, like `achieved`).  None when the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_f16_pmc_eval_kernel.json")
+    """HBM-side bytes per fused-kernel launch from the committed rocprofv3 PMC passes of THIS command
+    (tools/collect_pmc.sh: separate --pmc runs for FETCH_SIZE and WRITE_SIZE, KiB units, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 correction; average over the coarse and fine launches, like `achieved`).
+    The profile carries the hash of the kernel sources it was measured on; a profile of a different kernel is
+    refused (-> (None, reason)) instead of silently going stale."""
+    path = os.path.join(ROOT, PMC_PROFILE)
     try:
         d = json.load(open(path))
-        return (2.0 * d["FETCH_SIZE"]["avg_per_launch"] + d["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
     except Exception:
-        return None
+        return None, "no PMC profile committed for this kernel (%s absent)" % PMC_PROFILE
+    if d.get("_kernel_source_sha16") != kernel_source_sha16():
+        return None, "%s was measured on kernel sources %s, this build is %s: refused as stale" % (
+            PMC_PROFILE, d.get("_kernel_source_sha16"), kernel_source_sha16())
+    return (2.0 * d["FETCH_SIZE"]["avg_per_launch"] + d["WRITE_SIZE"]["avg_per_launch"]) * 1024.0, None
 
 
 def eager_gpu_baseline(scene, mlps, rays, dev, n=16384):
@@ -107,7 +124,7 @@ def eager_gpu_baseline(scene, mlps, rays, dev, n=16384):
     and its 50 000-ray eval chunking irrelevant at this size) on THIS GPU through PyTorch-ROCm.
     A reported baseline only -- never part of the product path."""
     from oracle import pnr_oracle as O
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     O.USE_GRID_SAMPLE = True
     sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
     ms = [{k: v.to(dev) for k, v in m.items()} for m in mlps]
@@ -127,6 +144,119 @@ def eager_gpu_baseline(scene, mlps, rays, dev, n=16384):
             "sample": "%d rays, one steady-state call (after a same-shape warm-up), %.2f s" % (r.shape[0], dt)}
 
 
+def extra_render_config(dev, prec, scene_name, n_img, n_oracle=128, n_f32=8192, steps=3):
+    """One of BASELINE configs[2] (srn_car 128x128, 2 views) / configs[3] on one GPU (DTU 400x300, 3 views, 176 MiB
+    grid): rays/s through render_par(rays) at 64+128, PSNR of a ray sample spread over the whole image (border
+    pixels included) vs the CPU oracle and vs the exact-fp32 HIP path.  Untimed extras: not part of `value`."""
+    from oracle import pnr_oracle as O
+    from testdata import synthetic
+    scene, meta, net, renderer, mlps = build(dev, prec, scene_name)
+    NS = scene["NS"]
+    rays1 = synthetic.target_rays(meta).reshape(-1, 8)
+    rays = rays1.repeat(n_img, 1).contiguous().to(dev)
+    R = rays.shape[0]
+    render_par = renderer.bind_parallel(net, None, simple_output=True).eval()
+    with torch.no_grad():
+        render_par(rays[None])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net._tables.clear()  # a freshly encoded scene per step: the lin_z fold is inside the time
+            render_par(rays[None])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        g = torch.Generator().manual_seed(3)
+        n_pix = rays1.shape[0]
+        idx = torch.randperm(n_pix, generator=g)[:n_f32]
+        W = meta["W"]
+        border = torch.cat([torch.arange(0, W, max(W // 16, 1)), n_pix - 1 - torch.arange(0, W, max(W // 16, 1))])  # first / last rows
+        idx[:border.numel()] = border
+        rs = rays1[idx]
+        noise = synthetic.make_noise(rs.shape[0], 64, 128, 16, seed=5)
+        nz = {k: v.to(dev) for k, v in noise.items()}
+        fast = renderer(net, rs.to(dev)[None], _noise=nz)
+        net.precision = "f32"
+        exact = renderer(net, rs.to(dev)[None], _noise=nz)
+        net.precision = prec
+        no = min(n_oracle, rs.shape[0])
+        ref = O.render(scene, mlps[0], mlps[1], rs[None, :no], {k: v[:no] for k, v in noise.items()}, 64, 128, 16,
+                       white_bkgd=meta["white_bkgd"])
+    span = float(meta["z_far"] - meta["z_near"])
+    out = {"workload": "%s %dx%d, %d source views, grid %s, 64+128, %d rays per call" % (
+               scene_name, meta["W"], meta["H"], NS, "x".join(str(v) for v in scene["latent"].shape), R),
+           "rays_per_s": R / dt, "ms_per_call": dt * 1e3,
+           "algorithmic_tflops": R / dt * 256 * (FLOP_PER_POINT_VIEW * NS + FLOP_PER_POINT_POOLED) / 1e12,
+           "psnr_db_vs_cpu_oracle": O.psnr(fast.fine.rgb[0, :no].cpu(), ref["fine"]["rgb"][0]), "oracle_rays": no,
+           "psnr_db_vs_f32_hip": O.psnr(fast.fine.rgb.cpu(), exact.fine.rgb.cpu()), "f32_rays": int(rs.shape[0]),
+           "depth_abs_err_p99_over_span_vs_f32_hip": float(torch.quantile((fast.fine.depth - exact.fine.depth).abs().flatten(), 0.99)) / span}
+    del net, renderer
+    torch.cuda.empty_cache()
+    return out
+
+
+def extra_train_step(dev, prec, steps=20, warmup=8):
+    """BASELINE configs[4]: sn64 training step, 4 objects x 128 rays, 64 coarse + 32 fine (16 depth), ResnetFC d=512,
+    forward + backward (+ Adam) through NeRFRenderer/_RenderWrapper in train mode (train/train.py:199-215)."""
+    from pixelnerf_amd.model import make_model
+    from pixelnerf_amd.render import NeRFRenderer
+    from pixelnerf_amd.util import DotMap
+    from pixelnerf_amd.util.conf import default_model_conf
+    from testdata import synthetic
+    scene, meta = synthetic.make_scene("train")
+    rays = synthetic.target_rays(meta, n_rays=128).to(dev)  # (4,128,8)
+    gt = torch.rand(4, 128, 3, device=dev)
+    net = make_model(default_model_conf(), precision=prec).to(dev).train()
+    net.mlp_coarse.load_state_dict(synthetic.make_mlp_params(11))
+    net.mlp_fine.load_state_dict(synthetic.make_mlp_params(12))
+    lat = scene["latent"].to(dev).clone().requires_grad_(True)
+    net.encoder.latent = lat
+    ls = torch.tensor([32.0, 32.0], device=dev)
+    net.encoder.latent_scaling = ls / (ls - 1) * 2.0
+    net.poses, net.image_shape = scene["poses"].to(dev), scene["image_shape"].to(dev)
+    net.focal, net.c = scene["focal"].to(dev), scene["c"].to(dev)
+    net.num_objs, net.num_views_per_obj = scene["SB"], scene["NS"]
+    rend = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).to(dev)
+    render_par = rend.bind_parallel(net, None, simple_output=False).train()
+    opt = torch.optim.Adam(list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters()), lr=1e-4)
+
+    def step():
+        rd = DotMap(render_par(rays, want_weights=True))
+        loss = ((rd.coarse.rgb - gt) ** 2).mean() + ((rd.fine.rgb - gt) ** 2).mean()
+        opt.zero_grad(set_to_none=True)
+        lat.grad = None
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": "sn64 training step: 4 objects x 128 rays, 64+32 (16 depth) samples, fwd+bwd+Adam, grads to both "
+                        "ResnetFCs and encoder.latent", "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "rays_per_s": 512 / dt,
+            "algorithmic_tflops": 512 / dt * 3.29e9 / 1e12, "loss": float(loss.item()), "steps": steps}
+
+
+def self_launch(n):
+    """Re-run this script under torch.distributed.run with n ranks on this node (replaces the reference's
+    single-process DataParallel seam, src/render/nerf.py:367-371)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,15 +270,17 @@ def main():
     ap.add_argument("--no-f32-check", action="store_true")
     ap.add_argument("--no-fold", action="store_true", help="run the lin_z GEMMs per sample instead of folding them into the grid")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: functional test on one GPU)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed BASELINE configs 3/4/5 section (extra.configs)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, RCCL), exactly the
+        # command the driver would have used; rank 0 of the child job prints the single JSON line
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
@@ -161,7 +293,8 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from pixelnerf_amd import _lib, ops, synthetic
+    from pixelnerf_amd import _lib, ops
+    from testdata import synthetic
     from pixelnerf_amd.dist import broadcast_encoded
 
     _lib.ensure_built()  # normally a no-op: the .so built by __graft_entry__.build() travels with the tree
@@ -214,6 +347,7 @@ def main():
         rays_per_s = world * R * args.steps / elapsed
         # roofline of the dominant kernel: algorithmic FLOP of rank 0's launches / their HIP-event time
         ach = (R * args.steps * flop_per_ray) / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        traffic, traffic_why = pmc_traffic_per_launch() if (args.prec == "f16" and R == 65536 and net.fold) else (None, "profile is for f16, 65536 rays, folded")
         res = {
             "metric": "rays/sec (64 coarse + 128 fine samples) at matched PSNR vs reference",
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -227,12 +361,13 @@ def main():
                        "lin_z_folded_into_grid": bool(net.fold)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.prec], "unit": "TFLOP/s",
                          "frac": ach / PEAK_TFLOPS[args.prec],
-                         "traffic": pmc_traffic_per_launch() if (args.prec == "f16" and R == 65536) else None,
+                         "traffic": traffic,
                          "traffic_note": "bytes per launch at the L2<->fabric interface (Infinity-Cache hits included): "
-                                         "2*FETCH_SIZE + WRITE_SIZE from profiles/r01_bench_f16_pmc_eval_kernel.json (tools/collect_pmc.sh); "
-                                         "algorithmic HBM bytes per launch are ~0.18 GB (z in, rgb-sigma out, weights+tables once); "
-                                         "the excess is the 5.4 MB weight stream (> 4 MB L2 per XCD) re-fetched from the Infinity Cache "
-                                         "once per tile pass and XCD -- measured to cost < 1 % (profiles/r01_gemm_experiments.md)",
+                                         "2*FETCH_SIZE + WRITE_SIZE from %s (tools/collect_pmc.sh, stamped with the kernel-source "
+                                         "hash %s); algorithmic HBM bytes per launch are ~0.18 GB (z in, rgb-sigma out, weights+tables "
+                                         "once); the excess is the 5.4 MB weight stream (> 4 MB L2 per XCD) re-fetched from the Infinity "
+                                         "Cache once per tile pass and XCD%s" % (PMC_PROFILE, kernel_source_sha16(),
+                                                                                  "" if traffic_why is None else "; NULL because " + traffic_why),
                          "kernel": "pnr::eval_kernel (fused per-point network)", "launches": n_launch,
                          "avg_launch_ms": kern_ms / max(n_launch, 1),
                          "flop_per_ray": flop_per_ray, "kernel_time_frac_of_step": kern_ms * 1e-3 / elapsed,
@@ -290,10 +425,21 @@ def main():
         if world == 1 and not args.no_eager_baseline:
             res["torch_eager_gpu_baseline"] = eager_gpu_baseline(scene, mlps, rays, dev)
             res["speedup_vs_torch_eager_gpu"] = rays_per_s / res["torch_eager_gpu_baseline"]["value"]
+        if world == 1 and not args.no_extras:
+            # BASELINE configs[2..4] on this one GPU, outside the timed region
+            extra = {}
+            for key, fn in (("srn_car", lambda: extra_render_config(dev, args.prec, "srn_car", 4)),
+                            ("dtu", lambda: extra_render_config(dev, args.prec, "dtu", 1)),
+                            ("train_step", lambda: extra_train_step(dev, args.prec))):
+                try:
+                    extra[key] = fn()
+                except Exception as e:  # an extra must never take the headline line down with it
+                    extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            res["extra"] = {"configs": extra}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

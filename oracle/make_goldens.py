@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(HERE, "ref_stubs"))
 sys.path.insert(1, os.path.join(REF, "src"))
 sys.path.insert(2, ROOT)
 
-from pixelnerf_amd import synthetic  # noqa: E402
+from testdata import synthetic  # noqa: E402
 
 # name: (scene, n_coarse, n_fine, n_fine_depth, rays/object, lindisp, use mlp_fine)
 SCENARIOS = {

@@ -112,7 +112,9 @@ class _RenderFunction(torch.autograd.Function):
                                          cfg["depth_std"], cfg["lindisp"], want_ranks=True)
             rgbs_f, dumps_f = ops.eval_ray_samples_train(scene, pf, rays, z_f)
             w_f, rgb_f, depth_f = ops.composite(rays, z_f, rgbs_f, cfg["white_bkgd"], want_weights=True)
-            passes.append(dict(z=z_f, rgbs=rgbs_f, dumps=dumps_f, coarse=False, ranks=ranks, n4=n4, depth_c=depth_c))
+            # depth_c is an OUTPUT of this Function: keeping the tensor itself in ctx would close the cycle
+            # output -> grad_fn -> ctx -> output and pin every dump of the step until the cyclic GC runs
+            passes.append(dict(z=z_f, rgbs=rgbs_f, dumps=dumps_f, coarse=False, ranks=ranks, n4=n4, depth_c=depth_c.detach()))
             outs += [rgb_f, depth_f, w_f]
         ctx.cfg, ctx.rays, ctx.scene, ctx.passes = cfg, rays, scene, passes
         ctx.latent_shape = latent.shape
@@ -161,6 +163,7 @@ class _RenderFunction(torch.autograd.Function):
                 zraw = ps["depth_c"].unsqueeze(1) + ps["n4"] * cfg["depth_std"]
                 live = ((zraw < rays[:, 7:8]) & (zraw > rays[:, 6:7])).float()
                 extra_depth = (dz.gather(1, ps["ranks"].long()) * live).sum(1)
+        ctx.passes = None  # release the 16-bit operand dumps (~12 KB per point and view) as soon as they are used
         out = [None, None, d_lat.permute(0, 3, 1, 2).contiguous() if need_latent else None]
         n_each = len(PARAM_NAMES)
         for slot in range(ctx.n_params // n_each):

@@ -94,11 +94,18 @@ __device__ __forceinline__ uint32_t pack2(float a, float b, __bf16) {
     return __builtin_bit_cast(uint32_t, h);
 }
 
+// MODE.FP16_OVFL = 1 for the rest of the wave's life (hwreg(HW_REG_MODE, 23, 1)): f16 conversions saturate
+template <typename P> __device__ __forceinline__ void f16_ovfl_mode() {
+    if constexpr (P::kIsF16) __builtin_amdgcn_s_setreg(1473, 1);
+}
+
 // 8 fp32 -> 8 x 16-bit, optional relu
 template <typename P, bool RELU>
 __device__ __forceinline__ typename P::T8 pack8(float v0, float v1, float v2, float v3, float v4, float v5,
                                                 float v6, float v7) {
-#ifdef PNR_F16_OVFL_RELU  // experiment: MODE.FP16_OVFL clamps overflowing f16 results, relu = v_pk_max_f16 after the convert
+    // f16: the fused kernels run with MODE.FP16_OVFL set (f16_ovfl_mode()), so v_cvt_pk_f16_f32 clamps an
+    // overflowing result to +-65504 instead of producing inf: relu + saturation = convert, then one v_pk_max_f16
+    // per pair (bit-identical to clamping in fp32 first; 2 VALU per pair instead of 3)
     if constexpr (RELU && P::kIsF16) {
         const f16x2 z = {(_Float16)0, (_Float16)0};
         const f16x2 h0 = __builtin_elementwise_max(__builtin_convertvector((f32x2){v0, v1}, f16x2), z);
@@ -109,7 +116,6 @@ __device__ __forceinline__ typename P::T8 pack8(float v0, float v1, float v2, fl
                          __builtin_bit_cast(uint32_t, h3)};
         return __builtin_bit_cast(typename P::T8, u);
     }
-#endif
     if (RELU) {
         // relu fused with saturation to the operand type's largest finite value: one v_med3_f32 per
         // element, and an fp16 activation can never become inf (65504 for f16; bf16 has fp32's range)
@@ -161,12 +167,14 @@ typedef Advance<0, RS_VIEW_END, RS_TOTAL> AdvanceFwd;
 
 // acc[it][jt] += W-fragments (ring) x B-fragments (LDS rows baddr0/baddr1, 32 B per k-step),
 // nbody*4 k-steps.
-template <typename P, typename ADV = AdvanceFwd>
-__device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT], const char *smem, uint32_t baddr0, uint32_t baddr1,
+template <typename P, typename ADV = AdvanceFwd, int JT_>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT_], const char *smem, uint32_t baddr0, uint32_t baddr1,
                                      int nbody, Ring<P> &R, int NS) {
-    typename P::T8 b[2][JT];
-    b[0][0] = lds8<P>(smem, baddr0);
-    b[0][1] = lds8<P>(smem, baddr1);
+    // column tile jt reads rows baddr0 + jt * (baddr1 - baddr0): 32 point rows further down the image
+    const uint32_t jstride = baddr1 - baddr0;
+    typename P::T8 b[2][JT_];
+#pragma unroll
+    for (int jt = 0; jt < JT_; ++jt) b[0][jt] = lds8<P>(smem, baddr0 + jt * jstride);
 #pragma unroll 1
     for (int body = 0; body < nbody; ++body) {
 
@@ -180,18 +188,19 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT], const char *smem, ui
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cur = j & 1;
-            // intended step order: LDS reads for step+1 | 4 MFMAs of this step | refill this ring
-            // slot (step+4).  hipcc re-orders this (it batches the 8 refills behind the last MFMA
+            // intended step order: LDS reads for step+1 | IT*JT MFMAs of this step | refill this ring
+            // slot (step+4).  hipcc re-orders this (it batches the refills behind the last MFMA
             // of the body); pinning the order with sched_barrier (-DPNR_PIN_SCHEDULE) gives the
             // textbook stream but measured 2-3 % SLOWER (profiles/r01_gemm_experiments.md), so
             // the compiler's schedule is the default.
+#pragma unroll
+            for (int jt = 0; jt < JT_; ++jt) {
 #ifndef PNR_EXP_NO_BLOAD  // experiment: B fragments stay what the first read returned; results are wrong
-            b[cur ^ 1][0] = lds8<P>(smem, baddr0 + (j + 1) * 32);
-            b[cur ^ 1][1] = lds8<P>(smem, baddr1 + (j + 1) * 32);
+                b[cur ^ 1][jt] = lds8<P>(smem, baddr0 + jt * jstride + (j + 1) * 32);
 #else
-            b[cur ^ 1][0] = b[cur][0];
-            b[cur ^ 1][1] = b[cur][1];
+                b[cur ^ 1][jt] = b[cur][jt];
 #endif
+            }
 #ifdef PNR_PIN_SCHEDULE
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -201,7 +210,7 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT], const char *smem, ui
 #pragma unroll
             for (int it = 0; it < IT; ++it)
 #pragma unroll
-                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = P::mfma(a[it], b[cur][jt], acc[it][jt]);
+                for (int jt = 0; jt < JT_; ++jt) acc[it][jt] = P::mfma(a[it], b[cur][jt], acc[it][jt]);
 #ifdef PNR_PIN_SCHEDULE
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -214,7 +223,6 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT], const char *smem, ui
 #endif
         }
         baddr0 += 128;
-        baddr1 += 128;
         ADV::step4(R, NS);
     }
 }
@@ -225,13 +233,13 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT], const char *smem, ui
 // HBM (training: operands of the weight-gradient GEMMs and relu masks of the backward chain);
 // dump_lane = array + ((first row of the tile + p)*512 + 32*wave*IT + 16h) elements, valid[jt]
 // guards rows beyond the last point.
-template <typename P, bool RELU = true, bool DUMP = false>
-__device__ __forceinline__ void write_act(const f32x16 (&acc)[IT][JT], char *smem, uint32_t waddr,
+template <typename P, bool RELU = true, bool DUMP = false, int JT_>
+__device__ __forceinline__ void write_act(const f32x16 (&acc)[IT][JT_], char *smem, uint32_t waddr,
                                           char *dump_lane = nullptr, const bool *valid = nullptr) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
+        for (int jt = 0; jt < JT_; ++jt) {
             const f32x16 &a = acc[it][jt];
             const uint32_t ad = waddr + jt * 32 * ROW_ACT + it * 64;
             const typename P::T8 lo = pack8<P, RELU>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
@@ -248,8 +256,8 @@ __device__ __forceinline__ void write_act(const f32x16 (&acc)[IT][JT], char *sme
         }
 }
 
-template <bool INIT>
-__device__ __forceinline__ void add_bias(f32x16 (&acc)[IT][JT], const float *bias_lane, int slot) {
+template <bool INIT, int JT_>
+__device__ __forceinline__ void add_bias(f32x16 (&acc)[IT][JT_], const float *bias_lane, int slot) {
     // bias_lane = bias + wave*BIAS_FLOATS_PER_WAVE + h*16 ; slot stride NW*BIAS_FLOATS_PER_WAVE
     const float *b = bias_lane + (size_t)slot * (NW * BIAS_FLOATS_PER_WAVE);
 #pragma unroll
@@ -258,7 +266,7 @@ __device__ __forceinline__ void add_bias(f32x16 (&acc)[IT][JT], const float *bia
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const f32x4 *>(b + it * 32 + i * 4);
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
+        for (int jt = 0; jt < JT_; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (INIT) acc[it][jt][r] = q[r >> 2][r & 3];

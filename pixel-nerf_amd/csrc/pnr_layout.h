@@ -109,17 +109,36 @@ constexpr size_t BWSTREAM_ELEMS_PER_WAVE = (size_t)BRS_TOTAL * IT * FRAG_ELEMS;
 constexpr size_t BPACKED_BYTES = BWSTREAM_ELEMS_PER_WAVE * NW * 2;
 constexpr int ROW_GOUT = 48;  // d(lin_out output) operand rows: 16 x 16-bit (4 real) + pad -> 3 slots/row
 
-// ---- LDS map of the fused kernel (bytes) ----
+// ---- LDS map of the fused kernel (bytes), per point-tile size ----
 constexpr int ROW_ACT = D_HID * 2 + 16;      // 1040 B per point row: 1024 B of 16-bit activations + one
                                              // 16-B slot of padding, so the 32 rows a ds_read_b128 touches
                                              // fall on distinct 16-B bank slots (65 slots/row, odd)
 constexpr int ROW_IN = D_IN_PAD * 2 + 16;    // 144 B: 9 slots/row -> conflict-free b128 reads
-constexpr int LDS_Z = 0;                     // latent features of the tile     65 KiB
-constexpr int LDS_A = LDS_Z + MT * ROW_ACT;  // relu(x) / relu(net) operand     65 KiB
-constexpr int LDS_IN = LDS_A + MT * ROW_ACT; // positional code + viewdir       9 KiB
-constexpr int LDS_META = LDS_IN + MT * ROW_IN;      // per point: 4 corner offsets + 4 weights
-constexpr int LDS_OUT = LDS_META + MT * 32;         // lin_out partials [NW][MT][4] floats
-constexpr int LDS_TOTAL = LDS_OUT + NW * MT * 16;   // 152,576 B  (<= 160 KiB)
-static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+// Tile<64>: two images -- Z (interpolated latent / table rows) and A (relu(x) / relu(net) operand) -- as the
+//           unfolded, training and multi-view instantiations need (lin_z reads Z while A is live).
+// Tile<96>: the folded single-view inference tile.  x + net for 96 points are 2 x 96 accumulator registers per
+//           wave (the 256-register budget of 2 waves/SIMD allows no more), and ONE image: the table rows of
+//           lin_z[b+1] are looked up into the activation image after fc_1[b] has finished reading it.  A weight
+//           fragment fetched from L2 now feeds 3 MFMAs instead of 2: the L2->CU stream per point drops by a third.
+template <int MT_> struct Tile {
+    static_assert(MT_ == 64 || MT_ == 96, "supported point tiles");
+    static constexpr int MT = MT_;            // points per tile
+    static constexpr int JT = MT_ / 32;       // MFMA column tiles of 32 points
+    static constexpr bool SINGLE_IMAGE = MT_ > 64;
+    static constexpr int LDS_Z = 0;
+    static constexpr int LDS_A = SINGLE_IMAGE ? 0 : MT_ * ROW_ACT;
+    static constexpr int LDS_IN = LDS_A + MT_ * ROW_ACT;       // positional code + viewdir
+    static constexpr int LDS_META = LDS_IN + MT_ * ROW_IN;     // per point: 4 corner offsets + 4 weights
+    static constexpr int LDS_OUT = LDS_META + MT_ * 32;        // lin_out partials [NW][MT][4] floats
+    static constexpr int LDS_TOTAL = LDS_OUT + NW * MT_ * 16;  // 152,576 B (64) / 129,024 B (96)
+    static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+};
+// the 64-point map under its historical names (backward chain, training instantiation)
+constexpr int LDS_Z = Tile<64>::LDS_Z;
+constexpr int LDS_A = Tile<64>::LDS_A;
+constexpr int LDS_IN = Tile<64>::LDS_IN;
+constexpr int LDS_META = Tile<64>::LDS_META;
+constexpr int LDS_OUT = Tile<64>::LDS_OUT;
+constexpr int LDS_TOTAL = Tile<64>::LDS_TOTAL;
 
 }  // namespace pnr

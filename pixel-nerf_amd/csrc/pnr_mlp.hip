@@ -21,16 +21,24 @@
 #include "pnr_device.h"
 #include "pnr_layout.h"
 
+// table-lookup batch sizes of the 96-point tile (points in flight per wave; 12 points per wave and table)
+#ifndef PNR_GB0
+#define PNR_GB0 6   // tile start: no accumulator is live
+#endif
+#ifndef PNR_GB12
+#define PNR_GB12 4  // inside blocks 0-1: the residual stream is live
+#endif
+
 namespace pnr {
 
 // ---------------------------------------------------------------- feature phase (geometry)
 // Thread (p = tid&63, sub = tid>>6).  Follows the reference op order without FMA contraction
 // so that fp32 intermediates round like the PyTorch eager path.
 #pragma clang fp contract(off)
-template <typename P, bool RAYS>
-__device__ __forceinline__ void geometry(const EvalParams &q, char *smem, int tile, int view, int tid) {
+template <typename P, bool RAYS, typename TL>
+__device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, int tile, int view, int p, int sub) {
     typedef typename P::T T;
-    const int p = tid & 63, sub = tid >> 6;
+    constexpr int MT = TL::MT, LDS_IN = TL::LDS_IN, LDS_META = TL::LDS_META;
     const int g = tile * MT + p;  // P < 2^31 (checked on the host)
     const bool valid = g < (int)q.P;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
@@ -85,9 +93,24 @@ __device__ __forceinline__ void geometry(const EvalParams &q, char *smem, int ti
 }
 #pragma clang fp contract(fast)
 
+// work items (point, sub): sub 0 = identity code + view direction + projection, 1..6 = one frequency band
+// (6 precise sinf), 7 = zero padding.  64-point tile: one item per thread; 96 points: 768 items over 512 threads.
+template <typename P, bool RAYS, typename TL>
+__device__ __forceinline__ void geometry(const EvalParams &q, char *smem, int tile, int view, int tid) {
+    if constexpr (TL::MT == 64) {
+        geometry_item<P, RAYS, TL>(q, smem, tile, view, tid & 63, tid >> 6);
+    } else {
+        // the six frequency bands first; the padding and projection items share the second, half-empty pass
+#pragma unroll 1
+        for (int wi = tid; wi < TL::MT * 8; wi += NTHREADS)
+            geometry_item<P, RAYS, TL>(q, smem, tile, view, wi % TL::MT, (wi / TL::MT + 1) & 7);
+    }
+}
+
 // bilinear lookup: wave handles points wave*8..+7; lane handles channels 8*lane..+7
-template <typename P, bool TRAIN, int GB>
+template <typename P, bool TRAIN, int GB, typename TL>
 __device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, int lane, int tile, int view) {
+    constexpr int MT = TL::MT, LDS_META = TL::LDS_META, LDS_Z = TL::LDS_Z;
     const float *lat = q.latent + lane * 8;
     // GB = points per batch (8 x 16-byte loads in flight per point); 4 when registers allow
     static_assert((MT / NW) % GB == 0, "gather batch");
@@ -135,8 +158,9 @@ __device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, 
 // Folded form (inference): the same bilinear combination over a per-texel TABLE T_b = W_z[b] . grid + b_z[b]
 // (16-bit, hidden features in storage order, pnr_fold_latent) gives lin_z[b](z) directly; the rows go to the
 // LDS_Z image and every lane adds its own slots to the residual stream (add_from_z).
-template <typename P, int GB>
+template <typename P, int GB, typename TL>
 __device__ __forceinline__ void gather_table(const EvalParams &q, char *smem, int wv, int lane, int b) {
+    constexpr int MT = TL::MT, LDS_META = TL::LDS_META, LDS_Z = TL::LDS_Z;
     const typename P::T *tab = reinterpret_cast<const typename P::T *>(q.tables) + (size_t)b * q.table_stride + lane * 8;
     static_assert((MT / NW) % GB == 0, "gather batch");
 #pragma unroll 1
@@ -188,12 +212,12 @@ __device__ __forceinline__ void gather_table(const EvalParams &q, char *smem, in
 }
 
 // x += this lane's slots of the 16-bit rows in the LDS_Z image (storage order = the accumulator map)
-template <typename P>
-__device__ __forceinline__ void add_from_z(f32x16 (&x)[IT][JT], const char *smem, uint32_t z_slot) {
+template <typename P, int JT_>
+__device__ __forceinline__ void add_from_z(f32x16 (&x)[IT][JT_], const char *smem, uint32_t z_slot) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
+        for (int jt = 0; jt < JT_; ++jt) {
             const uint32_t ad = z_slot + jt * 32 * ROW_ACT + it * 64;
             const typename P::T8 lo = *reinterpret_cast<const typename P::T8 *>(smem + ad);
             const typename P::T8 hi = *reinterpret_cast<const typename P::T8 *>(smem + ad + 16);
@@ -207,13 +231,14 @@ __device__ __forceinline__ void add_from_z(f32x16 (&x)[IT][JT], const char *smem
 
 // one residual block (+ the lin_z of the next block when with_z):
 //   net = fc_0(relu(x)); x += fc_1(relu(net)) [+ lin_z[b+1](z)]       resnetfc.py:55-62,174-182
-template <typename P, bool TIMING, bool TRAIN, bool FOLD>
-__device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b, bool with_z, Ring<P> &R,
+template <typename P, bool TIMING, bool TRAIN, bool FOLD, typename TL>
+__device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, int b, bool with_z, Ring<P> &R,
                                           int NS, const float *bias_lane, uint32_t a_rd0, uint32_t a_rd1,
                                           uint32_t z_rd0, uint32_t z_rd1, uint32_t a_wr, int tid,
                                           unsigned long long *tim, unsigned long long &tlast,
                                           const EvalParams &q, size_t dump_off, const bool *valid, int wv, int lane) {
     typedef Advance<0, FOLD ? RS_VIEW_END_F : RS_VIEW_END, FOLD ? RS_TOTAL_F : RS_TOTAL> ADV;
+    constexpr int JT = TL::JT;
     // dump_off: byte offset of this lane's 32-byte slot in a (rows,512) 16-bit dump array
     __syncthreads();  // every wave is done reading LDS_A (previous fc_1)
     PNR_T(PH_BAR1);
@@ -239,9 +264,10 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b
         if constexpr (FOLD) {  // lin_z[b+1](z) = bilinear lookup in table b+1 (LDS_Z is free: its last readers ran before fc_0)
             PNR_T(PH_GEMM_FC1_Z);
 #ifndef PNR_EXP_NO_LOOKUP12  // experiment: upper bound of hiding the block-1/2 lookups entirely (wrong results)
-            gather_table<P, 2>(q, smem, wv, lane, b + 1);  // the residual stream is live here: smaller batches
+            if constexpr (TL::SINGLE_IMAGE) __syncthreads();  // the rows land in the image fc_1 has just been reading
+            gather_table<P, TL::SINGLE_IMAGE ? PNR_GB12 : 2, TL>(q, smem, wv, lane, b + 1);  // the residual stream is live here: smaller batches
             __syncthreads();
-            add_from_z<P>(x, smem, a_wr - LDS_A + LDS_Z);
+            add_from_z<P>(x, smem, a_wr - TL::LDS_A + TL::LDS_Z);
 #endif
             PNR_T(PH_TABLE);
         } else {
@@ -251,11 +277,15 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][JT], char *smem, int b
     PNR_T(PH_GEMM_FC1_Z);
 }
 
-template <int PREC, bool RAYS, bool MV, bool TIMING = false, bool TRAIN = false, bool FOLD = false>
+template <int PREC, bool RAYS, bool MV, bool TIMING = false, bool TRAIN = false, bool FOLD = false, int MT_ = 64>
 __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams q) {
     typedef Prec<PREC> P;
+    typedef Tile<MT_> TL;
     typedef Advance<0, FOLD ? RS_VIEW_END_F : RS_VIEW_END, FOLD ? RS_TOTAL_F : RS_TOTAL> ADV;
+    constexpr int MT = TL::MT, JT = TL::JT;
+    constexpr int LDS_Z = TL::LDS_Z, LDS_A = TL::LDS_A, LDS_IN = TL::LDS_IN, LDS_OUT = TL::LDS_OUT;
     static_assert(!(FOLD && TRAIN), "the training instantiation keeps the lin_z GEMMs (their operands are dumped)");
+    static_assert(!TL::SINGLE_IMAGE || (FOLD && !MV), "the one-image tile is the folded single-view form");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -270,9 +300,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
     const uint32_t a_wr = LDS_A + pl * ROW_ACT + (wv * IT) * 64 + h * 32;
     const float *bias_lane = q.bias + wv * BIAS_FLOATS_PER_WAVE + h * 16;
 
-#if defined(PNR_F16_OVFL_RELU) || defined(PNR_F16_OVFL_MODE)
-    if constexpr (P::kIsF16) __builtin_amdgcn_s_setreg(1473, 1);  // hwreg(HW_REG_MODE, 23, 1): FP16_OVFL
-#endif
+    f16_ovfl_mode<P>();
     Ring<P> R;
     R.wave_base = q.wstream + (size_t)wv * ((FOLD ? RS_TOTAL_F : RS_TOTAL) * IT * 1024) + lane * 16;
     R.pf_rs = 0;
@@ -301,7 +329,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 #ifdef PNR_EXP_NO_FEATURE  // experiment: feature phase only for the first tile (stale LDS afterwards; wrong results)
             if (tile == (int)blockIdx.x) {
 #endif
-            geometry<P, RAYS>(q, smem, tile, view, tid);
+            geometry<P, RAYS, TL>(q, smem, tile, view, tid);
             __syncthreads();
             PNR_T(PH_GEOMETRY);
             if (TRAIN) {  // dump the lin_in operand rows (64 x 128 B) of this tile
@@ -311,8 +339,8 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                     *reinterpret_cast<u32x4 *>(q.d_in + (((long long)view * q.P + g) * D_IN_PAD + chunk * 8) * 2) =
                         *reinterpret_cast<const u32x4 *>(smem + LDS_IN + row * ROW_IN + chunk * 16);
             }
-            if constexpr (FOLD) gather_table<P, MV ? 2 : 4>(q, smem, wv, lane, 0);
-            else gather<P, TRAIN, MV ? 2 : 4>(q, smem, wv, lane, tile, view);  // multi-view also holds the view sum
+            if constexpr (FOLD) gather_table<P, TL::SINGLE_IMAGE ? PNR_GB0 : (MV ? 2 : 4), TL>(q, smem, wv, lane, 0);
+            else gather<P, TRAIN, MV ? 2 : 4, TL>(q, smem, wv, lane, tile, view);  // multi-view also holds the view sum
 #ifdef PNR_EXP_NO_FEATURE
             }
 #endif
@@ -325,7 +353,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             PNR_T(PH_GEMM_IN_Z0);
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b)
-                res_block<P, TIMING, TRAIN, FOLD>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
+                res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
                                                   a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane);
             if constexpr (MV) {
 #pragma unroll
@@ -347,7 +375,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
         }
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b)
-            res_block<P, TIMING, TRAIN, FOLD>(x, smem, b, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr, tid, tim, tlast,
+            res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr, tid, tim, tlast,
                                               q, dump_pooled, valid, wv, lane);
 
         if (q.dbg) {
@@ -421,20 +449,37 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 static bool g_profile = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
 
+static int num_cus();
+
+// tile size by instantiation: the folded single-view inference form runs 96-point tiles (one LDS image), everything
+// else (unfolded, multi-view, training dumps) the 64-point two-image tile
+static inline bool use_tile96(const EvalParams &q, bool mv) {
+#ifdef PNR_FORCE_TILE64
+    return false;
+#else
+    return q.tables && !mv && !q.d_z;
+#endif
+}
+
 template <int PREC, bool RAYS>
-static int launch(const EvalParams &q, bool mv, int grid, hipStream_t st) {
+static int launch(EvalParams &q, bool mv, hipStream_t st) {
     hipError_t e;
     auto k = mv ? eval_kernel<PREC, RAYS, true> : eval_kernel<PREC, RAYS, false>;
+    int mt = 64, lds = Tile<64>::LDS_TOTAL;
     if (RAYS && q.d_z) k = mv ? eval_kernel<PREC, true, true, false, true> : eval_kernel<PREC, true, false, false, true>;
+    else if (use_tile96(q, mv)) { k = eval_kernel<PREC, RAYS, false, false, false, true, 96>; mt = 96; lds = Tile<96>::LDS_TOTAL; }
     else if (q.tables) k = mv ? eval_kernel<PREC, RAYS, true, false, false, true> : eval_kernel<PREC, RAYS, false, false, false, true>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    const long long nt = (q.P + mt - 1) / mt;
+    q.ntiles = (int)nt;
+    const int grid = (int)(nt < num_cus() ? nt : num_cus());
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_kernel)");
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_profile) {
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, st);
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), LDS_TOTAL, st, q);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, q);
     if (g_profile) {
         hipEventRecord(e1, st);
         g_events.emplace_back(e0, e1);
@@ -469,13 +514,13 @@ static int eval_common(const PnrScene *s, const void *packed, int precision, Eva
     q.wstream = (const char *)packed;
     q.bias = (const float *)((const char *)packed + BIAS_OFFSET_BYTES);
     q.bout = (const float *)((const char *)packed + BOUT_OFFSET_BYTES);
-    const long long nt = (q.P + MT - 1) / MT;
-    if (q.P > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_eval: too many points (P must stay below 2^31)");
-    q.ntiles = (int)nt;
-    const int grid = (int)(nt < num_cus() ? nt : num_cus());
+    if (q.P > 0x7fffff80LL) return pnr_fail(PNR_E_INVALID, "pnr_eval: too many points (P must stay below 2^31)");
+    // texel offsets are 32-bit element indices into the grid / the tables (project_point)
+    if ((long long)s->SB * s->NS * s->Hl * s->Wl * C_LAT > 0xffffffffLL)
+        return pnr_fail(PNR_E_INVALID, "pnr_eval: feature grid too large (SB*NS*Hl*Wl*512 must stay below 2^32 elements)");
     const bool mv = s->NS > 1;
-    if (precision == PNR_PREC_F16) return rays ? launch<PNR_PREC_F16, true>(q, mv, grid, st) : launch<PNR_PREC_F16, false>(q, mv, grid, st);
-    if (precision == PNR_PREC_BF16) return rays ? launch<PNR_PREC_BF16, true>(q, mv, grid, st) : launch<PNR_PREC_BF16, false>(q, mv, grid, st);
+    if (precision == PNR_PREC_F16) return rays ? launch<PNR_PREC_F16, true>(q, mv, st) : launch<PNR_PREC_F16, false>(q, mv, st);
+    if (precision == PNR_PREC_BF16) return rays ? launch<PNR_PREC_BF16, true>(q, mv, st) : launch<PNR_PREC_BF16, false>(q, mv, st);
     return pnr_fail(PNR_E_INVALID, "pnr_eval: unknown precision");
 }
 
@@ -496,7 +541,8 @@ extern "C" int pnr_debug_phase_timing(const PnrScene *s, const void *packed, con
     q.wstream = (const char *)packed;
     q.bias = (const float *)((const char *)packed + BIAS_OFFSET_BYTES);
     q.bout = (const float *)((const char *)packed + BOUT_OFFSET_BYTES);
-    q.ntiles = (int)((q.P + MT - 1) / MT);
+    const int mt = tables ? 96 : 64;
+    q.ntiles = (int)((q.P + mt - 1) / mt);
     q.tables = (const char *)tables;  // non-null: folded stream
     q.table_stride = (long long)s->SB * s->NS * s->Hl * s->Wl * C_LAT;
     static float *scratch_out = nullptr;
@@ -507,11 +553,12 @@ extern "C" int pnr_debug_phase_timing(const PnrScene *s, const void *packed, con
         scratch_n = q.P;
     }
     q.out = scratch_out;
-    auto k = tables ? eval_kernel<PNR_PREC_F16, true, false, true, false, true> : eval_kernel<PNR_PREC_F16, true, false, true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    auto k = tables ? eval_kernel<PNR_PREC_F16, true, false, true, false, true, 96> : eval_kernel<PNR_PREC_F16, true, false, true>;
+    const int lds = tables ? Tile<96>::LDS_TOTAL : Tile<64>::LDS_TOTAL;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute");
     const int grid = q.ntiles < num_cus() ? q.ntiles : num_cus();
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), LDS_TOTAL, (hipStream_t)stream, q);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, q);
     return pnr_check_launch("eval_kernel<timing>");
 }
 

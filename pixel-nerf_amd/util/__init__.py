@@ -51,19 +51,36 @@ def coord_to_blender(dtype=torch.float32, device="cpu"):
 
 
 def pose_spherical(theta, phi, radius):
-    """src/util/util.py:309-323."""
-    from ..synthetic import pose_spherical as _ps
-    return _ps(theta, phi, radius)
+    """src/util/util.py:279-323: camera-to-world pose on a sphere (degrees), Blender -> OpenGL axes."""
+    def rot(axis, a):
+        c, s_ = math.cos(a), math.sin(a)
+        m = torch.eye(4)
+        if axis == "phi":
+            m[1, 1], m[1, 2], m[2, 1], m[2, 2] = c, -s_, s_, c
+        else:
+            m[0, 0], m[0, 2], m[2, 0], m[2, 2] = c, -s_, s_, c
+        return m
+    c2w = torch.eye(4)
+    c2w[2, 3] = radius
+    c2w = rot("phi", phi / 180.0 * math.pi) @ c2w
+    c2w = rot("theta", theta / 180.0 * math.pi) @ c2w
+    flip = torch.tensor([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=torch.float32)
+    return flip @ c2w
 
 
 def unproj_map(width, height, f, c=None, device="cpu"):
-    """src/util/util.py:113-143 (host tensors)."""
-    from ..synthetic import unproj_map as _um
+    """src/util/util.py:113-143: unit camera-space ray per pixel (H,W,3), OpenGL convention (x right, y up, -z forward)."""
     if torch.is_tensor(f):
         f = float(f) if f.numel() == 1 else (float(f.flatten()[0]), float(f.flatten()[1]))
     if torch.is_tensor(c):
         c = c.flatten().tolist()
-    return _um(width, height, f, c=c).to(device)
+    if c is None:
+        c = [width * 0.5, height * 0.5]
+    fx, fy = (float(f), float(f)) if isinstance(f, (float, int)) else (float(f[0]), float(f[1]))
+    ys = (torch.arange(height, dtype=torch.float32) - float(c[1])) / fy
+    xs = (torch.arange(width, dtype=torch.float32) - float(c[0])) / fx
+    d = torch.stack((xs[None, :].expand(height, -1), -ys[:, None].expand(-1, width), -torch.ones(height, width)), dim=-1)
+    return (d / torch.norm(d, dim=-1, keepdim=True)).to(device)
 
 
 def gen_rays(poses, width, height, focal, z_near, z_far, c=None, ndc=False):
@@ -80,5 +97,9 @@ def gen_rays(poses, width, height, focal, z_near, z_far, c=None, ndc=False):
     if poses.is_cuda:
         from .. import ops
         return ops.gen_rays(poses, width, height, focal, z_near, z_far, c=c)
-    from ..synthetic import gen_rays as _gr
-    return _gr(poses, width, height, focal, z_near, z_far, c=c)
+    B = poses.shape[0]
+    dirs = unproj_map(width, height, focal, c=c)[None].expand(B, -1, -1, -1)
+    centers = poses[:, None, None, :3, 3].expand(-1, height, width, -1)
+    raydir = torch.matmul(poses[:, None, None, :3, :3], dirs.unsqueeze(-1))[..., 0]
+    nf = torch.tensor([float(z_near), float(z_far)]).expand(B, height, width, 2)
+    return torch.cat((centers, raydir, nf), dim=-1)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import torch
 
-from pixelnerf_amd import synthetic
+from testdata import synthetic
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

@@ -137,7 +137,7 @@ def test_net_forward_and_stage_methods(dev):
 def test_encode_then_render_and_cache_invalidation(dev):
     """encode() with the plain-torch ResNet-34 trunk (random init) feeds the HIP path; the
     device scene and the packed weights are rebuilt when their sources change."""
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     from pixelnerf_amd.model import make_model
     from pixelnerf_amd.render import NeRFRenderer
     from pixelnerf_amd.util.conf import Conf, default_model_conf

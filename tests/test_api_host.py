@@ -66,7 +66,7 @@ def test_positional_encoding_module_matches_golden():
 def test_encode_state_conventions(net):
     """encode() leaves the reference's buffers (models.py:111-141); checked against the oracle's
     synthetic encode_state on CPU (the encoder trunk itself is plain PyTorch)."""
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     n2 = make_model(default_model_conf()).eval()
     src = torch.stack([synthetic.pose_spherical(30.0, -20.0, 2.7), synthetic.pose_spherical(80.0, -10.0, 2.7)])
     imgs = torch.rand(1, 2, 3, 64, 64) * 2 - 1

@@ -177,7 +177,8 @@ def test_latent_scatter_matches_autograd(dev, Hl, Wl):
     """d(interpolated latent) -> d(feature grid) for SB=2 x NS=2, against autograd through the oracle's lookup
     (encoder.py:80-109).  fp32 on both sides; atomics reorder sums: 1e-5 relative."""
     from helpers import scene_for
-    from pixelnerf_amd import ops, synthetic
+    from pixelnerf_amd import ops
+    from testdata import synthetic
     scene, meta = scene_for("mv_mini")
     scene = dict(scene)
     gen = torch.Generator().manual_seed(21)
@@ -312,7 +313,7 @@ def test_hip_gradients_match_reference_autograd_goldens(dev, name):
     relative L2 on its frozen subsample and within 3e-2 on its norm (f16 operands, fp32 accumulation)."""
     import gpu_grad_check
     from helpers import load_golden
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     gg = load_golden("gradients")
     g, scene, meta, mc, mf, rays, noise = golden_setup(name)
     Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])

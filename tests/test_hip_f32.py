@@ -108,7 +108,7 @@ def test_f32_chunking_is_invisible(ops, dev, monkeypatch):
 def test_fused_kernel_against_f32_path_at_full_size(ops, dev, prec, floor_db):
     """The shipped eval configuration (SRN 128x128 view, 64 + 128 samples, 16 of them depth samples) on
     16384 rays: the 16-bit fused kernel vs the exact-fp32 path, both on the GPU."""
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     s, meta = scene_for("srn_car")
     sc = dscene(ops, dev, "srn_car")
     rays = synthetic.target_rays(meta, n_rays=16384).reshape(-1, 8).to(dev)

@@ -100,7 +100,7 @@ def test_folded_render_forward_matches_reference(ops, dev, name, prec):
 def test_folded_and_unfolded_agree_and_variants_match(ops, dev):
     """Same network, both forms, 64x64 view at 64 samples: per-point outputs within the f16 band of each other;
     ray-sample and explicit-point variants of the folded kernel agree bitwise; deterministic."""
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     s, meta = scene_for("sn64")
     sc = dscene(ops, dev, "sn64")
     state = {k: v.to(dev) for k, v in mlp_params(11).items()}

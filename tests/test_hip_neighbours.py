@@ -13,7 +13,7 @@ import torch
 
 from helpers import golden_setup, load_golden, mlp_params, scene_for
 from oracle import pnr_oracle as O
-from pixelnerf_amd import synthetic
+from testdata import synthetic
 
 pytestmark = pytest.mark.gpu
 

@@ -111,7 +111,7 @@ def test_sample_fine_matches_reference(ops, dev, name):
 
 
 def test_gen_rays_matches_reference_formula(ops, dev):
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     for name in ("sn64", "dtu_mini"):
         _, meta = scene_for(name)
         poses = torch.stack([meta["pre"] @ synthetic.pose_spherical(t, -20.0, meta["radius"]) for t in (10.0, 75.0)])
@@ -215,7 +215,7 @@ def test_render_is_deterministic_and_chunk_invariant(ops, dev):
 
 def test_full_size_properties(ops, dev):
     """BASELINE config (2) at full size (64x64 image, 64+128): size-independent properties."""
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     scene, meta = scene_for("sn64")
     sc = dscene(ops, dev, "sn64")
     pc, pf = packed(ops, dev, 11, "f16"), packed(ops, dev, 12, "f16")
@@ -256,7 +256,7 @@ def test_empty_and_ragged_inputs(ops, dev):
     assert out["coarse"]["rgb"].shape == (0, 3)
     # ragged: 5 rays x 7 samples = 35 points (partial tile), and 3 rays x 50 (tiles straddle rays)
     scene, meta = scene_for("sn64")
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     rays_all = synthetic.target_rays(meta).reshape(-1, 8)
     for R, K in ((5, 7), (3, 50), (1, 1)):
         r = rays_all[100:100 + R].contiguous()
@@ -271,7 +271,7 @@ def test_empty_and_ragged_inputs(ops, dev):
 def test_object_boundary_inside_a_tile(ops, dev, prec):
     """SB=2 x NS=2 with 5 rays x 7 samples per object: 35 points per object, so the object (pose /
     feature-grid) switch happens in the middle of the first 64-point tile, for both variants."""
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     scene, meta = scene_for("mv_mini")
     sc = dscene(ops, dev, "mv_mini")
     pk = packed(ops, dev, 12, prec)
@@ -320,7 +320,7 @@ def test_fine_pass_on_the_coarse_network_reuses_coarse_outputs(ops, dev, fold):
     """mlp_fine is None (eval/eval.py:140, models.py:242): the fine pass runs the coarse network; render_forward then
     evaluates only the new samples and merges.  Must be bit-identical to passing the same network explicitly as the
     fine one (which evaluates all Kc+Kf samples)."""
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     s, meta = scene_for("mv_mini")
     sc = dscene(ops, dev, "mv_mini")
     state = {k: v.to(dev) for k, v in mlp_params(11).items()}

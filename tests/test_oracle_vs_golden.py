@@ -119,7 +119,7 @@ def test_render_end_to_end_matches_reference(name):
 def test_encoder_format_matches_reference(name):
     """Restated encoder output formatting vs SpatialEncoder.forward of the reference run on the same
     seeded stage tensors (oracle/make_goldens.py::neighbour_goldens)."""
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     g = load_golden("neighbours")
     lat, scaling = O.encoder_format(synthetic.pyramid_stages(name))
     np.testing.assert_array_equal(lat.numpy(), g[f"pyr_{name}_latent"])
@@ -127,7 +127,7 @@ def test_encoder_format_matches_reference(name):
 
 
 def test_gen_rays_restatement_matches_reference():
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     g = load_golden("neighbours")
     rays = synthetic.gen_rays(torch.from_numpy(g["rays_poses"]), 20, 15, torch.from_numpy(g["rays_focal"]), 0.8, 1.8,
                               c=torch.from_numpy(g["rays_c"]))
@@ -158,7 +158,7 @@ def test_oracle_autograd_matches_reference_autograd(name):
     per-tensor L2 norm + seeded subsample of every ResnetFC gradient of both networks and of encoder.latent,
     including the position gradient through the depth samples, nerf.py:292).  fp32 on both sides, different
     summation orders: norms within 1e-4, subsamples within 1e-3 relative (measured 1e-6 / 2e-4)."""
-    from pixelnerf_amd import synthetic
+    from testdata import synthetic
     gg = load_golden("gradients")
     g, scene, meta, mc, mf, rays, noise = golden_setup(name)
     Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])

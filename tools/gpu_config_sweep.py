@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from oracle import pnr_oracle as O  # noqa: E402
-from pixelnerf_amd import synthetic  # noqa: E402
+from testdata import synthetic  # noqa: E402
 
 FLOP_V, FLOP_P = 4.7616e6, 2.1012e6
 

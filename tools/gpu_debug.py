@@ -13,7 +13,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import pnr_oracle as O  # noqa: E402
-from pixelnerf_amd import ops, synthetic  # noqa: E402
+from pixelnerf_amd import ops  # noqa: E402
+from testdata import synthetic  # noqa: E402
 
 
 def staged_params(full, stage):

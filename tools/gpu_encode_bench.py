@@ -9,7 +9,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pixelnerf_amd import ops, synthetic  # noqa: E402
+from pixelnerf_amd import ops  # noqa: E402
+from testdata import synthetic  # noqa: E402
 
 
 def timeit(fn, n=20):

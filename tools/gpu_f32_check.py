@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import RENDER_SCENARIOS, golden_setup, load_golden, mlp_params, scene_for  # noqa: E402
-from pixelnerf_amd import ops, synthetic  # noqa: E402
+from pixelnerf_amd import ops  # noqa: E402
+from testdata import synthetic  # noqa: E402
 
 
 def dscene(name, dev):

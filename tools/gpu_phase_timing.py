@@ -3,7 +3,8 @@
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pixelnerf_amd import ops, synthetic
+from pixelnerf_amd import ops
+from testdata import synthetic
 
 dev = torch.device("cuda:0")
 scene, meta = synthetic.make_scene("sn64")
@@ -18,9 +19,10 @@ tab = ops.fold_latent(sc, state, "f16") if fold else None
 print("folded stream" if fold else "full stream (--no-fold)")
 for it in range(2):
     t = ops.debug_phase_timing(sc, pk, rays, z, tables=tab)
-ntile = (R * K // 64 + 255) // 256
+MT = int(os.environ.get('PNR_TILE', '64'))
+ntile = ((R * K + MT - 1) // MT + 255) // 256
 tot = [sum(v[w] for v in t.values()) for w in range(8)]
-print(f"tiles by WG0: {ntile}; per-tile ticks per wave: " + " ".join(f"{x/ntile:8.0f}" for x in tot))
+print(f"tile {MT} pts; tiles by WG0: {ntile}; per-tile ticks per wave: " + " ".join(f"{x/ntile:8.0f}" for x in tot))
 print("phase          " + " ".join(f"   wave{w}" for w in range(8)) + "   (ticks per tile)")
 for k, v in t.items():
     print(f"  {k:12s} " + " ".join(f"{x/ntile:8.0f}" for x in v))

@@ -8,12 +8,16 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pixelnerf_amd import ops, synthetic  # noqa: E402
+from pixelnerf_amd import ops  # noqa: E402
+from testdata import synthetic  # noqa: E402
 
 
 def main():
     dev = torch.device("cuda:0")
-    for scene_name, R, K in (("sn64", 16384, 64), ("sn64", 16384, 192), ("srn_car", 8192, 192)):
+    cases = (("sn64", 16384, 64), ("sn64", 16384, 192), ("srn_car", 8192, 192))
+    if "--sn64" in sys.argv:
+        cases = (("sn64", 16384, 64), ("sn64", 16384, 192))
+    for scene_name, R, K in cases:
         scene, meta = synthetic.make_scene(scene_name)
         NS = scene["NS"]
         sc = ops.make_scene(scene["latent"].to(dev), scene["poses"].to(dev), scene["focal"].to(dev),
@@ -23,7 +27,10 @@ def main():
         u = torch.rand(R, K, device=dev)
         z = ops.sample_coarse(rays, u)
         z, _ = torch.sort(z, dim=-1)
-        for prec, fold in (("f16", False), ("f16", True), ("bf16", False), ("bf16", True)):
+        combos = (("f16", False), ("f16", True), ("bf16", False), ("bf16", True))
+        if "--fold-only" in sys.argv:
+            combos = (("f16", True), ("bf16", True)) if "--bf16" in sys.argv else (("f16", True),)
+        for prec, fold in combos:
             state = {k: v.to(dev) for k, v in synthetic.make_mlp_params(11).items()}
             pk = ops.pack_mlp(state, prec, folded=fold)
             tab = ops.fold_latent(sc, state, prec) if fold else None

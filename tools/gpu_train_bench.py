@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pixelnerf_amd import synthetic  # noqa: E402
+from testdata import synthetic  # noqa: E402
 from pixelnerf_amd.model import make_model  # noqa: E402
 from pixelnerf_amd.render import NeRFRenderer  # noqa: E402
 from pixelnerf_amd.util import DotMap  # noqa: E402

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Print per-kernel register / scratch / LDS usage of a gfx950 code object or a built library.
+
+    python tools/kernel_regs.py [path/to/lib.so | file.s] [--filter eval_kernel]
+
+For a .so the embedded gfx950 code object is extracted with clang-offload-bundler; metadata is read
+with llvm-readelf --notes (the .amdgpu_metadata YAML).  Used to check that a kernel instantiation has
+.vgpr_spill_count 0 / .private_segment_fixed_size 0 (VERDICT r01 "What's weak" #6)."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+KEYS = [".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr_spill_count",
+        ".private_segment_fixed_size", ".group_segment_fixed_size"]
+
+
+def demangle(names):
+    out = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
+    return [o.strip() for o in out if o.strip()]
+
+
+def kernels_from_text(txt):
+    res = []
+    cur = None
+    for line in txt.splitlines():
+        m = re.match(r"\s*-?\s*(\.[a-z_]+):\s*(.*)$", line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2).strip().strip("'\"")
+        if k == ".name" and (v.startswith("_Z") or re.match(r"[A-Za-z_]\w*$", v)) and not v.startswith("q"):
+            if cur and ".vgpr_count" in cur:
+                res.append(cur)
+            cur = {".name": v}
+        elif cur is not None and k in KEYS:
+            cur[k] = v
+    if cur and ".vgpr_count" in cur:
+        res.append(cur)
+    return res
+
+
+def read_metadata(path):
+    if path.endswith(".s"):
+        return open(path).read()
+    data = open(path, "rb").read()
+    with tempfile.TemporaryDirectory() as td:
+        co = path
+        if b"__CLANG_OFFLOAD_BUNDLE__" in data:
+            co = os.path.join(td, "gfx950.co")
+            # the fat binary lives in the .hip_fatbin section of the host ELF
+            fb = os.path.join(td, "fatbin")
+            subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fb}", path],
+                           check=False, capture_output=True)
+            src = fb if os.path.exists(fb) else path
+            subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--unbundle",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={src}", f"--output={co}"],
+                           check=True, capture_output=True)
+        return subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    flt = None
+    if "--filter" in sys.argv:
+        flt = sys.argv[sys.argv.index("--filter") + 1]
+        args = [a for a in args if a != flt]
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = args[0] if args else os.path.join(here, "pixel-nerf_amd", "csrc", "libpixelnerf_hip.so")
+    ks = kernels_from_text(read_metadata(path))
+    names = demangle([k[".name"] for k in ks])
+    print("%5s %5s %5s %6s %8s %8s  kernel" % ("vgpr", "agpr", "sgpr", "spill", "scratch", "lds"))
+    for k, n in zip(ks, names):
+        n = re.sub(r"\(pnr\w*::EvalParams\)|\(.*\)$", "", n)
+        if flt and flt not in n:
+            continue
+        print("%5s %5s %5s %6s %8s %8s  %s" % (k.get(".vgpr_count"), k.get(".agpr_count", "0"), k.get(".sgpr_count"),
+                                              k.get(".vgpr_spill_count"), k.get(".private_segment_fixed_size"),
+                                              k.get(".group_segment_fixed_size"), n))
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,9 @@ def main():
     if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
         der["lds_bank_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
     res["_kernel"], res["_derived"] = kern, der
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res["_kernel_source_sha16"] = bench.kernel_source_sha16()  # bench.py refuses this profile once the kernel sources change
     res["_note"] = ("fused network kernel launches of `%s`; one rocprofv3 --pmc pass per counter group; FETCH_SIZE/WRITE_SIZE in KiB, "
                     "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)" % cmd)
     json.dump(res, open(os.path.join(out_dir, "pmc_eval_kernel.json"), "w"), indent=1)

@@ -22,7 +22,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from pixelnerf_amd import synthetic  # noqa: E402
+from testdata import synthetic  # noqa: E402
 from pixelnerf_amd.dist import broadcast_encoded  # noqa: E402
 
 
