@@ -288,6 +288,9 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.backend == "nccl" and torch.cuda.device_count() < world:
+            raise SystemExit("bench.py --gpus %d: RCCL needs one device per rank and this node has %d (use --backend gloo "
+                             "for a functional run on fewer devices)" % (world, torch.cuda.device_count()))
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -300,6 +303,7 @@ def main():
     _lib.ensure_built()  # normally a no-op: the .so built by __graft_entry__.build() travels with the tree
     scene, meta, net, renderer, mlps = build(dev, args.prec)
     net.fold = not args.no_fold
+    lat_shape = tuple(scene["latent"].shape)
     R = args.rays
     rays = make_rays(meta, R, rank).to(dev)
     render_par = renderer.bind_parallel(net, None, simple_output=True).eval()
@@ -309,7 +313,7 @@ def main():
         # (PixelNeRFNet.tables -> pnr_fold_latent, both networks) is redone INSIDE the timed step
         net._tables.clear()
         if world > 1:
-            broadcast_encoded(net, src=0)  # the single feature-grid broadcast (2 MiB for sn64)
+            broadcast_encoded(net, src=0, latent_shape=lat_shape)  # THE single feature-grid broadcast (2 MiB for sn64)
         with torch.no_grad():
             rgb, depth = render_par(rays[None])
         if world > 1:

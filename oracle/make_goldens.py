@@ -41,6 +41,16 @@ SCENARIOS = {
     "mv_mini_lindisp": ("mv_mini", 32, 16, 0, 32, True, True),   # SB=2 x NS=2, lindisp, Kfd=0
     "sn64_coarse_only_mlp": ("sn64", 16, 16, 16, 32, False, False),  # mlp_fine=None, Kf-Kfd=0
 }
+# adversarial scenarios: surface-like density (synthetic.surface_variant: sigma ~0 off a thin shell,
+# 50..300 on it -> peaked coarse weights), importance draw u2 = 1 - 2^-24 on column 0 of every 4th ray (searchsorted past the last cdf
+# entry whenever cdf[-1] rounds below 1: ind == Kc, a fine sample beyond `far`, negative last delta, nerf.py:138-141,181)
+ADVERSARIAL = {
+    "adv_surface_sn64":   ("sn64", 64, 128, 16, 96, False, True, dict(gain=100.0, tau=4.3)),
+    "adv_surface_srn":    ("srn_mini", 64, 128, 16, 64, False, True, dict(gain=100.0, tau=3.9)),
+    "adv_surface_dtu":    ("dtu_mini", 64, 128, 16, 64, False, True, dict(gain=100.0, tau=3.9)),
+    "adv_surface_coarse_net": ("sn64", 64, 128, 16, 64, False, False, dict(gain=100.0, tau=4.3)),  # mlp_fine=None re-use path
+}
+SCENARIOS.update({k: v[:7] for k, v in ADVERSARIAL.items()})
 MLP_SEED_COARSE, MLP_SEED_FINE, SCENE_SEED = 11, 12, 2
 
 
@@ -96,13 +106,17 @@ class _TorchProxy:
         return self._pop("randn_like", t.shape)
 
 
-def build_reference_net(use_fine):
+def build_reference_net(use_fine, surface=None):
     import model as ref_model
 
+    def params(seed):
+        p = synthetic.make_mlp_params(seed)
+        return p if surface is None else synthetic.surface_variant(p, surface["gain"], surface["tau"])
+
     net = ref_model.make_model(model_conf())
-    net.mlp_coarse.load_state_dict(synthetic.make_mlp_params(MLP_SEED_COARSE))
+    net.mlp_coarse.load_state_dict(params(MLP_SEED_COARSE))
     if use_fine:
-        net.mlp_fine.load_state_dict(synthetic.make_mlp_params(MLP_SEED_FINE))
+        net.mlp_fine.load_state_dict(params(MLP_SEED_FINE))
     else:
         net.mlp_fine = None  # eval/eval.py:140
     return net.eval()
@@ -131,6 +145,9 @@ def run_scenario(name):
     SB = rays.shape[0]
     R = SB * n_rays
     noise = synthetic.make_noise(R, Kc, Kf, Kfd)
+    surface = ADVERSARIAL[name][7] if name in ADVERSARIAL else None
+    if surface is not None and "u2" in noise:
+        noise["u2"][::4, 0] = float(np.float32(1.0) - np.float32(2.0 ** -24))  # every 4th ray: the largest uniform draw
 
     queue = [("rand_like", noise["u1"])]
     if Kf > 0:
@@ -139,7 +156,7 @@ def run_scenario(name):
         if Kfd > 0:
             queue += [("randn_like", noise["n4"])]
 
-    net = build_reference_net(use_fine)
+    net = build_reference_net(use_fine, surface)
     set_encode_state(net, scene)
     renderer = ref_nerf.NeRFRenderer(
         n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, depth_std=0.01,
@@ -183,6 +200,8 @@ def run_scenario(name):
         mlp_seed_coarse=MLP_SEED_COARSE, mlp_seed_fine=MLP_SEED_FINE, scene_seed=SCENE_SEED,
         rays=rays.numpy(),
     )
+    if surface is not None:
+        rec["sigma_gain"], rec["sigma_tau"] = surface["gain"], surface["tau"]
     for k, v in noise.items():
         rec["noise_" + k] = v.numpy()
     rec["coarse_rgb"] = out.coarse.rgb.numpy()
@@ -236,6 +255,31 @@ def stage_goldens():
         rec[f"{scene_name}_uv"] = uv.numpy()
         rec[f"{scene_name}_index"] = idx.numpy()
     return rec
+
+
+def plane_goldens():
+    """Points ON and BEHIND a source camera's image plane (SURVEY App. A "known sharp edges": no frustum culling,
+    `xc.z == 0` divides by zero, `xc.z > 0` mirrors; models.py:206-212,237-239) through the reference's
+    PixelNeRFNet.forward.  Scene plane_mini: source camera 0 is axis-aligned (world y = 2 is its plane z_cam = 0), so
+    the degenerate coordinates are exact in fp32: u = -x/0 = +-inf (border-clamped by grid_sample), 0/0 = NaN."""
+    rs = np.random.RandomState(5)
+    scene, meta = synthetic.make_scene("plane_mini", seed=SCENE_SEED)
+    net = build_reference_net(True)
+    set_encode_state(net, scene)
+    B = 64
+    xyz = rs.uniform(-1.0, 1.0, (1, B, 3)).astype(np.float32)
+    xyz[0, :16, 1] = 2.0                         # on camera 0's plane: uv = (+-inf, +-inf)
+    xyz[0, 0] = (0.0, 2.0, 0.0)                  # camera 0's centre: 0/0 in both coordinates
+    xyz[0, 1] = (0.3, 2.0, 0.0)                  # u = +inf, v = 0/0
+    xyz[0, 2] = (0.0, 2.0, -0.4)                 # u = 0/0, v = +-inf
+    xyz[0, 16:32, 1] = 2.0 + rs.uniform(0.01, 1.5, 16).astype(np.float32)  # behind camera 0 (mirrored projection)
+    xyz = torch.from_numpy(xyz)
+    vd = torch.from_numpy(rs.randn(1, B, 3).astype(np.float32))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    with torch.no_grad():
+        out_c = net(xyz, coarse=True, viewdirs=vd)
+        out_f = net(xyz, coarse=False, viewdirs=vd)
+    return dict(scene="plane_mini", xyz=xyz.numpy(), viewdirs=vd.numpy(), out_coarse=out_c.numpy(), out_fine=out_f.numpy())
 
 
 class _Const(torch.nn.Module):
@@ -362,14 +406,14 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "neighbours", "gradients", "manifest"])
+    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "adv_plane", "neighbours", "gradients", "manifest"])
     for name in names:
         if name == "manifest":
             path = os.path.join(outdir, "state_dict_manifest.txt")
             open(path, "w").write("\n".join(state_dict_manifest()) + "\n")
             print("wrote", path)
             continue
-        rec = (stage_goldens() if name == "stages" else neighbour_goldens() if name == "neighbours"
+        rec = (stage_goldens() if name == "stages" else neighbour_goldens() if name == "neighbours" else plane_goldens() if name == "adv_plane"
                else gradient_goldens() if name == "gradients" else run_scenario(name))
         path = os.path.join(outdir, name + ".npz")
         np.savez_compressed(path, **rec)

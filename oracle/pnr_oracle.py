@@ -10,7 +10,7 @@ Parity pin: the reference repository ships NO tests / golden vectors for this pa
 (SURVEY.md §4, §8c).  The oracle is therefore pinned against outputs of the reference
 itself: `oracle/make_goldens.py` imports the unmodified reference code from
 /root/reference (through the import stubs in oracle/ref_stubs/), runs it on the seeded
-scenes of `oracle/scenes.py` with pre-drawn noise, and freezes the outputs under
+scenes of `testdata/synthetic.py` with pre-drawn noise, and freezes the outputs under
 tests/golden/*.npz.  tests/test_oracle_vs_golden.py checks this restatement against those
 fixtures to ~1e-6.
 
@@ -81,6 +81,11 @@ def index_latent(latent, uv, image_shape):
     # padding_mode='border': clip coordinates into [0, size-1]
     ix = torch.clamp(ix, 0, Wl - 1)
     iy = torch.clamp(iy, 0, Hl - 1)
+    # a NaN coordinate (0/0: a point at a source camera's centre line, models.py:206-209) comes out of ATen's
+    # clip_coordinates as 0 -- pinned by tests/golden/adv_plane.npz (the reference run on such points): texel 0,
+    # finite output, no NaN propagation.  +-inf (x/0) is ordinary border clamping.
+    ix = torch.where(torch.isnan(ix), torch.zeros_like(ix), ix)
+    iy = torch.where(torch.isnan(iy), torch.zeros_like(iy), iy)
     ix0 = torch.floor(ix)
     iy0 = torch.floor(iy)
     ix1 = ix0 + 1

@@ -8,10 +8,10 @@ independent units, so here:
 
   * weights live on every rank (loaded once);
   * after `net.encode()` on one rank, `broadcast_encoded()` ships the feature grid with ONE
-    collective (+ one tiny metadata message): sn64 2 MiB, srn 16 MiB, DTU 176 MiB;
+    collective (camera metadata rides in front of the grid in the same buffer): sn64 2 MiB, srn 16 MiB, DTU 176 MiB;
   * each rank renders a contiguous slice of the rays on dim 1 (`shard_bounds`), exactly the
     split DataParallel(dim=1) makes;
-  * results come back with one all_gather of (rgb, depth) = 16 B/ray (`ShardedRenderWrapper`).
+  * results come back with ONE all_gather of the packed outputs, (rgb | depth) = 16 B/ray (`ShardedRenderWrapper`).
 
 No collective sits on the per-sample data path.  The sharding helpers are pure index
 arithmetic and are covered by world_size-2 gloo tests on CPU (tests/test_dist_gloo.py).
@@ -27,36 +27,57 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_encoded(net, src=0, group=None):
-    """Make rank `src`'s encode() state current on every rank: one broadcast of the feature grid
-    and one of the packed camera metadata (poses, focal, c, image_shape)."""
+_HDR = 8  # int64 header words, carried as exact small floats in front of the metadata
+
+
+def broadcast_encoded(net, src=0, group=None, latent_shape=None):
+    """Make rank `src`'s encode() state current on every rank with ONE collective when the receivers know the
+    grid shape (`latent_shape=(NV,512,Hl,Wl)`, the normal case: every rank knows the dataset's image size and view
+    count): a single flat broadcast of [header | poses, focal, c, image_shape, latent_scaling | feature grid].
+    Without `latent_shape` a first 8-word broadcast announces the shapes (two collectives in total).  No host
+    synchronisation on the sending side; receivers read the header back only in the shape-discovery form."""
     dev = net.poses.device
-    if dist.get_rank(group) == src:
+    is_src = dist.get_rank(group) == src
+    if is_src:
         lat = net.encoder.latent
-        hdr = torch.tensor([lat.shape[0], lat.shape[1], lat.shape[2], lat.shape[3], net.num_views_per_obj,
-                            net.num_objs, net.focal.shape[0], net.c.shape[0]], dtype=torch.int64, device=dev)
+        shape = tuple(lat.shape)
+        hdr = torch.tensor([shape[0], shape[1], shape[2], shape[3], net.num_views_per_obj, net.num_objs,
+                            net.focal.reshape(-1, 2).shape[0], net.c.reshape(-1, 2).shape[0]], dtype=torch.float32, device=dev)
+    elif latent_shape is None:
+        hdr = torch.zeros(_HDR, dtype=torch.float32, device=dev)
+    if latent_shape is None:
+        dist.broadcast(hdr, src, group=group)
+        NV, C, Hl, Wl, NS, SB, nf, nc = [int(v) for v in hdr.tolist()]
     else:
-        hdr = torch.zeros(8, dtype=torch.int64, device=dev)
-    dist.broadcast(hdr, src, group=group)
-    NV, C, Hl, Wl, NS, SB, nf, nc = [int(v) for v in hdr.tolist()]
-    n_meta = NV * 12 + nf * 2 + nc * 2 + 2 + 2
-    if dist.get_rank(group) == src:
-        meta = torch.cat([net.poses.reshape(-1).float(), net.focal.reshape(-1).float(), net.c.reshape(-1).float(),
-                          net.image_shape.reshape(-1).float(), net.encoder.latent_scaling.reshape(-1).float()])
-        lat = net.encoder.latent.contiguous()
-    else:
-        meta = torch.empty(n_meta, dtype=torch.float32, device=dev)
-        lat = torch.empty((NV, C, Hl, Wl), dtype=torch.float32, device=dev)
-    dist.broadcast(lat, src, group=group)      # THE feature-grid broadcast
-    dist.broadcast(meta, src, group=group)
-    if dist.get_rank(group) != src:
-        o = 0
-        net.encoder.latent = lat
-        net.poses = meta[o:o + NV * 12].reshape(NV, 3, 4).clone(); o += NV * 12
-        net.focal = meta[o:o + nf * 2].reshape(nf, 2).clone(); o += nf * 2
-        net.c = meta[o:o + nc * 2].reshape(nc, 2).clone(); o += nc * 2
-        net.image_shape = meta[o:o + 2].clone(); o += 2
-        net.encoder.latent_scaling = meta[o:o + 2].clone()
+        NV, C, Hl, Wl = [int(v) for v in latent_shape]
+        NS = SB = nf = nc = None
+    # metadata block has a fixed upper bound so that its size does not depend on values only the source knows:
+    # poses NV*12, focal <= NV*2, c <= NV*2, image_shape 2, latent_scaling 2
+    n_meta = _HDR + NV * 12 + NV * 2 + NV * 2 + 4
+    n_lat = NV * C * Hl * Wl
+    buf = torch.empty(n_meta + n_lat, dtype=torch.float32, device=dev)
+    if is_src:
+        if shape != (NV, C, Hl, Wl):
+            raise ValueError(f"broadcast_encoded: latent_shape {latent_shape} does not match the encoded grid {shape}")
+        meta = torch.zeros(n_meta, dtype=torch.float32, device=dev)
+        meta[:_HDR] = hdr
+        parts = [net.poses.reshape(-1).float(), net.focal.reshape(-1).float(), net.c.reshape(-1).float(),
+                 net.image_shape.reshape(-1).float(), net.encoder.latent_scaling.reshape(-1).float()]
+        offs = [_HDR, _HDR + NV * 12, _HDR + NV * 14, _HDR + NV * 16, _HDR + NV * 16 + 2]
+        for o, t in zip(offs, parts):
+            meta[o:o + t.numel()] = t.to(dev)
+        buf[:n_meta] = meta
+        buf[n_meta:] = net.encoder.latent.reshape(-1)
+    dist.broadcast(buf, src, group=group)      # THE feature-grid broadcast (metadata rides in front of it)
+    if not is_src:
+        h = buf[:_HDR].tolist()
+        NS, SB, nf, nc = int(h[4]), int(h[5]), int(h[6]), int(h[7])
+        net.encoder.latent = buf[n_meta:].reshape(NV, C, Hl, Wl)
+        net.poses = buf[_HDR:_HDR + NV * 12].reshape(NV, 3, 4).clone()
+        net.focal = buf[_HDR + NV * 12:_HDR + NV * 12 + nf * 2].reshape(nf, 2).clone()
+        net.c = buf[_HDR + NV * 14:_HDR + NV * 14 + nc * 2].reshape(nc, 2).clone()
+        net.image_shape = buf[_HDR + NV * 16:_HDR + NV * 16 + 2].clone()
+        net.encoder.latent_scaling = buf[_HDR + NV * 16 + 2:_HDR + NV * 16 + 4].clone()
         net.num_views_per_obj, net.num_objs = NS, SB
     return net
 
@@ -76,7 +97,8 @@ def _gather_dim1(t, sizes, group):
 class ShardedRenderWrapper(torch.nn.Module):
     """Callable like the reference's DataParallel(_RenderWrapper, dim=1): every rank passes the
     same rays (SB,B,8); rank r renders rays[:, lo_r:hi_r]; every rank returns the full result
-    (tuple (rgb, depth) for simple_output, else the nested dict)."""
+    (tuple (rgb, depth) for simple_output, else the nested dict).  All outputs of a call travel in ONE
+    all_gather: they are packed along the last axis ((rgb | depth) = 16 B/ray for simple_output)."""
 
     def __init__(self, wrapped, group=None):
         super().__init__()
@@ -84,16 +106,33 @@ class ShardedRenderWrapper(torch.nn.Module):
         self.group = group
 
     def forward(self, rays, want_weights=False):
+        net = getattr(self.wrapped, "net", None)
+        if net is not None and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
+            raise NotImplementedError(
+                "ShardedRenderWrapper is the inference path (no gradient all-reduce): train with one process per GPU "
+                "on its own ray batch and DistributedDataParallel / an explicit all_reduce of the gradients, or wrap "
+                "the call in torch.no_grad()")
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         B = rays.shape[1]
         bounds = [shard_bounds(B, r, world) for r in range(world)]
         sizes = [hi - lo for lo, hi in bounds]
         lo, hi = bounds[rank]
         local = self.wrapped(rays[:, lo:hi].contiguous(), want_weights=want_weights)
-
-        def gather(t):
-            return _gather_dim1(t, sizes, self.group)
-
+        # flatten the outputs to (SB, b, width) columns, pack, gather once, unpack
         if isinstance(local, tuple):
-            return tuple(gather(t) for t in local)
-        return {k: {kk: gather(vv) for kk, vv in v.items()} for k, v in local.items()}
+            leaves = [(None, i, t) for i, t in enumerate(local)]
+        else:
+            leaves = [(k, kk, vv) for k, v in local.items() for kk, vv in v.items()]
+        cols = [t.reshape(t.shape[0], t.shape[1], -1) for _, _, t in leaves]
+        widths = [c.shape[-1] for c in cols]
+        full = _gather_dim1(torch.cat(cols, dim=-1), sizes, self.group)
+        outs, o = [], 0
+        for (_, _, t), w in zip(leaves, widths):
+            outs.append(full[..., o:o + w].reshape((t.shape[0], B) + tuple(t.shape[2:])))
+            o += w
+        if isinstance(local, tuple):
+            return tuple(outs)
+        res = {}
+        for (k, kk, _), v in zip(leaves, outs):
+            res.setdefault(k, {})[kk] = v
+        return res

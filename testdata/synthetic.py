@@ -55,6 +55,18 @@ def make_mlp_params(seed, d_in=42, d_latent=512, d_hidden=512, n_blocks=5, combi
     return p
 
 
+def surface_variant(params, gain, tau):
+    """Surface-like density from a random network (adversarial fixtures): only the sigma row of lin_out is changed,
+    sigma' = relu(gain * (s - tau)) with s the network's own pre-activation density.  With tau near the 90th
+    percentile of s and gain ~100 the density is 0 on ~90 % of the samples and 50..300 on a thin shell, so the coarse
+    weights are PEAKED (a few bins carry everything), the inverse-CDF has long flat stretches and steep steps, and a
+    16-bit error in s is amplified gain-fold right at the shell's edge -- the regime a trained model renders in."""
+    q = {k: v.clone() for k, v in params.items()}
+    q["lin_out.weight"][3] *= gain
+    q["lin_out.bias"][3] = gain * (q["lin_out.bias"][3] - tau)
+    return q
+
+
 # ---------------------------------------------------------------------------- cameras
 
 
@@ -153,6 +165,11 @@ SCENES = {
                   z_near=1.2, z_far=4.0, radius=2.732,
                   src=[(30.0, -20.0), (100.0, -30.0), (200.0, -10.0), (300.0, -25.0)],
                   tgt=(75.0, -20.0), white_bkgd=True, blender=False),
+    # one axis-aligned source camera (pose entries exactly 0 / +-1, so points with camera-space z == 0 can be written
+    # down exactly in fp32) + one ordinary view: the "on / behind the camera plane" fixtures
+    "plane_mini": dict(W=32, H=32, NS=2, SB=1, Hl=16, Wl=16, focal=(59.7, 59.7), c=(16.0, 16.0),
+                       z_near=0.5, z_far=3.5, radius=2.0, src=[(0.0, 0.0), (70.0, -30.0)],
+                       tgt=(75.0, -20.0), white_bkgd=True, blender=False),
     # 2 objects x 2 views: exercises object-major view indexing (row = obj*NS + view)
     "mv_mini": dict(W=32, H=32, NS=2, SB=2, Hl=16, Wl=16, focal=(59.7, 59.7), c=(16.0, 16.0),
                     z_near=1.2, z_far=4.0, radius=2.732,

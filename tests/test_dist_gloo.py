@@ -66,6 +66,23 @@ def _worker(rank, world, port, B):
             enc.latent, enc.latent_scaling = ref["latent"].clone(), ref["ls"].clone()
             net.poses, net.focal, net.c = ref["poses"].clone(), ref["focal"].clone(), ref["c"].clone()
             net.image_shape, net.num_views_per_obj, net.num_objs = ref["image_shape"].clone(), 2, 2
+        calls = {"broadcast": 0, "all_gather": 0}
+        real_b, real_g = dist.broadcast, dist.all_gather
+        dist.broadcast = lambda *a, **k: (calls.__setitem__("broadcast", calls["broadcast"] + 1), real_b(*a, **k))[1]
+        dist.all_gather = lambda *a, **k: (calls.__setitem__("all_gather", calls["all_gather"] + 1), real_g(*a, **k))[1]
+        try:
+            # north_star: ONE broadcast of the encoded grid (receivers know the dataset's grid shape) ...
+            broadcast_encoded(net, src=0, latent_shape=(4, 6, 5, 7))
+            assert calls["broadcast"] == 1, calls
+            # ... and ONE gather of the packed outputs per render call, whatever the output structure
+            ShardedRenderWrapper(FakeWrapped(False))(rays, want_weights=True)
+            assert calls["all_gather"] == 1, calls
+        finally:
+            dist.broadcast, dist.all_gather = real_b, real_g
+        assert torch.equal(enc.latent, ref["latent"]) and torch.equal(net.poses, ref["poses"])
+        assert (net.num_views_per_obj, net.num_objs) == (2, 2)
+        if rank != 0:  # shape-discovery form (header first): wipe and receive again
+            enc.latent, net.poses, net.num_views_per_obj = torch.zeros(1, 1, 1, 1), torch.zeros(1, 3, 4), 1
         broadcast_encoded(net, src=0)
         assert torch.equal(enc.latent, ref["latent"]) and torch.equal(net.poses, ref["poses"])
         assert torch.equal(net.focal, ref["focal"]) and torch.equal(net.c, ref["c"])

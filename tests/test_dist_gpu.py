@@ -72,3 +72,20 @@ def test_sharded_render_matches_single_process():
     mp.spawn(_worker, args=(2, port, q), nprocs=2, join=True)
     res = dict(q.get() for _ in range(2))
     assert res == {0: "ok", 1: "ok"}, res
+
+
+def test_bench_self_launches_two_ranks(repo_root):
+    """`python bench.py --gpus 2` without torch.distributed.run around it (how a driver would call it) spawns its own
+    ranks and prints ONE JSON line with n_gpus = 2.  gloo backend: both ranks share the single device of the test box."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                          "--warmup", "1", "--rays", "8192"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["roofline"]["frac"] > 0

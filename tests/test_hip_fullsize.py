@@ -1,0 +1,112 @@
+"""
+GPU parity tests (-m gpu) at the FULL sizes of BASELINE configs[2] and configs[3] (VERDICT r01 "next" item 1a):
+
+  srn_car : 128x128 target view = 16 384 rays, 2 source views, (2,512,64,64) grid, 64 + 128 samples
+  dtu     : 400x300 target view (120 000 rays), 3 source views, (3,512,150,200) = 176 MiB grid, 64 + 128 samples;
+            8 192 rays spread over the whole image INCLUDING its border rows / columns (which project outside
+            the source views -> border-clamped lookups) -- 32-bit texel offsets close to their limit, the
+            multi-view instantiations, the pooling across 3 views.
+
+Each configuration, 16-bit fused kernel in its folded (default) and unfolded form:
+  * vs the CPU oracle (restatement of the reference, pinned to the reference's own outputs by
+    tests/test_oracle_vs_golden.py) on a 1 024-ray subset, identical rays / weights / grid / noise;
+  * vs the exact-fp32 HIP path (held to 2e-5 of the reference by tests/test_hip_f32.py) on ALL rays of the set.
+Tolerances are the ones of tests/test_hip_parity.py: f16 render PSNR >= 52 dB, depth p99 <= 5e-3 of the z span.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import mlp_params, scene_for
+from oracle import pnr_oracle as O
+from test_hip_parity import PREC_TOL
+
+pytestmark = pytest.mark.gpu
+
+N_ORACLE = 1024
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pixelnerf_amd import ops as _ops
+    return _ops
+
+
+def _ray_set(meta, n):
+    """n rays of the target view: every border pixel position on a stride + a seeded random interior sample."""
+    from testdata import synthetic
+    W, H = meta["W"], meta["H"]
+    rays = synthetic.target_rays(meta).reshape(-1, 8)
+    if n >= rays.shape[0]:
+        return rays
+    xs, ys = np.arange(0, W, 3), np.arange(0, H, 3)
+    border = np.concatenate([ys[:, None] * W + np.array([0, W - 1])[None], np.array([0, H - 1])[:, None] * W + xs[None]], axis=None)
+    corners = np.array([0, W - 1, (H - 1) * W, H * W - 1])
+    pick = np.unique(np.concatenate([corners, border]))
+    rs = np.random.RandomState(17)
+    rest = rs.permutation(np.setdiff1d(np.arange(W * H), pick))[: n - pick.size]
+    idx = np.concatenate([pick, rest])  # border pixels first: they are inside the oracle subset too
+    return rays[torch.from_numpy(idx).long()].contiguous()
+
+
+@pytest.fixture(scope="module")
+def cases(ops, dev):
+    """Per scene: device scene, rays, noise, the exact-fp32 HIP render of all rays and the CPU-oracle render of the
+    first N_ORACLE rays (computed once, shared by the precision / form parametrisations)."""
+    from testdata import synthetic
+    out = {}
+    for name, n in (("srn_car", 16384), ("dtu", 8192)):
+        s, meta = scene_for(name)
+        sc = ops.make_scene(s["latent"].to(dev), s["poses"].to(dev), s["focal"].to(dev), s["c"].to(dev), s["image_shape"], s["NS"])
+        rays = _ray_set(meta, n)
+        noise = synthetic.make_noise(rays.shape[0], 64, 128, 16, seed=31)
+        nz = {k: v.to(dev) for k, v in noise.items()}
+        st = [{k: v.to(dev) for k, v in mlp_params(seed).items()} for seed in (11, 12)]
+        f32 = ops.render_forward(sc, ops.pack_mlp(st[0], "f32"), ops.pack_mlp(st[1], "f32"), rays.to(dev), 64, 128, 16, nz,
+                                 white_bkgd=meta["white_bkgd"])
+        f32 = {p: {k: v.cpu() for k, v in d.items()} for p, d in f32.items()}
+        with torch.no_grad():
+            ref = O.render(s, mlp_params(11), mlp_params(12), rays[None, :N_ORACLE], {k: v[:N_ORACLE] for k, v in noise.items()},
+                           64, 128, 16, white_bkgd=meta["white_bkgd"])
+        out[name] = dict(sc=sc, meta=meta, rays=rays.to(dev), nz=nz, st=st, f32=f32, ref=ref)
+    return out
+
+
+def test_exact_fp32_path_matches_oracle_at_full_size(cases):
+    """the on-GPU yardstick itself, on the big grids: fp32 HIP path vs CPU oracle, fp32 tolerance (test_hip_f32.py)."""
+    for name, c in cases.items():
+        for p in ("coarse", "fine"):
+            a, b = c["f32"][p]["rgb"][:N_ORACLE], c["ref"][p]["rgb"][0]
+            assert O.psnr(a, b) >= 85.0, (name, p, O.psnr(a, b))
+
+
+@pytest.mark.parametrize("fold", [True, False], ids=["folded", "unfolded"])
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("name", ["srn_car", "dtu"])
+def test_full_size_render_matches_oracle_and_f32_path(ops, dev, cases, name, prec, fold):
+    c = cases[name]
+    tol = PREC_TOL[prec]
+    pk = [ops.pack_mlp(st, prec, folded=fold) for st in c["st"]]
+    tabs = tuple(ops.fold_latent(c["sc"], st, prec) for st in c["st"]) if fold else None
+    out = ops.render_forward(c["sc"], pk[0], pk[1], c["rays"], 64, 128, 16, c["nz"], white_bkgd=c["meta"]["white_bkgd"],
+                             tables=tabs)
+    span = float(c["meta"]["z_far"] - c["meta"]["z_near"])
+    for p in ("coarse", "fine"):
+        rgb, depth = out[p]["rgb"].cpu(), out[p]["depth"].cpu()
+        assert torch.isfinite(rgb).all() and torch.isfinite(depth).all()
+        # all rays vs the exact-fp32 HIP path
+        ps = O.psnr(rgb, c["f32"][p]["rgb"])
+        assert ps >= tol["psnr"], f"{name} {prec} {p}: PSNR vs f32 HIP path {ps:.1f} dB"
+        ed = (depth - c["f32"][p]["depth"]).abs().numpy()
+        assert np.percentile(ed, 99) <= tol["depth_p99"] * span, f"{name} {p}: depth p99 {np.percentile(ed, 99):.3e}"
+        # the oracle subset (contains every selected border pixel)
+        pso = O.psnr(rgb[:N_ORACLE], c["ref"][p]["rgb"][0])
+        assert pso >= tol["psnr"], f"{name} {prec} {p}: PSNR vs CPU oracle {pso:.1f} dB"
+        edo = (depth[:N_ORACLE] - c["ref"][p]["depth"][0]).abs().numpy()
+        assert np.percentile(edo, 99) <= tol["depth_p99"] * span
