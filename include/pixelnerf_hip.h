@@ -37,6 +37,8 @@ extern "C" {
 #define PNR_PREC_F16 0       /* fp16 operands, v_mfma_f32_32x32x16_f16  */
 #define PNR_PREC_BF16 1      /* bf16 operands, v_mfma_f32_32x32x16_bf16 */
 #define PNR_PREC_F32 2       /* exact fp32 validation path (pnr_eval_*_f32 only), v_mfma_f32_32x32x2_f32 */
+#define PNR_PREC_F16X3 3     /* fp32-class: every operand a (head, tail) pair of fp16, 3 f16 MFMAs per product,
+                                fp32 tables (pnr_*_split entries; pnr_render_forward_folded accepts it) */
 
 /* Encoded-scene state: exactly what PixelNeRFNet.encode() leaves in module buffers
  * (src/model/models.py:111-141, src/model/encoder.py:160-163), except that the feature grid
@@ -105,6 +107,23 @@ int pnr_render_forward_folded(const PnrScene *scene /*host*/, const void *packed
                               const float *n4, float *rgb_c, float *depth_c, float *weights_c,
                               float *rgb_f, float *depth_f, float *weights_f, void *workspace,
                               void *stream);
+
+/* ---- fp32-class accuracy on the f16 matrix cores (PNR_PREC_F16X3): same spans as the folded entries above
+ * (src/model/models.py:146-266, src/model/resnetfc.py:132-184), single source view, inference.
+ * w = wh + wl and x = xh + xl with f16 heads/tails, w x ~= wh xh + wh xl + wl xh accumulated in fp32 (error
+ * 2^-22 per product instead of 2^-11); lin_z folded into fp32 per-texel tables.  Agrees with the reference's fp32
+ * arithmetic to the bars of the exact-fp32 path (per-point |rgb| <= 2e-5) at several times the fp32-MFMA ceiling.
+ * packed_split: pnr_packed_mlp_split_bytes() bytes from pnr_pack_mlp_split; tables_f32: pnr_folded_tables_f32_bytes()
+ * bytes from pnr_fold_latent_f32 (layout of the 16-bit tables, 4 bytes per entry). */
+size_t pnr_packed_mlp_split_bytes(void);
+int pnr_pack_mlp_split(const PnrMlpWeights *w /*host*/, void *packed_split, void *stream);
+size_t pnr_folded_tables_f32_bytes(const PnrScene *scene /*host*/);
+int pnr_fold_latent_f32(const PnrScene *scene /*host*/, const PnrMlpWeights *w /*host*/, float *tables_f32, void *stream);
+int pnr_eval_ray_samples_split(const PnrScene *scene /*host*/, const void *packed_split, const void *tables_f32,
+                               const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
+                               void *stream);
+int pnr_eval_points_split(const PnrScene *scene /*host*/, const void *packed_split, const void *tables_f32,
+                          const float *xyz, const float *viewdirs, int B, float *rgbsigma, void *stream);
 
 /* encoder.latent NCHW -> NHWC (layout change for the lookup in src/model/encoder.py:80-109). */
 int pnr_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, void *stream);

@@ -12,11 +12,11 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelnerf_hip.so")  # override: A/B experiments
-SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_bwd.hip", "pnr_f32.hip", "pnr_encode.hip"]
+SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_split.hip", "pnr_bwd.hip", "pnr_f32.hip", "pnr_encode.hip"]
 HEADERS = ["pnr_common.h", "pnr_layout.h", "pnr_device.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
 
-PREC_F16, PREC_BF16, PREC_F32 = 0, 1, 2
-PRECISIONS = {"f16": PREC_F16, "fp16": PREC_F16, "bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32}
+PREC_F16, PREC_BF16, PREC_F32, PREC_F16X3 = 0, 1, 2, 3
+PRECISIONS = {"f16": PREC_F16, "fp16": PREC_F16, "bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32, "f16x3": PREC_F16X3}
 
 c_float_p = ctypes.c_void_p  # device pointers travel as plain addresses
 
@@ -87,6 +87,12 @@ PROTOTYPES = {
     "pnr_eval_points_folded": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _P, _I, _P, _P]),
     "pnr_render_forward_folded": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I,
                                        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pnr_packed_mlp_split_bytes": (_SZ, []),
+    "pnr_pack_mlp_split": (_I, [ctypes.POINTER(PnrMlpWeights), _P, _P]),
+    "pnr_folded_tables_f32_bytes": (_SZ, [ctypes.POINTER(PnrScene)]),
+    "pnr_fold_latent_f32": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P]),
+    "pnr_eval_ray_samples_split": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "pnr_eval_points_split": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _P, _P]),
     "pnr_eval_ray_samples_train": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _I, _I, _P,
                                         ctypes.POINTER(PnrTrainDumps), _P]),
     "pnr_storage_perm": (_I, [ctypes.POINTER(ctypes.c_int32)]),

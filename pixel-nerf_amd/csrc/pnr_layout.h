@@ -125,6 +125,7 @@ template <int MT_> struct Tile {
     static constexpr int MT = MT_;            // points per tile
     static constexpr int JT = MT_ / 32;       // MFMA column tiles of 32 points
     static constexpr bool SINGLE_IMAGE = MT_ > 64;
+    static constexpr int IN_LO_DELTA = 0;     // no split-operand image (pnr_split.hip has its own map)
     static constexpr int LDS_Z = 0;
     static constexpr int LDS_A = SINGLE_IMAGE ? 0 : MT_ * ROW_ACT;
     static constexpr int LDS_IN = LDS_A + MT_ * ROW_ACT;       // positional code + viewdir

@@ -31,82 +31,6 @@
 
 namespace pnr {
 
-// ---------------------------------------------------------------- feature phase (geometry)
-// Thread (p = tid&63, sub = tid>>6).  Follows the reference op order without FMA contraction
-// so that fp32 intermediates round like the PyTorch eager path.
-#pragma clang fp contract(off)
-template <typename P, bool RAYS, typename TL>
-__device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, int tile, int view, int p, int sub) {
-    typedef typename P::T T;
-    constexpr int MT = TL::MT, LDS_IN = TL::LDS_IN, LDS_META = TL::LDS_META;
-    const int g = tile * MT + p;  // P < 2^31 (checked on the host)
-    const bool valid = g < (int)q.P;
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
-    int obj = 0;
-    float X = 0, Y = 0, Z = 0;
-    if (valid) {
-        if (RAYS) {
-            const int r = g / q.K;
-            const float *ray = q.rays + (size_t)r * 8;
-            ox = ray[0]; oy = ray[1]; oz = ray[2]; dx = ray[3]; dy = ray[4]; dz = ray[5];
-            const float zz = q.z[g];
-            X = ox + zz * dx; Y = oy + zz * dy; Z = oz + zz * dz;  // nerf.py:185
-            obj = r / q.per_obj;
-        } else {
-            X = q.xyz[g * 3 + 0]; Y = q.xyz[g * 3 + 1]; Z = q.xyz[g * 3 + 2];
-            dx = q.viewdirs[g * 3 + 0]; dy = q.viewdirs[g * 3 + 1]; dz = q.viewdirs[g * 3 + 2];
-            obj = g / q.per_obj;
-        }
-    }
-    const float *pose = q.poses + (size_t)(obj * q.NS + view) * 12;  // row = obj*NS + view
-    // xyz_rot = R x (models.py:162-164)
-    const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
-    const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
-    const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
-    T *in_row = reinterpret_cast<T *>(smem + LDS_IN + p * ROW_IN);
-    if (sub == 0) {
-        // identity part of the code, rotated view direction (models.py:188-196), zero pad
-        const float dv0 = pose[0] * dx + pose[1] * dy + pose[2] * dz;
-        const float dv1 = pose[4] * dx + pose[5] * dy + pose[6] * dz;
-        const float dv2 = pose[8] * dx + pose[9] * dy + pose[10] * dz;
-        in_row[0] = (T)(valid ? xr0 : 0.f); in_row[1] = (T)(valid ? xr1 : 0.f); in_row[2] = (T)(valid ? xr2 : 0.f);
-        in_row[39] = (T)dv0; in_row[40] = (T)dv1; in_row[41] = (T)dv2;
-        // camera-space point, pinhole projection, bilinear corner setup
-        const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, valid);
-        uint32_t *mo = reinterpret_cast<uint32_t *>(smem + LDS_META + p * 32);
-        float *mw = reinterpret_cast<float *>(smem + LDS_META + p * 32 + 16);
-        mo[0] = pr.off[0]; mo[1] = pr.off[1]; mo[2] = pr.off[2]; mo[3] = pr.off[3];
-        mw[0] = pr.w[0]; mw[1] = pr.w[1]; mw[2] = pr.w[2]; mw[3] = pr.w[3];
-    } else if (sub <= 6) {
-        // frequency k = sub-1: sin(f x), sin(f x + pi/2), f = 1.5 * 2^k (code.py:15,37-41)
-        const float f = 1.5f * (float)(1 << (sub - 1));
-        const float HALF_PI = 1.57079637050628662109375f;  // fp32(pi/2), code.py:26
-        const float a0 = xr0 * f, a1 = xr1 * f, a2 = xr2 * f;
-        T *o = in_row + 3 + 6 * (sub - 1);
-        o[0] = (T)(valid ? sinf(a0) : 0.f); o[1] = (T)(valid ? sinf(a1) : 0.f); o[2] = (T)(valid ? sinf(a2) : 0.f);
-        o[3] = (T)(valid ? sinf(a0 + HALF_PI) : 0.f); o[4] = (T)(valid ? sinf(a1 + HALF_PI) : 0.f);
-        o[5] = (T)(valid ? sinf(a2 + HALF_PI) : 0.f);
-    } else {
-        // zero the K padding 42..63 (+ the 8-element row pad read by the last B prefetch)
-        for (int i = D_IN; i < D_IN_PAD + 8; ++i) in_row[i] = (T)0.f;
-    }
-}
-#pragma clang fp contract(fast)
-
-// work items (point, sub): sub 0 = identity code + view direction + projection, 1..6 = one frequency band
-// (6 precise sinf), 7 = zero padding.  64-point tile: one item per thread; 96 points: 768 items over 512 threads.
-template <typename P, bool RAYS, typename TL>
-__device__ __forceinline__ void geometry(const EvalParams &q, char *smem, int tile, int view, int tid) {
-    if constexpr (TL::MT == 64) {
-        geometry_item<P, RAYS, TL>(q, smem, tile, view, tid & 63, tid >> 6);
-    } else {
-        // the six frequency bands first; the padding and projection items share the second, half-empty pass
-#pragma unroll 1
-        for (int wi = tid; wi < TL::MT * 8; wi += NTHREADS)
-            geometry_item<P, RAYS, TL>(q, smem, tile, view, wi % TL::MT, (wi / TL::MT + 1) & 7);
-    }
-}
-
 // bilinear lookup: wave handles points wave*8..+7; lane handles channels 8*lane..+7
 template <typename P, bool TRAIN, int GB, typename TL>
 __device__ __forceinline__ void gather(const EvalParams &q, char *smem, int wv, int lane, int tile, int view) {

@@ -35,7 +35,8 @@ __device__ inline GemmSrc gemm_source(const PnrMlpWeights &p, int g) {
 }
 
 // FOLD: the stream without the three lin_z GEMMs (they are folded into per-texel tables, pnr_fold_latent)
-template <typename T, bool FOLD>
+// LO: the f16 TAIL of the weight, f16(w - f16(w)), for the split-operand kernel (pnr_split.hip)
+template <typename T, bool FOLD, bool LO = false>
 __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
     constexpr int TOTAL = FOLD ? RS_TOTAL_F : RS_TOTAL;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -79,7 +80,7 @@ __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
             if (i < D_OUT) v = src.w[i * D_HID + k];
         }
     }
-    out[idx] = (T)v;
+    out[idx] = LO ? (T)(v - (float)(T)v) : (T)v;
 }
 
 template <bool FOLD>
@@ -194,6 +195,41 @@ extern "C" int pnr_fold_latent(const PnrScene *s, const PnrMlpWeights *w, int pr
             return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: unknown precision");
     }
     return pnr_check_launch("pnr_fold_latent");
+}
+
+// fp32 tables for the split-operand kernel: same layout as the 16-bit tables, 4 bytes per entry
+extern "C" size_t pnr_folded_tables_f32_bytes(const PnrScene *s) { return 2 * pnr_folded_tables_bytes(s); }
+
+extern "C" int pnr_fold_latent_f32(const PnrScene *s, const PnrMlpWeights *w, float *tables, void *stream) {
+    using namespace pnr;
+    if (!s || !w || !tables || !s->latent_nhwc) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: null argument");
+    if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: bad scene shape");
+    const long long M = (long long)s->SB * s->NS * s->Hl * s->Wl;
+    if ((M + 63) / 64 > 0x7fffffffLL) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: grid too large");
+    dim3 grid((unsigned)((M + 63) / 64), D_HID / 64);
+    for (int b = 0; b < COMBINE_LAYER; ++b) {
+        if (!w->lin_z_w[b] || !w->lin_z_b[b]) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: null lin_z parameters");
+        hipLaunchKernelGGL(fold_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, w->lin_z_w[b],
+                           w->lin_z_b[b], tables + (size_t)b * M * D_HID, M, 3.4028234664e38f);
+    }
+    return pnr_check_launch("pnr_fold_latent_f32");
+}
+
+// split-operand stream: [head blob: folded f16 stream | biases | lin_out bias] [tail blob: folded f16 stream of w - f16(w)]
+extern "C" int pnr_pack_mlp_split(const PnrMlpWeights *w, void *packed, void *stream) {
+    using namespace pnr;
+    if (!w || !packed) return pnr_fail(PNR_E_INVALID, "pnr_pack_mlp_split: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)RS_TOTAL_F * IT * FRAG_ELEMS * NW;
+    const int threads = 256;
+    const unsigned blocks = (unsigned)((n + threads - 1) / threads);
+    hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, false>), dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed);
+    hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, true>), dim3(blocks), dim3(threads), 0, st, *w,
+                       (_Float16 *)((char *)packed + PACKED_BYTES));
+    const int nb = NBIAS * NW * BIAS_FLOATS_PER_WAVE;
+    hipLaunchKernelGGL(pack_bias_kernel<true>, dim3((nb + threads - 1) / threads), dim3(threads), 0, st, *w,
+                       (float *)((char *)packed + BIAS_OFFSET_BYTES), (float *)((char *)packed + BOUT_OFFSET_BYTES));
+    return pnr_check_launch("pnr_pack_mlp_split");
 }
 
 extern "C" size_t pnr_packed_mlp_bytes(void) { return pnr::PACKED_BYTES; }

@@ -290,6 +290,8 @@ extern "C" size_t pnr_render_workspace_bytes(int R, int Kc, int Kf) {
 
 static int eval_any(const PnrScene *scene, const void *packed, const void *tables, int precision, const float *rays,
                     const float *z, int R, int rays_per_obj, int K, float *rgbsigma, void *stream) {
+    if (precision == PNR_PREC_F16X3)  // fp32-class split-operand kernel (fp32 tables), pnr_split.hip
+        return pnr_eval_ray_samples_split(scene, packed, tables, rays, z, R, rays_per_obj, K, rgbsigma, stream);
     return tables ? pnr_eval_ray_samples_folded(scene, packed, tables, precision, rays, z, R, rays_per_obj, K, rgbsigma, stream)
                   : pnr_eval_ray_samples(scene, packed, precision, rays, z, R, rays_per_obj, K, rgbsigma, stream);
 }

@@ -1,0 +1,369 @@
+// pnr_split.hip -- the fused per-point network at fp32-class accuracy on the f16 matrix cores (gfx950).
+//
+// fp32 MFMA peaks at 157 TFLOP/s on MI355X, 1/16 of the f16 rate; an fp32 product, however, is recovered to
+// ~2^-22 from three f16 products when both operands are split into a rounded-to-f16 head and an f16 tail,
+//       w = wh + wl,  x = xh + xl :   w x ~= wh xh + wh xl + wl xh        (the dropped wl xl is 2^-22 |w x|),
+// each product exact in the fp32 accumulator (11 x 11 significand bits).  This kernel runs the SAME fused chain
+// as pnr_mlp.hip -- residual stream in the accumulators, weights streamed L2 -> VGPR, activations through LDS,
+// lin_z folded into per-texel tables (fp32 tables here) -- with every operand carried as such a pair:
+//   weights      two packed streams (head, tail) with the layout of the 16-bit folded stream   (pnr_pack_mlp_split)
+//   activations  two LDS images (head, tail); relu(v) -> h = f16(v), l = f16(v - h)
+//   tables       fp32 rows, bilinear blend in fp32, added to the accumulators as they are       (pnr_fold_latent_f32)
+// 3 MFMAs per (weight fragment, activation fragment) instead of 1, 2x the operand bytes: ~1/3 of the f16 kernel's
+// rate, several times the fp32-MFMA ceiling, at the accuracy class of the reference's own fp32 arithmetic
+// (tests/test_hip_split.py holds it to the bars of tests/test_hip_f32.py: per-point |rgb| <= 2e-5).
+// Single source view, folded form, inference.  The unfused fp32-MFMA path (pnr_f32.hip) remains the
+// implementation-independent yardstick and serves multi-view scenes.
+#include <hip/hip_runtime.h>
+
+#include "pnr_common.h"
+#include "pnr_device.h"
+#include "pnr_layout.h"
+
+namespace pnr {
+
+typedef Prec<PNR_PREC_F16> PH;
+typedef PH::T8 h8;
+
+// LDS map: two activation images (head / tail), two lin_in operand images, corner metadata, lin_out partials.
+// The fp32 table rows (2 KiB + 16 B pad per point) are looked up into the space of the two activation images
+// while those are free (tile start, and after fc_1 of blocks 0-1 has finished reading).
+struct SplitTile {
+    static constexpr int MT = 64, JT = 2;
+    static constexpr int A_HI = 0;
+    static constexpr int A_LO = MT * ROW_ACT;             // 66,560
+    static constexpr int LDS_IN = 2 * MT * ROW_ACT;        // 133,120 (head image of the lin_in operand)
+    static constexpr int IN_LO_DELTA = MT * ROW_IN;        // tail image right behind it
+    static constexpr int LDS_META = LDS_IN + 2 * MT * ROW_IN;
+    static constexpr int LDS_OUT = LDS_META + MT * 32;
+    static constexpr int LDS_TOTAL = LDS_OUT + NW * MT * 16;  // 161,792 B
+    static constexpr int ROW_TAB = D_HID * 4 + 16;          // fp32 table row: 2064 B (129 16-B slots: conflict-free)
+    static constexpr int LDS_Z = 0;                         // (geometry_item only needs LDS_IN / LDS_META)
+    static_assert(MT * ROW_TAB <= LDS_IN, "table image must fit in the space of the two activation images");
+    static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+};
+typedef SplitTile ST;
+
+struct SplitRing {
+    h8 h[4][IT], l[4][IT];
+    const char *base_h, *base_l;  // this wave's head / tail stream + lane*16
+    int pf_rs;
+};
+
+__device__ __forceinline__ void ring_advance(SplitRing &R) {
+    int rs = R.pf_rs + 4;
+    if (rs == RS_TOTAL_F) rs = 0;
+    R.pf_rs = rs;
+}
+
+__device__ __forceinline__ f32x16 mf(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// acc[it][jt] += (Wh + Wl)(Xh + Xl) without the tail-tail term; B rows at bhi0 + jt*jstride (+ lo_delta for the tails)
+__device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][ST::JT], const char *smem, uint32_t bhi0, uint32_t jstride,
+                                           uint32_t lo_delta, int nbody, SplitRing &R) {
+    constexpr int JT = ST::JT;
+    h8 bh[2][JT], bl[2][JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        bh[0][jt] = lds8<PH>(smem, bhi0 + jt * jstride);
+        bl[0][jt] = lds8<PH>(smem, bhi0 + jt * jstride + lo_delta);
+    }
+#pragma unroll 1
+    for (int body = 0; body < nbody; ++body) {
+        const size_t pf = (size_t)R.pf_rs * (IT * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cur = j & 1;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                bh[cur ^ 1][jt] = lds8<PH>(smem, bhi0 + jt * jstride + (j + 1) * 32);
+                bl[cur ^ 1][jt] = lds8<PH>(smem, bhi0 + jt * jstride + lo_delta + (j + 1) * 32);
+            }
+            h8 ah[IT], al[IT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) { ah[it] = R.h[j][it]; al[it] = R.l[j][it]; }
+            // the three products of one accumulator are spread over the step so that consecutive MFMAs are independent
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(ah[it], bh[cur][jt], acc[it][jt]);
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(ah[it], bl[cur][jt], acc[it][jt]);
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(al[it], bh[cur][jt], acc[it][jt]);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
+                R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
+            }
+        }
+        bhi0 += 128;
+        ring_advance(R);
+    }
+}
+
+// head / tail of 8 fp32 values (optionally through relu); MODE.FP16_OVFL is set: heads saturate at 65504
+template <bool RELU>
+__device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo) {
+    u32x4 uh, ul;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x2 p = {v[2 * k], v[2 * k + 1]};
+        if (RELU) { p[0] = fmaxf(p[0], 0.f); p[1] = fmaxf(p[1], 0.f); }
+        const f16x2 h = __builtin_convertvector(p, f16x2);
+        const f32x2 back = __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(p - back, f16x2);
+        uh[k] = __builtin_bit_cast(uint32_t, h);
+        ul[k] = __builtin_bit_cast(uint32_t, l);
+    }
+    hi = __builtin_bit_cast(h8, uh);
+    lo = __builtin_bit_cast(h8, ul);
+}
+
+// relu(acc) -> head / tail images (storage order, like write_act)
+__device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][ST::JT], char *smem, uint32_t waddr) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < ST::JT; ++jt) {
+            const f32x16 &a = acc[it][jt];
+            const uint32_t ad = waddr + jt * 32 * ROW_ACT + it * 64;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = a[8 * half + e];
+                h8 hi, lo;
+                split8<true>(v, hi, lo);
+                *reinterpret_cast<h8 *>(smem + ST::A_HI + ad + 16 * half) = hi;
+                *reinterpret_cast<h8 *>(smem + ST::A_LO + ad + 16 * half) = lo;
+            }
+        }
+}
+
+// fp32 bilinear lookup of table b: wave handles points wave*8..+7, lane handles storage slots 8*lane..+7
+// (two 16-byte loads per corner); rows land in the table image (ROW_TAB stride) at offset 0
+template <int GB>
+__device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem, int wv, int lane, int b) {
+    const float *tab = reinterpret_cast<const float *>(q.tables) + (size_t)b * q.table_stride + lane * 8;
+    static_assert((ST::MT / NW) % GB == 0, "gather batch");
+#pragma unroll 1
+    for (int i = 0; i < ST::MT / NW; i += GB) {
+        f32x4 v[GB][4][2];
+        f32x4 w[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int p = wv * (ST::MT / NW) + i + u;
+            const u32x4 off = *reinterpret_cast<const u32x4 *>(smem + ST::LDS_META + p * 32);
+            w[u] = *reinterpret_cast<const f32x4 *>(smem + ST::LDS_META + p * 32 + 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[u][c][0] = *reinterpret_cast<const f32x4 *>(tab + off[c]);
+                v[u][c][1] = *reinterpret_cast<const f32x4 *>(tab + off[c] + 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int p = wv * (ST::MT / NW) + i + u;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                f32x4 r = v[u][0][hh] * w[u][0];
+                r += v[u][1][hh] * w[u][1];
+                r += v[u][2][hh] * w[u][2];
+                r += v[u][3][hh] * w[u][3];
+                *reinterpret_cast<f32x4 *>(smem + p * ST::ROW_TAB + lane * 32 + hh * 16) = r;
+            }
+        }
+    }
+}
+
+// x += this lane's slots of the fp32 table rows
+__device__ __forceinline__ void add_from_table(f32x16 (&x)[IT][ST::JT], const char *smem, int pl, int h, int wv) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < ST::JT; ++jt) {
+            const char *row = smem + (jt * 32 + pl) * ST::ROW_TAB + ((wv * IT + it) * 32 + h * 16) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(row + 16 * k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[it][jt][4 * k + e] += t[e];
+            }
+        }
+}
+
+template <bool RAYS>
+__global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const EvalParams q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int JT = ST::JT, MT = ST::MT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+
+    const uint32_t a_rd0 = ST::A_HI + pl * ROW_ACT + h * 16;
+    const uint32_t in_rd0 = ST::LDS_IN + pl * ROW_IN + h * 16;
+    const uint32_t a_wr = pl * ROW_ACT + (wv * IT) * 64 + h * 32;
+    const float *bias_lane = q.bias + wv * BIAS_FLOATS_PER_WAVE + h * 16;
+
+    f16_ovfl_mode<PH>();
+    SplitRing R;
+    R.base_h = q.wstream + (size_t)wv * (RS_TOTAL_F * IT * 1024) + lane * 16;
+    R.base_l = R.base_h + PACKED_BYTES;  // the tail blob follows the head blob (pnr_pack_mlp_split)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            R.h[j][it] = gload8<PH>(R.base_h + j * (IT * 1024) + it * 1024);
+            R.l[j][it] = gload8<PH>(R.base_l + j * (IT * 1024) + it * 1024);
+        }
+    R.pf_rs = 4;
+
+    for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
+        f32x16 x[IT][JT];
+        __syncthreads();  // previous tile: every reader of the images / IN / META is done
+        geometry_item<PH, RAYS, ST>(q, smem, tile, 0, tid & 63, tid >> 6);
+        __syncthreads();
+        gather_table_f32<2>(q, smem, wv, lane, 0);
+        add_bias<true>(x, bias_lane, B_IN_Z0);
+        gemm_split(x, smem, in_rd0, 32 * ROW_IN, ST::IN_LO_DELTA, KS_IN / 4, R);  // lin_in   resnetfc.py:147
+        __syncthreads();  // table rows of every wave are in place
+        add_from_table(x, smem, pl, h, wv);                                       // lin_z[0] via table 0
+#pragma unroll 1
+        for (int b = 0; b < N_BLOCKS; ++b) {
+            __syncthreads();  // table rows / previous operand images are no longer read
+            write_split(x, smem, a_wr);
+            __syncthreads();
+            {
+                f32x16 net[IT][JT];
+                add_bias<true>(net, bias_lane, 1 + 2 * b);
+                gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R);  // fc_0
+                __syncthreads();
+                write_split(net, smem, a_wr);
+            }
+            __syncthreads();
+            add_bias<false>(x, bias_lane, 2 + 2 * b);
+            gemm_split(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R);        // fc_1
+            if (b + 1 < COMBINE_LAYER) {  // lin_z[b+1] via table b+1
+                __syncthreads();
+                gather_table_f32<2>(q, smem, wv, lane, b + 1);
+                __syncthreads();
+                add_from_table(x, smem, pl, h, wv);
+            }
+        }
+
+        // lin_out(relu(x)): each wave contracts its own 64 features (the wave's accumulators are the B operand)
+        {
+            f32x16 o[JT];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[jt][r] = 0.f;
+            const size_t pf = (size_t)R.pf_rs * (IT * 1024);
+#pragma unroll
+            for (int qk = 0; qk < 2 * IT; ++qk) {
+                const int xit = qk >> 1, rr = qk & 1;
+                const h8 ah = R.h[qk / IT][qk % IT], al = R.l[qk / IT][qk % IT];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = x[xit][jt][8 * rr + e];
+                    h8 bh, bl;
+                    split8<true>(v, bh, bl);
+                    o[jt] = mf(ah, bh, o[jt]);
+                    o[jt] = mf(ah, bl, o[jt]);
+                    o[jt] = mf(al, bh, o[jt]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
+                    R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
+                }
+            ring_advance(R);
+            if (h == 0) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    f32x4 t = {o[jt][0], o[jt][1], o[jt][2], o[jt][3]};
+                    *reinterpret_cast<f32x4 *>(smem + ST::LDS_OUT + (wv * MT + jt * 32 + pl) * 16) = t;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < MT) {
+            const long long g = (long long)tile * MT + tid;
+            f32x4 s = *reinterpret_cast<const f32x4 *>(q.bout);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const f32x4 *>(smem + ST::LDS_OUT + (w * MT + tid) * 16);
+            // models.py:260-265: rgb = sigmoid(out[:3]), sigma = relu(out[3])
+            f32x4 res = {1.f / (1.f + expf(-s[0])), 1.f / (1.f + expf(-s[1])), 1.f / (1.f + expf(-s[2])), fmaxf(s[3], 0.f)};
+            if (g < q.P) *reinterpret_cast<f32x4 *>(q.out + g * 4) = res;
+        }
+    }
+}
+
+static int split_launch(const PnrScene *s, const void *packed, const void *tables, EvalParams &q, bool rays, hipStream_t st) {
+    if (!s || !packed || !tables || !q.out) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: null argument");
+    if (s->SB <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: bad scene shape");
+    if (s->NS != 1)
+        return pnr_fail(PNR_E_INVALID, "pnr_eval_split: the split-operand kernel is single-view (use precision f32 for NS > 1)");
+    if (!(s->n_focal == 1 || s->n_focal == s->SB) || !(s->n_c == 1 || s->n_c == s->SB))
+        return pnr_fail(PNR_E_INVALID, "pnr_eval_split: focal / c must have 1 or SB rows");
+    if (q.P == 0) return PNR_OK;
+    if (q.P > 0x7fffff80LL) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: too many points (P must stay below 2^31)");
+    if ((long long)s->SB * s->Hl * s->Wl * C_LAT > 0xffffffffLL)
+        return pnr_fail(PNR_E_INVALID, "pnr_eval_split: feature grid too large (SB*Hl*Wl*512 must stay below 2^32 elements)");
+    q.latent = s->latent_nhwc; q.poses = s->poses; q.focal = s->focal; q.c = s->c;
+    q.SB = s->SB; q.NS = 1; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
+    q.img_w = s->img_w; q.img_h = s->img_h;
+    q.wstream = (const char *)packed;
+    q.bias = (const float *)((const char *)packed + BIAS_OFFSET_BYTES);
+    q.bout = (const float *)((const char *)packed + BOUT_OFFSET_BYTES);
+    q.tables = (const char *)tables;
+    q.table_stride = (long long)s->SB * s->Hl * s->Wl * C_LAT;
+    const long long nt = (q.P + ST::MT - 1) / ST::MT;
+    q.ntiles = (int)nt;
+    int dev = 0, ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        ncu = prop.multiProcessorCount;
+    const int grid = (int)(nt < ncu ? nt : ncu);
+    auto k = rays ? eval_split_kernel<true> : eval_split_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ST::LDS_TOTAL);
+    if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_split_kernel)");
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), ST::LDS_TOTAL, st, q);
+    return pnr_check_launch("eval_split_kernel");
+}
+
+}  // namespace pnr
+
+extern "C" size_t pnr_packed_mlp_split_bytes(void) { return 2 * pnr::PACKED_BYTES; }
+
+extern "C" int pnr_eval_ray_samples_split(const PnrScene *scene, const void *packed_split, const void *tables_f32,
+                                          const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
+                                          void *stream) {
+    if (R < 0 || K <= 0 || rays_per_obj <= 0) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split: bad sizes");
+    if (R > 0 && (!rays || !z)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split: null rays/z");
+    if (scene && (long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split: R != SB * rays_per_obj");
+    pnr::EvalParams q = {};
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
+    return pnr::split_launch(scene, packed_split, tables_f32, q, true, (hipStream_t)stream);
+}
+
+extern "C" int pnr_eval_points_split(const PnrScene *scene, const void *packed_split, const void *tables_f32, const float *xyz,
+                                     const float *viewdirs, int B, float *rgbsigma, void *stream) {
+    if (B < 0) return pnr_fail(PNR_E_INVALID, "pnr_eval_points_split: bad sizes");
+    if (B > 0 && (!xyz || !viewdirs)) return pnr_fail(PNR_E_INVALID, "pnr_eval_points_split: null xyz/viewdirs");
+    pnr::EvalParams q = {};
+    q.xyz = xyz; q.viewdirs = viewdirs; q.K = 1; q.per_obj = B > 0 ? B : 1;
+    q.P = scene ? (long long)scene->SB * B : 0; q.out = rgbsigma;
+    return pnr::split_launch(scene, packed_split, tables_f32, q, false, (hipStream_t)stream);
+}

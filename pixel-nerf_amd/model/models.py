@@ -27,8 +27,10 @@ class PixelNeRFNet(torch.nn.Module):
     def __init__(self, conf, stop_encoder_grad=False, precision="f16", fold=True):
         """:param conf PyHocon-like config subtree 'model' (util.Conf or a real ConfigTree)
         :param precision operand type of the 512-wide linears on the matrix cores: 'f16'
-        (default; PSNR >= 52 dB vs the fp32 reference), 'bf16' (>= 36 dB), or 'f32' -- the exact,
-        unfused validation path (inference only, ~1/20 of the f16 rate, agrees to ~1e-5).
+        (default; PSNR >= 52 dB vs the fp32 reference), 'bf16' (>= 36 dB), 'f16x3' -- fp32-class accuracy on the
+        f16 matrix cores (head/tail operand pairs, 3 MFMAs per product, ~1/3 of the f16 rate, per-point |rgb| <= 2e-5;
+        single source view, inference) -- or 'f32': the exact, unfused validation path (inference only, ~1/25 of the
+        f16 rate, agrees to ~1e-5; also what 'f16x3' falls back to for multi-view scenes).
         :param fold inference applies lin_z[b] to the encoded grid once per scene (per-texel tables) instead of
         once per sample -- the same function by linearity, 22-28 % fewer FLOPs per sample (ops.fold_latent)."""
         super().__init__()
@@ -139,14 +141,21 @@ class PixelNeRFNet(torch.nn.Module):
             self._scene = (key, sc)
         return self._scene[1]
 
+    def _effective_precision(self):
+        """'f16x3' is a single-view kernel: multi-view scenes run the unfused fp32 path instead (same accuracy class)."""
+        if self.precision == "f16x3" and int(self.num_views_per_obj) > 1:
+            return "f32"
+        return self.precision
+
     def _folding(self):
-        return self.fold and self.precision != "f32"
+        p = self._effective_precision()
+        return p == "f16x3" or (self.fold and p != "f32")
 
     def packed(self, coarse=True, folded=None):
         """models.py:242: the fine network falls back to the coarse one when mlp_fine is None.
         folded: None = what inference uses (self.fold); the training path asks for the full stream."""
         mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
-        return mlp.packed(self.precision, folded=self._folding() if folded is None else folded)
+        return mlp.packed(self._effective_precision(), folded=self._folding() if folded is None else folded)
 
     def tables(self, coarse=True):
         """lin_z folded into the current scene's grid for the coarse / fine network (None when fold is off);
@@ -155,11 +164,11 @@ class PixelNeRFNet(torch.nn.Module):
             return None
         mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
         sc = self.scene()
-        key = (id(sc), mlp._fingerprint(), self.precision)
+        key = (id(sc), mlp._fingerprint(), self._effective_precision())
         slot = "coarse" if mlp is self.mlp_coarse else "fine"
         hit = self._tables.get(slot)
         if hit is None or hit[0] != key:
-            self._tables[slot] = (key, ops.fold_latent(sc, dict(mlp.state_dict()), self.precision), sc)
+            self._tables[slot] = (key, ops.fold_latent(sc, dict(mlp.state_dict()), self._effective_precision()), sc)
         return self._tables[slot][1]
 
     def _no_autograd(self):

@@ -105,6 +105,14 @@ def pack_mlp(state, precision="f16", backward=False, folded=False):
             raise _lib.PixelNerfHipError("precision='f32' has no backward path")
         return PackedMLP(None, prec, weights=(w, keep))
     dev = keep["lin_in.weight"].device
+    if prec == _lib.PREC_F16X3:
+        # fp32-class split-operand form: head + tail streams of the folded network (always used with fp32 tables)
+        if backward:
+            raise _lib.PixelNerfHipError("precision='f16x3' is an inference form (no backward streams)")
+        buf = torch.empty(lib.pnr_packed_mlp_split_bytes(), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.pnr_pack_mlp_split(ctypes.byref(w), _p(buf), _stream()), "pnr_pack_mlp_split")
+        return PackedMLP(buf, prec, folded=True)
     if backward and folded:
         raise ValueError("the backward streams have no folded form")
     nbytes = lib.pnr_packed_mlp_bwd_bytes() if backward else lib.pnr_packed_mlp_bytes()
@@ -128,6 +136,12 @@ def fold_latent(scene, state, precision="f16"):
         raise _lib.PixelNerfHipError("precision='f32' has no folded form")
     w, keep = _weights_struct(state)
     NV, Hl, Wl, _ = scene.latent_nhwc.shape
+    if prec == _lib.PREC_F16X3:  # fp32 tables
+        tables = torch.empty((3, NV, Hl, Wl, 512), dtype=torch.float32, device=scene.device)
+        assert tables.numel() * 4 == lib.pnr_folded_tables_f32_bytes(scene.ref)
+        with torch.cuda.device(scene.device):
+            _lib.check(lib.pnr_fold_latent_f32(scene.ref, ctypes.byref(w), _p(tables), _stream()), "pnr_fold_latent_f32")
+        return tables
     dt = torch.float16 if prec == _lib.PREC_F16 else torch.bfloat16
     tables = torch.empty((3, NV, Hl, Wl, 512), dtype=dt, device=scene.device)
     assert tables.numel() * 2 == lib.pnr_folded_tables_bytes(scene.ref)
@@ -139,6 +153,11 @@ def fold_latent(scene, state, precision="f16"):
 def _check_fold(packed, tables, what):
     if packed.folded != (tables is not None):
         raise _lib.PixelNerfHipError(f"{what}: a folded network stream needs its fold_latent() tables (and only it takes them)")
+
+
+def _check_split_tables(tables):
+    if tables is None or tables.dtype != torch.float32:
+        raise _lib.PixelNerfHipError("precision='f16x3' takes the fp32 tables of fold_latent(scene, state, 'f16x3')")
 
 
 class Scene:
@@ -244,6 +263,12 @@ def eval_ray_samples(scene, packed, rays, z, tables=None):
                                                     _p(out), _p(ws), nbytes, _stream()), "pnr_eval_ray_samples_f32")
         return out
     _check_fold(packed, tables, "eval_ray_samples")
+    if packed.precision == _lib.PREC_F16X3:
+        _check_split_tables(tables)
+        with torch.cuda.device(rays.device):
+            _lib.check(lib.pnr_eval_ray_samples_split(scene.ref, packed.ptr, _p(tables), _p(rays), _p(z), R,
+                                                      max(R // scene.SB, 1), K, _p(out), _stream()), "pnr_eval_ray_samples_split")
+        return out
     with torch.cuda.device(rays.device):
         if tables is not None:
             _lib.check(lib.pnr_eval_ray_samples_folded(scene.ref, packed.ptr, _p(tables), packed.precision, _p(rays), _p(z), R,
@@ -270,6 +295,12 @@ def eval_points(scene, packed, xyz, viewdirs, tables=None):
                                                _stream()), "pnr_eval_points_f32")
         return out
     _check_fold(packed, tables, "eval_points")
+    if packed.precision == _lib.PREC_F16X3:
+        _check_split_tables(tables)
+        with torch.cuda.device(xyz.device):
+            _lib.check(lib.pnr_eval_points_split(scene.ref, packed.ptr, _p(tables), _p(xyz), _p(viewdirs), B, _p(out), _stream()),
+                       "pnr_eval_points_split")
+        return out
     with torch.cuda.device(xyz.device):
         if tables is not None:
             _lib.check(lib.pnr_eval_points_folded(scene.ref, packed.ptr, _p(tables), packed.precision, _p(xyz), _p(viewdirs),
@@ -344,6 +375,10 @@ def render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_
     rgb_f, depth_f, w_f = outs(Kc + Kf) if Kf > 0 else (None, None, None)
     ws = torch.empty(max(lib.pnr_render_workspace_bytes(R, Kc, Kf), 16), dtype=torch.uint8, device=dev)
     tc, tf = tables if tables is not None else (None, None)
+    if packed_coarse.precision == _lib.PREC_F16X3:
+        _check_split_tables(tc)
+        if packed_fine is not None:
+            _check_split_tables(tf)
     _check_fold(packed_coarse, tc, "render_forward")
     if packed_fine is not None:
         _check_fold(packed_fine, tf, "render_forward")

@@ -73,22 +73,24 @@ def robust_render_stats(rgb, depth, z_fine, g, span):
     there is positive, alpha = 1 - exp(+|delta| sigma) << 0: the ray's colour is then an ill-conditioned function of
     the inputs.  Whether such a sample exists hangs on `u >= cdf[-1]` with cdf[-1] = 1 +- 1 ulp, i.e. on the rounding
     of a 64-term sum -- two correct fp32 implementations (the reference on CPU vs on GPU, or vs the oracle) disagree on
-    it for a few rays.  Those rays are counted (`pastfar_disagree_frac`) and excluded from the PSNR / depth figures;
-    everything else, including rays where both sides agree on having the beyond-far sample, is compared.
-    -> dict(psnr, psnr_all, depth_p99_over_span, pastfar_disagree_frac, bin_flip_frac, n_rays)"""
+    it for a few rays (`pastfar_disagree_frac`), and where both have the sample, a density that is 0 on one side and
+    positive on the other changes the colour by orders of magnitude.  Rays on which EITHER side has a beyond-far
+    sample are therefore counted (`pastfar_frac`; only the forced rays, every 4th, can be among them) and excluded
+    from the PSNR / depth figures (`psnr_all` keeps them, for the record).
+    -> dict(psnr, psnr_all, depth_p99_over_span, pastfar_frac, pastfar_disagree_frac, bin_flip_frac, n_rays)"""
     rgb = np.asarray(rgb, np.float64).reshape(-1, 3)
     depth = np.asarray(depth, np.float64).reshape(-1)
     z = np.asarray(z_fine, np.float64).reshape(rgb.shape[0], -1)
     zg = g["fine_z"].astype(np.float64).reshape(z.shape)
     far = g["rays"].reshape(-1, 8)[:, 7].astype(np.float64)
     dis = (z[:, -1] > far) != (zg[:, -1] > far)
-    ok = ~dis
+    ok = ~((z[:, -1] > far) | (zg[:, -1] > far))
     mse = lambda a, b: float(np.mean((a - b) ** 2))  # noqa: E731
     ref_rgb, ref_d = g["fine_rgb"].reshape(-1, 3).astype(np.float64), g["fine_depth"].reshape(-1).astype(np.float64)
     return dict(
         psnr=-10.0 * np.log10(max(mse(rgb[ok], ref_rgb[ok]), 1e-30)),
         psnr_all=-10.0 * np.log10(max(mse(rgb, ref_rgb), 1e-30)),
         depth_p99_over_span=float(np.percentile(np.abs(depth[ok] - ref_d[ok]), 99)) / span,
-        pastfar_disagree_frac=float(dis.mean()),
+        pastfar_frac=float(1.0 - ok.mean()), pastfar_disagree_frac=float(dis.mean()),
         bin_flip_frac=float((np.abs(z - zg) > 1e-4 * span).mean()),
         n_rays=int(rgb.shape[0]))

@@ -1,0 +1,147 @@
+"""
+GPU parity tests (-m gpu) of the fp32-CLASS fast path (precision "f16x3", pixel-nerf_amd/csrc/pnr_split.hip): the fused
+network kernel with every operand carried as an fp16 (head, tail) pair -- three f16 MFMAs per product, fp32 accumulate,
+lin_z folded into fp32 tables.  It is held to EXACTLY the bars of the exact-fp32 validation path (tests/test_hip_f32.py)
+against the reference's own fp32 outputs (tests/golden, identical rays, weights, grid, noise):
+  * per point : |rgb| err <= 2e-5, sigma err <= 1e-4 * max(1, sigma)
+  * renders   : coarse rgb <= 2e-5, depth <= 1e-4 (far-near), weights <= 2e-5; the fine pass within the same bounds except
+                for a <= 2 % allowance of rays whose importance samples flipped a cdf bin at rounding level; PSNR >= 85 dB.
+Single-view scenes (the kernel's scope); multi-view scenes fall back to the unfused fp32 path at the API level.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import RENDER_SCENARIOS, assert_close_frac, golden_setup, load_golden, mlp_params, scene_for
+from oracle import pnr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SINGLE_VIEW = [n for n in RENDER_SCENARIOS if n.startswith(("sn64", "train"))]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pixelnerf_amd import ops as _ops
+    return _ops
+
+
+def dscene(ops, dev, name):
+    s, _ = scene_for(name)
+    return ops.make_scene(s["latent"].to(dev), s["poses"].to(dev), s["focal"].to(dev), s["c"].to(dev), s["image_shape"], s["NS"])
+
+
+def split_net(ops, dev, sc, seed):
+    state = {k: v.to(dev) for k, v in mlp_params(seed).items()}
+    return ops.pack_mlp(state, "f16x3"), ops.fold_latent(sc, state, "f16x3")
+
+
+def test_split_tables_are_lin_z_of_the_grid_in_fp32(ops, dev):
+    s, _ = scene_for("sn64")
+    sc = dscene(ops, dev, "sn64")
+    p = mlp_params(12)
+    tab = ops.fold_latent(sc, {k: v.to(dev) for k, v in p.items()}, "f16x3")
+    assert tab.dtype == torch.float32
+    perm = ops.storage_perm().long()
+    grid = s["latent"].permute(0, 2, 3, 1).double()
+    for b in range(3):
+        ref = grid @ p[f"lin_z.{b}.weight"].double().t() + p[f"lin_z.{b}.bias"].double()
+        got = torch.empty_like(ref)
+        got[..., perm] = tab[b].cpu().double()
+        assert (got - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("scene_name", ["sn64"])
+def test_split_eval_points_matches_reference(ops, dev, scene_name):
+    g = load_golden("stages")
+    sc = dscene(ops, dev, scene_name)
+    xyz = torch.from_numpy(g[f"{scene_name}_xyz"]).to(dev)
+    vd = torch.from_numpy(g[f"{scene_name}_viewdirs"]).to(dev)
+    for which, seed in (("coarse", 11), ("fine", 12)):
+        pk, tab = split_net(ops, dev, sc, seed)
+        out = ops.eval_points(sc, pk, xyz, vd, tables=tab).cpu().numpy()
+        ref = g[f"{scene_name}_out_{which}"]
+        assert np.isfinite(out).all()
+        e_rgb = np.abs(out[..., :3] - ref[..., :3]).max()
+        e_s = (np.abs(out[..., 3] - ref[..., 3]) / np.maximum(1.0, ref[..., 3])).max()
+        print(f"SPLIT eval_points {scene_name} {which}: rgb max err {e_rgb:.3e}, sigma rel err {e_s:.3e}")
+        assert e_rgb <= 2e-5, f"rgb max err {e_rgb:.3e}"
+        assert e_s <= 1e-4, f"sigma rel err {e_s:.3e}"
+
+
+@pytest.mark.parametrize("name", SINGLE_VIEW)
+def test_split_render_matches_reference(ops, dev, name):
+    g, scene, meta, mc, mf, rays, noise = golden_setup(name)
+    Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])
+    sc = dscene(ops, dev, str(g["scene"]))
+    pc, tc = split_net(ops, dev, sc, int(g["mlp_seed_coarse"]))
+    pf, tf = split_net(ops, dev, sc, int(g["mlp_seed_fine"])) if mf is not None else (None, None)
+    r = rays.reshape(-1, 8).to(dev)
+    out = ops.render_forward(sc, pc, pf, r, Kc, Kf, Kfd, {k: v.to(dev) for k, v in noise.items()},
+                             depth_std=float(g["depth_std"]), white_bkgd=bool(g["white_bkgd"]),
+                             lindisp=bool(g["lindisp"]), want_weights=True, tables=(tc, tf))
+    span = float(meta["z_far"] - meta["z_near"])
+    assert ("fine" in out) == (Kf > 0)
+    for p in ["coarse"] + (["fine"] if Kf > 0 else []):
+        K = Kc if p == "coarse" else Kc + Kf
+        flips = 0.0 if p == "coarse" else 2e-2
+        rgb, depth, w = out[p]["rgb"].cpu(), out[p]["depth"].cpu().numpy(), out[p]["weights"].cpu().numpy()
+        assert_close_frac(rgb.numpy(), g[f"{p}_rgb"].reshape(-1, 3), 2e-5, max_frac=flips, loose_atol=0.05, what=f"{p} rgb")
+        assert_close_frac(depth, g[f"{p}_depth"].reshape(-1), 1e-4 * span, max_frac=flips, loose_atol=0.05 * span, what=f"{p} depth")
+        if p == "coarse":
+            np.testing.assert_allclose(w, g["coarse_weights"].reshape(-1, K), rtol=0, atol=2e-5)
+        ps = O.psnr(rgb, torch.from_numpy(g[f"{p}_rgb"]).reshape(-1, 3))
+        print(f"SPLIT render {name} {p}: PSNR {ps:.1f} dB")
+        assert ps >= 85.0, f"{p} PSNR {ps:.1f} dB"
+
+
+def test_split_variants_agree_and_match_the_exact_fp32_path_at_full_size(ops, dev):
+    """65 536 samples-rays of the sn64 view: ray-sample and explicit-point variants agree bitwise; against the unfused
+    fp32-MFMA path (a different implementation of the same arithmetic class) the per-point error stays at 1e-5."""
+    from testdata import synthetic
+    s, meta = scene_for("sn64")
+    sc = dscene(ops, dev, "sn64")
+    state = {k: v.to(dev) for k, v in mlp_params(11).items()}
+    pk, tab = ops.pack_mlp(state, "f16x3"), ops.fold_latent(sc, state, "f16x3")
+    rays = synthetic.target_rays(meta).reshape(-1, 8).to(dev)
+    z = ops.sample_coarse(rays, torch.rand(rays.shape[0], 64, device=dev))
+    a = ops.eval_ray_samples(sc, pk, rays, z, tables=tab)
+    assert torch.equal(a, ops.eval_ray_samples(sc, pk, rays, z, tables=tab))
+    pts = (rays[:, None, :3] + z.unsqueeze(2) * rays[:, None, 3:6]).reshape(1, -1, 3)
+    vd = rays[:, None, 3:6].expand(-1, 64, -1).reshape(1, -1, 3)
+    b = ops.eval_points(sc, pk, pts.contiguous(), vd.contiguous(), tables=tab).reshape(a.shape)
+    assert torch.equal(a, b)
+    exact = ops.eval_ray_samples(sc, ops.pack_mlp(state, "f32"), rays, z)
+    e = (a - exact).abs()
+    print(f"SPLIT vs exact-fp32 path, {a.shape[0] * a.shape[1]} points: rgb max {e[..., :3].max().item():.3e}, "
+          f"sigma max {e[..., 3].max().item():.3e}")
+    assert e[..., :3].max().item() <= 2e-5 and (e[..., 3] / exact[..., 3].clamp(min=1.0)).max().item() <= 1e-4
+
+
+def test_split_api_scope(ops, dev):
+    """PixelNeRFNet(precision='f16x3'): single-view scenes run the split kernel, multi-view scenes the unfused fp32 path;
+    a 16-bit table set is refused."""
+    from pixelnerf_amd import _lib
+    from test_api_gpu import build_net
+    from pixelnerf_amd.render import NeRFRenderer
+    g, scene, meta, mc, mf, rays, noise = golden_setup("sn64_64_128")
+    net = build_net(dev, scene, precision="f16x3")
+    assert net.packed(True).precision == _lib.PREC_F16X3 and net.tables(True).dtype == torch.float32
+    rend = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=True).to(dev).eval()
+    with torch.no_grad():
+        out = rend(net, rays.to(dev), _noise={k: v.to(dev) for k, v in noise.items()})
+    assert O.psnr(out.fine.rgb.cpu(), torch.from_numpy(g["fine_rgb"])) >= 85.0
+    g2, scene2, *_ = golden_setup("srn_mini_64_128")
+    net2 = build_net(dev, scene2, precision="f16x3")
+    assert net2.packed(True).precision == _lib.PREC_F32 and net2.tables(True) is None
+    sc = dscene(ops, dev, "sn64")
+    state = {k: v.to(dev) for k, v in mlp_params(11).items()}
+    with pytest.raises(_lib.PixelNerfHipError):
+        ops.eval_points(sc, ops.pack_mlp(state, "f16x3"), torch.zeros(1, 8, 3, device=dev), torch.ones(1, 8, 3, device=dev),
+                        tables=ops.fold_latent(sc, state, "f16"))
