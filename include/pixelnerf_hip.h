@@ -200,6 +200,10 @@ typedef struct PnrBackwardDumps {
     void *g_fc1[5]; /* dL/d(blocks[b].fc_1 output) = dL/d(residual stream after block b), shapes as d_n */
     void *g_fc0[5]; /* dL/d(blocks[b].fc_0 output), shapes as d_a                                */
     void *g_x0;     /* (rows_v, 512) dL/d(residual stream in front of block 0) = dY of lin_in, lin_z[0] */
+    float *d_zlat;  /* (rows_v, 512) fp32, natural channel order: d(interpolated latent) = sum_b dY_b W_z[b]
+                       (resnetfc.py:175-180 backward), unscaled; NULL = not wanted                      */
+    float *d_in;    /* (rows_v, 42) fp32: d(positional code | view direction) = dY W_in (resnetfc.py:147
+                       backward), unscaled; NULL = not wanted (needs d_zlat)                              */
 } PnrBackwardDumps;
 
 int pnr_eval_ray_samples_train(const PnrScene *scene /*host*/, const void *packed, int precision,

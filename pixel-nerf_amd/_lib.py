@@ -53,7 +53,8 @@ class PnrTrainDumps(ctypes.Structure):
 
 
 class PnrBackwardDumps(ctypes.Structure):
-    _fields_ = [("g_fc1", ctypes.c_void_p * 5), ("g_fc0", ctypes.c_void_p * 5), ("g_x0", ctypes.c_void_p)]
+    _fields_ = [("g_fc1", ctypes.c_void_p * 5), ("g_fc0", ctypes.c_void_p * 5), ("g_x0", ctypes.c_void_p),
+                ("d_zlat", ctypes.c_void_p), ("d_in", ctypes.c_void_p)]
 
 
 # every symbol include/pixelnerf_hip.h declares: name -> (restype, argtypes)

@@ -3,13 +3,13 @@ Differentiable NeRFRenderer.forward (training; BASELINE config 5, train/train.py
 
 forward  : the inference kernels, with the network launches replaced by their training form
            (`pnr_eval_ray_samples_train`: same kernel + 16-bit dumps of every linear's input).
-backward : HIP kernels for everything that is not a plain GEMM --
+backward : HIP kernels only (no library GEMM, no torch matmul) --
              pnr_composite_backward   d(rgb, depth, weights)      -> d(per-point rgb sigma)
-             pnr_mlp_backward         fused data-gradient chain   -> per-layer output gradients dY
+             pnr_mlp_backward         fused data-gradient chain   -> per-layer output gradients dY,
+                                      d z_lat = sum_b dY_b W_z[b] and d(code) = dY W_in (transposed weight streams)
              pnr_latent_scatter       d(interpolated latent)      -> d(feature grid)
-             pnr_weight_grad          dW = dY^T X, db = sum dY    from the 16-bit dumps (MFMA, fp32 acc)
-           and library GEMMs (torch.matmul) only for the three plain products that remain:
-           d z_lat = sum_b dY_b W_z[b], d(code) = dY W_in, and the tiny lin_in / lin_out weights.
+             pnr_weight_grad_batched  dW = dY^T X, db = sum dY    from the 16-bit dumps (MFMA, fp32 acc), one launch
+             pnr_lin_out_grad         lin_out's 4 x 512 weight gradient
              pnr_position_backward    d(network inputs)           -> d(sample positions z)
 Gradients flow to every ResnetFC parameter of both networks and to `encoder.latent` (hence into
 the ResNet-34 through PyTorch autograd), including the reference's one position-gradient path:
@@ -23,20 +23,6 @@ import torch
 
 from . import ops
 
-_perm_cache = {}
-
-
-def _perms(device):
-    """perm[e] = feature at storage position e; inv[f] = storage position of feature f."""
-    key = str(device)
-    if key not in _perm_cache:
-        perm = ops.storage_perm(device)
-        inv = torch.empty_like(perm)
-        inv[perm] = torch.arange(512, device=device)
-        _perm_cache[key] = (perm, inv)
-    return _perm_cache[key]
-
-
 def _param_names():
     names = ["lin_in", "lin_out"] + [f"blocks.{b}.fc_{j}" for b in range(5) for j in (0, 1)] + [f"lin_z.{b}" for b in range(3)]
     return [n + s for n in names for s in (".weight", ".bias")]
@@ -48,8 +34,6 @@ PARAM_NAMES = _param_names()
 def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS, want_d_in=False):
     """All parameter gradients of one ResnetFC + d(interpolated latent) [+ d(lin_in operand)] from
     one backward pass.  fwd: ops.TrainDumps of the forward; g_out (P,4) fp32 = dL/d(lin_out output)."""
-    dev = g_out.device
-    perm, inv = _perms(dev)
     # run the 16-bit chain at a power-of-two scale that puts max|g| near 2^6 (exact to undo); the scale is picked
     # on the device (no host sync in the middle of the backward); a non-finite g poisons it with NaN
     sc = ops.grad_scale(g_out)
@@ -72,20 +56,10 @@ def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS, want_d_in=False):
     names.append("lin_in")
     for name, (dW, db) in zip(names, ops.weight_grad_batched(jobs, prec, 1.0, out_scale_dev=inv_s)):  # one launch, 14 linears
         grads[name + ".weight"], grads[name + ".bias"] = dW, db
-    d_zlat = None
-    for b in range(3):
-        gz = gzs[b]
-        # d z_lat += dY W_z[b]  (W in feature order; dY columns are in storage order): a plain
-        # (rows,512)x(512,512) library GEMM on the 16-bit operands (fp32 accumulation inside)
-        term = torch.matmul(gz, mlp_state[f"lin_z.{b}.weight"].detach()[perm].to(gz.dtype)).float()
-        d_zlat = term if d_zlat is None else d_zlat + term
-    d_zlat = d_zlat * inv_s
     grads["lin_out.weight"], grads["lin_out.bias"] = ops.lin_out_grad(g_out, fwd.d_x5, prec)
-    d_in = None
-    if want_d_in:  # dL/d(code | viewdir) = dY(lin_in) W_in   (rows_v, 42): 16-bit library GEMM like the lin_z terms
-        w_in = mlp_state["lin_in.weight"].detach()[perm].to(bd.g_x0.dtype)
-        d_in = (torch.matmul(bd.g_x0, w_in).float() * inv_s).contiguous()
-    return grads, d_zlat.contiguous(), d_in
+    # d z_lat = sum_b dY_b W_z[b] and d(code | viewdir) = dY W_in come out of the same fused chain (pnr_mlp_backward:
+    # four more transposed-stream GEMMs on gradient images the kernel already holds), fp32, unscaled
+    return grads, bd.d_zlat, (bd.d_in if want_d_in else None)
 
 
 class _RenderFunction(torch.autograd.Function):

@@ -41,7 +41,19 @@ __global__ void pack_weights_bwd_kernel(PnrMlpWeights p, T *__restrict__ out) {
     // A-operand row = output row of the transposed GEMM = INPUT feature of the layer
     const int f_row = wv * SL + it * 32 + i;
     float v = 0.f;
-    if (g == BG_OUT) {
+    if (g == BG_Z2 || g == BG_Z1 || g == BG_Z0) {
+        // d z_lat[c] += sum_f dY_b[f] W_z[b][f][c]: rows = latent channel c (natural order, wave w owns 64w..64w+63),
+        // K = hidden feature f in the storage order of the gradient image
+        const int b = g == BG_Z2 ? 2 : (g == BG_Z1 ? 1 : 0);
+        const int f_o = feat_of(s >> 1, s & 1, 8 * h + e);
+        v = p.lin_z_w[b][f_o * C_LAT + f_row];
+    } else if (g == BG_IN) {
+        // d(code | viewdir)[k] = sum_f dY[f] W_in[f][k]: every wave holds the FULL 64 (42 real) output rows and contracts
+        // only its own 64 hidden features = storage elements 64w + 16s + 8h + e (K-split, reduced across waves in LDS)
+        const int k_row = it * 32 + i;
+        const int f_o = feat_of(wv * IT + (s >> 1), s & 1, 8 * h + e);
+        if (k_row < D_IN) v = p.lin_in_w[f_o * D_IN + k_row];
+    } else if (g == BG_OUT) {
         const int k = s * 16 + h * 8 + e;  // natural order of the 4 network outputs, zero padded
         if (k < D_OUT) v = p.lin_out_w[k * D_HID + f_row];
     } else {
@@ -65,6 +77,8 @@ struct BwdParams {
     long long P;
     int NS, ntiles;
     char *g_fc1[5], *g_fc0[5], *g_x0;
+    float *d_zlat;  // (NS*P, 512) fp32, natural channel order: d(interpolated latent)   (nullable: skip)
+    float *d_in;    // (NS*P, 42)  fp32: d(positional code | view direction)             (nullable: skip)
 };
 
 // acc = (dump row element != 0) ? acc : 0 ; dump holds relu(.) as 16-bit in storage order
@@ -224,7 +238,83 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
 #pragma unroll 1
             for (int b = COMBINE_LAYER - 1; b >= 0; --b)
                 bwd_block<P>(G, smem, b, R, NS, q, off_view, valid, a_rd0, a_rd1, a_wr);
-            dump_only<P>(G, q.g_x0 + off_view, valid);  // dY of lin_in and lin_z[0] (and of lin_z[b]: g_fc1[b-1])
+            if (!q.d_zlat) {
+                dump_only<P>(G, q.g_x0 + off_view, valid);  // dY of lin_in and lin_z[0] (and of lin_z[b]: g_fc1[b-1])
+                continue;
+            }
+            // ---- d z_lat = sum_b dY_b W_z[b] and d(code) = dY_0 W_in (resnetfc.py:147,175-180 backward): four more
+            // transposed-stream GEMMs on gradient images this tile has just produced.  dY_2, dY_1 (= g_fc1[1], g_fc1[0])
+            // come back from their dumps (written by this workgroup a moment ago, L2-resident), dY_0 = G is in registers.
+            const float inv_scale = 1.f / (q.scale_dev ? *q.scale_dev : q.scale);
+            f32x16 Z[IT][JT];
+            zero_acc(Z);
+#pragma unroll 1
+            for (int b = COMBINE_LAYER - 1; b >= 1; --b) {
+                __threadfence_block();
+                __syncthreads();  // the image's readers are done; the dump rows of this tile are visible
+                {
+                    const char *src = q.g_fc1[b - 1] + (size_t)view * (size_t)q.P * (D_HID * 2);
+#pragma unroll
+                    for (int u = 0; u < MT / NW; ++u) {
+                        const int row = wv * (MT / NW) + u;
+                        const long long g = (long long)tile * MT + row;
+                        u32x4 v = {0, 0, 0, 0};
+                        if (g < q.P) v = *reinterpret_cast<const u32x4 *>(src + (size_t)g * (D_HID * 2) + lane * 16);
+                        *reinterpret_cast<u32x4 *>(smem + LDS_A + row * ROW_ACT + lane * 16) = v;
+                    }
+                }
+                __syncthreads();
+                gemm<P, AdvanceBwd>(Z, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);  // lin_z[b]^T dY_b
+            }
+            __syncthreads();
+            write_act<P, false, true>(G, smem, a_wr, q.g_x0 + off_view, valid);  // dY of lin_in and lin_z[0]
+            __syncthreads();
+            gemm<P, AdvanceBwd>(Z, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);      // lin_z[0]^T dY_0
+            {   // accumulator (channel 32T + (r&3) + 8(r>>2) + 4h, point) -> fp32 rows, 16-byte pieces
+                float *dst = q.d_zlat + ((size_t)view * (size_t)q.P + (size_t)tile * MT + pl) * C_LAT + (wv * IT) * 32 + 4 * h;
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        if (!valid[jt]) continue;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            f32x4 v = {Z[it][jt][4 * k], Z[it][jt][4 * k + 1], Z[it][jt][4 * k + 2], Z[it][jt][4 * k + 3]};
+                            *reinterpret_cast<f32x4 *>(dst + (size_t)jt * 32 * C_LAT + it * 32 + 8 * k) = v * inv_scale;
+                        }
+                    }
+            }
+            // lin_in^T, K-split: this wave's 64 hidden features = bytes [128 wv, 128 wv + 128) of every image row
+            zero_acc(Z);
+            gemm<P, AdvanceBwd>(Z, smem, a_rd0 + wv * 128, a_rd1 + wv * 128, KS_IN / 4, R, NS);
+            __syncthreads();  // every wave is done with the image: its space (and LDS_Z below it) takes the partials
+            {
+                // partial[w][point][k], 66-float rows: lanes of a half-wave write consecutive points -> distinct banks
+                float *part = reinterpret_cast<float *>(smem) + (size_t)wv * (MT * 66);
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            part[(jt * 32 + pl) * 66 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = Z[it][jt][r];
+            }
+            __syncthreads();
+            if (q.d_in) {
+                const int pnt = tid >> 3, k0 = (tid & 7) * 8;
+                const long long g = (long long)tile * MT + pnt;
+                if (g < q.P) {
+#pragma unroll
+                    for (int k = k0; k < k0 + 8; ++k) {
+                        if (k >= D_IN) break;
+                        float sum = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) sum += reinterpret_cast<const float *>(smem)[(size_t)w * (MT * 66) + pnt * 66 + k];
+                        q.d_in[((size_t)view * (size_t)q.P + (size_t)g) * D_IN + k] = sum * inv_scale;
+                    }
+                }
+            }
+            __syncthreads();  // the partials are consumed before the next view / tile reuses the space
         }
     }
 }
@@ -810,6 +900,8 @@ extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const Pnr
     q.wstream = (const char *)packed_bwd;
     q.g_out = g_out; q.scale = grad_scale; q.scale_dev = grad_scale_dev; q.P = P; q.NS = NS; q.ntiles = (int)((P + MT - 1) / MT);
     q.d_x5 = (const char *)fwd->d_x5; q.g_x0 = (char *)out->g_x0;
+    q.d_zlat = out->d_zlat; q.d_in = out->d_in;
+    if (q.d_in && !q.d_zlat) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: d_in needs d_zlat (they are produced together)");
     if (!q.d_x5 || !q.g_x0) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: null dump");
     for (int b = 0; b < 5; ++b) {
         q.d_a[b] = (const char *)fwd->d_a[b]; q.d_n[b] = (const char *)fwd->d_n[b];

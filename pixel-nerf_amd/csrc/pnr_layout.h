@@ -100,10 +100,13 @@ __host__ __device__ constexpr int slot_of(int f) {
 // ---- backward chain: transposed weight stream, consumption order per tile ----
 //   head (pooled, once): lin_out^T (4 ring steps, k-step 0 real) | fc_1[4]^T fc_0[4]^T fc_1[3]^T fc_0[3]^T
 //   per source view    : fc_1[2]^T fc_0[2]^T fc_1[1]^T fc_0[1]^T fc_1[0]^T fc_0[0]^T
-enum BGemm { BG_OUT = 0, BG_FC1_4, BG_FC0_4, BG_FC1_3, BG_FC0_3, BG_FC1_2, BG_FC0_2, BG_FC1_1, BG_FC0_1, BG_FC1_0, BG_FC0_0, NBGEMM };
+//                        | lin_z[2]^T lin_z[1]^T lin_z[0]^T  (d z_lat = sum_b dY_b W_z[b])
+//                        | lin_in^T (4 ring steps: every wave contracts its own 64 hidden features, K-split)
+enum BGemm { BG_OUT = 0, BG_FC1_4, BG_FC0_4, BG_FC1_3, BG_FC0_3, BG_FC1_2, BG_FC0_2, BG_FC1_1, BG_FC0_1, BG_FC1_0, BG_FC0_0,
+             BG_Z2, BG_Z1, BG_Z0, BG_IN, NBGEMM };
 __host__ __device__ constexpr int bgemm_offset(int g) { return g == 0 ? 0 : KS_IN + (g - 1) * KS_BIG; }
 constexpr int BRS_HEAD_END = bgemm_offset(BG_FC1_2);  // 132
-constexpr int BRS_TOTAL = bgemm_offset(NBGEMM);       // 324
+constexpr int BRS_TOTAL = bgemm_offset(BG_IN) + KS_IN;  // 424
 static_assert(BRS_HEAD_END % 4 == 0 && BRS_TOTAL % 4 == 0, "ring depth 4 needs aligned segments");
 constexpr size_t BWSTREAM_ELEMS_PER_WAVE = (size_t)BRS_TOTAL * IT * FRAG_ELEMS;
 constexpr size_t BPACKED_BYTES = BWSTREAM_ELEMS_PER_WAVE * NW * 2;

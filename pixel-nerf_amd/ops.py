@@ -617,12 +617,19 @@ class TrainDumps:
 
 
 class BackwardDumps:
+    """Outputs of the fused data-gradient chain: every layer's dY (16-bit rows, operands of the weight-gradient GEMMs)
+    plus, in fp32, d(interpolated latent) = sum_b dY_b W_z[b] and d(code | viewdir) = dY W_in."""
+
     def __init__(self, fwd, device):
         self.g_fc1 = [torch.empty_like(t) for t in fwd.d_n]
         self.g_fc0 = [torch.empty_like(t) for t in fwd.d_a]
         self.g_x0 = torch.empty_like(fwd.d_z)
+        rows = fwd.d_z.shape[0]
+        self.d_zlat = torch.empty((rows, 512), dtype=torch.float32, device=device)
+        self.d_in = torch.empty((rows, 42), dtype=torch.float32, device=device)
         s = _lib.PnrBackwardDumps()
         s.g_x0 = self.g_x0.data_ptr()
+        s.d_zlat, s.d_in = self.d_zlat.data_ptr(), self.d_in.data_ptr()
         for b in range(5):
             s.g_fc1[b], s.g_fc0[b] = self.g_fc1[b].data_ptr(), self.g_fc0[b].data_ptr()
         self.struct = s

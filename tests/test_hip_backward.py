@@ -306,6 +306,39 @@ def test_grad_scale_is_picked_on_device(dev):
     assert torch.equal(a.g_x0, b.g_x0) and all(torch.equal(x, y) for x, y in zip(a.g_fc0, b.g_fc0))
 
 
+@pytest.mark.parametrize("name,prec", [("train_64_32", "f16"), ("srn_mini_64_128", "f16"), ("srn_mini_64_128", "bf16")])
+def test_fused_chain_latent_and_input_gradients(dev, name, prec):
+    """d z_lat = sum_b dY_b W_z[b] and d(code | viewdir) = dY_0 W_in, computed inside pnr_mlp_backward (transposed weight
+    streams), against the same products formed in fp32 from the chain's own 16-bit dY dumps and the 16-bit-rounded weights:
+    identical operands, fp32 accumulation on both sides -> agreement at accumulation-order level."""
+    from pixelnerf_amd import ops
+    g_, scene, meta, mc, mf, rays, noise = golden_setup(name)
+    sc = ops.make_scene(scene["latent"].to(dev), scene["poses"].to(dev), scene["focal"].to(dev), scene["c"].to(dev),
+                        scene["image_shape"], scene["NS"])
+    params = {k: v.to(dev) for k, v in mf.items()}
+    pk, pkb = ops.pack_mlp(params, prec), ops.pack_mlp(params, prec, backward=True)
+    r = rays.reshape(-1, 8).to(dev)
+    z = torch.from_numpy(g_["coarse_z"]).to(dev)[:, :37].contiguous()  # 37 samples per ray: ragged last tile
+    _, dumps = ops.eval_ray_samples_train(sc, pk, r, z)
+    gen = torch.Generator().manual_seed(5)
+    g_out = (torch.randn(r.shape[0] * z.shape[1], 4, generator=gen) * 0.02).to(dev)
+    s = ops.grad_scale(g_out)
+    bd = ops.mlp_backward(pkb, dumps, g_out, s[0:1])
+    torch.cuda.synchronize()
+    dt = torch.float16 if prec == "f16" else torch.bfloat16
+    perm = ops.storage_perm(dev)  # perm[e] = feature at storage position e
+    inv_s = float(s[1].item())
+    gz = [bd.g_x0, bd.g_fc1[0], bd.g_fc1[1]]
+    want = sum(gz[b].float() @ params[f"lin_z.{b}.weight"][perm].to(dt).float() for b in range(3)) * inv_s
+    want_in = (bd.g_x0.float() @ params["lin_in.weight"][perm].to(dt).float()) * inv_s
+    rows = scene["NS"] * r.shape[0] * z.shape[1]
+    assert bd.d_zlat.shape == (rows, 512) and bd.d_in.shape == (rows, 42)
+    for got, ref, what in ((bd.d_zlat, want, "d_zlat"), (bd.d_in, want_in, "d_in")):
+        assert torch.isfinite(got).all()
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-5 * max(ref.abs().max().item(), 1e-12) + 1e-12, f"{what}: max err {err:.3e} vs scale {ref.abs().max().item():.3e}"
+
+
 @pytest.mark.parametrize("name", ["train_64_32", "srn_mini_64_128"])
 def test_hip_gradients_match_reference_autograd_goldens(dev, name):
     """HIP training path vs the gradients of the UNMODIFIED reference's own backward (tests/golden/gradients.npz,

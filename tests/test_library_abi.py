@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol(lib, repo_root):
 
 
 def test_struct_layouts_match_header():
-    # PnrScene: 4 pointers, 6 int32, 2 floats; PnrMlpWeights: 30 pointers; dumps: 13 / 11 pointers
-    assert ctypes.sizeof(_lib.PnrTrainDumps) == 13 * 8 and ctypes.sizeof(_lib.PnrBackwardDumps) == 11 * 8
+    # PnrScene: 4 pointers, 6 int32, 2 floats; PnrMlpWeights: 30 pointers; dumps: 13 / 13 pointers (11 dY dumps + d_zlat + d_in)
+    assert ctypes.sizeof(_lib.PnrTrainDumps) == 13 * 8 and ctypes.sizeof(_lib.PnrBackwardDumps) == 13 * 8
     assert ctypes.sizeof(_lib.PnrScene) == 4 * 8 + 6 * 4 + 2 * 4
     assert ctypes.sizeof(_lib.PnrMlpWeights) == 30 * 8
 
@@ -43,7 +43,9 @@ def test_host_only_entry_points(lib):
     # packed stream: 8 waves x 424 ring steps x 2 fragments x 1 KiB + biases + b_out
     assert lib.pnr_packed_mlp_bytes() == 8 * 424 * 2 * 1024 + 11 * 8 * 64 * 4 + 16
     assert lib.pnr_render_workspace_bytes(0, 64, 128) == 0
-    assert lib.pnr_packed_mlp_bwd_bytes() == 8 * 324 * 2 * 1024
+    # backward stream: head 132 + per view (6 block GEMMs + 3 lin_z^T) x 32 + lin_in^T 4 = 424 ring steps
+    assert lib.pnr_packed_mlp_bwd_bytes() == 8 * 424 * 2 * 1024
+    assert lib.pnr_packed_mlp_split_bytes() == 2 * lib.pnr_packed_mlp_bytes()
     assert lib.pnr_weight_grad_workspace_bytes() == 32 * (512 * 512 + 512) * 4
     perm = (ctypes.c_int32 * 512)()
     assert lib.pnr_storage_perm(perm) == 0 and sorted(perm) == list(range(512)) and perm[16] == 4 and perm[1] == 1
