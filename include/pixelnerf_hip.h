@@ -316,19 +316,42 @@ int pnr_render_forward(const PnrScene *scene /*host*/, const void *packed_coarse
 int pnr_gen_rays(const float *poses, int NV, int W, int H, float fx, float fy, float cx, float cy,
                  float z_near, float z_far, float *rays, void *stream);
 
+/* ---- counter-based random draws (production mode; SURVEY.md 7 "hard parts", nerf.py:111,135,141,158) ------------
+ * The reference draws its jitter / importance / depth-sample noise with four torch.rand launches per call.  The
+ * seeded entries below draw inside the sampling kernels instead: Philox4x32-10, key = 64-bit seed, counter =
+ * (global ray id, value index / 4, draw id), uniforms = 24 random bits in [0,1), normals by Box-Muller.  A value
+ * depends only on (seed, global ray id, draw, index): an image does not change with chunking or with sharding
+ * the rays across GPUs (ray_id_offset / ray_id_stride place a shard inside the whole ray set: id =
+ * (r / rays_per_obj) * ray_id_stride + r % rays_per_obj + ray_id_offset; 0 / 0 = the call IS the whole set).
+ * pnr_philox_noise writes the same draws out as the explicit tensors of pnr_render_forward (u1 (R,Kc), u2, u3
+ * (R,Kimp), n4 (R,Kfd)); pnr_philox_raw is the bare block function on the host, for known-answer tests. */
+int pnr_philox_noise(unsigned long long seed, long long ray_id_offset, int ray_id_stride, int rays_per_obj, int R,
+                     int Kc, int Kimp, int Kfd, float *u1, float *u2, float *u3, float *n4, void *stream);
+int pnr_philox_raw(const uint32_t *counter4 /*host*/, const uint32_t *key2 /*host*/, uint32_t *out4 /*host*/);
+/* NeRFRenderer.forward (nerf.py:251-303) with in-kernel draws; tables_* NULL = unfolded streams. */
+int pnr_render_forward_seeded(const PnrScene *scene /*host*/, const void *packed_coarse, const void *tables_coarse,
+                              const void *packed_fine /*nullable*/, const void *tables_fine, int precision,
+                              const float *rays, int R, int rays_per_obj, int Kc, int Kf, int Kfd, float depth_std,
+                              int white_bkgd, int lindisp, unsigned long long seed, long long ray_id_offset,
+                              int ray_id_stride, float *rgb_c, float *depth_c, float *weights_c, float *rgb_f,
+                              float *depth_f, float *weights_f, void *workspace, void *stream);
+
 /* ---- next-row helpers (continued): render whole target views ----------
- * util.gen_rays + NeRFRenderer.forward in ONE call (what eval/eval.py:247-279 and
- * eval/gen_video.py do per object: build all rays of the target views on the host, copy, render):
- * poses_c2w (NV,4,4) device, views grouped per object (NV = SB * views_per_object); the rays of all
- * NV*H*W pixels are generated into the workspace; outputs / noise are laid out as in
- * pnr_render_forward with R = NV*H*W. */
+ * util.gen_rays + NeRFRenderer.forward in ONE call (what eval/eval.py:247-279 and eval/gen_video.py do per
+ * object: build all rays of the target views on the host, copy, render): poses_c2w (NV,4,4) device, views
+ * grouped per object (NV = SB * views_per_object).  The rays are NOT materialised: the sampling, network and
+ * compositing kernels regenerate the ray of a pixel from (pose, intrinsics, pixel id) where they need it, in
+ * gen_rays' operation order (bit-identical to pnr_gen_rays + pnr_render_forward).  tables_* NULL = unfolded
+ * streams.  Noise: explicit tensors laid out as in pnr_render_forward with R = NV*H*W, or all four NULL ->
+ * in-kernel draws from `seed` (ray id = pixel index in the (NV,H,W) order). */
 size_t pnr_render_views_workspace_bytes(int NV, int W, int H, int Kc, int Kf);
-int pnr_render_views(const PnrScene *scene /*host*/, const void *packed_coarse, const void *packed_fine,
-                     int precision, const float *poses_c2w, int NV, int W, int H, float fx, float fy,
-                     float cx, float cy, float z_near, float z_far, int Kc, int Kf, int Kfd,
-                     float depth_std, int white_bkgd, int lindisp, const float *u1, const float *u2,
-                     const float *u3, const float *n4, float *rgb_c, float *depth_c, float *weights_c,
-                     float *rgb_f, float *depth_f, float *weights_f, void *workspace, void *stream);
+int pnr_render_views(const PnrScene *scene /*host*/, const void *packed_coarse, const void *tables_coarse,
+                     const void *packed_fine /*nullable*/, const void *tables_fine, int precision,
+                     const float *poses_c2w, int NV, int W, int H, float fx, float fy, float cx, float cy,
+                     float z_near, float z_far, int Kc, int Kf, int Kfd, float depth_std, int white_bkgd,
+                     int lindisp, const float *u1, const float *u2, const float *u3, const float *n4,
+                     unsigned long long seed, float *rgb_c, float *depth_c, float *weights_c, float *rgb_f,
+                     float *depth_f, float *weights_f, void *workspace, void *stream);
 
 /* ---- next-row helpers: encoder output formatting --------------------
  * src/model/encoder.py:150-163: F.interpolate(bilinear, align_corners=True) of every ResNet stage

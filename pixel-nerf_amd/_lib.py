@@ -13,7 +13,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelnerf_hip.so")  # override: A/B experiments
 SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_split.hip", "pnr_bwd.hip", "pnr_f32.hip", "pnr_encode.hip"]
-HEADERS = ["pnr_common.h", "pnr_layout.h", "pnr_device.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
+HEADERS = ["pnr_common.h", "pnr_layout.h", "pnr_device.h", "pnr_raysrc.h", "pnr_internal.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
 
 PREC_F16, PREC_BF16, PREC_F32, PREC_F16X3 = 0, 1, 2, 3
 PRECISIONS = {"f16": PREC_F16, "fp16": PREC_F16, "bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32, "f16x3": PREC_F16X3}
@@ -71,8 +71,12 @@ PROTOTYPES = {
     "pnr_eval_ray_samples": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _I, _I, _P, _P]),
     "pnr_eval_points": (_I, [ctypes.POINTER(PnrScene), _P, _I, _P, _P, _I, _P, _P]),
     "pnr_render_views_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
-    "pnr_render_views": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F,
-                              _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pnr_render_views": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F,
+                              _I, _I, _P, _P, _P, _P, ctypes.c_ulonglong, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pnr_philox_noise": (_I, [ctypes.c_ulonglong, ctypes.c_longlong, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "pnr_philox_raw": (_I, [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
+    "pnr_render_forward_seeded": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I,
+                                       ctypes.c_ulonglong, ctypes.c_longlong, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pnr_pyramid_to_latent": (_I, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                    ctypes.POINTER(ctypes.c_int), _I, _I, _P, _P, _P]),
     "pnr_sample_training_rays": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),

@@ -6,6 +6,7 @@
 
 #include "pnr_common.h"
 #include "pnr_layout.h"
+#include "pnr_raysrc.h"
 
 namespace pnr {
 
@@ -53,11 +54,13 @@ struct EvalParams {
     long long table_stride;  // elements per table
     // points: variant A (rays + z) or B (xyz + viewdirs)
     const float *rays, *z, *xyz, *viewdirs;
+    RaySrc cam;        // variant A with rays == NULL: rays are regenerated from the camera (cam.rays stays NULL)
     int K;             // samples per ray (A)
     int per_obj;       // rays per object (A) or points per object (B)
     long long P;       // total points
     int ntiles;
     float *out;        // (P,4)
+    float *mv_ws;      // multi-view: per-workgroup scratch for the parked view sum (MT x 512 fp32 each)
     float *dbg;        // optional debug dump of the final residual stream x (P,512), may be null
     unsigned long long *tim;  // phase-timing accumulators (TIMING instantiation only)
     // TRAIN instantiation: 16-bit row-major dumps of every linear layer's input operand
@@ -351,8 +354,13 @@ __device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, i
     if (valid) {
         if (RAYS) {
             const int r = g / q.K;
-            const float *ray = q.rays + (size_t)r * 8;
-            ox = ray[0]; oy = ray[1]; oz = ray[2]; dx = ray[3]; dy = ray[4]; dz = ray[5];
+            if (q.rays) {
+                const float *ray = q.rays + (size_t)r * 8;
+                ox = ray[0]; oy = ray[1]; oz = ray[2]; dx = ray[3]; dy = ray[4]; dz = ray[5];
+            } else {  // util.gen_rays evaluated in place (same operation order as gen_rays_kernel: same bits)
+                const Ray8 ry = load_ray(q.cam, r);
+                ox = ry.ox; oy = ry.oy; oz = ry.oz; dx = ry.dx; dy = ry.dy; dz = ry.dz;
+            }
             const float zz = q.z[g];
             X = ox + zz * dx; Y = oy + zz * dy; Z = oz + zz * dz;  // nerf.py:185
             obj = r / q.per_obj;

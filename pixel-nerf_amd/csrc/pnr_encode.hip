@@ -187,35 +187,6 @@ extern "C" int pnr_eval_epilogue(const float *rgb, const float *depth, int n_vie
     return pnr_check_launch("pnr_eval_epilogue");
 }
 
-static size_t rays_bytes(int NV, int W, int H) { return (((size_t)NV * W * H * 8 * sizeof(float)) + 255) & ~(size_t)255; }
-
-extern "C" size_t pnr_render_views_workspace_bytes(int NV, int W, int H, int Kc, int Kf) {
-    if (NV <= 0 || W <= 0 || H <= 0) return 0;
-    const long long R = (long long)NV * W * H;
-    if (R > 0x7fffffffLL) return 0;
-    return rays_bytes(NV, W, H) + pnr_render_workspace_bytes((int)R, Kc, Kf);
-}
-
-extern "C" int pnr_render_views(const PnrScene *scene, const void *packed_coarse, const void *packed_fine, int precision,
-                                const float *poses_c2w, int NV, int W, int H, float fx, float fy, float cx, float cy,
-                                float z_near, float z_far, int Kc, int Kf, int Kfd, float depth_std, int white_bkgd,
-                                int lindisp, const float *u1, const float *u2, const float *u3, const float *n4, float *rgb_c,
-                                float *depth_c, float *weights_c, float *rgb_f, float *depth_f, float *weights_f,
-                                void *workspace, void *stream) {
-    if (!scene || NV < 0 || W <= 0 || H <= 0) return pnr_fail(PNR_E_INVALID, "pnr_render_views: bad sizes");
-    if (NV == 0) return PNR_OK;
-    if (scene->SB <= 0 || NV % scene->SB != 0) return pnr_fail(PNR_E_INVALID, "pnr_render_views: NV must be a multiple of SB (views grouped per object)");
-    const long long R = (long long)NV * W * H;
-    if (R > 0x7fffffffLL) return pnr_fail(PNR_E_INVALID, "pnr_render_views: too many rays for one call");
-    if (!workspace) return pnr_fail(PNR_E_INVALID, "pnr_render_views: null workspace");
-    float *rays = (float *)workspace;
-    int rc;
-    if ((rc = pnr_gen_rays(poses_c2w, NV, W, H, fx, fy, cx, cy, z_near, z_far, rays, stream))) return rc;
-    return pnr_render_forward(scene, packed_coarse, packed_fine, precision, rays, (int)R, (int)(R / scene->SB), Kc, Kf, Kfd,
-                              depth_std, white_bkgd, lindisp, u1, u2, u3, n4, rgb_c, depth_c, weights_c, rgb_f, depth_f,
-                              weights_f, (char *)workspace + rays_bytes(NV, W, H), stream);
-}
-
 extern "C" int pnr_pyramid_to_latent(const float *const *stages, const int *channels, const int *heights, const int *widths,
                                      int n_stages, int NV, float *latent_nhwc, float *latent_nchw, void *stream) {
     if (n_stages < 1 || n_stages > pnr::MAX_STAGES) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: 1..5 stages");

@@ -1,0 +1,18 @@
+// pnr_internal.h -- entry points shared between the translation units of libpixelnerf_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pnr_common.h"
+#include "pnr_raysrc.h"
+
+namespace pnr {
+
+// fused network on (ray, z) samples with the rays taken from `src` (explicit array or camera): dispatches on
+// `precision` (F16 / BF16 kernels of pnr_mlp.hip, F16X3 split-operand kernel of pnr_split.hip); tables == NULL selects
+// the unfolded stream.
+int eval_samples_src(const PnrScene *scene, const void *packed, const void *tables, int precision, const RaySrc &src,
+                     const float *z, int R, int rays_per_obj, int K, float *rgbsigma, hipStream_t stream);
+int eval_samples_split_src(const PnrScene *scene, const void *packed_split, const void *tables_f32, const RaySrc &src,
+                           const float *z, int R, int rays_per_obj, int K, float *rgbsigma, hipStream_t stream);
+
+}  // namespace pnr

@@ -19,6 +19,7 @@
 
 #include "pnr_common.h"
 #include "pnr_device.h"
+#include "pnr_internal.h"
 #include "pnr_layout.h"
 
 // table-lookup batch sizes of the 96-point tile (points in flight per wave; 12 points per wave and table)
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
     constexpr int MT = TL::MT, JT = TL::JT;
     constexpr int LDS_Z = TL::LDS_Z, LDS_A = TL::LDS_A, LDS_IN = TL::LDS_IN, LDS_OUT = TL::LDS_OUT;
     static_assert(!(FOLD && TRAIN), "the training instantiation keeps the lin_z GEMMs (their operands are dumped)");
-    static_assert(!TL::SINGLE_IMAGE || (FOLD && !MV), "the one-image tile is the folded single-view form");
+    static_assert(!TL::SINGLE_IMAGE || FOLD, "the one-image tile is the folded form (lin_z as table lookups)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -239,7 +240,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 
     for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
         f32x16 x[IT][JT];
-        f32x16 xsum[MV ? IT : 1][MV ? JT : 1];
         // training dumps: this lane's 32-byte slot in a (rows,512) array, row = [view*P +] point
         bool valid[JT];
 #pragma unroll
@@ -280,22 +280,33 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                 res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
                                                   a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane);
             if constexpr (MV) {
+                // mean over source views (util.combine_interleaved, util.py:461-466).  The running view sum is PARKED in
+                // a per-workgroup scratch (q.mv_ws, L2-resident, each lane re-reads only what it wrote itself: no
+                // synchronisation) instead of 64-96 live registers across three residual blocks -- the multi-view
+                // instantiations then have the single-view register budget (no scratch spills, 96-point tile).
+                // Fixed summation order view 0 + view 1 + ...: deterministic.
+                // layout [thread][slot]: one base register + immediate offsets (a [slot][thread] layout needs an address pair
+                // per slot -- 32 more live registers exactly where the budget is tightest; the 4x more cache lines touched
+                // per instruction cost ~1 k cycles per view boundary, nothing next to a tile)
+                f32x4 *ws = reinterpret_cast<f32x4 *>(q.mv_ws) + ((size_t)blockIdx.x * NTHREADS + tid) * (IT * JT * 4);
+                const bool first = view == 0, last = view + 1 == NS;
+                const float inv = 1.f / (float)NS;
 #pragma unroll
-                for (int it = 0; it < IT; ++it)
+                for (int it = 0; it < IT; ++it) {
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt) {
-                        if (view == 0) xsum[it][jt] = x[it][jt];
-                        else xsum[it][jt] += x[it][jt];
-                    }
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            f32x4 *slot = ws + (it * JT + jt) * 4 + k;
+                            f32x4 v = {x[it][jt][4 * k], x[it][jt][4 * k + 1], x[it][jt][4 * k + 2], x[it][jt][4 * k + 3]};
+                            if (!first) v += *slot;
+                            if (!last) *slot = v;
+                            else v *= inv;
+                            x[it][jt][4 * k] = v[0]; x[it][jt][4 * k + 1] = v[1]; x[it][jt][4 * k + 2] = v[2]; x[it][jt][4 * k + 3] = v[3];
+                        }
+                    __builtin_amdgcn_sched_barrier(0);  // one feature tile row at a time: bounds the loads in flight (registers)
+                }
             }
-        }
-        if constexpr (MV) {
-            // mean over source views (util.combine_interleaved, util.py:461-466)
-            const float inv = 1.f / (float)NS;
-#pragma unroll
-            for (int it = 0; it < IT; ++it)
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) x[it][jt] = xsum[it][jt] * inv;
         }
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b)
@@ -381,8 +392,36 @@ static inline bool use_tile96(const EvalParams &q, bool mv) {
 #ifdef PNR_FORCE_TILE64
     return false;
 #else
-    return q.tables && !mv && !q.d_z;
+#ifdef PNR_MV_TILE96
+    (void)mv;
+    return q.tables && !q.d_z;
+#else
+    return q.tables && !mv && !q.d_z;  // multi-view: the 64-point tile
 #endif
+#endif
+}
+
+// per (device, stream) scratch of the multi-view instantiations: the parked view sum, one tile of fp32 accumulators per
+// workgroup (256 x 192 KiB = 48 MiB).  The one allocation this library makes itself (first multi-view launch on a
+// stream); it is tied to the stream so that concurrent launches on different streams never share it.
+static float *mv_scratch(hipStream_t st, size_t bytes) {
+    struct Slot { int dev; hipStream_t st; float *p; size_t bytes; };
+    static std::vector<Slot> slots;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (auto &sl : slots)
+        if (sl.dev == dev && sl.st == st) {
+            if (sl.bytes >= bytes) return sl.p;
+            (void)hipFree(sl.p);
+            sl.p = nullptr; sl.bytes = 0;
+            if (hipMalloc(&sl.p, bytes) != hipSuccess) return nullptr;
+            sl.bytes = bytes;
+            return sl.p;
+        }
+    Slot sl = {dev, st, nullptr, bytes};
+    if (hipMalloc(&sl.p, bytes) != hipSuccess) return nullptr;
+    slots.push_back(sl);
+    return sl.p;
 }
 
 template <int PREC, bool RAYS>
@@ -391,11 +430,22 @@ static int launch(EvalParams &q, bool mv, hipStream_t st) {
     auto k = mv ? eval_kernel<PREC, RAYS, true> : eval_kernel<PREC, RAYS, false>;
     int mt = 64, lds = Tile<64>::LDS_TOTAL;
     if (RAYS && q.d_z) k = mv ? eval_kernel<PREC, true, true, false, true> : eval_kernel<PREC, true, false, false, true>;
-    else if (use_tile96(q, mv)) { k = eval_kernel<PREC, RAYS, false, false, false, true, 96>; mt = 96; lds = Tile<96>::LDS_TOTAL; }
+    else if (use_tile96(q, mv)) {
+#ifdef PNR_MV_TILE96
+        k = mv ? eval_kernel<PREC, RAYS, true, false, false, true, 96> : eval_kernel<PREC, RAYS, false, false, false, true, 96>;
+#else
+        k = eval_kernel<PREC, RAYS, false, false, false, true, 96>;
+#endif
+        mt = 96; lds = Tile<96>::LDS_TOTAL;
+    }
     else if (q.tables) k = mv ? eval_kernel<PREC, RAYS, true, false, false, true> : eval_kernel<PREC, RAYS, false, false, false, true>;
     const long long nt = (q.P + mt - 1) / mt;
     q.ntiles = (int)nt;
     const int grid = (int)(nt < num_cus() ? nt : num_cus());
+    if (mv) {
+        q.mv_ws = mv_scratch(st, (size_t)num_cus() * 96 * D_HID * sizeof(float));
+        if (!q.mv_ws) return pnr_fail(PNR_E_HIP, "pnr_eval: cannot allocate the multi-view pooling scratch (48 MiB)");
+    }
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_kernel)");
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -490,15 +540,24 @@ static float *g_dbg_ptr = nullptr;
 // test hook (not part of the public header): dump the final residual stream of the next launches
 extern "C" int pnr_debug_set_x_dump(float *ptr) { g_dbg_ptr = ptr; return PNR_OK; }
 
+int pnr::eval_samples_src(const PnrScene *scene, const void *packed, const void *tables, int precision, const RaySrc &src,
+                          const float *z, int R, int rays_per_obj, int K, float *rgbsigma, hipStream_t stream) {
+    if (precision == PNR_PREC_F16X3) return eval_samples_split_src(scene, packed, tables, src, z, R, rays_per_obj, K, rgbsigma, stream);
+    if (R < 0 || K <= 0 || rays_per_obj <= 0) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples: bad sizes");
+    if (R > 0 && ((!src.rays && !src.poses) || !z)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples: null rays/z");
+    if (scene && (long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples: R != SB * rays_per_obj");
+    pnr::EvalParams q = {};
+    q.rays = src.rays; q.cam = src; q.cam.rays = nullptr;
+    q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma; q.dbg = g_dbg_ptr;
+    return pnr::eval_common(scene, packed, precision, q, true, stream, tables);
+}
+
 static int eval_ray_samples_impl(const PnrScene *scene, const void *packed, const void *tables, int precision,
                                  const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
                                  void *stream) {
-    if (R < 0 || K <= 0 || rays_per_obj <= 0) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples: bad sizes");
-    if (R > 0 && (!rays || !z)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples: null rays/z");
-    if (scene && (long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples: R != SB * rays_per_obj");
-    pnr::EvalParams q = {};
-    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma; q.dbg = g_dbg_ptr;
-    return pnr::eval_common(scene, packed, precision, q, true, (hipStream_t)stream, tables);
+    pnr::RaySrc src = {};
+    src.rays = rays;
+    return pnr::eval_samples_src(scene, packed, tables, precision, src, z, R, rays_per_obj, K, rgbsigma, (hipStream_t)stream);
 }
 
 extern "C" int pnr_eval_ray_samples(const PnrScene *scene, const void *packed, int precision, const float *rays,

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include "pnr_common.h"
+#include "pnr_internal.h"
+#include "pnr_raysrc.h"
 
 namespace pnr {
 
@@ -29,15 +31,15 @@ __device__ __forceinline__ float linspace_at(float end, int n, int i) {
 }
 
 // NeRFRenderer.sample_coarse, nerf.py:98-118
-__global__ void sample_coarse_kernel(const float *__restrict__ rays, const float *__restrict__ u1, int R, int Kc,
-                                     int lindisp, float *__restrict__ z) {
+__global__ void sample_coarse_kernel(const RaySrc rs, const NoiseSrc ns, int R, int Kc, int lindisp, float *__restrict__ z) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)R * Kc) return;
     const int r = (int)(idx / Kc), i = (int)(idx % Kc);
-    const float near = rays[(size_t)r * 8 + 6], far = rays[(size_t)r * 8 + 7];
+    float near, far;
+    load_bounds(rs, r, near, far);
     const float step = 1.0f / (float)Kc;
     float t = linspace_at(1.f - step, Kc, i);
-    t = t + u1[idx] * step;
+    t = t + noise_u1(ns, r, i, Kc) * step;
     z[idx] = z_from_t(near, far, t, lindisp);
 }
 
@@ -67,9 +69,8 @@ __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
 
 // NeRFRenderer.sample_fine (nerf.py:120-148) + sample_fine_depth (:150-161) + cat/sort (:294-295)
 __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64)
-sample_fine_kernel(const float *__restrict__ rays, const float *__restrict__ wc, const float *__restrict__ depth_c,
-                   const float *__restrict__ zc, const float *__restrict__ u2, const float *__restrict__ u3,
-                   const float *__restrict__ n4, int R, int Kc, int Kimp, int Kfd, float depth_std, int lindisp,
+sample_fine_kernel(const RaySrc rs, const float *__restrict__ wc, const float *__restrict__ depth_c,
+                   const float *__restrict__ zc, const NoiseSrc ns, int R, int Kc, int Kimp, int Kfd, float depth_std, int lindisp,
                    float *__restrict__ zout, int *__restrict__ depth_ranks, float *__restrict__ z_new,
                    int *__restrict__ ranks_all) {
     __shared__ float s_cdf[WAVES_PER_BLOCK][MAX_KC + 1];
@@ -79,7 +80,8 @@ sample_fine_kernel(const float *__restrict__ rays, const float *__restrict__ wc,
     const bool active = r0 < R;  // inactive wavefronts still take part in the block barriers
     const int r = active ? r0 : R - 1;
     float *cdf = s_cdf[wv], *zs = s_z[wv];
-    const float near = rays[(size_t)r * 8 + 6], far = rays[(size_t)r * 8 + 7];
+    float near, far;
+    load_bounds(rs, r, near, far);
     const int Ktot = Kc + Kimp + Kfd;
 
     if (Kimp > 0) {
@@ -101,7 +103,7 @@ sample_fine_kernel(const float *__restrict__ rays, const float *__restrict__ wc,
     for (int i = lane; i < Kc; i += 64) zs[i] = zc[(size_t)r * Kc + i];
     __syncthreads();
     for (int j = lane; j < Kimp; j += 64) {
-        const float u = u2[(size_t)r * Kimp + j];
+        const float u = noise_u2(ns, r, j, Kimp);
         // searchsorted(cdf, u, right=True): number of entries <= u      (nerf.py:138)
         int lo = 0, hi = Kc + 1;
         while (lo < hi) {
@@ -109,11 +111,11 @@ sample_fine_kernel(const float *__restrict__ rays, const float *__restrict__ wc,
             if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
         }
         const float ind = fmaxf((float)lo - 1.0f, 0.0f);  // :138-139 (may equal Kc)
-        const float t = (ind + u3[(size_t)r * Kimp + j]) / (float)Kc;  // :141
+        const float t = (ind + noise_u3(ns, r, j, Kimp)) / (float)Kc;  // :141
         zs[Kc + j] = z_from_t(near, far, t, lindisp);
     }
     for (int j = lane; j < Kfd; j += 64) {
-        float z = depth_c[r] + n4[(size_t)r * Kfd + j] * depth_std;  // :157-158
+        float z = depth_c[r] + noise_n4(ns, r, j, Kfd) * depth_std;  // :157-158
         z = fmaxf(fminf(z, far), near);                              // :160
         zs[Kc + Kimp + j] = z;
     }
@@ -150,13 +152,14 @@ __global__ void merge_rgbsigma_kernel(const float4 *__restrict__ rgbs_c, const f
 
 // NeRFRenderer.composite, nerf.py:178-182 (deltas) and :223-249
 __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64)
-composite_kernel(const float *__restrict__ rays, const float *__restrict__ z, const float4 *__restrict__ rgbs, int R,
+composite_kernel(const RaySrc rs, const float *__restrict__ z, const float4 *__restrict__ rgbs, int R,
                  int K, int white_bkgd, float *__restrict__ weights, float *__restrict__ rgb,
                  float *__restrict__ depth) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * WAVES_PER_BLOCK + wv;
     if (r >= R) return;
-    const float far = rays[(size_t)r * 8 + 7];
+    float near_unused, far;
+    load_bounds(rs, r, near_unused, far);
     const float *zr = z + (size_t)r * K;
     float carry = 1.f;  // transmittance in front of this chunk: prod_{j<c0} (1 - a_j + 1e-10)
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_w = 0.f;
@@ -217,42 +220,94 @@ __global__ void gen_rays_kernel(const float *__restrict__ poses, int NV, int W, 
 }
 #pragma clang fp contract(fast)
 
+// the counter-based draws written out as tensors (the same functions the sampling kernels call): lets a caller -- and
+// the tests -- feed the explicit-noise interface with exactly what the seeded interface would draw
+__global__ void philox_fill_kernel(const NoiseSrc ns, int R, int Kc, int Kimp, int Kfd, float *__restrict__ u1,
+                                   float *__restrict__ u2, float *__restrict__ u3, float *__restrict__ n4) {
+    const int per = Kc + 2 * Kimp + Kfd;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)R * per) return;
+    const long long r = idx / per;
+    int i = (int)(idx % per);
+    if (i < Kc) { u1[r * Kc + i] = gen_uniform(ns, DRAW_U1, r, i); return; }
+    i -= Kc;
+    if (i < Kimp) { u2[r * Kimp + i] = gen_uniform(ns, DRAW_U2, r, i); return; }
+    i -= Kimp;
+    if (i < Kimp) { u3[r * Kimp + i] = gen_uniform(ns, DRAW_U3, r, i); return; }
+    i -= Kimp;
+    n4[r * Kfd + i] = gen_normal(ns, r, i);
+}
+
 }  // namespace pnr
 
 using namespace pnr;
+
+static RaySrc explicit_rays(const float *rays) {
+    RaySrc s = {};
+    s.rays = rays;
+    return s;
+}
+static NoiseSrc explicit_noise(const float *u1, const float *u2, const float *u3, const float *n4) {
+    NoiseSrc n = {};
+    n.u1 = u1; n.u2 = u2; n.u3 = u3; n.n4 = n4;
+    n.id_stride = 1; n.per_obj = 1;
+    return n;
+}
+static NoiseSrc seeded_noise(unsigned long long seed, long long id_offset, int id_stride, int rays_per_obj) {
+    NoiseSrc n = {};
+    n.seed_lo = (uint32_t)seed; n.seed_hi = (uint32_t)(seed >> 32);
+    n.id_offset = id_offset;
+    n.per_obj = rays_per_obj > 0 ? rays_per_obj : 1;
+    n.id_stride = id_stride > 0 ? id_stride : n.per_obj;
+    return n;
+}
+
+static int sample_coarse_src(const RaySrc &rs, const NoiseSrc &ns, int R, int Kc, int lindisp, float *z, void *stream) {
+    const long long n = (long long)R * Kc;
+    hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rs, ns, R, Kc, lindisp, z);
+    return pnr_check_launch("pnr_sample_coarse");
+}
 
 extern "C" int pnr_sample_coarse(const float *rays, const float *u1, int R, int Kc, int lindisp, float *z,
                                  void *stream) {
     if (R < 0 || Kc <= 0) return pnr_fail(PNR_E_INVALID, "pnr_sample_coarse: bad sizes");
     if (R == 0) return PNR_OK;
     if (!rays || !u1 || !z) return pnr_fail(PNR_E_INVALID, "pnr_sample_coarse: null argument");
-    const long long n = (long long)R * Kc;
-    hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays,
-                       u1, R, Kc, lindisp, z);
-    return pnr_check_launch("pnr_sample_coarse");
+    return sample_coarse_src(explicit_rays(rays), explicit_noise(u1, nullptr, nullptr, nullptr), R, Kc, lindisp, z, stream);
 }
 
-static int sample_fine_impl(const float *rays, const float *weights_c, const float *depth_c, const float *z_coarse,
-                            const float *u2, const float *u3, const float *n4, int R, int Kc, int Kimp, int Kfd,
-                            float depth_std, int lindisp, float *z_sorted, int32_t *depth_ranks, float *z_new,
-                            int32_t *ranks_all, void *stream) {
+static int sample_fine_src(const RaySrc &rs, const float *weights_c, const float *depth_c, const float *z_coarse,
+                           const NoiseSrc &ns, int R, int Kc, int Kimp, int Kfd, float depth_std, int lindisp, float *z_sorted,
+                           int32_t *depth_ranks, float *z_new, int32_t *ranks_all, void *stream) {
     if (R < 0 || Kc <= 0 || Kimp < 0 || Kfd < 0) return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: bad sizes");
     if (Kc > MAX_KC || Kc + Kimp + Kfd > MAX_KTOT)
         return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: supports n_coarse <= 256 and n_coarse + n_fine <= 512");
     if (R == 0) return PNR_OK;
-    if (!rays || !z_coarse || !z_sorted || (Kimp > 0 && (!weights_c || !u2 || !u3)) || (Kfd > 0 && (!depth_c || !n4)))
+    if (!z_coarse || !z_sorted || (Kimp > 0 && !weights_c) || (Kfd > 0 && !depth_c))
         return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: null argument");
     hipLaunchKernelGGL(sample_fine_kernel, dim3((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(WAVES_PER_BLOCK * 64),
-                       0, (hipStream_t)stream, rays, weights_c, depth_c, z_coarse, u2, u3, n4, R, Kc, Kimp, Kfd,
-                       depth_std, lindisp, z_sorted, depth_ranks, z_new, ranks_all);
+                       0, (hipStream_t)stream, rs, weights_c, depth_c, z_coarse, ns, R, Kc, Kimp, Kfd, depth_std, lindisp,
+                       z_sorted, depth_ranks, z_new, ranks_all);
     return pnr_check_launch("pnr_sample_fine");
 }
 
 extern "C" int pnr_sample_fine(const float *rays, const float *weights_c, const float *depth_c, const float *z_coarse,
                                const float *u2, const float *u3, const float *n4, int R, int Kc, int Kimp, int Kfd,
                                float depth_std, int lindisp, float *z_sorted, int32_t *depth_ranks, void *stream) {
-    return sample_fine_impl(rays, weights_c, depth_c, z_coarse, u2, u3, n4, R, Kc, Kimp, Kfd, depth_std, lindisp, z_sorted,
-                            depth_ranks, nullptr, nullptr, stream);
+    if (R < 0 || Kc <= 0 || Kimp < 0 || Kfd < 0) return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: bad sizes");
+    if (Kc > MAX_KC || Kc + Kimp + Kfd > MAX_KTOT)
+        return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: supports n_coarse <= 256 and n_coarse + n_fine <= 512");
+    if (R > 0 && (!rays || (Kimp > 0 && (!u2 || !u3)) || (Kfd > 0 && !n4)))
+        return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: null argument");
+    return sample_fine_src(explicit_rays(rays), weights_c, depth_c, z_coarse, explicit_noise(nullptr, u2, u3, n4), R, Kc, Kimp,
+                           Kfd, depth_std, lindisp, z_sorted, depth_ranks, nullptr, nullptr, stream);
+}
+
+static int composite_src(const RaySrc &rs, const float *z, const float *rgbsigma, int R, int K, int white_bkgd, float *weights,
+                         float *rgb, float *depth, void *stream) {
+    hipLaunchKernelGGL(composite_kernel, dim3((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(WAVES_PER_BLOCK * 64), 0,
+                       (hipStream_t)stream, rs, z, (const float4 *)rgbsigma, R, K, white_bkgd, weights, rgb, depth);
+    return pnr_check_launch("pnr_composite");
 }
 
 extern "C" int pnr_composite(const float *rays, const float *z, const float *rgbsigma, int R, int K, int white_bkgd,
@@ -260,9 +315,7 @@ extern "C" int pnr_composite(const float *rays, const float *z, const float *rgb
     if (R < 0 || K <= 0) return pnr_fail(PNR_E_INVALID, "pnr_composite: bad sizes");
     if (R == 0) return PNR_OK;
     if (!rays || !z || !rgbsigma || !rgb || !depth) return pnr_fail(PNR_E_INVALID, "pnr_composite: null argument");
-    hipLaunchKernelGGL(composite_kernel, dim3((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(WAVES_PER_BLOCK * 64), 0,
-                       (hipStream_t)stream, rays, z, (const float4 *)rgbsigma, R, K, white_bkgd, weights, rgb, depth);
-    return pnr_check_launch("pnr_composite");
+    return composite_src(explicit_rays(rays), z, rgbsigma, R, K, white_bkgd, weights, rgb, depth, stream);
 }
 
 extern "C" int pnr_gen_rays(const float *poses, int NV, int W, int H, float fx, float fy, float cx, float cy,
@@ -274,6 +327,25 @@ extern "C" int pnr_gen_rays(const float *poses, int NV, int W, int H, float fx, 
     hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, poses, NV,
                        W, H, fx, fy, cx, cy, z_near, z_far, rays);
     return pnr_check_launch("pnr_gen_rays");
+}
+
+extern "C" int pnr_philox_noise(unsigned long long seed, long long id_offset, int id_stride, int rays_per_obj, int R, int Kc,
+                                int Kimp, int Kfd, float *u1, float *u2, float *u3, float *n4, void *stream) {
+    if (R < 0 || Kc < 0 || Kimp < 0 || Kfd < 0) return pnr_fail(PNR_E_INVALID, "pnr_philox_noise: bad sizes");
+    if ((Kc > 0 && !u1) || (Kimp > 0 && (!u2 || !u3)) || (Kfd > 0 && !n4)) return pnr_fail(PNR_E_INVALID, "pnr_philox_noise: null output");
+    const long long n = (long long)R * (Kc + 2 * Kimp + Kfd);
+    if (n == 0) return PNR_OK;
+    hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       seeded_noise(seed, id_offset, id_stride, rays_per_obj), R, Kc, Kimp, Kfd, u1, u2, u3, n4);
+    return pnr_check_launch("pnr_philox_noise");
+}
+
+extern "C" int pnr_philox_raw(const uint32_t *counter4 /*host*/, const uint32_t *key2 /*host*/, uint32_t *out4 /*host*/) {
+    if (!counter4 || !key2 || !out4) return pnr_fail(PNR_E_INVALID, "pnr_philox_raw: null argument");
+    const U4 c = {counter4[0], counter4[1], counter4[2], counter4[3]};
+    const U4 r = philox4x32_10(c, key2[0], key2[1]);  // the same inline function the kernels call, compiled for the host
+    out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
+    return PNR_OK;
 }
 
 // workspace layout (floats): z_c [R*Kc] | rgbs_c [R*Kc*4] | w_c [R*Kc] | z_f [R*Kt] | rgbs_f [R*Kt*4]
@@ -288,24 +360,21 @@ extern "C" size_t pnr_render_workspace_bytes(int R, int Kc, int Kf) {
     return fl * sizeof(float);
 }
 
-static int eval_any(const PnrScene *scene, const void *packed, const void *tables, int precision, const float *rays,
-                    const float *z, int R, int rays_per_obj, int K, float *rgbsigma, void *stream) {
-    if (precision == PNR_PREC_F16X3)  // fp32-class split-operand kernel (fp32 tables), pnr_split.hip
-        return pnr_eval_ray_samples_split(scene, packed, tables, rays, z, R, rays_per_obj, K, rgbsigma, stream);
-    return tables ? pnr_eval_ray_samples_folded(scene, packed, tables, precision, rays, z, R, rays_per_obj, K, rgbsigma, stream)
-                  : pnr_eval_ray_samples(scene, packed, precision, rays, z, R, rays_per_obj, K, rgbsigma, stream);
-}
-
-static int render_forward_impl(const PnrScene *scene, const void *packed_coarse, const void *tables_coarse,
-                               const void *packed_fine, const void *tables_fine, int precision, const float *rays, int R, int rays_per_obj, int Kc, int Kf, int Kfd,
-                                  float depth_std, int white_bkgd, int lindisp, const float *u1, const float *u2,
-                                  const float *u3, const float *n4, float *rgb_c, float *depth_c, float *weights_c,
-                                  float *rgb_f, float *depth_f, float *weights_f, void *workspace, void *stream) {
+// NeRFRenderer.forward (nerf.py:251-303) for any ray source / noise source
+static int render_impl(const PnrScene *scene, const void *packed_coarse, const void *tables_coarse, const void *packed_fine,
+                       const void *tables_fine, int precision, const RaySrc &rs, const NoiseSrc &ns, int R, int rays_per_obj,
+                       int Kc, int Kf, int Kfd, float depth_std, int white_bkgd, int lindisp, float *rgb_c, float *depth_c,
+                       float *weights_c, float *rgb_f, float *depth_f, float *weights_f, void *workspace, void *stream) {
     if (R < 0 || Kc <= 0 || Kf < 0 || Kfd < 0 || Kfd > Kf)
         return pnr_fail(PNR_E_INVALID, "pnr_render_forward: bad sample counts");
     if (R == 0) return PNR_OK;
     if (!workspace || !rgb_c || !depth_c || (Kf > 0 && (!rgb_f || !depth_f)))
         return pnr_fail(PNR_E_INVALID, "pnr_render_forward: null output / workspace");
+    if (!rs.rays && !rs.poses) return pnr_fail(PNR_E_INVALID, "pnr_render_forward: null rays");
+    const bool gen = !ns.u1 && !ns.u2 && !ns.u3 && !ns.n4;
+    if (!gen && (!ns.u1 || (Kf - Kfd > 0 && (!ns.u2 || !ns.u3)) || (Kfd > 0 && !ns.n4)))
+        return pnr_fail(PNR_E_INVALID, "pnr_render_forward: explicit noise needs u1 [, u2, u3] [, n4] (pass none of them for seeded draws)");
+    hipStream_t st = (hipStream_t)stream;
     const size_t r = (size_t)R, kc = (size_t)Kc, kt = (size_t)(Kc + Kf);
     float *ws = (float *)workspace;
     float *z_c = ws; ws += align64(r * kc);
@@ -318,25 +387,26 @@ static int render_forward_impl(const PnrScene *scene, const void *packed_coarse,
     int32_t *ranks = (int32_t *)ws;
     if (weights_c) w_c = weights_c;  // write straight into the caller's buffer
     int rc;
-    if ((rc = pnr_sample_coarse(rays, u1, R, Kc, lindisp, z_c, stream))) return rc;
-    if ((rc = eval_any(scene, packed_coarse, tables_coarse, precision, rays, z_c, R, rays_per_obj, Kc, rgbs_c, stream))) return rc;
-    if ((rc = pnr_composite(rays, z_c, rgbs_c, R, Kc, white_bkgd, w_c, rgb_c, depth_c, stream))) return rc;
+    if ((rc = sample_coarse_src(rs, ns, R, Kc, lindisp, z_c, stream))) return rc;
+    if ((rc = eval_samples_src(scene, packed_coarse, tables_coarse, precision, rs, z_c, R, rays_per_obj, Kc, rgbs_c, st))) return rc;
+    if ((rc = composite_src(rs, z_c, rgbs_c, R, Kc, white_bkgd, w_c, rgb_c, depth_c, stream))) return rc;
     if (Kf > 0) {
         if (packed_fine) {
-            if ((rc = pnr_sample_fine(rays, w_c, depth_c, z_c, u2, u3, n4, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, nullptr, stream))) return rc;
-            if ((rc = eval_any(scene, packed_fine, tables_fine, precision, rays, z_f, R, rays_per_obj, Kc + Kf, rgbs_f, stream))) return rc;
+            if ((rc = sample_fine_src(rs, w_c, depth_c, z_c, ns, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, nullptr, nullptr,
+                                      nullptr, stream))) return rc;
+            if ((rc = eval_samples_src(scene, packed_fine, tables_fine, precision, rs, z_f, R, rays_per_obj, Kc + Kf, rgbs_f, st))) return rc;
         } else {
             // mlp_fine is None (models.py:242, eval/eval.py:140): the fine pass runs the coarse network on the merged
             // samples, Kc of which it has just evaluated -- evaluate the Kf new ones only and merge in sorted order
-            if ((rc = sample_fine_impl(rays, w_c, depth_c, z_c, u2, u3, n4, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, nullptr,
-                                       z_new, ranks, stream))) return rc;
-            if ((rc = eval_any(scene, packed_coarse, tables_coarse, precision, rays, z_new, R, rays_per_obj, Kf, rgbs_new, stream))) return rc;
+            if ((rc = sample_fine_src(rs, w_c, depth_c, z_c, ns, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, nullptr, z_new,
+                                      ranks, stream))) return rc;
+            if ((rc = eval_samples_src(scene, packed_coarse, tables_coarse, precision, rs, z_new, R, rays_per_obj, Kf, rgbs_new, st))) return rc;
             const long long n = (long long)R * (Kc + Kf);
-            hipLaunchKernelGGL(merge_rgbsigma_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+            hipLaunchKernelGGL(merge_rgbsigma_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                (const float4 *)rgbs_c, (const float4 *)rgbs_new, ranks, R, Kc, Kf, (float4 *)rgbs_f);
             if ((rc = pnr_check_launch("merge_rgbsigma_kernel"))) return rc;
         }
-        if ((rc = pnr_composite(rays, z_f, rgbs_f, R, Kc + Kf, white_bkgd, weights_f, rgb_f, depth_f, stream))) return rc;
+        if ((rc = composite_src(rs, z_f, rgbs_f, R, Kc + Kf, white_bkgd, weights_f, rgb_f, depth_f, stream))) return rc;
     }
     return PNR_OK;
 }
@@ -346,9 +416,10 @@ extern "C" int pnr_render_forward(const PnrScene *scene, const void *packed_coar
                                   float depth_std, int white_bkgd, int lindisp, const float *u1, const float *u2,
                                   const float *u3, const float *n4, float *rgb_c, float *depth_c, float *weights_c,
                                   float *rgb_f, float *depth_f, float *weights_f, void *workspace, void *stream) {
-    return render_forward_impl(scene, packed_coarse, nullptr, packed_fine, nullptr, precision, rays, R, rays_per_obj, Kc, Kf,
-                               Kfd, depth_std, white_bkgd, lindisp, u1, u2, u3, n4, rgb_c, depth_c, weights_c, rgb_f, depth_f,
-                               weights_f, workspace, stream);
+    if (R > 0 && !u1) return pnr_fail(PNR_E_INVALID, "pnr_render_forward: null u1 (pnr_render_forward_seeded draws in-kernel)");
+    return render_impl(scene, packed_coarse, nullptr, packed_fine, nullptr, precision, explicit_rays(rays),
+                       explicit_noise(u1, u2, u3, n4), R, rays_per_obj, Kc, Kf, Kfd, depth_std, white_bkgd, lindisp, rgb_c, depth_c,
+                       weights_c, rgb_f, depth_f, weights_f, workspace, stream);
 }
 
 extern "C" int pnr_render_forward_folded(const PnrScene *scene, const void *packed_coarse, const void *tables_coarse,
@@ -359,7 +430,51 @@ extern "C" int pnr_render_forward_folded(const PnrScene *scene, const void *pack
                                          float *weights_f, void *workspace, void *stream) {
     if (!tables_coarse || (packed_fine && !tables_fine))
         return pnr_fail(PNR_E_INVALID, "pnr_render_forward_folded: every folded network needs its tables");
-    return render_forward_impl(scene, packed_coarse, tables_coarse, packed_fine, tables_fine, precision, rays, R, rays_per_obj,
-                               Kc, Kf, Kfd, depth_std, white_bkgd, lindisp, u1, u2, u3, n4, rgb_c, depth_c, weights_c, rgb_f,
-                               depth_f, weights_f, workspace, stream);
+    if (R > 0 && !u1) return pnr_fail(PNR_E_INVALID, "pnr_render_forward_folded: null u1 (pnr_render_forward_seeded draws in-kernel)");
+    return render_impl(scene, packed_coarse, tables_coarse, packed_fine, tables_fine, precision, explicit_rays(rays),
+                       explicit_noise(u1, u2, u3, n4), R, rays_per_obj, Kc, Kf, Kfd, depth_std, white_bkgd, lindisp, rgb_c, depth_c,
+                       weights_c, rgb_f, depth_f, weights_f, workspace, stream);
+}
+
+extern "C" int pnr_render_forward_seeded(const PnrScene *scene, const void *packed_coarse, const void *tables_coarse,
+                                         const void *packed_fine, const void *tables_fine, int precision, const float *rays,
+                                         int R, int rays_per_obj, int Kc, int Kf, int Kfd, float depth_std, int white_bkgd,
+                                         int lindisp, unsigned long long seed, long long ray_id_offset, int ray_id_stride,
+                                         float *rgb_c, float *depth_c, float *weights_c, float *rgb_f, float *depth_f,
+                                         float *weights_f, void *workspace, void *stream) {
+    if ((tables_coarse == nullptr) != (tables_fine == nullptr) && packed_fine)
+        return pnr_fail(PNR_E_INVALID, "pnr_render_forward_seeded: both networks folded or neither");
+    return render_impl(scene, packed_coarse, tables_coarse, packed_fine, tables_fine, precision, explicit_rays(rays),
+                       seeded_noise(seed, ray_id_offset, ray_id_stride, rays_per_obj), R, rays_per_obj, Kc, Kf, Kfd, depth_std,
+                       white_bkgd, lindisp, rgb_c, depth_c, weights_c, rgb_f, depth_f, weights_f, workspace, stream);
+}
+
+// util.gen_rays + NeRFRenderer.forward for whole target views (eval/eval.py:247-279): the rays are never materialised
+extern "C" size_t pnr_render_views_workspace_bytes(int NV, int W, int H, int Kc, int Kf) {
+    if (NV <= 0 || W <= 0 || H <= 0) return 0;
+    const long long R = (long long)NV * W * H;
+    if (R > 0x7fffffffLL) return 0;
+    return pnr_render_workspace_bytes((int)R, Kc, Kf);
+}
+
+extern "C" int pnr_render_views(const PnrScene *scene, const void *packed_coarse, const void *tables_coarse,
+                                const void *packed_fine, const void *tables_fine, int precision, const float *poses_c2w, int NV,
+                                int W, int H, float fx, float fy, float cx, float cy, float z_near, float z_far, int Kc, int Kf,
+                                int Kfd, float depth_std, int white_bkgd, int lindisp, const float *u1, const float *u2,
+                                const float *u3, const float *n4, unsigned long long seed, float *rgb_c, float *depth_c,
+                                float *weights_c, float *rgb_f, float *depth_f, float *weights_f, void *workspace, void *stream) {
+    if (!scene || NV < 0 || W <= 0 || H <= 0) return pnr_fail(PNR_E_INVALID, "pnr_render_views: bad sizes");
+    if (NV == 0) return PNR_OK;
+    if (!poses_c2w) return pnr_fail(PNR_E_INVALID, "pnr_render_views: null poses");
+    if (scene->SB <= 0 || NV % scene->SB != 0) return pnr_fail(PNR_E_INVALID, "pnr_render_views: NV must be a multiple of SB (views grouped per object)");
+    const long long R = (long long)NV * W * H;
+    if (R > 0x7fffffffLL) return pnr_fail(PNR_E_INVALID, "pnr_render_views: too many rays for one call");
+    if (packed_fine && ((tables_coarse == nullptr) != (tables_fine == nullptr)))
+        return pnr_fail(PNR_E_INVALID, "pnr_render_views: both networks folded or neither");
+    RaySrc rs = {};
+    rs.poses = poses_c2w; rs.W = W; rs.H = H; rs.fx = fx; rs.fy = fy; rs.cx = cx; rs.cy = cy; rs.z_near = z_near; rs.z_far = z_far;
+    const int per_obj = (int)(R / scene->SB);
+    const NoiseSrc ns = (u1 || u2 || u3 || n4) ? explicit_noise(u1, u2, u3, n4) : seeded_noise(seed, 0, per_obj, per_obj);
+    return render_impl(scene, packed_coarse, tables_coarse, packed_fine, tables_fine, precision, rs, ns, (int)R, per_obj, Kc, Kf, Kfd,
+                       depth_std, white_bkgd, lindisp, rgb_c, depth_c, weights_c, rgb_f, depth_f, weights_f, workspace, stream);
 }

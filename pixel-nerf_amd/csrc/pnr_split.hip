@@ -18,6 +18,7 @@
 
 #include "pnr_common.h"
 #include "pnr_device.h"
+#include "pnr_internal.h"
 #include "pnr_layout.h"
 
 namespace pnr {
@@ -347,15 +348,23 @@ static int split_launch(const PnrScene *s, const void *packed, const void *table
 
 extern "C" size_t pnr_packed_mlp_split_bytes(void) { return 2 * pnr::PACKED_BYTES; }
 
+int pnr::eval_samples_split_src(const PnrScene *scene, const void *packed_split, const void *tables_f32, const RaySrc &src,
+                                const float *z, int R, int rays_per_obj, int K, float *rgbsigma, hipStream_t stream) {
+    if (R < 0 || K <= 0 || rays_per_obj <= 0) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split: bad sizes");
+    if (R > 0 && ((!src.rays && !src.poses) || !z)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split: null rays/z");
+    if (scene && (long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split: R != SB * rays_per_obj");
+    pnr::EvalParams q = {};
+    q.rays = src.rays; q.cam = src; q.cam.rays = nullptr;
+    q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
+    return pnr::split_launch(scene, packed_split, tables_f32, q, true, stream);
+}
+
 extern "C" int pnr_eval_ray_samples_split(const PnrScene *scene, const void *packed_split, const void *tables_f32,
                                           const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
                                           void *stream) {
-    if (R < 0 || K <= 0 || rays_per_obj <= 0) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split: bad sizes");
-    if (R > 0 && (!rays || !z)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split: null rays/z");
-    if (scene && (long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split: R != SB * rays_per_obj");
-    pnr::EvalParams q = {};
-    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
-    return pnr::split_launch(scene, packed_split, tables_f32, q, true, (hipStream_t)stream);
+    pnr::RaySrc src = {};
+    src.rays = rays;
+    return pnr::eval_samples_split_src(scene, packed_split, tables_f32, src, z, R, rays_per_obj, K, rgbsigma, (hipStream_t)stream);
 }
 
 extern "C" int pnr_eval_points_split(const PnrScene *scene, const void *packed_split, const void *tables_f32, const float *xyz,

@@ -117,7 +117,16 @@ class ShardedRenderWrapper(torch.nn.Module):
         bounds = [shard_bounds(B, r, world) for r in range(world)]
         sizes = [hi - lo for lo, hi in bounds]
         lo, hi = bounds[rank]
-        local = self.wrapped(rays[:, lo:hi].contiguous(), want_weights=want_weights)
+        rend = getattr(self.wrapped, "renderer", None)
+        if rend is not None and hasattr(rend, "ray_id_offset"):
+            # counter-based draws are keyed by the GLOBAL ray id: the sharded image equals the unsharded one (every rank
+            # must run with the same torch seed; the per-renderer call counter advances in lock-step)
+            rend.ray_id_offset, rend.ray_id_stride = lo, B
+        try:
+            local = self.wrapped(rays[:, lo:hi].contiguous(), want_weights=want_weights)
+        finally:
+            if rend is not None and hasattr(rend, "ray_id_offset"):
+                rend.ray_id_offset, rend.ray_id_stride = 0, 0
         # flatten the outputs to (SB, b, width) columns, pack, gather once, unpack
         if isinstance(local, tuple):
             leaves = [(None, i, t) for i, t in enumerate(local)]

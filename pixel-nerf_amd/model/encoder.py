@@ -7,6 +7,8 @@ forward() builds the (SB*NS, 512, Hl, Wl) feature pyramid exactly as the referen
 (encoder.py:111-164); the per-sample bilinear lookup `index()` (encoder.py:80-109) is NOT
 called by the product path -- it is fused into the HIP network kernel, which reads the
 channel-last copy of `latent` made by `latent_nhwc()`."""
+import warnings
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -65,8 +67,10 @@ class SpatialEncoder(nn.Module):
             raise NotImplementedError("only the resnet18/34 backbones of the shipped configs (encoder.py:56)")
         if norm_type != "batch":
             raise NotImplementedError("norm_type != batch is not used by any shipped config")
-        # `pretrained` ImageNet weights cannot be fetched offline: load them through the
-        # reference checkpoint (state_dict keys encoder.model.*) instead.
+        # `pretrained` ImageNet weights cannot be fetched offline (torchvision and the network are absent): take them
+        # from a local torchvision-format state_dict (PIXELNERF_RESNET_WEIGHTS=/path/resnet34.pth) or load a
+        # pixelNeRF checkpoint (state_dict keys encoder.model.*) afterwards; say so instead of silently starting from
+        # a random trunk where the reference would start from ImageNet features.
         self.feature_scale = feature_scale
         self.use_first_pool = use_first_pool
         self.model = _ResNet([3, 4, 6, 3] if backbone == "resnet34" else [2, 2, 2, 2])
@@ -76,6 +80,18 @@ class SpatialEncoder(nn.Module):
         self.register_buffer("latent", torch.empty(1, 1, 1, 1), persistent=False)
         self.register_buffer("latent_scaling", torch.empty(2, dtype=torch.float32), persistent=False)
         self._nhwc = None
+        if pretrained:
+            import os
+            path = os.environ.get("PIXELNERF_RESNET_WEIGHTS")
+            if path and os.path.exists(path):
+                sd = torch.load(path, map_location="cpu")
+                missing = self.model.load_state_dict({k: v for k, v in sd.items() if not k.startswith("fc.")}, strict=False)
+                if missing.missing_keys:
+                    warnings.warn(f"SpatialEncoder: {path} lacks {len(missing.missing_keys)} trunk tensors")
+            else:
+                warnings.warn("SpatialEncoder(pretrained=True): no ImageNet weights available offline -- the ResNet trunk is "
+                              "randomly initialised until a checkpoint is loaded (set PIXELNERF_RESNET_WEIGHTS to a "
+                              "torchvision resnet state_dict to reproduce the reference's initialisation)")
 
     def forward(self, x):
         """encoder.py:111-164."""
@@ -135,6 +151,10 @@ class SpatialEncoder(nn.Module):
     def index(self, uv, cam_z=None, image_size=(), z_bounds=None):
         """encoder.py:80-109, for callers that use the encoder on its own (the renderer does
         not: the lookup is fused into the network kernel)."""
+        with torch.profiler.record_function("encoder_index"):  # encoder.py:90
+            return self._index(uv, image_size)
+
+    def _index(self, uv, image_size):
         if uv.shape[0] == 1 and self.latent.shape[0] > 1:
             uv = uv.expand(self.latent.shape[0], -1, -1)
         if len(image_size) > 0:

@@ -182,6 +182,10 @@ class PixelNeRFNet(torch.nn.Module):
     def forward(self, xyz, coarse=True, viewdirs=None, far=False):
         """Predict (r,g,b,sigma) at world-space points; src/model/models.py:146-266.
         :param xyz (SB,B,3), viewdirs (SB,B,3) -> (SB,B,4)."""
+        with torch.profiler.record_function("model_inference"):  # the reference's scope name (models.py:156)
+            return self._forward_points(xyz, coarse, viewdirs)
+
+    def _forward_points(self, xyz, coarse, viewdirs):
         self._check_supported()
         self._no_autograd()
         assert viewdirs is not None  # models.py:186

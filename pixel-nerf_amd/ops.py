@@ -328,10 +328,64 @@ def composite(rays, z, rgbsigma, white_bkgd=False, want_weights=True):
     return weights, rgb, depth
 
 
+def philox_noise(R, n_coarse, n_fine, n_fine_depth, seed, device, ray_id_offset=0, ray_id_stride=0, rays_per_obj=0):
+    """The draws the seeded renderer entries make in-kernel, written out as the explicit noise dict
+    (u1 (R,Kc)[, u2, u3 (R,Kf-Kfd)][, n4 (R,Kfd)]): Philox4x32-10 keyed by `seed`, counter (global ray id, index/4, draw)."""
+    lib = _lib.load()
+    Kc, Kf, Kfd = int(n_coarse), int(n_fine), int(n_fine_depth)
+    Kimp = max(Kf - Kfd, 0) if Kf > 0 else 0
+    Kfd = Kfd if Kf > 0 else 0
+    out = {"u1": torch.empty((R, Kc), dtype=torch.float32, device=device)}
+    if Kimp > 0:
+        out["u2"] = torch.empty((R, Kimp), dtype=torch.float32, device=device)
+        out["u3"] = torch.empty((R, Kimp), dtype=torch.float32, device=device)
+    if Kfd > 0:
+        out["n4"] = torch.empty((R, Kfd), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.pnr_philox_noise(int(seed) & (2 ** 64 - 1), int(ray_id_offset), int(ray_id_stride), int(rays_per_obj) or R,
+                                        R, Kc, Kimp, Kfd, _p(out["u1"]), _p(out.get("u2")), _p(out.get("u3")), _p(out.get("n4")),
+                                        _stream()), "pnr_philox_noise")
+    return out
+
+
+def _render_outputs(R, Kc, Kf, want_weights, dev):
+    def outs(K):
+        return (torch.empty((R, 3), dtype=torch.float32, device=dev),
+                torch.empty((R,), dtype=torch.float32, device=dev),
+                torch.empty((R, K), dtype=torch.float32, device=dev) if want_weights else None)
+    return outs(Kc), (outs(Kc + Kf) if Kf > 0 else (None, None, None))
+
+
+def _render_result(c, f, Kf, want_weights):
+    ret = {"coarse": {"rgb": c[0], "depth": c[1]}}
+    if want_weights:
+        ret["coarse"]["weights"] = c[2]
+    if Kf > 0:
+        ret["fine"] = {"rgb": f[0], "depth": f[1]}
+        if want_weights:
+            ret["fine"]["weights"] = f[2]
+    return ret
+
+
+def _explicit_noise(noise, R, Kc, Kf, Kfd):
+    Kimp = Kf - Kfd
+    u1 = _f32(noise["u1"], "u1", (R, Kc))
+    u2 = u3 = n4 = None
+    if Kf > 0 and Kimp > 0:
+        u2, u3 = _f32(noise["u2"], "u2", (R, Kimp)), _f32(noise["u3"], "u3", (R, Kimp))
+    if Kf > 0 and Kfd > 0:
+        n4 = _f32(noise["n4"], "n4", (R, Kfd))
+    return u1, u2, u3, n4
+
+
 def render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_fine_depth, noise,
-                   depth_std=0.01, white_bkgd=False, lindisp=False, want_weights=False, tables=None):
+                   depth_std=0.01, white_bkgd=False, lindisp=False, want_weights=False, tables=None,
+                   seed=0, ray_id_offset=0, ray_id_stride=0):
     """Whole NeRFRenderer.forward (nerf.py:251-303) for rays (R,8) in object-major order.
-    noise: dict(u1[,u2,u3][,n4]).  Returns {"coarse": {...}, "fine": {...}} of flat tensors.
+    noise: dict(u1[,u2,u3][,n4]) of pre-drawn tensors, or None: the sampling kernels draw from the counter-based
+    generator keyed by `seed` (ops.philox_noise gives the same values as tensors); ray_id_offset / ray_id_stride place a
+    shard of rays inside the whole ray set so that a sharded render equals the unsharded one.
+    Returns {"coarse": {...}, "fine": {...}} of flat tensors.
     tables: (tables_coarse, tables_fine|None) from fold_latent() when the networks are folded streams."""
     lib = _lib.load()
     rays = _f32(rays, "rays", (None, 8))
@@ -342,16 +396,14 @@ def render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_
         raise ValueError("n_fine_depth must not exceed n_fine")
     if R % scene.SB != 0:
         raise ValueError("number of rays must be a multiple of the number of objects")
-    u1 = _f32(noise["u1"], "u1", (R, Kc))
-    u2 = u3 = n4 = None
-    if Kf > 0 and Kimp > 0:
-        u2, u3 = _f32(noise["u2"], "u2", (R, Kimp)), _f32(noise["u3"], "u3", (R, Kimp))
-    if Kf > 0 and Kfd > 0:
-        n4 = _f32(noise["n4"], "n4", (R, Kfd))
     if packed_fine is not None and packed_fine.precision != packed_coarse.precision:
         raise ValueError("coarse and fine networks must be packed at the same precision")
+    per_obj = max(R // scene.SB, 1)
     if packed_coarse.precision == _lib.PREC_F32:
         # exact-fp32 validation path: the same stages, one C call each
+        if noise is None:
+            noise = philox_noise(R, Kc, Kf, Kfd, seed, dev, ray_id_offset, ray_id_stride, per_obj)
+        u1, u2, u3, n4 = _explicit_noise(noise, R, Kc, Kf, Kfd)
         z_c = sample_coarse(rays, u1, lindisp)
         w_c, rgb_c, depth_c = composite(rays, z_c, eval_ray_samples(scene, packed_coarse, rays, z_c), white_bkgd, True)
         ret = {"coarse": {"rgb": rgb_c, "depth": depth_c}}
@@ -366,13 +418,7 @@ def render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_
                 ret["fine"]["weights"] = w_f
         return ret
 
-    def outs(K):
-        return (torch.empty((R, 3), dtype=torch.float32, device=dev),
-                torch.empty((R,), dtype=torch.float32, device=dev),
-                torch.empty((R, K), dtype=torch.float32, device=dev) if want_weights else None)
-
-    rgb_c, depth_c, w_c = outs(Kc)
-    rgb_f, depth_f, w_f = outs(Kc + Kf) if Kf > 0 else (None, None, None)
+    c, f = _render_outputs(R, Kc, Kf, want_weights, dev)
     ws = torch.empty(max(lib.pnr_render_workspace_bytes(R, Kc, Kf), 16), dtype=torch.uint8, device=dev)
     tc, tf = tables if tables is not None else (None, None)
     if packed_coarse.precision == _lib.PREC_F16X3:
@@ -382,29 +428,27 @@ def render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_
     _check_fold(packed_coarse, tc, "render_forward")
     if packed_fine is not None:
         _check_fold(packed_fine, tf, "render_forward")
+    pf = packed_fine.ptr if packed_fine is not None else None
     with torch.cuda.device(dev):
-        if tc is not None:
-            _lib.check(lib.pnr_render_forward_folded(
-                scene.ref, packed_coarse.ptr, _p(tc), packed_fine.ptr if packed_fine is not None else None, _p(tf),
-                packed_coarse.precision, _p(rays), R, max(R // scene.SB, 1), Kc, Kf, Kfd, float(depth_std),
-                int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4),
-                _p(rgb_c), _p(depth_c), _p(w_c), _p(rgb_f), _p(depth_f), _p(w_f), _p(ws), _stream()),
-                "pnr_render_forward_folded")
+        if noise is None:
+            _lib.check(lib.pnr_render_forward_seeded(
+                scene.ref, packed_coarse.ptr, _p(tc), pf, _p(tf), packed_coarse.precision, _p(rays), R, per_obj, Kc, Kf, Kfd,
+                float(depth_std), int(bool(white_bkgd)), int(bool(lindisp)), int(seed) & (2 ** 64 - 1), int(ray_id_offset),
+                int(ray_id_stride), _p(c[0]), _p(c[1]), _p(c[2]), _p(f[0]), _p(f[1]), _p(f[2]), _p(ws), _stream()),
+                "pnr_render_forward_seeded")
         else:
-            _lib.check(lib.pnr_render_forward(
-                scene.ref, packed_coarse.ptr, packed_fine.ptr if packed_fine is not None else None,
-                packed_coarse.precision, _p(rays), R, max(R // scene.SB, 1), Kc, Kf, Kfd, float(depth_std),
-                int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4),
-                _p(rgb_c), _p(depth_c), _p(w_c), _p(rgb_f), _p(depth_f), _p(w_f), _p(ws), _stream()),
-                "pnr_render_forward")
-    ret = {"coarse": {"rgb": rgb_c, "depth": depth_c}}
-    if want_weights:
-        ret["coarse"]["weights"] = w_c
-    if Kf > 0:
-        ret["fine"] = {"rgb": rgb_f, "depth": depth_f}
-        if want_weights:
-            ret["fine"]["weights"] = w_f
-    return ret
+            u1, u2, u3, n4 = _explicit_noise(noise, R, Kc, Kf, Kfd)
+            if tc is not None:
+                _lib.check(lib.pnr_render_forward_folded(
+                    scene.ref, packed_coarse.ptr, _p(tc), pf, _p(tf), packed_coarse.precision, _p(rays), R, per_obj, Kc, Kf, Kfd,
+                    float(depth_std), int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4),
+                    _p(c[0]), _p(c[1]), _p(c[2]), _p(f[0]), _p(f[1]), _p(f[2]), _p(ws), _stream()), "pnr_render_forward_folded")
+            else:
+                _lib.check(lib.pnr_render_forward(
+                    scene.ref, packed_coarse.ptr, pf, packed_coarse.precision, _p(rays), R, per_obj, Kc, Kf, Kfd,
+                    float(depth_std), int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4),
+                    _p(c[0]), _p(c[1]), _p(c[2]), _p(f[0]), _p(f[1]), _p(f[2]), _p(ws), _stream()), "pnr_render_forward")
+    return _render_result(c, f, Kf, want_weights)
 
 
 def gen_rays(poses, width, height, focal, z_near, z_far, c=None):
@@ -422,10 +466,13 @@ def gen_rays(poses, width, height, focal, z_near, z_far, c=None):
 
 
 def render_views(scene, packed_coarse, packed_fine, poses_c2w, width, height, focal, z_near, z_far, n_coarse, n_fine,
-                 n_fine_depth, noise, c=None, depth_std=0.01, white_bkgd=False, lindisp=False, want_weights=False):
+                 n_fine_depth, noise, c=None, depth_std=0.01, white_bkgd=False, lindisp=False, want_weights=False, tables=None,
+                 seed=0):
     """util.gen_rays + NeRFRenderer.forward in one C call (eval/eval.py:247-279): poses_c2w (NV,4,4),
-    views grouped per object; every pixel of every view is rendered.  Returns the same nested dict as
-    render_forward with R = NV*H*W rows (reshape to (NV,H,W,...))."""
+    views grouped per object; every pixel of every view is rendered, its ray regenerated inside the kernels (no ray
+    array).  noise: explicit dict laid out for R = NV*H*W rays, or None for in-kernel draws from `seed`.
+    tables: (tables_coarse, tables_fine|None) for folded streams.  Returns the same nested dict as render_forward with
+    R = NV*H*W rows (reshape to (NV,H,W,...))."""
     lib = _lib.load()
     poses = _f32(poses_c2w, "poses_c2w", (None, 4, 4))
     NV, W, H = poses.shape[0], int(width), int(height)
@@ -433,46 +480,34 @@ def render_views(scene, packed_coarse, packed_fine, poses_c2w, width, height, fo
     if packed_coarse.precision == _lib.PREC_F32:
         rays = gen_rays(poses, W, H, focal, z_near, z_far, c).reshape(-1, 8)
         return render_forward(scene, packed_coarse, packed_fine, rays, n_coarse, n_fine, n_fine_depth, noise, depth_std,
-                              white_bkgd, lindisp, want_weights)
+                              white_bkgd, lindisp, want_weights, seed=seed)
     Kc, Kf, Kfd = int(n_coarse), int(n_fine), int(n_fine_depth)
-    Kimp = Kf - Kfd
-    if Kf > 0 and Kimp < 0:
+    if Kf > 0 and Kf - Kfd < 0:
         raise ValueError("n_fine_depth must not exceed n_fine")
     if NV % scene.SB != 0:
         raise ValueError("number of views must be a multiple of the number of objects")
     fx, fy = (float(focal), float(focal)) if not hasattr(focal, "__len__") else (float(focal[0]), float(focal[-1]))
     cx, cy = (W * 0.5, H * 0.5) if c is None else (float(c[0]), float(c[1]))
-    u1 = _f32(noise["u1"], "u1", (R, Kc))
-    u2 = u3 = n4 = None
-    if Kf > 0 and Kimp > 0:
-        u2, u3 = _f32(noise["u2"], "u2", (R, Kimp)), _f32(noise["u3"], "u3", (R, Kimp))
-    if Kf > 0 and Kfd > 0:
-        n4 = _f32(noise["n4"], "n4", (R, Kfd))
     if packed_fine is not None and packed_fine.precision != packed_coarse.precision:
         raise ValueError("coarse and fine networks must be packed at the same precision")
-
-    def outs(K):
-        return (torch.empty((R, 3), dtype=torch.float32, device=dev),
-                torch.empty((R,), dtype=torch.float32, device=dev),
-                torch.empty((R, K), dtype=torch.float32, device=dev) if want_weights else None)
-
-    rgb_c, depth_c, w_c = outs(Kc)
-    rgb_f, depth_f, w_f = outs(Kc + Kf) if Kf > 0 else (None, None, None)
+    tc, tf = tables if tables is not None else (None, None)
+    _check_fold(packed_coarse, tc, "render_views")  # a folded stream without its tables would read as garbage
+    if packed_fine is not None:
+        _check_fold(packed_fine, tf, "render_views")
+    if packed_coarse.precision == _lib.PREC_F16X3:
+        _check_split_tables(tc)
+    u1 = u2 = u3 = n4 = None
+    if noise is not None:
+        u1, u2, u3, n4 = _explicit_noise(noise, R, Kc, Kf, Kfd)
+    co, fo = _render_outputs(R, Kc, Kf, want_weights, dev)
     ws = torch.empty(max(lib.pnr_render_views_workspace_bytes(NV, W, H, Kc, Kf), 16), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.pnr_render_views(
-            scene.ref, packed_coarse.ptr, packed_fine.ptr if packed_fine is not None else None, packed_coarse.precision,
-            _p(poses), NV, W, H, fx, fy, cx, cy, float(z_near), float(z_far), Kc, Kf, Kfd, float(depth_std),
-            int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4),
-            _p(rgb_c), _p(depth_c), _p(w_c), _p(rgb_f), _p(depth_f), _p(w_f), _p(ws), _stream()), "pnr_render_views")
-    ret = {"coarse": {"rgb": rgb_c, "depth": depth_c}}
-    if want_weights:
-        ret["coarse"]["weights"] = w_c
-    if Kf > 0:
-        ret["fine"] = {"rgb": rgb_f, "depth": depth_f}
-        if want_weights:
-            ret["fine"]["weights"] = w_f
-    return ret
+            scene.ref, packed_coarse.ptr, _p(tc), packed_fine.ptr if packed_fine is not None else None, _p(tf),
+            packed_coarse.precision, _p(poses), NV, W, H, fx, fy, cx, cy, float(z_near), float(z_far), Kc, Kf, Kfd,
+            float(depth_std), int(bool(white_bkgd)), int(bool(lindisp)), _p(u1), _p(u2), _p(u3), _p(n4), int(seed) & (2 ** 64 - 1),
+            _p(co[0]), _p(co[1]), _p(co[2]), _p(fo[0]), _p(fo[1]), _p(fo[2]), _p(ws), _stream()), "pnr_render_views")
+    return _render_result(co, fo, Kf, want_weights)
 
 
 def pyramid_to_latent(stages, want_nchw=True):

@@ -8,9 +8,13 @@ C call (pnr_render_forward).  Any other `model(xyz, coarse=, viewdirs=)` callabl
 sampling and compositing run as HIP kernels around the caller's model, chunked by
 eval_batch_size exactly like the reference.
 
-Random numbers are drawn with torch's generator on the ray device in the reference's draw
-order (nerf.py:111,135,141,158), so a seeded run consumes the same stream as the reference
-on that device; tests inject pre-drawn noise through `_noise`.
+Random numbers.  `rng="philox"` (default in eval mode with a pixelnerf_amd net): the sampling kernels draw from a
+counter-based generator (Philox4x32-10) keyed by a 64-bit seed -- `torch.initial_seed()` of the ray device's generator
+mixed with a per-renderer call counter, so `torch.manual_seed(s)` makes a run reproducible without any device-side
+launch or HBM traffic for noise; a draw depends only on (seed, global ray id, draw, index), so chunked or multi-GPU
+sharded renders give the same image as one call.  `rng="torch"` (and training, and generic model callables): torch's
+generator on the ray device, in the reference's draw order (nerf.py:111,135,141,158).  Tests inject pre-drawn noise
+through `_noise`.
 """
 import torch
 
@@ -30,7 +34,8 @@ class _RenderWrapper(torch.nn.Module):
     def forward(self, rays, want_weights=False):
         if rays.shape[0] == 0:
             return (torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device))
-        outputs = self.renderer(self.net, rays, want_weights=want_weights and not self.simple_output)
+        with torch.profiler.record_function("render_par"):
+            outputs = self.renderer(self.net, rays, want_weights=want_weights and not self.simple_output)
         if self.simple_output:
             if self.renderer.using_fine:
                 return outputs.fine.rgb, outputs.fine.depth
@@ -42,8 +47,14 @@ class NeRFRenderer(torch.nn.Module):
     """NeRF renderer; parameters as src/render/nerf.py:45-96."""
 
     def __init__(self, n_coarse=128, n_fine=0, n_fine_depth=0, noise_std=0.0, depth_std=0.01,
-                 eval_batch_size=100000, white_bkgd=False, lindisp=False, sched=None):
+                 eval_batch_size=100000, white_bkgd=False, lindisp=False, sched=None, rng="philox"):
         super().__init__()
+        if rng not in ("philox", "torch"):
+            raise ValueError("rng must be 'philox' (in-kernel counter-based draws) or 'torch'")
+        self.rng = rng
+        self._calls = 0         # per-renderer call counter mixed into the Philox seed
+        self.ray_id_offset = 0  # placement of this call's rays inside a larger ray set (set by sharding wrappers)
+        self.ray_id_stride = 0
         self.n_coarse, self.n_fine, self.n_fine_depth = n_coarse, n_fine, n_fine_depth
         self.noise_std, self.depth_std = noise_std, depth_std
         self.eval_batch_size = eval_batch_size
@@ -89,6 +100,10 @@ class NeRFRenderer(torch.nn.Module):
         """nerf.py:163-249 for an arbitrary model callable: points/viewdirs, chunked model
         calls (eval_batch_size), then the HIP compositing kernel.
         :return weights (B,K), rgb (B,3), depth (B)"""
+        with torch.profiler.record_function("renderer_composite"):  # nerf.py:175
+            return self._composite(model, rays, z_samp, coarse, sb)
+
+    def _composite(self, model, rays, z_samp, coarse, sb):
         B, K = z_samp.shape
         points = (rays[:, None, :3] + z_samp.unsqueeze(2) * rays[:, None, 3:6]).reshape(-1, 3)
         use_viewdirs = hasattr(model, "use_viewdirs") and model.use_viewdirs
@@ -133,6 +148,10 @@ class NeRFRenderer(torch.nn.Module):
         :param model nerf model: (SB,B,3) points [+ viewdirs] -> (SB,B,4) rgb sigma
         :param rays [origins(3), directions(3), near, far] (SB,B,8)
         :return DotMap {coarse:{rgb (SB,B,3), depth (SB,B)[, weights (SB,B,K)]}, fine:{...}}"""
+        with torch.profiler.record_function("renderer_forward"):  # the reference's scope name (nerf.py:264)
+            return self._forward(model, rays, want_weights, _noise)
+
+    def _forward(self, model, rays, want_weights, _noise):
         if self.sched is not None and self.last_sched.item() > 0:
             self.n_coarse = self.sched[1][self.last_sched.item() - 1]
             self.n_fine = self.sched[2][self.last_sched.item() - 1]
@@ -140,11 +159,13 @@ class NeRFRenderer(torch.nn.Module):
         SB = rays.shape[0]
         rays = rays.reshape(-1, 8).float().contiguous()
         R = rays.shape[0]
-        noise = self._draw_noise(R, rays.device) if _noise is None else _noise
+        fused = hasattr(model, "scene") and hasattr(model, "packed")
+        seeded = _noise is None and fused and self.rng == "philox" and not (self.training and torch.is_grad_enabled())
+        noise = _noise if (_noise is not None or seeded) else self._draw_noise(R, rays.device)
         Kf = self.n_fine if self.using_fine else 0
         Kfd = min(self.n_fine_depth, Kf)
 
-        if hasattr(model, "scene") and hasattr(model, "packed"):  # pixelnerf_amd.PixelNeRFNet: one C call
+        if fused:  # pixelnerf_amd.PixelNeRFNet: one C call
             if self.training and self.noise_std > 0.0:
                 raise NotImplementedError("noise_std > 0 (unused by every shipped config) is not fused")
             model._check_supported()
@@ -154,6 +175,8 @@ class NeRFRenderer(torch.nn.Module):
                 or (model.encoder.latent.requires_grad and not model.stop_encoder_grad))
             if needs_grad:  # training: differentiable path (HIP forward with operand dumps + HIP backward)
                 from ..autograd import render_autograd
+                if noise is None:
+                    noise = self._draw_noise(R, rays.device)
                 res = render_autograd(self, model, rays, noise, want_weights)
             else:
                 # mlp_fine is None (eval/eval.py:140): pass no fine network, so the fine pass re-uses the coarse pass's
@@ -163,7 +186,9 @@ class NeRFRenderer(torch.nn.Module):
                 res = ops.render_forward(model.scene(), model.packed(True), model.packed(False) if own_fine else None,
                                          rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
                                          white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights,
-                                         tables=None if tc is None else (tc, model.tables(False) if own_fine else None))
+                                         tables=None if tc is None else (tc, model.tables(False) if own_fine else None),
+                                         seed=self._next_seed(rays.device) if seeded else 0,
+                                         ray_id_offset=self.ray_id_offset, ray_id_stride=self.ray_id_stride)
             outputs = DotMap(coarse=self._format(res["coarse"], SB, want_weights))
             if Kf > 0:
                 outputs.fine = self._format(res["fine"], SB, want_weights)
@@ -179,6 +204,16 @@ class NeRFRenderer(torch.nn.Module):
             wf, rgbf, depthf = self.composite(model, rays, z_all, coarse=False, sb=SB)
             outputs.fine = self._format(dict(rgb=rgbf, depth=depthf, weights=wf), SB, want_weights)
         return outputs
+
+    def _next_seed(self, device):
+        """64-bit Philox key of this call: the device generator's seed (torch.manual_seed) mixed with the call counter
+        (splitmix64 finaliser) -- host arithmetic only."""
+        base = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()].initial_seed()
+        x = (base + 0x9E3779B97F4A7C15 * (self._calls + 1)) & (2 ** 64 - 1)
+        self._calls += 1
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        return x ^ (x >> 31)
 
     @staticmethod
     def _format(d, SB, want_weights):
@@ -207,7 +242,7 @@ class NeRFRenderer(torch.nn.Module):
                    n_fine_depth=conf.get_int("n_fine_depth", 0), noise_std=conf.get_float("noise_std", 0.0),
                    depth_std=conf.get_float("depth_std", 0.01), white_bkgd=conf.get_float("white_bkgd", white_bkgd),
                    lindisp=lindisp, eval_batch_size=conf.get_int("eval_batch_size", eval_batch_size),
-                   sched=conf.get_list("sched", None))
+                   sched=conf.get_list("sched", None), rng=conf.get_string("rng", "philox"))
 
     def bind_parallel(self, net, gpus=None, simple_output=False):
         """nerf.py:354-371.  Returns a module callable as `(rays (SB,B,8), want_weights=False)`.
@@ -219,11 +254,73 @@ class NeRFRenderer(torch.nn.Module):
         wrapped = _RenderWrapper(net, self, simple_output=simple_output)
         if gpus is not None and len(gpus) > 1:
             import torch.distributed as dist
+            print("Using multi-GPU", gpus)
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 from ..dist import ShardedRenderWrapper
-                print("Using multi-GPU", gpus)
                 return ShardedRenderWrapper(wrapped)
-            raise NotImplementedError(
-                "multi-GPU rendering runs one process per GPU: launch with `python -m torch.distributed.run "
-                "--nproc-per-node N ...`, init_process_group('nccl'), then bind_parallel(net, gpus)")
+            # single process, several devices -- what `eval/eval.py --gpu_id "0 1"` asks for (nerf.py:367-371)
+            return _MultiDeviceRenderWrapper(net, self, simple_output, gpus)
         return wrapped
+
+
+class _MultiDeviceRenderWrapper(torch.nn.Module):
+    """Single-process counterpart of the reference's DataParallel(_RenderWrapper, gpus, dim=1) (nerf.py:367-371): rays
+    are split on dim 1 across the listed devices, every device renders its slice with its own replica of the
+    network (weights copied once and refreshed when they change; the encoded scene -- feature grid, poses, focal, c --
+    is copied per call, as DataParallel's replicate does), results are concatenated on the first device.  Kernel
+    launches are asynchronous, so the slices run concurrently.  Inference only; training across GPUs is one process
+    per GPU (pixelnerf_amd.dist)."""
+
+    def __init__(self, net, renderer, simple_output, gpus):
+        super().__init__()
+        self.net, self.renderer, self.simple_output = net, renderer, simple_output
+        self.devices = [torch.device("cuda", int(g)) for g in gpus]
+        self._replicas = {}  # device index in the list -> (weights fingerprint, net replica, renderer replica)
+
+    def _replica(self, i):
+        import copy
+        fp = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
+        hit = self._replicas.get(i)
+        if hit is None or hit[0] != fp:
+            enc_lat = self.net.encoder.latent  # not a parameter: do not drag the grid through deepcopy
+            self.net.encoder.latent = torch.empty(0)
+            try:
+                rep = copy.deepcopy(self.net).to(self.devices[i])
+            finally:
+                self.net.encoder.latent = enc_lat
+            self._replicas[i] = (fp, rep, copy.deepcopy(self.renderer).to(self.devices[i]))
+        _, rep, rend = self._replicas[i]
+        dev = self.devices[i]
+        src = self.net
+        rep.encoder.latent = src.encoder.latent.to(dev, non_blocking=True)
+        rep.encoder.latent_scaling = src.encoder.latent_scaling.to(dev, non_blocking=True)
+        rep.poses, rep.focal, rep.c = src.poses.to(dev, non_blocking=True), src.focal.to(dev, non_blocking=True), src.c.to(dev, non_blocking=True)
+        rep.image_shape = src.image_shape.to(dev, non_blocking=True)
+        rep.num_objs, rep.num_views_per_obj, rep.mlp_fine = src.num_objs, src.num_views_per_obj, (rep.mlp_fine if src.mlp_fine is not None else None)
+        rep.precision, rep.fold = src.precision, src.fold
+        for k in ("n_coarse", "n_fine", "n_fine_depth", "using_fine", "white_bkgd", "lindisp", "depth_std"):
+            setattr(rend, k, getattr(self.renderer, k))
+        rend.train(self.renderer.training)
+        return rep, rend
+
+    def forward(self, rays, want_weights=False):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+            raise NotImplementedError("bind_parallel(net, gpus) in one process is the inference path; wrap the call in "
+                                      "torch.no_grad(), or train with one process per GPU (pixelnerf_amd.dist)")
+        from ..dist import shard_bounds
+        B, n = rays.shape[1], len(self.devices)
+        outs = []
+        for i, dev in enumerate(self.devices):
+            lo, hi = shard_bounds(B, i, n)
+            if hi == lo:
+                continue
+            rep, rend = self._replica(i)
+            rend.ray_id_offset, rend.ray_id_stride, rend._calls = lo, B, self.renderer._calls  # same draws as one device
+            with torch.cuda.device(dev):
+                part = _RenderWrapper(rep, rend, self.simple_output)(rays[:, lo:hi].to(dev, non_blocking=True), want_weights=want_weights)
+            outs.append(part)
+        self.renderer._calls += 1
+        home = self.devices[0]
+        if self.simple_output:
+            return tuple(torch.cat([o[j].to(home) for o in outs], dim=1) for j in range(2))
+        return {k: {kk: torch.cat([o[k][kk].to(home) for o in outs], dim=1) for kk in outs[0][k]} for k in outs[0]}

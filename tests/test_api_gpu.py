@@ -190,3 +190,32 @@ def test_renderer_api_exact_fp32_mode(dev, name):
     for p in ("coarse", "fine"):
         assert O.psnr(out[p].rgb.cpu(), torch.from_numpy(g[f"{p}_rgb"])) >= 85.0
     np.testing.assert_allclose(out.coarse.weights.cpu().numpy(), g["coarse_weights"], rtol=0, atol=2e-5)
+
+
+def test_bind_parallel_single_process_multi_device(dev):
+    """eval/eval.py --gpu_id "0 1": bind_parallel(net, gpus) in ONE process without a process group shards the rays on dim 1
+    across the listed devices (reference: DataParallel(dim=1), nerf.py:367-371).  The test box has one GPU, so both
+    "devices" are cuda:0 -- the sharding, replication and concatenation logic is what is exercised; rays are independent
+    units and the in-kernel draws are keyed by the global ray id, so the sharded render must equal the single-device
+    render bit for bit."""
+    from pixelnerf_amd.render import NeRFRenderer
+    g, scene, meta, mc, mf, rays, noise = golden_setup("sn64_64_128")
+    net = build_net(dev, scene)
+    renderer = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=True).to(dev).eval()
+    par = renderer.bind_parallel(net, [0, 0], simple_output=True).eval()
+    assert type(par).__name__ == "_MultiDeviceRenderWrapper"
+    r = rays.to(dev)
+    with torch.no_grad():
+        renderer._calls = 0
+        rgb, depth = par(r)
+        renderer._calls = 0  # same Philox seed: the draws are keyed by the global ray id, so sharding must not change a bit
+        ref_rgb, ref_depth = renderer.bind_parallel(net, [0], simple_output=True).eval()(r)
+    assert rgb.shape == (1, r.shape[1], 3) and depth.shape == (1, r.shape[1]) and torch.isfinite(rgb).all()
+    assert torch.equal(rgb, ref_rgb) and torch.equal(depth, ref_depth)
+    full = renderer.bind_parallel(net, [0, 0], simple_output=False).eval()
+    with torch.no_grad():
+        d = full(r, want_weights=True)
+    assert d["fine"]["weights"].shape == (1, r.shape[1], 192) and d["coarse"]["rgb"].shape == (1, r.shape[1], 3)
+    net.mlp_coarse.lin_in.weight.requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        par(r)

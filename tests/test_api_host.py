@@ -111,8 +111,8 @@ def test_bind_parallel_and_wrapper(net):
     assert isinstance(r.bind_parallel(net, [0]), _RenderWrapper)
     rgb, depth = w(torch.zeros(0, 5, 8))  # empty super-batch guard, nerf.py:23-27
     assert rgb.shape == (0, 3) and depth.shape == (0,)
-    with pytest.raises(NotImplementedError):  # >1 GPU without a process group
-        r.bind_parallel(net, [0, 1])
+    # >1 GPU without a process group: single-process sharding over the listed devices, like the reference's DataParallel
+    assert type(r.bind_parallel(net, [0, 1])).__name__ == "_MultiDeviceRenderWrapper"
     with pytest.raises(AssertionError):
         r(net, torch.zeros(5, 8))  # rays must be (SB,B,8), nerf.py:269
 
@@ -132,3 +132,17 @@ def test_conf_dotmap_and_helpers():
     assert abs(psnr(torch.zeros(4), torch.full((4,), 0.1)) - 20.0) < 1e-4
     rays = gen_rays(torch.eye(4)[None], 4, 3, 2.0, 0.5, 1.5)
     assert rays.shape == (1, 3, 4, 8) and torch.allclose(rays[..., 3:6].norm(dim=-1), torch.ones(1, 3, 4))
+
+
+def test_pretrained_encoder_without_weights_warns():
+    """conf/default.conf asks for pretrained=True; ImageNet weights are not available offline -- that must be loud."""
+    import warnings
+    from pixelnerf_amd.model.encoder import SpatialEncoder
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        SpatialEncoder(pretrained=True)
+    assert any("randomly initialised" in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        SpatialEncoder(pretrained=False)
+    assert not w

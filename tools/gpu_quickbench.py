@@ -17,6 +17,8 @@ def main():
     cases = (("sn64", 16384, 64), ("sn64", 16384, 192), ("srn_car", 8192, 192))
     if "--sn64" in sys.argv:
         cases = (("sn64", 16384, 64), ("sn64", 16384, 192))
+    if "--srn" in sys.argv:
+        cases = (("srn_car", 8192, 192),)
     for scene_name, R, K in cases:
         scene, meta = synthetic.make_scene(scene_name)
         NS = scene["NS"]
