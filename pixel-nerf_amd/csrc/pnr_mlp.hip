@@ -244,6 +244,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
         bool valid[JT];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) valid[jt] = (long long)tile * MT + jt * 32 + pl < q.P;
+#ifdef PNR_EXP_MV_XSUM_REGS  // A/B experiment: the round-1 form, running view sum in 64 live registers (spills)
+        f32x16 xsum[MV ? IT : 1][MV ? JT : 1];
+#endif
         const size_t dump_pooled = (((size_t)tile * MT + pl) * D_HID + (wv * IT) * 32 + h * 16) * 2;
 #pragma unroll 1
         for (int view = 0; view < NS; ++view) {
@@ -279,6 +282,19 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             for (int b = 0; b < COMBINE_LAYER; ++b)
                 res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
                                                   a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane);
+#ifdef PNR_EXP_MV_XSUM_REGS
+            if constexpr (MV) {
+                const float inv = 1.f / (float)NS;
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        if (view == 0) xsum[it][jt] = x[it][jt];
+                        else xsum[it][jt] += x[it][jt];
+                        if (view + 1 == NS) x[it][jt] = xsum[it][jt] * inv;
+                    }
+            }
+#else
             if constexpr (MV) {
                 // mean over source views (util.combine_interleaved, util.py:461-466).  The running view sum is PARKED in
                 // a per-workgroup scratch (q.mv_ws, L2-resident, each lane re-reads only what it wrote itself: no
@@ -307,6 +323,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                     __builtin_amdgcn_sched_barrier(0);  // one feature tile row at a time: bounds the loads in flight (registers)
                 }
             }
+#endif
         }
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b)

@@ -10,8 +10,8 @@ eval_batch_size exactly like the reference.
 
 Random numbers.  `rng="philox"` (default in eval mode with a pixelnerf_amd net): the sampling kernels draw from a
 counter-based generator (Philox4x32-10) keyed by a 64-bit seed -- `torch.initial_seed()` of the ray device's generator
-mixed with a per-renderer call counter, so `torch.manual_seed(s)` makes a run reproducible without any device-side
-launch or HBM traffic for noise; a draw depends only on (seed, global ray id, draw, index), so chunked or multi-GPU
+mixed with that generator's Philox offset (advanced per call, host side), so `torch.manual_seed(s)` makes a run
+reproducible exactly as it does for the reference, without any device-side launch or HBM traffic for noise; a draw depends only on (seed, global ray id, draw, index), so chunked or multi-GPU
 sharded renders give the same image as one call.  `rng="torch"` (and training, and generic model callables): torch's
 generator on the ray device, in the reference's draw order (nerf.py:111,135,141,158).  Tests inject pre-drawn noise
 through `_noise`.
@@ -52,7 +52,7 @@ class NeRFRenderer(torch.nn.Module):
         if rng not in ("philox", "torch"):
             raise ValueError("rng must be 'philox' (in-kernel counter-based draws) or 'torch'")
         self.rng = rng
-        self._calls = 0         # per-renderer call counter mixed into the Philox seed
+        self._seed_override = None  # set by the multi-device wrapper: every shard of one call uses the same key
         self.ray_id_offset = 0  # placement of this call's rays inside a larger ray set (set by sharding wrappers)
         self.ray_id_stride = 0
         self.n_coarse, self.n_fine, self.n_fine_depth = n_coarse, n_fine, n_fine_depth
@@ -206,11 +206,16 @@ class NeRFRenderer(torch.nn.Module):
         return outputs
 
     def _next_seed(self, device):
-        """64-bit Philox key of this call: the device generator's seed (torch.manual_seed) mixed with the call counter
-        (splitmix64 finaliser) -- host arithmetic only."""
-        base = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()].initial_seed()
-        x = (base + 0x9E3779B97F4A7C15 * (self._calls + 1)) & (2 ** 64 - 1)
-        self._calls += 1
+        """64-bit Philox key of this call, from the ray device's torch generator: (seed, Philox offset) mixed by a
+        splitmix64 finaliser, and the generator's offset is advanced as a torch.rand launch would advance it.  Host
+        arithmetic only (no launch, no sync); `torch.manual_seed(s)` resets it exactly like it resets the reference's
+        draws, successive calls get fresh draws."""
+        if self._seed_override is not None:
+            return self._seed_override
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        base, off = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(off + 4)
+        x = (base + 0x9E3779B97F4A7C15 * (off // 4 + 1)) & (2 ** 64 - 1)
         x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
         x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
         return x ^ (x >> 31)
@@ -309,17 +314,17 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
                                       "torch.no_grad(), or train with one process per GPU (pixelnerf_amd.dist)")
         from ..dist import shard_bounds
         B, n = rays.shape[1], len(self.devices)
+        seed = self.renderer._next_seed(self.devices[0])  # one key per call, shared by all shards
         outs = []
         for i, dev in enumerate(self.devices):
             lo, hi = shard_bounds(B, i, n)
             if hi == lo:
                 continue
             rep, rend = self._replica(i)
-            rend.ray_id_offset, rend.ray_id_stride, rend._calls = lo, B, self.renderer._calls  # same draws as one device
+            rend.ray_id_offset, rend.ray_id_stride, rend._seed_override = lo, B, seed  # same draws as one device
             with torch.cuda.device(dev):
                 part = _RenderWrapper(rep, rend, self.simple_output)(rays[:, lo:hi].to(dev, non_blocking=True), want_weights=want_weights)
             outs.append(part)
-        self.renderer._calls += 1
         home = self.devices[0]
         if self.simple_output:
             return tuple(torch.cat([o[j].to(home) for o in outs], dim=1) for j in range(2))

@@ -70,12 +70,13 @@ def test_renderer_api_matches_reference(dev, name):
 
 
 def test_seeded_noise_stream_follows_reference_draw_order(dev):
-    """A seeded call consumes torch's generator exactly as the reference does:
-    rand(R,Kc), rand(R,Kf-Kfd), rand(R,Kf-Kfd), randn(R,Kfd)  (nerf.py:111,135,141,158)."""
+    """rng="torch": a seeded call consumes torch's generator exactly as the reference does:
+    rand(R,Kc), rand(R,Kf-Kfd), rand(R,Kf-Kfd), randn(R,Kfd)  (nerf.py:111,135,141,158).  (The default, rng="philox",
+    draws in-kernel and is covered by tests/test_hip_rng.py.)"""
     from pixelnerf_amd.render import NeRFRenderer
     g, scene, meta, mc, mf, rays, noise = golden_setup("sn64_64_128")
     net = build_net(dev, scene)
-    renderer = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=True).to(dev).eval()
+    renderer = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=True, rng="torch").to(dev).eval()
     r = rays.to(dev)
     R = r.shape[0] * r.shape[1]
     with torch.no_grad():
@@ -206,9 +207,9 @@ def test_bind_parallel_single_process_multi_device(dev):
     assert type(par).__name__ == "_MultiDeviceRenderWrapper"
     r = rays.to(dev)
     with torch.no_grad():
-        renderer._calls = 0
+        torch.manual_seed(11)
         rgb, depth = par(r)
-        renderer._calls = 0  # same Philox seed: the draws are keyed by the global ray id, so sharding must not change a bit
+        torch.manual_seed(11)  # same Philox key: the draws are keyed by the global ray id, so sharding must not change a bit
         ref_rgb, ref_depth = renderer.bind_parallel(net, [0], simple_output=True).eval()(r)
     assert rgb.shape == (1, r.shape[1], 3) and depth.shape == (1, r.shape[1]) and torch.isfinite(rgb).all()
     assert torch.equal(rgb, ref_rgb) and torch.equal(depth, ref_depth)
