@@ -217,7 +217,12 @@ def extra_train_step(dev, prec, steps=20, warmup=8):
     net.num_objs, net.num_views_per_obj = scene["SB"], scene["NS"]
     rend = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).to(dev)
     render_par = rend.bind_parallel(net, None, simple_output=False).train()
-    opt = torch.optim.Adam(list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters()), lr=1e-4)
+    # the reference's optimizer (train/trainer.py: torch.optim.Adam); `fused=True` is PyTorch's single-kernel form of the
+    # same update -- the optimizer is outside the hot path, so it is taken in its cheapest stock form
+    try:
+        opt = torch.optim.Adam(list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters()), lr=1e-4, fused=True)
+    except Exception:
+        opt = torch.optim.Adam(list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters()), lr=1e-4)
 
     def step():
         rd = DotMap(render_par(rays, want_weights=True))
@@ -236,9 +241,28 @@ def extra_train_step(dev, prec, steps=20, warmup=8):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"workload": "sn64 training step: 4 objects x 128 rays, 64+32 (16 depth) samples, fwd+bwd+Adam, grads to both "
-                        "ResnetFCs and encoder.latent", "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "rays_per_s": 512 / dt,
-            "algorithmic_tflops": 512 / dt * 3.29e9 / 1e12, "loss": float(loss.item()), "steps": steps}
+    out = {"workload": "sn64 training step: 4 objects x 128 rays, 64+32 (16 depth) samples, fwd+bwd+Adam, grads to both "
+                       "ResnetFCs and encoder.latent", "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "rays_per_s": 512 / dt,
+           "algorithmic_tflops": 512 / dt * 3.29e9 / 1e12, "loss": float(loss.item()), "steps": steps,
+           "launch_mode": "eager launches (one Python-sequenced HIP launch per kernel)"}
+    # the same step captured ONCE into a HIP graph (torch.cuda.CUDAGraph: forward, backward and a capturable Adam) and
+    # replayed: no per-kernel launch latency, no Python between the ~35 kernels.  Run as a CHILD process
+    # (tools/gpu_train_graph.py): a failure inside graph capture must never take this benchmark line down.
+    import subprocess
+    try:
+        child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_train_graph.py"), "step"], capture_output=True,
+                               text=True, timeout=300)
+        line = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+        if child.returncode == 0 and line:
+            r = json.loads(line[-1])["step"]
+            out["hip_graph"] = {"ms_per_step": r["graph_ms"], "steps_per_s": 1e3 / r["graph_ms"], "rays_per_s": 512e3 / r["graph_ms"],
+                                "algorithmic_tflops": 512e3 / r["graph_ms"] * 3.29e9 / 1e12, "eager_ms_per_step_same_process": r["eager_ms"],
+                                "loss": r["loss"]}
+        else:
+            out["hip_graph"] = {"error": "child rc=%d: %s" % (child.returncode, child.stderr[-300:])}
+    except Exception as e:
+        out["hip_graph"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    return out
 
 
 def self_launch(n):

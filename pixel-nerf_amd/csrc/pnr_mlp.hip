@@ -122,13 +122,34 @@ __device__ __forceinline__ void gather_table(const EvalParams &q, char *smem, in
             }
 #endif
             float r[8];
+            if constexpr (P::kIsF16) {
+                // v_fma_mix_f32: fp32 FMA that converts its f16 operand on the fly (op_sel picks the half of the packed
+                // register) -- the same fused multiply-adds in the same order as the generic form below, without the 32
+                // separate v_cvt_f32_f16 per point the compiler otherwise emits (the blend is VALU-bound)
+                const u32x4 c0 = __builtin_bit_cast(u32x4, v[u][0]), c1 = __builtin_bit_cast(u32x4, v[u][1]);
+                const u32x4 c2 = __builtin_bit_cast(u32x4, v[u][2]), c3 = __builtin_bit_cast(u32x4, v[u][3]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float a = (float)v[u][0][e] * w[u][0];
-                a += (float)v[u][1][e] * w[u][1];
-                a += (float)v[u][2][e] * w[u][2];
-                a += (float)v[u][3][e] * w[u][3];
-                r[e] = a;
+                for (int k = 0; k < 4; ++k) {
+                    float lo, hi;
+                    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(c0[k]), "v"(w[u][0]));
+                    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(c0[k]), "v"(w[u][0]));
+                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(c1[k]), "v"(w[u][1]), "v"(lo));
+                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(c1[k]), "v"(w[u][1]), "v"(hi));
+                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(c2[k]), "v"(w[u][2]), "v"(lo));
+                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(c2[k]), "v"(w[u][2]), "v"(hi));
+                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(c3[k]), "v"(w[u][3]), "v"(lo));
+                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(c3[k]), "v"(w[u][3]), "v"(hi));
+                    r[2 * k] = lo; r[2 * k + 1] = hi;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a = (float)v[u][0][e] * w[u][0];
+                    a += (float)v[u][1][e] * w[u][1];
+                    a += (float)v[u][2][e] * w[u][2];
+                    a += (float)v[u][3][e] * w[u][3];
+                    r[e] = a;
+                }
             }
             *reinterpret_cast<typename P::T8 *>(smem + LDS_Z + p * ROW_ACT + lane * 16) =
                 pack8<P, false>(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
@@ -146,10 +167,21 @@ __device__ __forceinline__ void add_from_z(f32x16 (&x)[IT][JT_], const char *sme
             const uint32_t ad = z_slot + jt * 32 * ROW_ACT + it * 64;
             const typename P::T8 lo = *reinterpret_cast<const typename P::T8 *>(smem + ad);
             const typename P::T8 hi = *reinterpret_cast<const typename P::T8 *>(smem + ad + 16);
+            if constexpr (P::kIsF16) {  // x += f16 -> one v_fma_mix_f32 (x = h * 1.0 + x) instead of convert + add
+                const u32x4 ul = __builtin_bit_cast(u32x4, lo), uh = __builtin_bit_cast(u32x4, hi);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                x[it][jt][r] += (float)lo[r];
-                x[it][jt][8 + r] += (float)hi[r];
+                for (int k = 0; k < 4; ++k) {
+                    asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x[it][jt][2 * k]) : "v"(ul[k]));
+                    asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x[it][jt][2 * k + 1]) : "v"(ul[k]));
+                    asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x[it][jt][8 + 2 * k]) : "v"(uh[k]));
+                    asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x[it][jt][8 + 2 * k + 1]) : "v"(uh[k]));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    x[it][jt][r] += (float)lo[r];
+                    x[it][jt][8 + r] += (float)hi[r];
+                }
             }
         }
 }
@@ -301,10 +333,14 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                 // synchronisation) instead of 64-96 live registers across three residual blocks -- the multi-view
                 // instantiations then have the single-view register budget (no scratch spills, 96-point tile).
                 // Fixed summation order view 0 + view 1 + ...: deterministic.
-                // layout [thread][slot]: one base register + immediate offsets (a [slot][thread] layout needs an address pair
-                // per slot -- 32 more live registers exactly where the budget is tightest; the 4x more cache lines touched
-                // per instruction cost ~1 k cycles per view boundary, nothing next to a tile)
+                // layout [slot][thread]: every instruction moves 1 KiB of consecutive bytes per wave
+#ifdef PNR_EXP_MV_THREAD_MAJOR  // A/B: [thread][slot] layout (one address register, 4x the cache lines per instruction)
                 f32x4 *ws = reinterpret_cast<f32x4 *>(q.mv_ws) + ((size_t)blockIdx.x * NTHREADS + tid) * (IT * JT * 4);
+                constexpr int SLOT_STRIDE = 1;
+#else
+                f32x4 *ws = reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid;
+                constexpr int SLOT_STRIDE = NTHREADS;
+#endif
                 const bool first = view == 0, last = view + 1 == NS;
                 const float inv = 1.f / (float)NS;
 #pragma unroll
@@ -313,7 +349,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                     for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            f32x4 *slot = ws + (it * JT + jt) * 4 + k;
+                            f32x4 *slot = ws + ((it * JT + jt) * 4 + k) * SLOT_STRIDE;
                             f32x4 v = {x[it][jt][4 * k], x[it][jt][4 * k + 1], x[it][jt][4 * k + 2], x[it][jt][4 * k + 3]};
                             if (!first) v += *slot;
                             if (!last) *slot = v;

@@ -160,7 +160,9 @@ class NeRFRenderer(torch.nn.Module):
         rays = rays.reshape(-1, 8).float().contiguous()
         R = rays.shape[0]
         fused = hasattr(model, "scene") and hasattr(model, "packed")
-        seeded = _noise is None and fused and self.rng == "philox" and not (self.training and torch.is_grad_enabled())
+        # (inside a HIP-graph capture the generator's offset cannot be read on the host: torch's own graph-safe draws are used)
+        seeded = (_noise is None and fused and self.rng == "philox" and not (self.training and torch.is_grad_enabled())
+                  and not (rays.is_cuda and torch.cuda.is_current_stream_capturing()))
         noise = _noise if (_noise is not None or seeded) else self._draw_noise(R, rays.device)
         Kf = self.n_fine if self.using_fine else 0
         Kfd = min(self.n_fine_depth, Kf)
@@ -287,12 +289,24 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
         fp = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
         hit = self._replicas.get(i)
         if hit is None or hit[0] != fp:
-            enc_lat = self.net.encoder.latent  # not a parameter: do not drag the grid through deepcopy
-            self.net.encoder.latent = torch.empty(0)
+            # not parameters: do not drag the grid, the device-side scene descriptor (ctypes) or the packed streams through
+            # deepcopy -- the replica rebuilds its own lazily
+            src = self.net
+            keep = (src.encoder.latent, src._scene, src._tables, getattr(src.encoder, "_nhwc", None))
+            packs = [(m, m._packed) for m in (src.mlp_coarse, src.mlp_fine) if m is not None]
+            src.encoder.latent, src._scene, src._tables = torch.empty(0), None, {}
+            if hasattr(src.encoder, "_nhwc"):
+                src.encoder._nhwc = None
+            for m, _ in packs:
+                m._packed = {}
             try:
-                rep = copy.deepcopy(self.net).to(self.devices[i])
+                rep = copy.deepcopy(src).to(self.devices[i])
             finally:
-                self.net.encoder.latent = enc_lat
+                src.encoder.latent, src._scene, src._tables = keep[0], keep[1], keep[2]
+                if hasattr(src.encoder, "_nhwc"):
+                    src.encoder._nhwc = keep[3]
+                for m, pk in packs:
+                    m._packed = pk
             self._replicas[i] = (fp, rep, copy.deepcopy(self.renderer).to(self.devices[i]))
         _, rep, rend = self._replicas[i]
         dev = self.devices[i]

@@ -7,7 +7,7 @@ REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$REPO/gpurun_out/pmc"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-eager-baseline --no-f32-check $*"
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-eager-baseline --no-f32-check --no-extras $*"
 run() {  # name, counters...
     local name=$1; shift
     timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -o "pmc_$name" -- $CMD > "$OUT/$name.log" 2>&1

@@ -23,7 +23,8 @@ def main():
     rays = synthetic.target_rays(meta, n_rays=128).to(dev)  # (4,128,8)
     gt = torch.rand(4, 128, 3, device=dev)
     mc, mf = synthetic.make_mlp_params(11), synthetic.make_mlp_params(12)
-    for prec in ("f16", "bf16", "f16"):
+    quick = "--quick" in sys.argv  # profiling runs: one precision, no eager baseline
+    for prec in (("f16",) if quick else ("f16", "bf16", "f16")):
         net = make_model(default_model_conf(), precision=prec).to(dev).train()
         net.mlp_coarse.load_state_dict(mc)
         net.mlp_fine.load_state_dict(mf)
@@ -59,6 +60,8 @@ def main():
         dt = (time.perf_counter() - t0) / n
         print(f"HIP {prec}: {dt*1e3:8.2f} ms/step  {1/dt:7.2f} steps/s  {512/dt:9.0f} rays/s   loss {loss.item():.5f}", flush=True)
 
+    if quick:
+        return
     # eager PyTorch-ROCm autograd baseline (oracle restatement, fp32)
     from oracle import pnr_oracle as O
     O.USE_GRID_SAMPLE = True
