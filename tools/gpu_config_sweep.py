@@ -18,8 +18,12 @@ FLOP_V, FLOP_P = 4.7616e6, 2.1012e6
 
 def main():
     dev = torch.device("cuda:0")
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    precs = ("f16",) if "--f16" in sys.argv else ("f16", "bf16")
     for scene_name, n_img in (("sn64", 16), ("srn_car", 4), ("dtu", 1)):
-        for prec in ("f16", "bf16"):
+        if only and scene_name not in only:
+            continue
+        for prec in precs:
             scene, meta, net, renderer, mlps = bench.build(dev, prec, scene_name)
             rays = synthetic.target_rays(meta).reshape(-1, 8)
             rays = rays.repeat(n_img, 1).contiguous().to(dev)
