@@ -16,9 +16,8 @@
  *     enqueued on it, nothing synchronises;
  *   - return value: 0 = ok, negative = PNR_E_* ; pnr_last_error() gives a message (host,
  *     thread-local);
- *   - memory is owned by the caller (torch tensors in the Python host).  The library allocates nothing, with ONE
- *     exception: the first multi-view (NS > 1) network launch on a stream allocates a 48 MiB per-(device, stream)
- *     scratch with hipMalloc (the parked view sum of the pooling step, util.combine_interleaved) and keeps it.
+ *   - memory is owned by the caller (torch tensors in the Python host); the library
+ *     allocates nothing.
  */
 #ifndef PIXELNERF_HIP_H
 #define PIXELNERF_HIP_H

@@ -188,15 +188,17 @@ __device__ __forceinline__ void add_from_z(f32x16 (&x)[IT][JT_], const char *sme
 
 // one residual block (+ the lin_z of the next block when with_z):
 //   net = fc_0(relu(x)); x += fc_1(relu(net)) [+ lin_z[b+1](z)]       resnetfc.py:55-62,174-182
-template <typename P, bool TIMING, bool TRAIN, bool FOLD, typename TL>
+template <typename P, bool TIMING, bool TRAIN, bool FOLD, typename TL, bool MV_PARK = false>
 __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, int b, bool with_z, Ring<P> &R,
                                           int NS, const float *bias_lane, uint32_t a_rd0, uint32_t a_rd1,
                                           uint32_t z_rd0, uint32_t z_rd1, uint32_t a_wr, int tid,
                                           unsigned long long *tim, unsigned long long &tlast,
-                                          const EvalParams &q, size_t dump_off, const bool *valid, int wv, int lane) {
+                                          const EvalParams &q, size_t dump_off, const bool *valid, int wv, int lane,
+                                          f32x4 *park = nullptr, bool park_first = true, bool park_last = true, float park_inv = 1.f) {
     typedef Advance<0, FOLD ? RS_VIEW_END_F : RS_VIEW_END, FOLD ? RS_TOTAL_F : RS_TOTAL> ADV;
     constexpr int JT = TL::JT;
     // dump_off: byte offset of this lane's 32-byte slot in a (rows,512) 16-bit dump array
+    // park (multi-view, last per-view block only): this thread's slots of the parked running view sum (see eval_kernel)
     __syncthreads();  // every wave is done reading LDS_A (previous fc_1)
     PNR_T(PH_BAR1);
     write_act<P, true, TRAIN>(x, smem, a_wr, TRAIN ? q.d_a[b] + dump_off : nullptr, valid);
@@ -216,7 +218,33 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
     __syncthreads();
     PNR_T(PH_BAR4);
     add_bias<false>(x, bias_lane, 2 + 2 * b);
+    // multi-view pooling: the running sum of the previous views comes back from its scratch UNDER this GEMM (`net` is dead,
+    // its registers hold the loads in flight), so the view boundary costs no exposed memory round trip
+    f32x4 parked[(MV_PARK ? IT * JT * 4 : 1)];
+    if constexpr (MV_PARK) {
+        if (park && !park_first) {
+#pragma unroll
+            for (int i = 0; i < IT * JT * 4; ++i) parked[i] = park[i * NTHREADS];  // [slot][thread]: 1 KiB per wave-instruction
+        }
+    }
     gemm<P, ADV>(x, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
+    if constexpr (MV_PARK) {
+        if (park) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = (it * JT + jt) * 4 + k;
+                        f32x4 v = {x[it][jt][4 * k], x[it][jt][4 * k + 1], x[it][jt][4 * k + 2], x[it][jt][4 * k + 3]};
+                        if (!park_first) v += parked[i];
+                        if (!park_last) park[i * NTHREADS] = v;
+                        else v *= park_inv;
+                        x[it][jt][4 * k] = v[0]; x[it][jt][4 * k + 1] = v[1]; x[it][jt][4 * k + 2] = v[2]; x[it][jt][4 * k + 3] = v[3];
+                    }
+        }
+    }
     if (with_z) {
         if constexpr (FOLD) {  // lin_z[b+1](z) = bilinear lookup in table b+1 (LDS_Z is free: its last readers ran before fc_0)
             PNR_T(PH_GEMM_FC1_Z);
@@ -276,7 +304,11 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
         bool valid[JT];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) valid[jt] = (long long)tile * MT + jt * 32 + pl < q.P;
-#ifdef PNR_EXP_MV_XSUM_REGS  // A/B experiment: the round-1 form, running view sum in 64 live registers (spills)
+#ifndef PNR_MV_PARK
+        // multi-view: running view sum in 64 live registers.  The instantiation then sits at the 256-register limit and spills
+        // 20-40 registers to scratch OUTSIDE the GEMM loops; the spill-free alternatives (-DPNR_MV_PARK: sum parked in an
+        // L2-resident scratch, simple or prefetched under the last fc_1) measured 2.7-4 % and 4-8 % SLOWER on the same box
+        // (profiles/r02_mv_pooling_ab.txt), so the registers stay.
         f32x16 xsum[MV ? IT : 1][MV ? JT : 1];
 #endif
         const size_t dump_pooled = (((size_t)tile * MT + pl) * D_HID + (wv * IT) * 32 + h * 16) * 2;
@@ -310,12 +342,12 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             if constexpr (FOLD) add_from_z<P>(x, smem, a_wr - LDS_A + LDS_Z);  // lin_z[0] via table 0
             else gemm<P, ADV>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);  // lin_z[0]   resnetfc.py:175-180
             PNR_T(PH_GEMM_IN_Z0);
+#if !defined(PNR_MV_PARK)
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b)
                 res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
                                                   a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane);
-#ifdef PNR_EXP_MV_XSUM_REGS
-            if constexpr (MV) {
+            if constexpr (MV) {  // mean over source views (util.combine_interleaved, util.py:461-466)
                 const float inv = 1.f / (float)NS;
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
@@ -327,37 +359,25 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                     }
             }
 #else
-            if constexpr (MV) {
-                // mean over source views (util.combine_interleaved, util.py:461-466).  The running view sum is PARKED in
-                // a per-workgroup scratch (q.mv_ws, L2-resident, each lane re-reads only what it wrote itself: no
-                // synchronisation) instead of 64-96 live registers across three residual blocks -- the multi-view
-                // instantiations then have the single-view register budget (no scratch spills, 96-point tile).
-                // Fixed summation order view 0 + view 1 + ...: deterministic.
-                // layout [slot][thread]: every instruction moves 1 KiB of consecutive bytes per wave
-#ifdef PNR_EXP_MV_THREAD_MAJOR  // A/B: [thread][slot] layout (one address register, 4x the cache lines per instruction)
-                f32x4 *ws = reinterpret_cast<f32x4 *>(q.mv_ws) + ((size_t)blockIdx.x * NTHREADS + tid) * (IT * JT * 4);
-                constexpr int SLOT_STRIDE = 1;
-#else
-                f32x4 *ws = reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid;
-                constexpr int SLOT_STRIDE = NTHREADS;
-#endif
-                const bool first = view == 0, last = view + 1 == NS;
-                const float inv = 1.f / (float)NS;
-#pragma unroll
-                for (int it = 0; it < IT; ++it) {
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            f32x4 *slot = ws + ((it * JT + jt) * 4 + k) * SLOT_STRIDE;
-                            f32x4 v = {x[it][jt][4 * k], x[it][jt][4 * k + 1], x[it][jt][4 * k + 2], x[it][jt][4 * k + 3]};
-                            if (!first) v += *slot;
-                            if (!last) *slot = v;
-                            else v *= inv;
-                            x[it][jt][4 * k] = v[0]; x[it][jt][4 * k + 1] = v[1]; x[it][jt][4 * k + 2] = v[2]; x[it][jt][4 * k + 3] = v[3];
-                        }
-                    __builtin_amdgcn_sched_barrier(0);  // one feature tile row at a time: bounds the loads in flight (registers)
-                }
+            if constexpr (!MV) {
+#pragma unroll 1
+                for (int b = 0; b < COMBINE_LAYER; ++b)
+                    res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
+                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane);
+            } else {
+#pragma unroll 1
+            for (int b = 0; b + 1 < COMBINE_LAYER; ++b)
+                res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, true, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
+                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane);
+            // last per-view block.  Multi-view: mean over source views (util.combine_interleaved, util.py:461-466) -- the
+            // running view sum is PARKED in a per-workgroup scratch (q.mv_ws, [slot][thread] layout, each lane re-reads
+            // only what it wrote itself: no synchronisation) instead of 64 live registers across three residual blocks;
+            // it is fetched back under the block's fc_1 GEMM and the sum / mean is formed right behind it.  Fixed
+            // summation order view 0 + view 1 + ...: deterministic.
+            f32x4 *ws = MV ? reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid : nullptr;
+            res_block<P, TIMING, TRAIN, FOLD, TL, MV>(x, smem, COMBINE_LAYER - 1, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
+                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, ws, view == 0,
+                                                      view + 1 == NS, 1.f / (float)NS);
             }
 #endif
         }
@@ -454,10 +474,9 @@ static inline bool use_tile96(const EvalParams &q, bool mv) {
 #endif
 }
 
-// per (device, stream) scratch of the multi-view instantiations: the parked view sum, one tile of fp32 accumulators per
-// workgroup (256 x 192 KiB = 48 MiB).  The one allocation this library makes itself (first multi-view launch on a
-// stream); it is tied to the stream so that concurrent launches on different streams never share it.
-static float *mv_scratch(hipStream_t st, size_t bytes) {
+// (-DPNR_MV_PARK builds only) per (device, stream) scratch of the multi-view instantiations: the parked view sum, one tile
+// of fp32 accumulators per workgroup (256 x 192 KiB = 48 MiB), allocated at the first multi-view launch on a stream.
+[[maybe_unused]] static float *mv_scratch(hipStream_t st, size_t bytes) {
     struct Slot { int dev; hipStream_t st; float *p; size_t bytes; };
     static std::vector<Slot> slots;
     int dev = 0;
@@ -495,10 +514,12 @@ static int launch(EvalParams &q, bool mv, hipStream_t st) {
     const long long nt = (q.P + mt - 1) / mt;
     q.ntiles = (int)nt;
     const int grid = (int)(nt < num_cus() ? nt : num_cus());
+#ifdef PNR_MV_PARK
     if (mv) {
         q.mv_ws = mv_scratch(st, (size_t)num_cus() * 96 * D_HID * sizeof(float));
         if (!q.mv_ws) return pnr_fail(PNR_E_HIP, "pnr_eval: cannot allocate the multi-view pooling scratch (48 MiB)");
     }
+#endif
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_kernel)");
     hipEvent_t e0 = nullptr, e1 = nullptr;
