@@ -1004,12 +1004,23 @@ extern "C" int pnr_lin_out_grad(const float *g_out, const void *x5, long long P,
 
 constexpr int DW_MAX_SPLIT = 32;
 static int dw_nsplit(int n_jobs, long long max_rows) {
-    // >= ~512 workgroups of 8 waves (2 per CU) from 4 tiles x jobs x slices; slices of at least 256 rows
-    int nsplit = (512 + 4 * n_jobs - 1) / (4 * n_jobs);
+    // 4 tiles x jobs x slices workgroups of 8 waves, one per CU at a time: pick the slice count whose workgroup total fills
+    // whole rounds of the chip (14 jobs: 9 slices = 504 workgroups = 1.97 rounds; the former "at least 512" rule gave 10
+    // slices = 560 = 2.19 rounds, i.e. a third round at 19 % occupancy); slices of at least 256 rows
+    const int cus = bwd_num_cus();
+    const int per = 4 * n_jobs;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int ns = 1; ns <= DW_MAX_SPLIT && (long long)per * ns <= 3LL * cus; ++ns) {
+        const long long blocks = (long long)per * ns;
+        const long long rounds = (blocks + cus - 1) / cus;
+        const double eff = (double)blocks / (double)(rounds * cus);
+        if (blocks >= cus && eff > best_eff + 1e-9) { best_eff = eff; best = ns; }
+        else if (blocks < cus) best = ns;  // fewer workgroups than CUs: more slices is always better
+    }
     const long long cap = (max_rows + 255) / 256;
-    if (nsplit > cap) nsplit = (int)cap;
-    if (nsplit > DW_MAX_SPLIT) nsplit = DW_MAX_SPLIT;
-    return nsplit < 1 ? 1 : nsplit;
+    if (best > cap) best = (int)cap;
+    return best < 1 ? 1 : best;
 }
 
 extern "C" size_t pnr_weight_grad_batched_workspace_bytes(int n_jobs, long long max_rows) {

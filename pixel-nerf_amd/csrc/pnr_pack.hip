@@ -133,11 +133,18 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, float *__restr
 // order.  lin_z[b](bilinear(grid)) == bilinear(table[b]) by linearity (the bilinear weights sum to 1), so the
 // per-point stream loses three of its 13.4 GEMMs.  Block = 4 waves = 64 texels x 64 features, K staged 32 at a time.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+// blockIdx.z = table b: the three tables of a network are ONE launch (the sn64 grid gives 128 blocks per table, a launch-
+// and latency-bound 62 us each when launched one by one)
+struct FoldJobs {
+    const float *W[COMBINE_LAYER], *bias[COMBINE_LAYER];
+};
 template <typename T>
 __global__ void __launch_bounds__(256)
-fold_kernel(const float *__restrict__ grid, const float *__restrict__ W, const float *__restrict__ bias, T *__restrict__ table,
-            long long M, float max_finite) {
+fold_kernel(const float *__restrict__ grid, const FoldJobs jobs, T *__restrict__ tables, long long M, float max_finite) {
     __shared__ float sX[64][33], sW[64][33];
+    const float *__restrict__ W = jobs.W[blockIdx.z];
+    const float *__restrict__ bias = jobs.bias[blockIdx.z];
+    T *__restrict__ table = tables + (size_t)blockIdx.z * (size_t)M * D_HID;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const long long m0 = (long long)blockIdx.x * 64;
     const int n0 = blockIdx.y * 64;
@@ -182,18 +189,18 @@ extern "C" int pnr_fold_latent(const PnrScene *s, const PnrMlpWeights *w, int pr
     if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: bad scene shape");
     const long long M = (long long)s->SB * s->NS * s->Hl * s->Wl;
     if ((M + 63) / 64 > 0x7fffffffLL) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: grid too large");
-    dim3 grid((unsigned)((M + 63) / 64), D_HID / 64);
+    dim3 grid((unsigned)((M + 63) / 64), D_HID / 64, COMBINE_LAYER);
+    FoldJobs jobs;
     for (int b = 0; b < COMBINE_LAYER; ++b) {
         if (!w->lin_z_w[b] || !w->lin_z_b[b]) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: null lin_z parameters");
-        if (precision == PNR_PREC_F16)
-            hipLaunchKernelGGL(fold_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, w->lin_z_w[b],
-                               w->lin_z_b[b], (_Float16 *)tables + (size_t)b * M * D_HID, M, 65504.0f);
-        else if (precision == PNR_PREC_BF16)
-            hipLaunchKernelGGL(fold_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, w->lin_z_w[b],
-                               w->lin_z_b[b], (__bf16 *)tables + (size_t)b * M * D_HID, M, 3.3895314e38f);
-        else
-            return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: unknown precision");
+        jobs.W[b] = w->lin_z_w[b]; jobs.bias[b] = w->lin_z_b[b];
     }
+    if (precision == PNR_PREC_F16)
+        hipLaunchKernelGGL(fold_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, jobs, (_Float16 *)tables, M, 65504.0f);
+    else if (precision == PNR_PREC_BF16)
+        hipLaunchKernelGGL(fold_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, jobs, (__bf16 *)tables, M, 3.3895314e38f);
+    else
+        return pnr_fail(PNR_E_INVALID, "pnr_fold_latent: unknown precision");
     return pnr_check_launch("pnr_fold_latent");
 }
 
@@ -206,12 +213,13 @@ extern "C" int pnr_fold_latent_f32(const PnrScene *s, const PnrMlpWeights *w, fl
     if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: bad scene shape");
     const long long M = (long long)s->SB * s->NS * s->Hl * s->Wl;
     if ((M + 63) / 64 > 0x7fffffffLL) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: grid too large");
-    dim3 grid((unsigned)((M + 63) / 64), D_HID / 64);
+    dim3 grid((unsigned)((M + 63) / 64), D_HID / 64, COMBINE_LAYER);
+    FoldJobs jobs;
     for (int b = 0; b < COMBINE_LAYER; ++b) {
         if (!w->lin_z_w[b] || !w->lin_z_b[b]) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: null lin_z parameters");
-        hipLaunchKernelGGL(fold_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, w->lin_z_w[b],
-                           w->lin_z_b[b], tables + (size_t)b * M * D_HID, M, 3.4028234664e38f);
+        jobs.W[b] = w->lin_z_w[b]; jobs.bias[b] = w->lin_z_b[b];
     }
+    hipLaunchKernelGGL(fold_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, jobs, tables, M, 3.4028234664e38f);
     return pnr_check_launch("pnr_fold_latent_f32");
 }
 

@@ -125,6 +125,12 @@ class NeRFRenderer(torch.nn.Module):
             for pnts in split_points:
                 val_all.append(model(pnts.contiguous(), coarse=coarse))
         out = torch.cat(val_all, dim=dim).reshape(B, K, -1)
+        if torch.is_grad_enabled() and out.requires_grad:
+            # the HIP compositing kernel below is not an autograd node: silently returning gradient-free outputs would
+            # "train" nothing.  The differentiable path is the fused one (pixelnerf_amd.PixelNeRFNet through forward()).
+            raise NotImplementedError(
+                "NeRFRenderer with a generic model callable is inference-only (no gradient flows through the HIP compositing "
+                "kernel): wrap the call in torch.no_grad(), or train a pixelnerf_amd PixelNeRFNet, whose renders are differentiable")
         if self.training and self.noise_std > 0.0:
             out = torch.cat([out[..., :3], out[..., 3:4] + torch.randn_like(out[..., 3:4]) * self.noise_std], -1)
         return ops.composite(rays, z_samp, out[..., :4].contiguous(), self.white_bkgd, want_weights=True)
