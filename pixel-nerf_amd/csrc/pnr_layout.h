@@ -134,7 +134,11 @@ template <int MT_> struct Tile {
     static constexpr int LDS_IN = LDS_A + MT_ * ROW_ACT;       // positional code + viewdir
     static constexpr int LDS_META = LDS_IN + MT_ * ROW_IN;     // per point: 4 corner offsets + 4 weights
     static constexpr int LDS_OUT = LDS_META + MT_ * 32;        // lin_out partials [NW][MT][4] floats
-    static constexpr int LDS_TOTAL = LDS_OUT + NW * MT_ * 16;  // 152,576 B (64) / 129,024 B (96)
+    // the 96-point tile has room for the network's bias table (11 slots x 512 fp32, accumulator order): the 20 accumulator
+    // initialisations of a tile then read LDS instead of waiting for an L2 round trip in front of every GEMM
+    static constexpr bool BIAS_IN_LDS = SINGLE_IMAGE;
+    static constexpr int LDS_BIAS = LDS_OUT + NW * MT_ * 16;
+    static constexpr int LDS_TOTAL = LDS_BIAS + (BIAS_IN_LDS ? 11 * NW * IT * 32 * 4 : 0);  // 152,576 B (64) / 151,552 B (96)
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 };
 // the 64-point map under its historical names (backward chain, training instantiation)

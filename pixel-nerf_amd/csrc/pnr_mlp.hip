@@ -284,6 +284,13 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
     const uint32_t in_rd0 = LDS_IN + pl * ROW_IN + h * 16, in_rd1 = in_rd0 + 32 * ROW_IN;
     const uint32_t a_wr = LDS_A + pl * ROW_ACT + (wv * IT) * 64 + h * 32;
     const float *bias_lane = q.bias + wv * BIAS_FLOATS_PER_WAVE + h * 16;
+    if constexpr (TL::BIAS_IN_LDS) {
+        static_assert(NBIAS == 11, "LDS_BIAS size");
+        for (int i = tid; i < NBIAS * NW * BIAS_FLOATS_PER_WAVE / 4; i += NTHREADS)
+            reinterpret_cast<f32x4 *>(smem + TL::LDS_BIAS)[i] = reinterpret_cast<const f32x4 *>(q.bias)[i];
+        bias_lane = reinterpret_cast<const float *>(smem + TL::LDS_BIAS) + wv * BIAS_FLOATS_PER_WAVE + h * 16;
+        // (published by the first tile's top-of-tile barrier)
+    }
 
     f16_ovfl_mode<P>();
     Ring<P> R;
