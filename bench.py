@@ -177,6 +177,15 @@ def extra_render_config(dev, prec, scene_name, n_img, n_oracle=128, n_f32=8192, 
         fast = renderer(net, rs.to(dev)[None], _noise=nz)
         net.precision = "f32"
         exact = renderer(net, rs.to(dev)[None], _noise=nz)
+        # the fp32-class fast path (split f16 operands, 32-point tiles for multi-view scenes) on the same rays
+        net.precision = "f16x3"
+        split = renderer(net, rs.to(dev)[None], _noise=nz)
+        render_par(rays[None])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        render_par(rays[None])
+        torch.cuda.synchronize()
+        dt_split = time.perf_counter() - t0
         net.precision = prec
         no = min(n_oracle, rs.shape[0])
         ref = O.render(scene, mlps[0], mlps[1], rs[None, :no], {k: v[:no] for k, v in noise.items()}, 64, 128, 16,
@@ -188,7 +197,9 @@ def extra_render_config(dev, prec, scene_name, n_img, n_oracle=128, n_f32=8192, 
            "algorithmic_tflops": R / dt * 256 * (FLOP_PER_POINT_VIEW * NS + FLOP_PER_POINT_POOLED) / 1e12,
            "psnr_db_vs_cpu_oracle": O.psnr(fast.fine.rgb[0, :no].cpu(), ref["fine"]["rgb"][0]), "oracle_rays": no,
            "psnr_db_vs_f32_hip": O.psnr(fast.fine.rgb.cpu(), exact.fine.rgb.cpu()), "f32_rays": int(rs.shape[0]),
-           "depth_abs_err_p99_over_span_vs_f32_hip": float(torch.quantile((fast.fine.depth - exact.fine.depth).abs().flatten(), 0.99)) / span}
+           "depth_abs_err_p99_over_span_vs_f32_hip": float(torch.quantile((fast.fine.depth - exact.fine.depth).abs().flatten(), 0.99)) / span,
+           "f16x3": {"rays_per_s": R / dt_split, "psnr_db_vs_f32_hip": O.psnr(split.fine.rgb.cpu(), exact.fine.rgb.cpu()),
+                     "rgb_max_abs_err_vs_f32_hip": float((split.coarse.rgb - exact.coarse.rgb).abs().max())}}
     del net, renderer
     torch.cuda.empty_cache()
     return out

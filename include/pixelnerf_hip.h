@@ -109,7 +109,7 @@ int pnr_render_forward_folded(const PnrScene *scene /*host*/, const void *packed
                               void *stream);
 
 /* ---- fp32-class accuracy on the f16 matrix cores (PNR_PREC_F16X3): same spans as the folded entries above
- * (src/model/models.py:146-266, src/model/resnetfc.py:132-184), single source view, inference.
+ * (src/model/models.py:146-266, src/model/resnetfc.py:132-184), any number of source views, inference.
  * w = wh + wl and x = xh + xl with f16 heads/tails, w x ~= wh xh + wh xl + wl xh accumulated in fp32 (error
  * 2^-22 per product instead of 2^-11); lin_z folded into fp32 per-texel tables.  Agrees with the reference's fp32
  * arithmetic to the bars of the exact-fp32 path (per-point |rgb| <= 2e-5) at several times the fp32-MFMA ceiling.

@@ -12,8 +12,8 @@
 // 3 MFMAs per (weight fragment, activation fragment) instead of 1, 2x the operand bytes: ~1/3 of the f16 kernel's
 // rate, several times the fp32-MFMA ceiling, at the accuracy class of the reference's own fp32 arithmetic
 // (tests/test_hip_split.py holds it to the bars of tests/test_hip_f32.py: per-point |rgb| <= 2e-5).
-// Single source view, folded form, inference.  The unfused fp32-MFMA path (pnr_f32.hip) remains the
-// implementation-independent yardstick and serves multi-view scenes.
+// Folded form, inference; 64-point tiles for one source view, 32-point tiles with the view sum in registers for
+// several.  The unfused fp32-MFMA path (pnr_f32.hip) remains the implementation-independent yardstick.
 #include <hip/hip_runtime.h>
 
 #include "pnr_common.h"
@@ -29,40 +29,42 @@ typedef PH::T8 h8;
 // LDS map: two activation images (head / tail), two lin_in operand images, corner metadata, lin_out partials.
 // The fp32 table rows (2 KiB + 16 B pad per point) are looked up into the space of the two activation images
 // while those are free (tile start, and after fc_1 of blocks 0-1 has finished reading).
-struct SplitTile {
-    static constexpr int MT = 64, JT = 2;
+template <int MT_> struct SplitTileT {
+    static_assert(MT_ == 64 || MT_ == 32, "64 points (single view) or 32 points (multi-view: the view sum needs the registers)");
+    static constexpr int MT = MT_, JT = MT_ / 32;
     static constexpr int A_HI = 0;
-    static constexpr int A_LO = MT * ROW_ACT;             // 66,560
+    static constexpr int A_LO = MT * ROW_ACT;             // 66,560 (64)
     static constexpr int LDS_IN = 2 * MT * ROW_ACT;        // 133,120 (head image of the lin_in operand)
     static constexpr int IN_LO_DELTA = MT * ROW_IN;        // tail image right behind it
     static constexpr int LDS_META = LDS_IN + 2 * MT * ROW_IN;
     static constexpr int LDS_OUT = LDS_META + MT * 32;
-    static constexpr int LDS_TOTAL = LDS_OUT + NW * MT * 16;  // 161,792 B
+    static constexpr int LDS_TOTAL = LDS_OUT + NW * MT * 16;  // 161,792 B (64) / 80,896 B (32)
     static constexpr int ROW_TAB = D_HID * 4 + 16;          // fp32 table row: 2064 B (129 16-B slots: conflict-free)
     static constexpr int LDS_Z = 0;                         // (geometry_item only needs LDS_IN / LDS_META)
     static_assert(MT * ROW_TAB <= LDS_IN, "table image must fit in the space of the two activation images");
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 };
-typedef SplitTile ST;
 
 struct SplitRing {
     h8 h[4][IT], l[4][IT];
     const char *base_h, *base_l;  // this wave's head / tail stream + lane*16
-    int pf_rs;
+    int pf_rs, pf_view;
 };
 
-__device__ __forceinline__ void ring_advance(SplitRing &R) {
-    int rs = R.pf_rs + 4;
-    if (rs == RS_TOTAL_F) rs = 0;
-    R.pf_rs = rs;
+// prefetch cursor: the per-view segment [0, RS_VIEW_END_F) is consumed NS times, then the pooled tail, then wrap
+__device__ __forceinline__ void ring_advance(SplitRing &R, int NS) {
+    int rs = R.pf_rs + 4, v = R.pf_view;
+    if (rs == RS_VIEW_END_F && v + 1 < NS) { v += 1; rs = 0; }
+    else if (rs == RS_TOTAL_F) { rs = 0; v = 0; }
+    R.pf_rs = rs; R.pf_view = v;
 }
 
 __device__ __forceinline__ f32x16 mf(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // acc[it][jt] += (Wh + Wl)(Xh + Xl) without the tail-tail term; B rows at bhi0 + jt*jstride (+ lo_delta for the tails)
-__device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][ST::JT], const char *smem, uint32_t bhi0, uint32_t jstride,
-                                           uint32_t lo_delta, int nbody, SplitRing &R) {
-    constexpr int JT = ST::JT;
+template <int JT>
+__device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *smem, uint32_t bhi0, uint32_t jstride,
+                                           uint32_t lo_delta, int nbody, SplitRing &R, int NS) {
     h8 bh[2][JT], bl[2][JT];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
@@ -103,7 +105,7 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][ST::JT], const char
             }
         }
         bhi0 += 128;
-        ring_advance(R);
+        ring_advance(R, NS);
     }
 }
 
@@ -126,11 +128,12 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo) {
 }
 
 // relu(acc) -> head / tail images (storage order, like write_act)
-__device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][ST::JT], char *smem, uint32_t waddr) {
+template <typename ST, int JT>
+__device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][JT], char *smem, uint32_t waddr) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
 #pragma unroll
-        for (int jt = 0; jt < ST::JT; ++jt) {
+        for (int jt = 0; jt < JT; ++jt) {
             const f32x16 &a = acc[it][jt];
             const uint32_t ad = waddr + jt * 32 * ROW_ACT + it * 64;
 #pragma unroll
@@ -148,7 +151,7 @@ __device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][ST::JT], cha
 
 // fp32 bilinear lookup of table b: wave handles points wave*8..+7, lane handles storage slots 8*lane..+7
 // (two 16-byte loads per corner); rows land in the table image (ROW_TAB stride) at offset 0
-template <int GB>
+template <int GB, typename ST>
 __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem, int wv, int lane, int b) {
     const float *tab = reinterpret_cast<const float *>(q.tables) + (size_t)b * q.table_stride + lane * 8;
     static_assert((ST::MT / NW) % GB == 0, "gather batch");
@@ -183,11 +186,12 @@ __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem
 }
 
 // x += this lane's slots of the fp32 table rows
-__device__ __forceinline__ void add_from_table(f32x16 (&x)[IT][ST::JT], const char *smem, int pl, int h, int wv) {
+template <typename ST, int JT>
+__device__ __forceinline__ void add_from_table(f32x16 (&x)[IT][JT], const char *smem, int pl, int h, int wv) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
 #pragma unroll
-        for (int jt = 0; jt < ST::JT; ++jt) {
+        for (int jt = 0; jt < JT; ++jt) {
             const char *row = smem + (jt * 32 + pl) * ST::ROW_TAB + ((wv * IT + it) * 32 + h * 16) * 4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -198,14 +202,19 @@ __device__ __forceinline__ void add_from_table(f32x16 (&x)[IT][ST::JT], const ch
         }
 }
 
-template <bool RAYS>
+// MV: multi-view scenes run 32-point tiles (JT = 1): x + net + the running view sum are 3 x 32 accumulator registers next to
+// the 64-register head/tail ring, like the 64-point single-view form (x + net = 128).  Views go through blocks 0-2 one after
+// the other, the mean is formed in registers before block 3 (util.combine_interleaved, util.py:461-466).
+template <bool RAYS, bool MV>
 __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const EvalParams q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef SplitTileT<MV ? 32 : 64> ST;
     constexpr int JT = ST::JT, MT = ST::MT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 31, h = lane >> 5;
+    const int NS = MV ? q.NS : 1;
 
     const uint32_t a_rd0 = ST::A_HI + pl * ROW_ACT + h * 16;
     const uint32_t in_rd0 = ST::LDS_IN + pl * ROW_IN + h * 16;
@@ -224,39 +233,60 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             R.l[j][it] = gload8<PH>(R.base_l + j * (IT * 1024) + it * 1024);
         }
     R.pf_rs = 4;
+    R.pf_view = 0;
+
+    // one residual block on x (resnetfc.py:66-88); lookup: lin_z[b+1] via table b+1 behind it
+    auto block = [&](f32x16 (&x)[IT][JT], int b, bool lookup) {
+        __syncthreads();  // table rows / previous operand images are no longer read
+        write_split<ST>(x, smem, a_wr);
+        __syncthreads();
+        {
+            f32x16 net[IT][JT];
+            add_bias<true>(net, bias_lane, 1 + 2 * b);
+            gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);  // fc_0
+            __syncthreads();
+            write_split<ST>(net, smem, a_wr);
+        }
+        __syncthreads();
+        add_bias<false>(x, bias_lane, 2 + 2 * b);
+        gemm_split(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);        // fc_1
+        if (lookup) {
+            __syncthreads();
+            gather_table_f32<2, ST>(q, smem, wv, lane, b + 1);
+            __syncthreads();
+            add_from_table<ST>(x, smem, pl, h, wv);
+        }
+    };
 
     for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
         f32x16 x[IT][JT];
-        __syncthreads();  // previous tile: every reader of the images / IN / META is done
-        geometry_item<PH, RAYS, ST>(q, smem, tile, 0, tid & 63, tid >> 6);
-        __syncthreads();
-        gather_table_f32<2>(q, smem, wv, lane, 0);
-        add_bias<true>(x, bias_lane, B_IN_Z0);
-        gemm_split(x, smem, in_rd0, 32 * ROW_IN, ST::IN_LO_DELTA, KS_IN / 4, R);  // lin_in   resnetfc.py:147
-        __syncthreads();  // table rows of every wave are in place
-        add_from_table(x, smem, pl, h, wv);                                       // lin_z[0] via table 0
+        f32x16 xsum[MV ? IT : 1][MV ? JT : 1];
 #pragma unroll 1
-        for (int b = 0; b < N_BLOCKS; ++b) {
-            __syncthreads();  // table rows / previous operand images are no longer read
-            write_split(x, smem, a_wr);
+        for (int view = 0; view < NS; ++view) {
+            __syncthreads();  // previous tile / view: every reader of the images / IN / META is done
+            if (MT == 64 || tid < MT * 8) geometry_item<PH, RAYS, ST>(q, smem, tile, view, tid % MT, tid / MT);
             __syncthreads();
-            {
-                f32x16 net[IT][JT];
-                add_bias<true>(net, bias_lane, 1 + 2 * b);
-                gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R);  // fc_0
-                __syncthreads();
-                write_split(net, smem, a_wr);
-            }
-            __syncthreads();
-            add_bias<false>(x, bias_lane, 2 + 2 * b);
-            gemm_split(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R);        // fc_1
-            if (b + 1 < COMBINE_LAYER) {  // lin_z[b+1] via table b+1
-                __syncthreads();
-                gather_table_f32<2>(q, smem, wv, lane, b + 1);
-                __syncthreads();
-                add_from_table(x, smem, pl, h, wv);
+            gather_table_f32<2, ST>(q, smem, wv, lane, 0);
+            add_bias<true>(x, bias_lane, B_IN_Z0);
+            gemm_split(x, smem, in_rd0, 32 * ROW_IN, ST::IN_LO_DELTA, KS_IN / 4, R, NS);  // lin_in   resnetfc.py:147
+            __syncthreads();  // table rows of every wave are in place
+            add_from_table<ST>(x, smem, pl, h, wv);                                           // lin_z[0] via table 0
+#pragma unroll 1
+            for (int b = 0; b < COMBINE_LAYER; ++b) block(x, b, b + 1 < COMBINE_LAYER);
+            if constexpr (MV) {  // fixed summation order view 0 + view 1 + ...: deterministic
+                const float inv = 1.f / (float)NS;
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        if (view == 0) xsum[it][jt] = x[it][jt];
+                        else xsum[it][jt] += x[it][jt];
+                        if (view + 1 == NS) x[it][jt] = xsum[it][jt] * inv;
+                    }
             }
         }
+#pragma unroll 1
+        for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b) block(x, b, false);
 
         // lin_out(relu(x)): each wave contracts its own 64 features (the wave's accumulators are the B operand)
         {
@@ -289,7 +319,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
                     R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
                     R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
                 }
-            ring_advance(R);
+            ring_advance(R, NS);
             if (h == 0) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
@@ -314,33 +344,36 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
 static int split_launch(const PnrScene *s, const void *packed, const void *tables, EvalParams &q, bool rays, hipStream_t st) {
     if (!s || !packed || !tables || !q.out) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: null argument");
     if (s->SB <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: bad scene shape");
-    if (s->NS != 1)
-        return pnr_fail(PNR_E_INVALID, "pnr_eval_split: the split-operand kernel is single-view (use precision f32 for NS > 1)");
+    if (s->NS <= 0) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: NS must be positive");
     if (!(s->n_focal == 1 || s->n_focal == s->SB) || !(s->n_c == 1 || s->n_c == s->SB))
         return pnr_fail(PNR_E_INVALID, "pnr_eval_split: focal / c must have 1 or SB rows");
     if (q.P == 0) return PNR_OK;
     if (q.P > 0x7fffff80LL) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: too many points (P must stay below 2^31)");
-    if ((long long)s->SB * s->Hl * s->Wl * C_LAT > 0xffffffffLL)
-        return pnr_fail(PNR_E_INVALID, "pnr_eval_split: feature grid too large (SB*Hl*Wl*512 must stay below 2^32 elements)");
+    if ((long long)s->SB * s->NS * s->Hl * s->Wl * C_LAT > 0xffffffffLL)
+        return pnr_fail(PNR_E_INVALID, "pnr_eval_split: feature grid too large (SB*NS*Hl*Wl*512 must stay below 2^32 elements)");
     q.latent = s->latent_nhwc; q.poses = s->poses; q.focal = s->focal; q.c = s->c;
-    q.SB = s->SB; q.NS = 1; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
+    q.SB = s->SB; q.NS = s->NS; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
     q.img_w = s->img_w; q.img_h = s->img_h;
     q.wstream = (const char *)packed;
     q.bias = (const float *)((const char *)packed + BIAS_OFFSET_BYTES);
     q.bout = (const float *)((const char *)packed + BOUT_OFFSET_BYTES);
     q.tables = (const char *)tables;
-    q.table_stride = (long long)s->SB * s->Hl * s->Wl * C_LAT;
-    const long long nt = (q.P + ST::MT - 1) / ST::MT;
+    q.table_stride = (long long)s->SB * s->NS * s->Hl * s->Wl * C_LAT;
+    const bool mv = s->NS > 1;
+    const int MT = mv ? SplitTileT<32>::MT : SplitTileT<64>::MT;
+    const int lds = mv ? SplitTileT<32>::LDS_TOTAL : SplitTileT<64>::LDS_TOTAL;
+    const long long nt = (q.P + MT - 1) / MT;
     q.ntiles = (int)nt;
     int dev = 0, ncu = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         ncu = prop.multiProcessorCount;
     const int grid = (int)(nt < ncu ? nt : ncu);
-    auto k = rays ? eval_split_kernel<true> : eval_split_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ST::LDS_TOTAL);
+    auto k = mv ? (rays ? eval_split_kernel<true, true> : eval_split_kernel<false, true>)
+                : (rays ? eval_split_kernel<true, false> : eval_split_kernel<false, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_split_kernel)");
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), ST::LDS_TOTAL, st, q);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, q);
     return pnr_check_launch("eval_split_kernel");
 }
 

@@ -29,8 +29,8 @@ class PixelNeRFNet(torch.nn.Module):
         :param precision operand type of the 512-wide linears on the matrix cores: 'f16'
         (default; PSNR >= 52 dB vs the fp32 reference), 'bf16' (>= 36 dB), 'f16x3' -- fp32-class accuracy on the
         f16 matrix cores (head/tail operand pairs, 3 MFMAs per product, ~1/3 of the f16 rate, per-point |rgb| <= 2e-5;
-        single source view, inference) -- or 'f32': the exact, unfused validation path (inference only, ~1/25 of the
-        f16 rate, agrees to ~1e-5; also what 'f16x3' falls back to for multi-view scenes).
+        inference) -- or 'f32': the exact, unfused validation path (inference only, ~1/25 of the f16 rate, agrees
+        to ~1e-5).
         :param fold inference applies lin_z[b] to the encoded grid once per scene (per-texel tables) instead of
         once per sample -- the same function by linearity, 22-28 % fewer FLOPs per sample (ops.fold_latent)."""
         super().__init__()
@@ -142,9 +142,6 @@ class PixelNeRFNet(torch.nn.Module):
         return self._scene[1]
 
     def _effective_precision(self):
-        """'f16x3' is a single-view kernel: multi-view scenes run the unfused fp32 path instead (same accuracy class)."""
-        if self.precision == "f16x3" and int(self.num_views_per_obj) > 1:
-            return "f32"
         return self.precision
 
     def _folding(self):

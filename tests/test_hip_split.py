@@ -6,7 +6,7 @@ against the reference's own fp32 outputs (tests/golden, identical rays, weights,
   * per point : |rgb| err <= 2e-5, sigma err <= 1e-4 * max(1, sigma)
   * renders   : coarse rgb <= 2e-5, depth <= 1e-4 (far-near), weights <= 2e-5; the fine pass within the same bounds except
                 for a <= 2 % allowance of rays whose importance samples flipped a cdf bin at rounding level; PSNR >= 85 dB.
-Single-view scenes (the kernel's scope); multi-view scenes fall back to the unfused fp32 path at the API level.
+Single-view scenes run 64-point tiles, multi-view scenes 32-point tiles with the view sum in registers.
 """
 import numpy as np
 import pytest
@@ -17,7 +17,7 @@ from oracle import pnr_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-SINGLE_VIEW = [n for n in RENDER_SCENARIOS if n.startswith(("sn64", "train"))]
+SCENARIOS = list(RENDER_SCENARIOS)
 
 
 @pytest.fixture(scope="module")
@@ -57,7 +57,7 @@ def test_split_tables_are_lin_z_of_the_grid_in_fp32(ops, dev):
         assert (got - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("scene_name", ["sn64"])
+@pytest.mark.parametrize("scene_name", ["sn64", "dtu_mini", "mv_mini"])
 def test_split_eval_points_matches_reference(ops, dev, scene_name):
     g = load_golden("stages")
     sc = dscene(ops, dev, scene_name)
@@ -75,7 +75,7 @@ def test_split_eval_points_matches_reference(ops, dev, scene_name):
         assert e_s <= 1e-4, f"sigma rel err {e_s:.3e}"
 
 
-@pytest.mark.parametrize("name", SINGLE_VIEW)
+@pytest.mark.parametrize("name", SCENARIOS)
 def test_split_render_matches_reference(ops, dev, name):
     g, scene, meta, mc, mf, rays, noise = golden_setup(name)
     Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])
@@ -125,8 +125,7 @@ def test_split_variants_agree_and_match_the_exact_fp32_path_at_full_size(ops, de
 
 
 def test_split_api_scope(ops, dev):
-    """PixelNeRFNet(precision='f16x3'): single-view scenes run the split kernel, multi-view scenes the unfused fp32 path;
-    a 16-bit table set is refused."""
+    """PixelNeRFNet(precision='f16x3'): single- and multi-view scenes run the split kernel; a 16-bit table set is refused."""
     from pixelnerf_amd import _lib
     from test_api_gpu import build_net
     from pixelnerf_amd.render import NeRFRenderer
@@ -137,9 +136,12 @@ def test_split_api_scope(ops, dev):
     with torch.no_grad():
         out = rend(net, rays.to(dev), _noise={k: v.to(dev) for k, v in noise.items()})
     assert O.psnr(out.fine.rgb.cpu(), torch.from_numpy(g["fine_rgb"])) >= 85.0
-    g2, scene2, *_ = golden_setup("srn_mini_64_128")
+    g2, scene2, _, _, _, rays2, noise2 = golden_setup("srn_mini_64_128")
     net2 = build_net(dev, scene2, precision="f16x3")
-    assert net2.packed(True).precision == _lib.PREC_F32 and net2.tables(True) is None
+    assert net2.packed(True).precision == _lib.PREC_F16X3 and net2.tables(True).dtype == torch.float32
+    with torch.no_grad():
+        out2 = rend(net2, rays2.to(dev), _noise={k: v.to(dev) for k, v in noise2.items()})
+    assert O.psnr(out2.fine.rgb.cpu(), torch.from_numpy(g2["fine_rgb"])) >= 85.0
     sc = dscene(ops, dev, "sn64")
     state = {k: v.to(dev) for k, v in mlp_params(11).items()}
     with pytest.raises(_lib.PixelNerfHipError):

@@ -19,7 +19,7 @@ FLOP_V, FLOP_P = 4.7616e6, 2.1012e6
 def main():
     dev = torch.device("cuda:0")
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
-    precs = ("f16",) if "--f16" in sys.argv else ("f16", "bf16")
+    precs = ("f16",) if "--f16" in sys.argv else ("f16x3",) if "--f16x3" in sys.argv else ("f16", "bf16")
     for scene_name, n_img in (("sn64", 16), ("srn_car", 4), ("dtu", 1)):
         if only and scene_name not in only:
             continue

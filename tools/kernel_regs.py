@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Print per-kernel register / scratch / LDS usage of a gfx950 code object or a built library.
 
-    python tools/kernel_regs.py [path/to/lib.so | file.s] [--filter eval_kernel]
+    python tools/kernel_regs.py [path/to/lib.so | file.s | file.hip] [--filter eval_kernel] [-DMACRO ...]
+
+A .hip source is compiled to gfx950 assembly first (device side only, the library's flags plus any -D given); a library built
+from several translation units carries one code object per unit and only the first is read -- pass the .hip file instead.
 
 For a .so the embedded gfx950 code object is extracted with clang-offload-bundler; metadata is read
 with llvm-readelf --notes (the .amdgpu_metadata YAML).  Used to check that a kernel instantiation has
@@ -41,9 +44,15 @@ def kernels_from_text(txt):
     return res
 
 
-def read_metadata(path):
+def read_metadata(path, defines=()):
     if path.endswith(".s"):
         return open(path).read()
+    if path.endswith(".hip"):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                            "-Wno-unused-value", *defines, path, "-o", out], check=True)
+            return open(out).read()
     data = open(path, "rb").read()
     with tempfile.TemporaryDirectory() as td:
         co = path
@@ -61,14 +70,15 @@ def read_metadata(path):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    defines = [a for a in sys.argv[1:] if a.startswith("-D")]
+    args = [a for a in sys.argv[1:] if not a.startswith("-")]
     flt = None
     if "--filter" in sys.argv:
         flt = sys.argv[sys.argv.index("--filter") + 1]
         args = [a for a in args if a != flt]
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = args[0] if args else os.path.join(here, "pixel-nerf_amd", "csrc", "libpixelnerf_hip.so")
-    ks = kernels_from_text(read_metadata(path))
+    ks = kernels_from_text(read_metadata(path, defines))
     names = demangle([k[".name"] for k in ks])
     print("%5s %5s %5s %6s %8s %8s  kernel" % ("vgpr", "agpr", "sgpr", "spill", "scratch", "lds"))
     for k, n in zip(ks, names):
