@@ -81,49 +81,57 @@ struct BwdParams {
     float *d_in;    // (NS*P, 42)  fp32: d(positional code | view direction)             (nullable: skip)
 };
 
-// acc = (dump row element != 0) ? acc : 0 ; dump holds relu(.) as 16-bit in storage order
-template <typename P>
-__device__ __forceinline__ void apply_mask(f32x16 (&acc)[IT][JT], const char *dump_lane, const bool *valid) {
+// relu masks: the forward dump holds relu(.) as 16-bit values in storage order; this lane's 16 values per MFMA tile are
+// fetched BEFORE the GEMM whose result they gate (32 registers in flight under it) so that the HBM round trip of the
+// dump -- written a whole forward + compositing pass earlier -- is not exposed behind every GEMM of the chain
+struct MaskRegs {
+    u32x4 m[IT][JT][2];
+};
+__device__ __forceinline__ void load_mask(MaskRegs &mk, const char *dump_lane, const bool *valid) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            u32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
-            if (valid[jt]) {
+            mk.m[it][jt][0] = mk.m[it][jt][1] = u32x4{0, 0, 0, 0};
+#ifndef PNR_BWD_NOMASK
+            if (valid[jt])
+#else
+            if (valid[jt] && dump_lane == nullptr)
+#endif
+            {
                 const char *d = dump_lane + (size_t)jt * 32 * (D_HID * 2) + it * 64;
-                lo = *reinterpret_cast<const u32x4 *>(d);
-                hi = *reinterpret_cast<const u32x4 *>(d + 16);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t word = r < 8 ? lo[r >> 1] : hi[(r - 8) >> 1];
-                const uint32_t bits = (r & 1) ? (word >> 16) : (word & 0xffffu);
-                acc[it][jt][r] = bits ? acc[it][jt][r] : 0.f;
+                mk.m[it][jt][0] = *reinterpret_cast<const u32x4 *>(d);
+                mk.m[it][jt][1] = *reinterpret_cast<const u32x4 *>(d + 16);
             }
         }
 }
 
-// G += (dump != 0) ? t : 0
-template <typename P>
-__device__ __forceinline__ void masked_add(f32x16 (&G)[IT][JT], const f32x16 (&t)[IT][JT], const char *dump_lane,
-                                           const bool *valid) {
+// acc = (dump element != 0) ? acc : 0
+__device__ __forceinline__ void apply_mask(f32x16 (&acc)[IT][JT], const MaskRegs &mk) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            u32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
-            if (valid[jt]) {
-                const char *d = dump_lane + (size_t)jt * 32 * (D_HID * 2) + it * 64;
-                lo = *reinterpret_cast<const u32x4 *>(d);
-                hi = *reinterpret_cast<const u32x4 *>(d + 16);
-            }
+        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t word = r < 8 ? lo[r >> 1] : hi[(r - 8) >> 1];
+                const uint32_t word = mk.m[it][jt][r >> 3][(r & 7) >> 1];
+                const uint32_t bits = (r & 1) ? (word >> 16) : (word & 0xffffu);
+                acc[it][jt][r] = bits ? acc[it][jt][r] : 0.f;
+            }
+}
+
+// G += (dump element != 0) ? t : 0
+__device__ __forceinline__ void masked_add(f32x16 (&G)[IT][JT], const f32x16 (&t)[IT][JT], const MaskRegs &mk) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t word = mk.m[it][jt][r >> 3][(r & 7) >> 1];
                 const uint32_t bits = (r & 1) ? (word >> 16) : (word & 0xffffu);
                 G[it][jt][r] += bits ? t[it][jt][r] : 0.f;
             }
-        }
 }
 
 template <typename P>
@@ -159,15 +167,18 @@ __device__ __forceinline__ void bwd_block(f32x16 (&G)[IT][JT], char *smem, int b
     write_act<P, false, true>(G, smem, a_wr, q.g_fc1[b] + off, valid);
     __syncthreads();
     f32x16 t[IT][JT];
+    MaskRegs mk;
+    load_mask(mk, q.d_n[b] + off, valid);
     zero_acc(t);
     gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
-    apply_mask<P>(t, q.d_n[b] + off, valid);
+    apply_mask(t, mk);
     __syncthreads();
     write_act<P, false, true>(t, smem, a_wr, q.g_fc0[b] + off, valid);
     __syncthreads();
+    load_mask(mk, q.d_a[b] + off, valid);
     zero_acc(t);
     gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
-    masked_add<P>(G, t, q.d_a[b] + off, valid);
+    masked_add(G, t, mk);
 }
 
 template <int PREC, bool MV>
@@ -211,9 +222,13 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
         }
         __syncthreads();
         f32x16 G[IT][JT];
-        zero_acc(G);
-        gemm<P, AdvanceBwd>(G, smem, in_rd0, in_rd1, KS_IN / 4, R, NS);  // lin_out^T g_out
-        apply_mask<P>(G, q.d_x5 + off_pooled, valid);                     // . [x5 > 0]
+        {
+            MaskRegs mk;
+            load_mask(mk, q.d_x5 + off_pooled, valid);
+            zero_acc(G);
+            gemm<P, AdvanceBwd>(G, smem, in_rd0, in_rd1, KS_IN / 4, R, NS);  // lin_out^T g_out
+            apply_mask(G, mk);                                                // . [x5 > 0]
+        }
 #pragma unroll 1
         for (int b = N_BLOCKS - 1; b >= COMBINE_LAYER; --b)
             bwd_block<P>(G, smem, b, R, NS, q, off_pooled, valid, a_rd0, a_rd1, a_wr);
@@ -327,8 +342,8 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
 // per 16-lane group a [4 rows][16 columns] block, lane c receives column c.  Row stride 576 B puts the
 // 4 rows of a block and the two blocks of a 32-lane half on disjoint banks.
 // Block = 8 waves = one 256x256 tile of dW (wave = 64x128 = 2x4 MFMA tiles: every operand element is
-// fetched from L2 twice, not four times as with 128x128 tiles); blockIdx.y = slice of the
-// rows (split-K), blockIdx.z = job: all linears of a network go in ONE launch.  Every slice writes its own
+// fetched from L2 twice, not four times as with 128x128 tiles); the 1-D grid enumerates (tile, slice of the
+// rows = split-K, job): all linears of a network go in ONE launch.  Every slice writes its own
 // partial (part[job][z][512][512], bpart[job][z][512]) with plain stores and dw_reduce_kernel sums them in
 // a fixed order -> bit-reproducible, no atomics.  bpart = bias gradient sum_r dY[r][o].
 constexpr int DW_MAX_JOBS = 16;
@@ -360,19 +375,27 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
     typedef Prec<PREC> P;
     typedef typename P::T T;
     constexpr int SR = 32, LDB = 576;  // rows per slab, LDS row stride in bytes (256 columns + 64 B pad: 144 dwords = 16 mod 64)
-    __shared__ __attribute__((aligned(16))) char sY[SR * LDB];
-    __shared__ __attribute__((aligned(16))) char sX[SR * LDB];
+    __shared__ __attribute__((aligned(16))) char sYb[2][SR * LDB];  // double-buffered: slab s+1 is written while s is multiplied
+    __shared__ __attribute__((aligned(16))) char sXb[2][SR * LDB];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int job = blockIdx.z;
+    // XCD-aware placement.  The four 256x256 tiles of one (job, row slice) read the SAME dY / X rows; workgroups are dealt
+    // to the 8 XCDs round-robin by linear id, so a (tile, slice, job) grid puts the four on four different L2s and every
+    // operand byte crosses the fabric twice.  Here the linear id is re-read as (XCD, k): four consecutive k of one XCD
+    // are the four tiles of a group, so the group's operands are fetched into ONE L2 once.
+    const int lid = blockIdx.x, ngroups = gridDim.x >> 2, full = (ngroups >> 3) * 32;
+    int grp, tile4;
+    if (lid < full) { const int k = lid >> 3; grp = (k >> 2) * 8 + (lid & 7); tile4 = k & 3; }
+    else { const int rem = lid - full; grp = (full >> 2) + (rem >> 2); tile4 = rem & 3; }  // last partial row of groups
+    const int job = grp / jobs.nsplit, slice = grp - job * jobs.nsplit;
     const T *dY = reinterpret_cast<const T *>(jobs.dY[job]);
     const T *X = reinterpret_cast<const T *>(jobs.X[job]);
     const long long rows = jobs.rows[job];
     const int nx = jobs.nx[job];
     long long per = (rows + jobs.nsplit - 1) / jobs.nsplit;
     per = (per + SR - 1) / SR * SR;
-    const int o0 = (blockIdx.x >> 1) * 256, k0 = (blockIdx.x & 1) * 256;
+    const int o0 = (tile4 >> 1) * 256, k0 = (tile4 & 1) * 256;
     if (k0 >= nx) return;  // narrow X (lin_in): only the first column tile exists
-    const long long r_begin = (long long)blockIdx.y * per;
+    const long long r_begin = (long long)slice * per;
     const long long r_end = r_begin + per < rows ? r_begin + per : rows;
     const int wo = (w >> 1) * 64, wk = (w & 1) * 128;  // wave tile: 64 (o) x 128 (k) = 2 x 4 MFMA tiles
     const int i = lane & 31, kh = lane >> 5;
@@ -403,17 +426,27 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
     // this lane's corner of the [4][16] transpose blocks: row 8kh + (c16>>2), column 16*((lane>>4)&1) + 4*(c16&3)
     const int c16 = lane & 15;
     const int frag_off = (8 * kh + (c16 >> 2)) * LDB + (16 * ((lane >> 4) & 1) + 4 * (c16 & 3)) * 2;
-    if (r_begin < r_end) load_slab(r_begin);
-    for (long long r0 = r_begin; r0 < r_end; r0 += SR) {
+    auto store_slab = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int chunk = t + u * 512;
             const int srow = chunk >> 5, scol = (chunk & 31) * 8;
-            *reinterpret_cast<u32x4 *>(sY + srow * LDB + scol * 2) = vy[u];
-            *reinterpret_cast<u32x4 *>(sX + srow * LDB + scol * 2) = vx[u];
+            *reinterpret_cast<u32x4 *>(sYb[buf] + srow * LDB + scol * 2) = vy[u];
+            *reinterpret_cast<u32x4 *>(sXb[buf] + srow * LDB + scol * 2) = vx[u];
         }
-        __syncthreads();
-        if (r0 + SR < r_end) load_slab(r0 + SR);
+    };
+    if (r_begin < r_end) {
+        load_slab(r_begin);
+        store_slab(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (long long r0 = r_begin; r0 < r_end; r0 += SR, cur ^= 1) {
+        const bool more = r0 + SR < r_end;
+#ifndef PNR_DW_NOLOAD
+        if (more) load_slab(r0 + SR);  // in flight under this slab's MFMAs
+#endif
+        const char *sY = sYb[cur], *sX = sXb[cur];
 #pragma unroll
         for (int ks = 0; ks < SR / 16; ++ks) {
             typename P::T8 af[2], bf[4];
@@ -425,17 +458,20 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(af[a], bf[b], acc[a][b]);
-            if ((blockIdx.x & 1) == 0 && (w & 1) == 0) {
+            if ((tile4 & 1) == 0 && (w & 1) == 0) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bsum[a] += (float)af[a][e];
             }
         }
+#ifndef PNR_DW_NOSTORE
+        if (more) store_slab(cur ^ 1);  // the other buffer: its readers passed the barrier of the previous slab
+#endif
         __syncthreads();
     }
     // D layout: column j = lane&31 -> k, row (r&3)+8(r>>2)+4kh -> o
-    float *pz = part + ((size_t)job * jobs.nsplit + blockIdx.y) * (D_HID * D_HID);
+    float *pz = part + ((size_t)job * jobs.nsplit + slice) * (D_HID * D_HID);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -445,11 +481,11 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
                 const int orow = o0 + wo + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 pz[(size_t)orow * D_HID + k0 + wk + b * 32 + i] = acc[a][b][r];
             }
-    if ((blockIdx.x & 1) == 0 && (w & 1) == 0) {
+    if ((tile4 & 1) == 0 && (w & 1) == 0) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);  // both row halves of every k-step
-            if (kh == 0) bpart[((size_t)job * jobs.nsplit + blockIdx.y) * D_HID + o0 + wo + a * 32 + i] = v;
+            if (kh == 0) bpart[((size_t)job * jobs.nsplit + slice) * D_HID + o0 + wo + a * 32 + i] = v;
         }
     }
 }
@@ -656,89 +692,154 @@ latent_scatter_kernel(const EvalParams q, const float *__restrict__ d_zlat, floa
 
 // Small grids (Hl*Wl <= SLAB_MAX_TEXELS, e.g. the 32x32 / 64x64 grids of sn64 / SRN): dozens of samples hit
 // every texel, so global atomics serialise on a few thousand addresses.  Instead one workgroup owns an
-// (image, 8-channel slice) slab of the gradient grid in LDS: it walks all points of that image's object,
-// accumulates the four bilinear corners with LDS atomics, and adds the slab to HBM once (one global atomic
-// per non-zero slab element; up to 4 workgroups share an (image, slice) by splitting the points).  Points
-// are projected in batches of 256 (one per thread), corner texels / weights parked in LDS.
-constexpr int SLAB_CS = 8;                // channels per slab
-constexpr int SLAB_MAX_TEXELS = 4608;     // 4608 * 8 floats = 144 KiB of LDS
+// (image, CS-channel slice) slab of the gradient grid in LDS: it walks a slice of that image's object's points,
+// accumulates the four bilinear corners into the slab, and adds the slab to HBM once (one global atomic per
+// non-zero slab element; the workgroups that split an object's points share the (image, slice)).
+//
+// The slab is 64-bit FIXED POINT and accumulated with ds_add_u64: gfx950 executes LDS fp32 atomic adds one lane at a
+// time for the whole CU (192 clocks per wave instruction, 0.33 lanes/clk/CU, independent of the address pattern), 64-bit
+// integer adds at 35-39 clocks per instruction AND overlapped across waves (tools/ubench/lds_atomic.hip: 7 lanes/clk/CU
+// at 4 waves) -- the fp32-atomic form of this kernel spent 175 of its 210 us in them.  Scale: a power of two that puts
+// the workgroup's max |gradient| (found first, LDS max on the float bits) at 2^40: 2^23 contributions of headroom,
+// resolution 2^-40 of the max -- finer than the fp32 sum it replaces wherever that matters -- and the slab sum no
+// longer depends on the order of the adds.
+//
+// Thread = a run of 8 consecutive samples x ALL channels of the slice: it projects its own points (the texel /
+// weight bookkeeping is per point, not per channel), reads CS*4 contiguous bytes of each gradient row, and keeps an
+// fp32 register accumulator per corner that goes to the slab only when the corner's texel changes -- consecutive
+// samples of a ray mostly share their grid cell.  A workgroup covers 2048 samples per round; the host splits an
+// object's points so that one round is the normal case (the run's gradients are then loaded once, for max and sum).
+constexpr int SLAB_MAX_BYTES = 160 * 1024;  // whole LDS
+constexpr int SLAB_RUN = 8;                 // consecutive samples per thread
+constexpr int SLAB_PTS = 256 * SLAB_RUN;    // samples per workgroup round
+template <int CS>
 __global__ void __launch_bounds__(256)
-latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat, float *__restrict__ d_latent) {
-    extern __shared__ float slab[];  // [Hl*Wl][SLAB_CS] then 256 x (4 texels, 4 weights)
+latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat, float *__restrict__ d_latent, const int ysplit,
+                           const int row) {  // row: u64 slots per texel (CS + 1: bank-spreading pad, or CS when it must)
+    extern __shared__ unsigned long long slab[];  // [Hl*Wl][row]
+    __shared__ unsigned wg_max;
+    constexpr int NV = CS / 4;  // 16-byte loads per sample
     const int t = threadIdx.x;
     const int texels = q.Hl * q.Wl;
-    int *m_tex = reinterpret_cast<int *>(slab + (size_t)texels * SLAB_CS);
-    float *m_w = reinterpret_cast<float *>(m_tex + 256 * 4);
-    const int nslices = C_LAT / SLAB_CS;
-    const int img = blockIdx.x / nslices, cs = blockIdx.x % nslices;  // img = obj * NS + view
+    const int nslices = C_LAT / CS;
+    constexpr int GRP = 32 / CS;  // slices that share a 128-byte line of a d_zlat / d_latent row
+    // XCD-aware placement (as in dw_kernel): the slices that share 128-byte lines form a group that lands on ONE XCD
+    // (consecutive per-XCD slots), so a line is fetched into one L2 once
+    const int lid = blockIdx.x, ngroups = gridDim.x / GRP, full = (ngroups >> 3) * (8 * GRP);
+    int grp, sub;
+    if (lid < full) { const int k = lid >> 3; grp = (k / GRP) * 8 + (lid & 7); sub = k % GRP; }
+    else { const int rem = lid - full; grp = full / GRP + rem / GRP; sub = rem % GRP; }
+    const int cs = (grp % (nslices / GRP)) * GRP + sub;
+    const int yslice = (grp / (nslices / GRP)) % ysplit;
+    const int img = grp / ((nslices / GRP) * ysplit);     // img = obj * NS + view
     const int obj = img / q.NS, view = img % q.NS;
-    for (int i = t; i < texels * SLAB_CS; i += 256) slab[i] = 0.f;
+    for (int i = t; i < texels * row; i += 256) slab[i] = 0ull;
+    if (t == 0) wg_max = 0u;
     const long long pts = (long long)q.per_obj * q.K;  // points of this object
     const long long g_begin = (long long)obj * pts;
-    // blockIdx.y = slice of the object's points (multiples of 256): more workgroups per CU hide the load latency
-    long long per = (pts + gridDim.y - 1) / gridDim.y;
-    per = (per + 255) / 256 * 256;
-    const long long p_begin = (long long)blockIdx.y * per, p_end = p_begin + per < pts ? p_begin + per : pts;
+    long long per = (pts + ysplit - 1) / ysplit;
+    per = (per + SLAB_PTS - 1) / SLAB_PTS * SLAB_PTS;
+    const long long p_begin = (long long)yslice * per, p_end = p_begin + per < pts ? p_begin + per : pts;
     const uint32_t rowbase = (uint32_t)img * (uint32_t)texels;
     const float *pose = q.poses + (size_t)img * 12;
-    // thread = (channel, run of 8 consecutive points).  Consecutive samples of a ray mostly share their grid cell:
-    // each corner keeps a register accumulator that is flushed to the slab (one LDS atomic) only when its texel
-    // changes, and lanes with the same channel work on different runs -- same-address LDS atomics, which
-    // serialise badly, become rare.
-    constexpr int RUN = 256 / (256 / SLAB_CS);  // 8 points per thread and batch
-    const int ch = t & (SLAB_CS - 1), run = t / SLAB_CS;
-    __syncthreads();
-    for (long long b0 = p_begin; b0 < p_end; b0 += 256) {
-        // all 8 gradient loads of this thread for the batch go out first, the projection runs under them
-        float v[RUN];
+    const float *grad = d_zlat + ((size_t)view * q.P + (size_t)g_begin) * C_LAT + cs * CS;
+    f32x4 v[SLAB_RUN][NV];
+    auto load_run = [&](long long b0) {
 #pragma unroll
-        for (int j = 0; j < RUN; ++j) {
-            const long long pnt = b0 + run * RUN + j;
-            v[j] = pnt < p_end ? d_zlat[((size_t)view * q.P + (size_t)(g_begin + pnt)) * C_LAT + cs * SLAB_CS + ch] : 0.f;
-        }
-        if (b0 + t < p_end) {
-            const int g = (int)(g_begin + b0 + t);
-            const int r = g / q.K;
-            const float *ray = q.rays + (size_t)r * 8;
-            const float zz = q.z[g];
-            const float X = ray[0] + zz * ray[3], Y = ray[1] + zz * ray[4], Z = ray[2] + zz * ray[5];
-            const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
-            const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
-            const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
-            const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, true);
+        for (int j = 0; j < SLAB_RUN; ++j)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                m_tex[t * 4 + c] = (int)(pr.off[c] / C_LAT - rowbase);
-                m_w[t * 4 + c] = pr.w[c];
+            for (int u = 0; u < NV; ++u) {
+                v[j][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (b0 + j < p_end) v[j][u] = reinterpret_cast<const f32x4 *>(grad + (size_t)(b0 + j) * C_LAT)[u];
             }
-        }
-        __syncthreads();
-        int cur[4] = {-1, -1, -1, -1};
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    };
+    // ---- max |gradient| of this workgroup's samples (rounds beyond the first are read twice: rare, see the host side)
+    const long long b_first = p_begin + (long long)t * SLAB_RUN;
+    float m = 0.f;
+    for (long long b0 = b_first + SLAB_PTS; b0 < p_end; b0 += SLAB_PTS) {
+        load_run(b0);
 #pragma unroll
-        for (int j = 0; j < RUN; ++j) {
-            const int i = run * RUN + j;
-            if (b0 + i < p_end) {
+        for (int j = 0; j < SLAB_RUN; ++j)
+#pragma unroll
+            for (int u = 0; u < NV; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][u][e]));
+    }
+    load_run(b_first);
+#pragma unroll
+    for (int j = 0; j < SLAB_RUN; ++j)
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][u][e]));
+    __syncthreads();  // slab zeroed, wg_max initialised
+    if (m == m) atomicMax(&wg_max, __float_as_uint(fminf(m, 3.0e38f)));  // non-negative floats order like their bits; NaN: skipped
+    __syncthreads();
+    // scale 2^(40 - exponent(max)); the exponent is clamped so that scale and 1/scale stay normal numbers
+    int ex = (int)(wg_max >> 23) - 127;
+    ex = ex < -80 ? -80 : (ex > 80 ? 80 : ex);
+    const float scale = __uint_as_float((uint32_t)(127 + 40 - ex) << 23);
+    const float inv_scale = __uint_as_float((uint32_t)(127 - 40 + ex) << 23);
+    for (long long b0 = b_first; b0 < p_end; b0 += SLAB_PTS) {
+        if (b0 != b_first) load_run(b0);
+        int cur[4] = {-1, -1, -1, -1};
+        float acc[4][CS];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < CS; ++e) acc[c][e] = 0.f;
+        auto flush = [&](int c) {
+#pragma unroll
+            for (int e = 0; e < CS; ++e) {
+                const float f = acc[c][e] * scale;
+                // |f| <= 8 * 2^41 for finite inputs; Inf / NaN gradients (a diverged step) are dropped here, they still
+                // poison the weight gradients through the other kernels
+#ifdef PNR_SC_NOATOM
+                if (f == 123.f)
+#endif
+                if (fabsf(f) < 9.0e18f && f != 0.f) atomicAdd(&slab[cur[c] * row + e], (unsigned long long)(long long)f);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < SLAB_RUN; ++j) {
+            if (b0 + j < p_end) {
+                const int g = (int)(g_begin + b0 + j);
+                const int r = g / q.K;
+                const float *ray = q.rays + (size_t)r * 8;
+                const float zz = q.z[g];
+                const float X = ray[0] + zz * ray[3], Y = ray[1] + zz * ray[4], Z = ray[2] + zz * ray[5];
+                const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
+                const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
+                const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
+                const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, true);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int tex = m_tex[i * 4 + c];
+                    const int tex = (int)(pr.off[c] / C_LAT - rowbase);
                     if (tex != cur[c]) {
-                        if (acc[c] != 0.f) atomicAdd(&slab[cur[c] * SLAB_CS + ch], acc[c]);
+                        if (cur[c] >= 0) flush(c);
                         cur[c] = tex;
-                        acc[c] = 0.f;
+#pragma unroll
+                        for (int e = 0; e < CS; ++e) acc[c][e] = 0.f;
                     }
-                    acc[c] += m_w[i * 4 + c] * v[j];
+                    const float w = pr.w[c];
+#pragma unroll
+                    for (int u = 0; u < NV; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[c][4 * u + e] += w * v[j][u][e];
                 }
             }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (acc[c] != 0.f) atomicAdd(&slab[cur[c] * SLAB_CS + ch], acc[c]);
-        __syncthreads();
+            if (cur[c] >= 0) flush(c);
     }
-    for (int i = t; i < texels * SLAB_CS; i += 256) {
-        const float sv = slab[i];
-        if (sv != 0.f) atomicAdd(d_latent + ((size_t)rowbase + i / SLAB_CS) * C_LAT + cs * SLAB_CS + (i % SLAB_CS), sv);
+    __syncthreads();
+#ifdef PNR_SC_NOFLUSH
+    if (slab[t] == 123ull)
+#endif
+    for (int i = t; i < texels * CS; i += 256) {
+        const long long sv = (long long)slab[(i / CS) * row + (i % CS)];
+        if (sv != 0) atomicAdd(d_latent + ((size_t)rowbase + i / CS) * C_LAT + cs * CS + (i % CS), (float)sv * inv_scale);
     }
 }
 
@@ -784,12 +885,37 @@ position_bwd_kernel(const EvalParams q, const float *__restrict__ d_in42, const 
         const float *se = q.latent + (rowbase + (size_t)y1 * q.Wl + x1) * C_LAT + lane * 8;
         const float *dz = d_zlat + (size_t)idx * C_LAT + lane * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float a = nw[e], b = ne[e], c = sw[e], d = se[e], gq = dz[e];
-            six += gq * ((1.f - ay) * (b - a) + ay * (d - c));   // d zlat / d ix
-            siy += gq * ((1.f - ax) * (c - a) + ax * (d - b));   // d zlat / d iy
+        for (int hh = 0; hh < 2; ++hh) {  // 16-byte loads: 10 in flight per lane
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(nw + 4 * hh), b = *reinterpret_cast<const f32x4 *>(ne + 4 * hh);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(sw + 4 * hh), d = *reinterpret_cast<const f32x4 *>(se + 4 * hh);
+            const f32x4 gq = *reinterpret_cast<const f32x4 *>(dz + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                six += gq[e] * ((1.f - ay) * (b[e] - a[e]) + ay * (d[e] - c[e]));   // d zlat / d ix
+                siy += gq[e] * ((1.f - ax) * (c[e] - a[e]) + ax * (d[e] - b[e]));   // d zlat / d iy
+            }
         }
     }
+    // positional code: [x, sin(f_k x), sin(f_k x + pi/2)] , f_k = 1.5 * 2^k  (code.py:37-41).  Lane l < 18 differentiates
+    // band k = l / 3 of coordinate c = l % 3; lanes 18..20 carry the identity part; summed per coordinate below
+    float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
+    {
+        const float *gi = d_in42 + (size_t)idx * D_IN;
+        const float HALF_PI = 1.57079637050628662109375f;
+        if (lane < 21) {
+            const int k = lane / 3, c = lane - 3 * k;
+            const float xc = c == 0 ? xr0 : (c == 1 ? xr1 : xr2);
+            float term;
+            if (k < 6) {
+                const float f = 1.5f * (float)(1 << k), a = xc * f;
+                term = f * (cosf(a) * gi[3 + 6 * k + c] + cosf(a + HALF_PI) * gi[3 + 6 * k + 3 + c]);
+            } else {
+                term = gi[c];
+            }
+            gc0 = c == 0 ? term : 0.f; gc1 = c == 1 ? term : 0.f; gc2 = c == 2 ? term : 0.f;
+        }
+    }
+    gc0 = wsum(gc0); gc1 = wsum(gc1); gc2 = wsum(gc2);
     six = wsum(six);
     siy = wsum(siy);
     if (lane == 0) {
@@ -799,19 +925,7 @@ position_bwd_kernel(const EvalParams q, const float *__restrict__ d_in42, const 
         float g0 = -fo[0] / xc2 * du;
         float g1 = -fo[1] / xc2 * dv;
         float g2 = (xc0 * fo[0] * du + xc1 * fo[1] * dv) / (xc2 * xc2);
-        // positional code: [x, sin(f_k x), sin(f_k x + pi/2)] , f_k = 1.5 * 2^k  (code.py:37-41)
-        const float *gi = d_in42 + (size_t)idx * D_IN;
-        const float xr[3] = {xr0, xr1, xr2};
-        float gc[3] = {gi[0], gi[1], gi[2]};
-        const float HALF_PI = 1.57079637050628662109375f;
-        for (int k = 0; k < 6; ++k) {
-            const float f = 1.5f * (float)(1 << k);
-            for (int c = 0; c < 3; ++c) {
-                const float a = xr[c] * f;
-                gc[c] += f * (cosf(a) * gi[3 + 6 * k + c] + cosf(a + HALF_PI) * gi[3 + 6 * k + 3 + c]);
-            }
-        }
-        g0 += gc[0]; g1 += gc[1]; g2 += gc[2];
+        g0 += gc0; g1 += gc1; g2 += gc2;
         // x_world gradient = R^T g ; dz = ray_dir . that
         const float wx = pose[0] * g0 + pose[4] * g1 + pose[8] * g2;
         const float wy = pose[1] * g0 + pose[5] * g1 + pose[9] * g2;
@@ -1049,7 +1163,7 @@ extern "C" int pnr_weight_grad_batched(const PnrWeightGradJob *jobs, int n_jobs,
     J.nsplit = dw_nsplit(n_jobs, max_rows);
     float *part = (float *)workspace;
     float *bpart = part + (size_t)n_jobs * J.nsplit * D_HID * D_HID;
-    dim3 grid(4, (unsigned)J.nsplit, (unsigned)n_jobs);
+    dim3 grid(4u * (unsigned)J.nsplit * (unsigned)n_jobs);  // (tile, slice, job) decoded XCD-aware in the kernel
     hipStream_t st = (hipStream_t)stream;
     if (precision == PNR_PREC_F16)
         hipLaunchKernelGGL(dw_kernel<PNR_PREC_F16>, grid, dim3(512), 0, st, J, part, bpart);
@@ -1107,20 +1221,28 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
     q.SB = s->SB; q.NS = s->NS; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
     q.img_w = s->img_w; q.img_h = s->img_h;
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
-    if (q.Hl * q.Wl <= SLAB_MAX_TEXELS) {  // small grid: LDS slabs, no global atomics
-        const size_t lds = (size_t)q.Hl * q.Wl * SLAB_CS * sizeof(float) + 256 * 8 * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(latent_scatter_slab_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_MAX_TEXELS * SLAB_CS * 4 + 8192);
-            if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(latent_scatter_slab_kernel)");
-            attr_set = true;
-        }
+    const int texels = q.Hl * q.Wl;
+    // small grid: LDS slabs.  8 channels per slab with a padded row when that fits the LDS, else 4 (64x64: unpadded)
+    int cs = 0, row = 0;
+    if ((size_t)texels * 9 * 8 <= SLAB_MAX_BYTES - 64) { cs = 8; row = 9; }
+    else if ((size_t)texels * 5 * 8 <= SLAB_MAX_BYTES - 64) { cs = 4; row = 5; }
+    else if ((size_t)texels * 4 * 8 <= SLAB_MAX_BYTES - 64) { cs = 4; row = 4; }
+    if (cs) {
+        const size_t lds = (size_t)texels * row * 8;
+        auto k = cs == 8 ? latent_scatter_slab_kernel<8> : latent_scatter_slab_kernel<4>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           SLAB_MAX_BYTES - 64);
+        if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(latent_scatter_slab_kernel)");
         const long long pts = (long long)rays_per_obj * K;
-        int psplit = (int)((pts + 4095) / 4096);  // >= 16 batches of 256 points per workgroup
-        if (psplit > 4) psplit = 4;
-        hipLaunchKernelGGL(latent_scatter_slab_kernel, dim3((unsigned)(q.SB * q.NS * (C_LAT / SLAB_CS)), psplit), dim3(256), lds,
-                           (hipStream_t)stream, q, d_zlat, d_latent_nhwc);
+        // one round of 2048 samples per workgroup while that keeps the slab flushes (one per workgroup) in proportion:
+        // at most 8 workgroups share an (image, slice)
+#ifndef PNR_SC_PTS
+#define PNR_SC_PTS SLAB_PTS
+#endif
+        int psplit = (int)((pts + PNR_SC_PTS - 1) / PNR_SC_PTS);
+        if (psplit > 8) psplit = 8;
+        hipLaunchKernelGGL(k, dim3((unsigned)(q.SB * q.NS * (C_LAT / cs) * psplit)), dim3(256), lds, (hipStream_t)stream, q, d_zlat,
+                           d_latent_nhwc, psplit, row);
         return pnr_check_launch("pnr_latent_scatter");
     }
     const long long n = ((q.P + SCATTER_RUN - 1) / SCATTER_RUN) * q.NS;  // wavefronts

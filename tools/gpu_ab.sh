@@ -3,6 +3,7 @@
 # kernel-level quick bench (f16 folded, sn64) and the per-phase timing; results -> gpurun_out/ab_<name>.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
+shopt -s nullglob
 for lib in default build/libpnr_*.so; do
     name=$(basename "$lib" .so); name=${name#libpnr_}
     case "$name" in t64*) export PNR_TILE=64 ;; *) export PNR_TILE=96 ;; esac
