@@ -160,6 +160,15 @@ int pnr_eval_points(const PnrScene *scene /*host*/, const void *packed, int prec
                     const float *xyz, const float *viewdirs, int B, float *rgbsigma,
                     void *stream);
 
+/* ResnetFC.forward on explicit rows (src/model/resnetfc.py:132-184): zx (rows, 512 + 42) fp32 = [latent | code+viewdir]
+ * per row, rows ordered [group][view][point] with combine_inner_dims = (NS, B) (mean over the NS views before block 3,
+ * util.py:461-471; NS = 1: no pooling, B ignored beyond divisibility).  out (rows / NS, 4) is lin_out's RAW output
+ * (no sigmoid / relu: those are PixelNeRFNet.forward's, models.py:260-265).  Unfused fp32 linears, same kernels as the
+ * exact-fp32 path below; workspace = pnr_resnetfc_forward_f32_workspace_bytes(rows, NS). */
+size_t pnr_resnetfc_forward_f32_workspace_bytes(long long rows, int NS);
+int pnr_resnetfc_forward_f32(const PnrMlpWeights *w /*host*/, const float *zx, long long rows, int NS, int B, float *out,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- exact-fp32 evaluation (validation grade) --------------------------------------------------
  * Same contract as pnr_eval_ray_samples / pnr_eval_points (PixelNeRFNet.forward, models.py:161-265)
  * with every operand in fp32: unfused, one GEMM launch per nn.Linear on the fp32 MFMA, activations

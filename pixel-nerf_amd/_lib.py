@@ -81,6 +81,8 @@ PROTOTYPES = {
                                    ctypes.POINTER(ctypes.c_int), _I, _I, _P, _P, _P]),
     "pnr_sample_training_rays": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "pnr_eval_epilogue": (_I, [_P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "pnr_resnetfc_forward_f32_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
+    "pnr_resnetfc_forward_f32": (_I, [ctypes.POINTER(PnrMlpWeights), _P, ctypes.c_longlong, _I, _I, _P, _P, _SZ, _P]),
     "pnr_eval_f32_workspace_bytes": (_SZ, [_I, ctypes.c_longlong]),
     "pnr_eval_ray_samples_f32": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _I, _I, _P,
                                       _P, _SZ, _P]),

@@ -146,6 +146,61 @@ class _RenderFunction(torch.autograd.Function):
         return tuple(out)
 
 
+class _PointsFunction(torch.autograd.Function):
+    """Differentiable PixelNeRFNet.forward on explicit points (src/model/models.py:146-266): (SB*B, 3) points and view
+    directions -> (SB*B, 4) = (sigmoid rgb, relu sigma).  The points go through the training kernels as one-sample rays
+    (origin = point, direction = viewdir, z = 0).  Gradients: the 30 ResnetFC parameters and the latent grid; the
+    points themselves are inputs (no gradient), as on the renderer path."""
+
+    @staticmethod
+    def forward(ctx, cfg, xyz, viewdirs, latent, *params):
+        net, coarse = cfg["net"], cfg["coarse"]
+        scene = net.scene()
+        R = xyz.shape[0]
+        rays = torch.cat([xyz, viewdirs, torch.zeros((R, 2), dtype=torch.float32, device=xyz.device)], dim=1).contiguous()
+        z = torch.zeros((R, 1), dtype=torch.float32, device=xyz.device)
+        rgbs, dumps = ops.eval_ray_samples_train(scene, net.packed(coarse, folded=False), rays, z)
+        ctx.cfg, ctx.scene, ctx.rays, ctx.z, ctx.dumps = cfg, scene, rays, z, dumps
+        ctx.latent_shape = latent.shape
+        out = rgbs.reshape(R, 4)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        net, coarse = ctx.cfg["net"], ctx.cfg["coarse"]
+        g = g.contiguous().float()
+        # through the output activations (models.py:260-265): rgb = sigmoid(.), sigma = relu(.)
+        d_pre = torch.cat([g[:, :3] * out[:, :3] * (1.0 - out[:, :3]), g[:, 3:] * (out[:, 3:] > 0).float()], dim=1).contiguous()
+        mlp = net.mlp_coarse if (coarse or net.mlp_fine is None) else net.mlp_fine
+        grads, d_zlat, _ = _mlp_grads(dict(mlp.named_parameters()), mlp.packed_bwd(net.precision), ctx.dumps, d_pre, ctx.scene.NS)
+        d_lat = None
+        if ctx.needs_input_grad[3]:
+            n, c, hl, wl = ctx.latent_shape
+            d_lat = torch.zeros((n, hl, wl, c), dtype=torch.float32, device=g.device)
+            ops.latent_scatter(ctx.scene, ctx.rays, ctx.z, d_zlat, d_lat)
+            d_lat = d_lat.permute(0, 3, 1, 2).contiguous()
+        ctx.dumps = None
+        return (None, None, None, d_lat) + tuple(grads[n] for n in PARAM_NAMES)
+
+
+def points_autograd(net, xyz, viewdirs, coarse):
+    """net(xyz, viewdirs) with autograd: (SB,B,3) x 2 -> (SB,B,4)."""
+    if xyz.requires_grad or viewdirs.requires_grad:
+        raise NotImplementedError("gradients with respect to the query points / view directions are not implemented "
+                                  "(the renderer path does not need them: rays are inputs)")
+    SB, B, _ = xyz.shape
+    latent = net.encoder.latent
+    if net.stop_encoder_grad:
+        latent = latent.detach()
+    mlp = net.mlp_coarse if (coarse or net.mlp_fine is None) else net.mlp_fine
+    named = dict(mlp.named_parameters())
+    out = _PointsFunction.apply(dict(net=net, coarse=coarse), xyz.reshape(-1, 3).float().contiguous(),
+                                viewdirs.reshape(-1, 3).float().contiguous(), latent, *[named[n] for n in PARAM_NAMES])
+    return out.reshape(SB, B, 4)
+
+
 def render_autograd(renderer, net, rays, noise, want_weights):
     """Differentiable twin of the one-call inference path; returns {coarse:{...}, fine:{...}} of
     flat tensors like ops.render_forward."""

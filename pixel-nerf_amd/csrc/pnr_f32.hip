@@ -136,6 +136,16 @@ __global__ void pool_f32_kernel(const float *__restrict__ x, float *__restrict__
     xp[idx] = s / (float)NS;
 }
 
+// xp[(o*B + p)][f] = mean_v x[((o*NS + v)*B + p)][f] : util.combine_interleaved with inner dims (NS, B) (util.py:461-471)
+__global__ void pool_interleaved_f32_kernel(const float *__restrict__ x, float *__restrict__ xp, long long groups, int NS, int B) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= groups * B * D_HID) return;
+    const long long o = idx / ((long long)B * D_HID), rem = idx - o * (long long)B * D_HID;
+    float s = 0.f;
+    for (int v = 0; v < NS; ++v) s += x[((size_t)o * NS + v) * (size_t)B * D_HID + rem];
+    xp[idx] = s / (float)NS;
+}
+
 __global__ void out_f32_kernel(const float *__restrict__ o, float *__restrict__ rgbs, int np) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= np) return;
@@ -205,6 +215,49 @@ static int eval_f32(const PnrScene *s, const PnrMlpWeights *w, EvalParams q, boo
 }
 
 }  // namespace pnr
+
+extern "C" size_t pnr_resnetfc_forward_f32_workspace_bytes(long long rows, int NS) {
+    if (rows <= 0 || NS <= 0 || rows % NS != 0) return 0;
+    return ((size_t)rows * 2 + (NS > 1 ? (size_t)(rows / NS) * 2 : 0)) * pnr::D_HID * sizeof(float);
+}
+
+extern "C" int pnr_resnetfc_forward_f32(const PnrMlpWeights *w, const float *zx, long long rows, int NS, int B, float *out,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace pnr;
+    if (!w || !out || !workspace || rows < 0 || NS <= 0 || B <= 0)
+        return pnr_fail(PNR_E_INVALID, "pnr_resnetfc_forward_f32: bad argument");
+    if (rows == 0) return PNR_OK;
+    if (!zx) return pnr_fail(PNR_E_INVALID, "pnr_resnetfc_forward_f32: null zx");
+    if (rows % ((long long)NS * B) != 0)
+        return pnr_fail(PNR_E_INVALID, "pnr_resnetfc_forward_f32: rows must be a multiple of combine_inner_dims = (NS, B)");
+    if (workspace_bytes < pnr_resnetfc_forward_f32_workspace_bytes(rows, NS))
+        return pnr_fail(PNR_E_INVALID, "pnr_resnetfc_forward_f32: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int ld = C_LAT + D_IN;  // zx row: [z (512) | x (42)]   resnetfc.py:141-143
+    const long long np = rows / NS;
+    float *x = (float *)workspace;
+    float *net = x + (size_t)rows * D_HID;
+    float *xp = net + (size_t)rows * D_HID;
+    float *netp = xp + (size_t)np * D_HID;
+    linear(st, zx + C_LAT, ld, w->lin_in_w, w->lin_in_b, x, D_HID, rows, D_HID, D_IN, false, false);   // resnetfc.py:147
+    for (int b = 0; b < COMBINE_LAYER; ++b) {
+        linear(st, zx, ld, w->lin_z_w[b], w->lin_z_b[b], x, D_HID, rows, D_HID, C_LAT, false, true);   // :175-180
+        linear(st, x, D_HID, w->fc0_w[b], w->fc0_b[b], net, D_HID, rows, D_HID, D_HID, true, false);    // :55-57
+        linear(st, net, D_HID, w->fc1_w[b], w->fc1_b[b], x, D_HID, rows, D_HID, D_HID, true, true);     // :58-62
+    }
+    float *xs = x, *ns = net;
+    if (NS > 1) {  // util.combine_interleaved(x, (NS, B), "average")   resnetfc.py:168-170
+        const long long n = np * D_HID;
+        hipLaunchKernelGGL(pool_interleaved_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xp, np / B, NS, B);
+        xs = xp; ns = netp;
+    }
+    for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b) {
+        linear(st, xs, D_HID, w->fc0_w[b], w->fc0_b[b], ns, D_HID, np, D_HID, D_HID, true, false);
+        linear(st, ns, D_HID, w->fc1_w[b], w->fc1_b[b], xs, D_HID, np, D_HID, D_HID, true, true);
+    }
+    linear(st, xs, D_HID, w->lin_out_w, w->lin_out_b, out, D_OUT, np, D_OUT, D_HID, true, false);       // :183 (raw output)
+    return pnr_check_launch("pnr_resnetfc_forward_f32");
+}
 
 extern "C" size_t pnr_eval_f32_workspace_bytes(int NS, long long chunk_points) {
     if (NS <= 0 || chunk_points <= 0) return 0;

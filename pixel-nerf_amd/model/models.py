@@ -168,12 +168,10 @@ class PixelNeRFNet(torch.nn.Module):
             self._tables[slot] = (key, ops.fold_latent(sc, dict(mlp.state_dict()), self._effective_precision()), sc)
         return self._tables[slot][1]
 
-    def _no_autograd(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "autograd through a direct net(xyz, viewdirs) call is not implemented: training goes "
-                "through NeRFRenderer (render_par(rays), as train/train.py does); wrap direct calls in "
-                "torch.no_grad()")
+    def _wants_grad(self):
+        lat = getattr(self.encoder, "latent", None)
+        return torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                            or (torch.is_tensor(lat) and lat.requires_grad))
 
     # ------------------------------------------------------------------ forward (HIP)
     def forward(self, xyz, coarse=True, viewdirs=None, far=False):
@@ -184,12 +182,16 @@ class PixelNeRFNet(torch.nn.Module):
 
     def _forward_points(self, xyz, coarse, viewdirs):
         self._check_supported()
-        self._no_autograd()
         assert viewdirs is not None  # models.py:186
         SB, B, _ = xyz.shape
         sc = self.scene()
         if SB != sc.SB:
             raise ValueError(f"xyz has {SB} objects but encode() saw {sc.SB}")
+        if self._wants_grad():  # differentiable twin: training kernels + HIP backward (parameters and latent grid)
+            if self._effective_precision() not in ("f16", "bf16"):
+                raise NotImplementedError("training runs on the 16-bit MFMA paths (precision 'f16' / 'bf16')")
+            from .. import autograd
+            return autograd.points_autograd(self, xyz, viewdirs.reshape(SB, B, 3), coarse)
         return ops.eval_points(sc, self.packed(coarse), xyz.float(), viewdirs.reshape(SB, B, 3).float(),
                                tables=self.tables(coarse))
 

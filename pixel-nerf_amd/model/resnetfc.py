@@ -5,6 +5,7 @@ initialisation (src/model/resnetfc.py:10-130), so that reference checkpoints loa
 The arithmetic of ResnetFC.forward (resnetfc.py:132-184) runs inside the fused HIP kernel
 (csrc/pnr_mlp.hip); `packed(precision)` hands the kernel its fragment stream and re-packs
 whenever a parameter changed."""
+import torch
 from torch import nn
 
 from .. import ops
@@ -82,9 +83,25 @@ class ResnetFC(nn.Module):
         return self._packed[key][1]
 
     def forward(self, zx, combine_inner_dims=(1,), combine_index=None, dim_size=None):
-        raise NotImplementedError(
-            "ResnetFC.forward is fused into the HIP network kernel together with the feature lookup; "
-            "call PixelNeRFNet.forward / NeRFRenderer instead")
+        """src/model/resnetfc.py:132-184 on explicit rows zx (..., d_latent + d_in): the exact-fp32 HIP linears
+        (pnr_resnetfc_forward_f32), inference only.  The renderer never comes here -- PixelNeRFNet.forward runs the
+        fused kernel, which also does the feature lookup; this entry serves callers that hold their own (z, x) rows."""
+        if not self.supported():
+            raise NotImplementedError("HIP ResnetFC supports the shipped shape only (conf/default_mv.conf)")
+        if combine_index is not None:
+            raise NotImplementedError("combine_index (frustum culling) is commented out in the reference as well")
+        if torch.is_grad_enabled() and (zx.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                "autograd through a direct ResnetFC.forward call is not implemented: training goes through "
+                "NeRFRenderer (train/train.py:199-215); wrap direct calls in torch.no_grad()")
+        assert zx.size(-1) == self.d_latent + self.d_in
+        dims = tuple(int(d) for d in combine_inner_dims)
+        flat = zx.reshape(-1, zx.shape[-1])
+        out = ops.resnetfc_forward(dict(self.state_dict()), flat, dims)
+        if dims == (1,):
+            return out.reshape(*zx.shape[:-1], self.d_out)
+        # util.combine_interleaved: (-1, NS, B, ...) mean over dim 1 -> (-1, B, ...)   util.py:461-471
+        return out.reshape(-1, dims[1], *zx.shape[1:-1], self.d_out)
 
     @classmethod
     def from_conf(cls, conf, d_in, **kwargs):

@@ -281,6 +281,42 @@ def eval_ray_samples(scene, packed, rays, z, tables=None):
     return out
 
 
+RESNETFC_CHUNK_ROWS = 1 << 17  # rows per launch set of resnetfc_forward (workspace 0.5 GB)
+
+
+def resnetfc_forward(state, zx, combine_inner_dims=(1,)):
+    """ResnetFC.forward on explicit rows (src/model/resnetfc.py:132-184): zx (rows, 554) fp32 = [latent | code+viewdir],
+    combine_inner_dims = (1,) or (NS, B) with rows ordered [group][view][point]; returns lin_out's raw output
+    (rows / NS, 4).  Unfused fp32 linears (the exact-fp32 path's kernels); whole (NS, B) groups per launch set."""
+    lib = _lib.load()
+    zx = _f32(zx, "zx")
+    if zx.dim() != 2 or zx.shape[1] != 554:
+        raise ValueError("resnetfc_forward: zx must be (rows, 512 + 42)")
+    rows = zx.shape[0]
+    dims = tuple(int(d) for d in combine_inner_dims)
+    if dims == (1,):
+        NS, B = 1, 1
+    elif len(dims) == 2:
+        NS, B = dims
+    else:
+        raise ValueError("resnetfc_forward: combine_inner_dims must be (1,) or (NS, B)")
+    if rows % (NS * B) != 0:
+        raise ValueError("resnetfc_forward: rows must be a multiple of NS * B")
+    w, keep = _weights_struct(state)
+    out = torch.empty((rows // NS, 4), dtype=torch.float32, device=zx.device)
+    group = NS * B
+    step = max(group, RESNETFC_CHUNK_ROWS // group * group)
+    nbytes = lib.pnr_resnetfc_forward_f32_workspace_bytes(min(step, rows) if rows else group, NS)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=zx.device)
+    with torch.cuda.device(zx.device):
+        for r0 in range(0, rows, step):
+            n = min(step, rows - r0)
+            _lib.check(lib.pnr_resnetfc_forward_f32(ctypes.byref(w), _p(zx[r0:r0 + n]), n, NS, B, _p(out[r0 // NS:(r0 + n) // NS]),
+                                                    _p(ws), nbytes, _stream()), "pnr_resnetfc_forward_f32")
+    del keep
+    return out
+
+
 def eval_points(scene, packed, xyz, viewdirs, tables=None):
     """xyz, viewdirs (SB,B,3) -> (SB,B,4)."""
     lib = _lib.load()

@@ -81,13 +81,15 @@ def test_encode_state_conventions(net):
     assert torch.allclose(ls, torch.tensor([32 / 31 * 2, 32 / 31 * 2]))
 
 
-def test_forward_requires_hip_device_and_no_autograd(net):
+def test_forward_requires_hip_device(net):
     xyz, vd = torch.zeros(1, 4, 3), torch.zeros(1, 4, 3)
-    with pytest.raises(NotImplementedError):  # grad mode: backward not built in round 1
+    with pytest.raises(_lib.PixelNerfHipError):  # CPU module: no fallback, with or without autograd
         net(xyz, coarse=True, viewdirs=vd)
-    with torch.no_grad(), pytest.raises(_lib.PixelNerfHipError):  # CPU module: no fallback
+    with torch.no_grad(), pytest.raises(_lib.PixelNerfHipError):
         net(xyz, coarse=True, viewdirs=vd)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):  # ResnetFC.forward on explicit rows is inference-only
+        net.mlp_coarse(torch.zeros(2, 554))
+    with torch.no_grad(), pytest.raises(_lib.PixelNerfHipError):
         net.mlp_coarse(torch.zeros(2, 554))
 
 

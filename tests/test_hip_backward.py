@@ -383,3 +383,39 @@ def test_hip_gradients_match_reference_autograd_goldens(dev, name):
         got_s = flat[synthetic.grad_sample_index(flat.size, key)]
         assert abs(np.linalg.norm(flat.astype(np.float64)) - ref_n) <= 3e-2 * ref_n, key
         assert np.linalg.norm(got_s - ref_s) <= 3e-2 * np.linalg.norm(ref_s), f"{key}: {np.linalg.norm(got_s - ref_s) / np.linalg.norm(ref_s):.3e}"
+
+
+@pytest.mark.parametrize("scene_name", ["train", "mv_mini"])
+def test_direct_forward_is_differentiable(dev, scene_name):
+    """net(xyz, viewdirs) with grad enabled (src/model/models.py:146-266 under autograd): parameter and latent-grid
+    gradients of a random linear functional of the (rgb, sigma) outputs, against torch autograd through the oracle."""
+    from helpers import mlp_params, scene_for
+    from test_api_gpu import build_net
+    scene, meta = scene_for(scene_name)
+    SB, B = scene["SB"], 96
+    gen = torch.Generator().manual_seed(13)
+    xyz = (torch.rand(SB, B, 3, generator=gen) - 0.5) * 1.6
+    vd = torch.nn.functional.normalize(torch.randn(SB, B, 3, generator=gen), dim=-1)
+    gw = torch.randn(SB, B, 4, generator=gen)
+    p = {k: v.clone().requires_grad_(True) for k, v in mlp_params(11).items()}
+    sc = dict(scene)
+    sc["latent"] = scene["latent"].clone().requires_grad_(True)
+    ref = O.pixelnerf_forward(sc, p, xyz, vd)
+    (ref * gw).sum().backward()
+    net = build_net(dev, scene, precision="f16").train()
+    lat = scene["latent"].to(dev).clone().requires_grad_(True)
+    net.encoder.latent = lat
+    out = net(xyz.to(dev), coarse=True, viewdirs=vd.to(dev))
+    assert out.shape == (SB, B, 4) and out.requires_grad
+    assert (out.detach().cpu() - ref.detach()).abs().max() <= 2e-2
+    (out * gw.to(dev)).sum().backward()
+    pairs = [("latent", lat.grad.cpu(), sc["latent"].grad)]
+    pairs += [(k, v.grad.cpu(), p[k].grad) for k, v in net.mlp_coarse.named_parameters()]
+    assert all(v.grad is None for v in net.mlp_fine.parameters())
+    for k, a, b in pairs:
+        rel = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+        cos = float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm() + 1e-30))
+        # 16-bit operand chain on 96 points per object (no averaging over a batch of rays): 5e-2 / 0.998
+        assert rel <= 5e-2 and cos >= 0.998, f"{k}: rel err {rel:.3e}, cos {cos:.6f}"
+    with pytest.raises(NotImplementedError):
+        net(xyz.to(dev).requires_grad_(True), coarse=True, viewdirs=vd.to(dev))

@@ -133,3 +133,31 @@ def test_f32_has_no_training_path(ops, dev):
     sc = dscene(ops, dev, "sn64")
     with pytest.raises(_lib.PixelNerfHipError):
         ops.eval_ray_samples_train(sc, packed(ops, dev, 11), torch.zeros(64, 8, device=dev), torch.ones(64, 8, device=dev))
+
+
+@pytest.mark.parametrize("dims,rows", [((1,), 777), ((2, 96), 2 * 2 * 96), ((3, 50), 4 * 3 * 50)])
+def test_resnetfc_forward_on_explicit_rows(ops, dev, dims, rows, monkeypatch):
+    """ResnetFC.forward (src/model/resnetfc.py:132-184) on caller-held (z | x) rows, incl. util.combine_interleaved's
+    [group][view][point] row order (util.py:461-471): the exact-fp32 HIP linears against the oracle's restatement, and
+    through the nn.Module with the reference's output shapes; launch-set chunking is invisible."""
+    from pixelnerf_amd.model.model_util import make_mlp
+    from pixelnerf_amd.util.conf import default_model_conf
+    p = mlp_params(11)
+    gen = torch.Generator().manual_seed(5)
+    zx = torch.cat([torch.randn(rows, 512, generator=gen) * 0.5, torch.rand(rows, 42, generator=gen) * 2 - 1], dim=1)
+    ref = O.resnetfc_forward(p, zx, dims)
+    state = {k: v.to(dev) for k, v in p.items()}
+    got = ops.resnetfc_forward(state, zx.to(dev), dims)
+    assert got.shape == (rows // dims[0], 4)
+    err = (got.cpu() - ref.reshape(-1, 4)).abs().max().item()
+    print(f"resnetfc_forward {dims}: max abs err {err:.3e} (|out| max {ref.abs().max().item():.2f})")
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item())
+    monkeypatch.setattr(ops, "RESNETFC_CHUNK_ROWS", 256)
+    assert torch.equal(ops.resnetfc_forward(state, zx.to(dev), dims), got)
+    mlp = make_mlp(default_model_conf()["mlp_coarse"], 42, 512).to(dev)
+    mlp.load_state_dict(p)
+    with torch.no_grad():
+        out = mlp(zx.to(dev), combine_inner_dims=dims)
+    assert out.shape == ref.shape and torch.equal(out.reshape(-1, 4), got)
+    with pytest.raises(NotImplementedError):
+        mlp(zx.to(dev), combine_inner_dims=dims)  # grad enabled, trainable parameters
