@@ -24,14 +24,14 @@ namespace pnr {
 typedef Advance<BRS_HEAD_END, BRS_TOTAL, BRS_TOTAL> AdvanceBwd;
 
 // ---------------------------------------------------------------- transposed weight stream
+// one thread = one lane's 8-element fragment slice (16-byte store)
 template <typename T>
 __global__ void pack_weights_bwd_kernel(PnrMlpWeights p, T *__restrict__ out) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= BWSTREAM_ELEMS_PER_WAVE * NW) return;
-    const int e = idx & 7;
-    const int lane = (idx >> 3) & 63;
-    const int it = (idx >> 9) % IT;
-    const size_t rest = idx / (FRAG_ELEMS * IT);
+    const size_t idx8 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx8 >= BWSTREAM_ELEMS_PER_WAVE / 8 * NW) return;
+    const int lane = idx8 & 63;
+    const int it = (idx8 >> 6) % IT;
+    const size_t rest = idx8 / ((FRAG_ELEMS / 8) * IT);
     const int rs = rest % BRS_TOTAL;
     const int wv = rest / BRS_TOTAL;
     int g = 0;
@@ -40,31 +40,37 @@ __global__ void pack_weights_bwd_kernel(PnrMlpWeights p, T *__restrict__ out) {
     const int i = lane & 31, h = lane >> 5;
     // A-operand row = output row of the transposed GEMM = INPUT feature of the layer
     const int f_row = wv * SL + it * 32 + i;
-    float v = 0.f;
-    if (g == BG_Z2 || g == BG_Z1 || g == BG_Z0) {
-        // d z_lat[c] += sum_f dY_b[f] W_z[b][f][c]: rows = latent channel c (natural order, wave w owns 64w..64w+63),
-        // K = hidden feature f in the storage order of the gradient image
-        const int b = g == BG_Z2 ? 2 : (g == BG_Z1 ? 1 : 0);
-        const int f_o = feat_of(s >> 1, s & 1, 8 * h + e);
-        v = p.lin_z_w[b][f_o * C_LAT + f_row];
-    } else if (g == BG_IN) {
-        // d(code | viewdir)[k] = sum_f dY[f] W_in[f][k]: every wave holds the FULL 64 (42 real) output rows and contracts
-        // only its own 64 hidden features = storage elements 64w + 16s + 8h + e (K-split, reduced across waves in LDS)
-        const int k_row = it * 32 + i;
-        const int f_o = feat_of(wv * IT + (s >> 1), s & 1, 8 * h + e);
-        if (k_row < D_IN) v = p.lin_in_w[f_o * D_IN + k_row];
-    } else if (g == BG_OUT) {
-        const int k = s * 16 + h * 8 + e;  // natural order of the 4 network outputs, zero padded
-        if (k < D_OUT) v = p.lin_out_w[k * D_HID + f_row];
-    } else {
-        const int b = 4 - (g - 1) / 2;       // BG_FC1_4, BG_FC0_4, BG_FC1_3, ... -> block index
-        const bool fc1 = ((g - 1) & 1) == 0;
-        const float *w = fc1 ? p.fc1_w[b] : p.fc0_w[b];
-        // K index = OUTPUT feature of the layer, in the storage order of the gradient image
-        const int f_o = feat_of(s >> 1, s & 1, 8 * h + e);
-        v = w[f_o * D_HID + f_row];
+    __attribute__((aligned(16))) T o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = 0.f;
+        if (g == BG_Z2 || g == BG_Z1 || g == BG_Z0) {
+            // d z_lat[c] += sum_f dY_b[f] W_z[b][f][c]: rows = latent channel c (natural order, wave w owns 64w..64w+63),
+            // K = hidden feature f in the storage order of the gradient image
+            const int b = g == BG_Z2 ? 2 : (g == BG_Z1 ? 1 : 0);
+            const int f_o = feat_of(s >> 1, s & 1, 8 * h + e);
+            v = p.lin_z_w[b][f_o * C_LAT + f_row];
+        } else if (g == BG_IN) {
+            // d(code | viewdir)[k] = sum_f dY[f] W_in[f][k]: every wave holds the FULL 64 (42 real) output rows and
+            // contracts only its own 64 hidden features = storage elements 64w + 16s + 8h + e (K-split, reduced across
+            // waves in LDS)
+            const int k_row = it * 32 + i;
+            const int f_o = feat_of(wv * IT + (s >> 1), s & 1, 8 * h + e);
+            if (k_row < D_IN) v = p.lin_in_w[f_o * D_IN + k_row];
+        } else if (g == BG_OUT) {
+            const int k = s * 16 + h * 8 + e;  // natural order of the 4 network outputs, zero padded
+            if (k < D_OUT) v = p.lin_out_w[k * D_HID + f_row];
+        } else {
+            const int b = 4 - (g - 1) / 2;       // BG_FC1_4, BG_FC0_4, BG_FC1_3, ... -> block index
+            const bool fc1 = ((g - 1) & 1) == 0;
+            const float *w = fc1 ? p.fc1_w[b] : p.fc0_w[b];
+            // K index = OUTPUT feature of the layer, in the storage order of the gradient image
+            const int f_o = feat_of(s >> 1, s & 1, 8 * h + e);
+            v = w[f_o * D_HID + f_row];
+        }
+        o[e] = (T)v;
     }
-    out[idx] = (T)v;
+    *reinterpret_cast<uint4 *>(out + idx8 * 8) = *reinterpret_cast<const uint4 *>(o);
 }
 
 // ---------------------------------------------------------------- fused data-gradient chain
@@ -93,12 +99,7 @@ __device__ __forceinline__ void load_mask(MaskRegs &mk, const char *dump_lane, c
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             mk.m[it][jt][0] = mk.m[it][jt][1] = u32x4{0, 0, 0, 0};
-#ifndef PNR_BWD_NOMASK
-            if (valid[jt])
-#else
-            if (valid[jt] && dump_lane == nullptr)
-#endif
-            {
+            if (valid[jt]) {
                 const char *d = dump_lane + (size_t)jt * 32 * (D_HID * 2) + it * 64;
                 mk.m[it][jt][0] = *reinterpret_cast<const u32x4 *>(d);
                 mk.m[it][jt][1] = *reinterpret_cast<const u32x4 *>(d + 16);
@@ -443,9 +444,7 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
     int cur = 0;
     for (long long r0 = r_begin; r0 < r_end; r0 += SR, cur ^= 1) {
         const bool more = r0 + SR < r_end;
-#ifndef PNR_DW_NOLOAD
         if (more) load_slab(r0 + SR);  // in flight under this slab's MFMAs
-#endif
         const char *sY = sYb[cur], *sX = sXb[cur];
 #pragma unroll
         for (int ks = 0; ks < SR / 16; ++ks) {
@@ -465,9 +464,7 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
                     for (int e = 0; e < 8; ++e) bsum[a] += (float)af[a][e];
             }
         }
-#ifndef PNR_DW_NOSTORE
         if (more) store_slab(cur ^ 1);  // the other buffer: its readers passed the barrier of the previous slab
-#endif
         __syncthreads();
     }
     // D layout: column j = lane&31 -> k, row (r&3)+8(r>>2)+4kh -> o
@@ -794,9 +791,6 @@ latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat,
                 const float f = acc[c][e] * scale;
                 // |f| <= 8 * 2^41 for finite inputs; Inf / NaN gradients (a diverged step) are dropped here, they still
                 // poison the weight gradients through the other kernels
-#ifdef PNR_SC_NOATOM
-                if (f == 123.f)
-#endif
                 if (fabsf(f) < 9.0e18f && f != 0.f) atomicAdd(&slab[cur[c] * row + e], (unsigned long long)(long long)f);
             }
         };
@@ -834,9 +828,6 @@ latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat,
             if (cur[c] >= 0) flush(c);
     }
     __syncthreads();
-#ifdef PNR_SC_NOFLUSH
-    if (slab[t] == 123ull)
-#endif
     for (int i = t; i < texels * CS; i += 256) {
         const long long sv = (long long)slab[(i / CS) * row + (i % CS)];
         if (sv != 0) atomicAdd(d_latent + ((size_t)rowbase + i / CS) * C_LAT + cs * CS + (i % CS), (float)sv * inv_scale);
@@ -950,7 +941,7 @@ extern "C" size_t pnr_packed_mlp_bwd_bytes(void) { return BPACKED_BYTES; }
 
 extern "C" int pnr_pack_mlp_bwd(const PnrMlpWeights *w, int precision, void *packed_bwd, void *stream) {
     if (!w || !packed_bwd) return pnr_fail(PNR_E_INVALID, "pnr_pack_mlp_bwd: null argument");
-    const size_t n = BWSTREAM_ELEMS_PER_WAVE * NW;
+    const size_t n = BWSTREAM_ELEMS_PER_WAVE / 8 * NW;  // one thread per 8 elements
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (precision == PNR_PREC_F16)
         hipLaunchKernelGGL(pack_weights_bwd_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *w, (_Float16 *)packed_bwd);
@@ -1236,10 +1227,7 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
         const long long pts = (long long)rays_per_obj * K;
         // one round of 2048 samples per workgroup while that keeps the slab flushes (one per workgroup) in proportion:
         // at most 8 workgroups share an (image, slice)
-#ifndef PNR_SC_PTS
-#define PNR_SC_PTS SLAB_PTS
-#endif
-        int psplit = (int)((pts + PNR_SC_PTS - 1) / PNR_SC_PTS);
+        int psplit = (int)((pts + SLAB_PTS - 1) / SLAB_PTS);
         if (psplit > 8) psplit = 8;
         hipLaunchKernelGGL(k, dim3((unsigned)(q.SB * q.NS * (C_LAT / cs) * psplit)), dim3(256), lds, (hipStream_t)stream, q, d_zlat,
                            d_latent_nhwc, psplit, row);

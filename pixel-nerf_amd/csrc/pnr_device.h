@@ -268,6 +268,8 @@ __device__ __forceinline__ void write_act(const f32x16 (&acc)[IT][JT_], char *sm
             if (DUMP) {
                 if (valid[jt]) {
                     char *d = dump_lane + (size_t)jt * 32 * (D_HID * 2) + it * 64;
+                    // plain stores: streaming (nontemporal) stores for the dumps + loads for the masks measured 5 % SLOWER
+                    // on the training step -- the dumps are served to the backward kernels from the Infinity Cache
                     *reinterpret_cast<typename P::T8 *>(d) = lo;
                     *reinterpret_cast<typename P::T8 *>(d + 16) = hi;
                 }

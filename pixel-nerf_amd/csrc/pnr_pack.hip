@@ -36,15 +36,15 @@ __device__ inline GemmSrc gemm_source(const PnrMlpWeights &p, int g) {
 
 // FOLD: the stream without the three lin_z GEMMs (they are folded into per-texel tables, pnr_fold_latent)
 // LO: the f16 TAIL of the weight, f16(w - f16(w)), for the split-operand kernel (pnr_split.hip)
+// One thread = one lane's 8-element fragment slice (a 16-byte store; the index arithmetic is paid once per 8 elements).
 template <typename T, bool FOLD, bool LO = false>
 __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
     constexpr int TOTAL = FOLD ? RS_TOTAL_F : RS_TOTAL;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)TOTAL * IT * FRAG_ELEMS * NW) return;
-    const int e = idx & 7;
-    const int lane = (idx >> 3) & 63;
-    const int it = (idx >> 9) % IT;
-    const size_t rest = idx / (FRAG_ELEMS * IT);
+    const size_t idx8 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx8 >= (size_t)TOTAL * IT * (FRAG_ELEMS / 8) * NW) return;
+    const int lane = idx8 & 63;
+    const int it = (idx8 >> 6) % IT;
+    const size_t rest = idx8 / ((FRAG_ELEMS / 8) * IT);
     const int rs = rest % TOTAL;
     const int wv = rest / TOTAL;
     int g = 0, s = 0;
@@ -59,28 +59,33 @@ __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
     const int i = lane & 31, h = lane >> 5;
     const int f_out = wv * SL + it * 32 + i;
     const GemmSrc src = gemm_source(p, g);
-    float v = 0.f;
-    if (src.kind == 0) {
-        const int k = s * 16 + h * 8 + e;
-        if (k < D_IN) v = src.w[f_out * D_IN + k];
-    } else if (src.kind == 1) {
-        const int k = s * 16 + h * 8 + e;
-        v = src.w[f_out * C_LAT + k];
-    } else if (src.kind == 2) {
-        // B operand comes from the LDS activation buffer: k-step s reads storage elements
-        // 16s..16s+15 = what half (s&1) of feature tile (s>>1) wrote as registers 8h+e.
-        const int k = feat_of(s >> 1, s & 1, 8 * h + e);
-        v = src.w[f_out * D_HID + k];
-    } else {
-        // lin_out: B operand = the wave's own accumulators; k-step q = IT*s + it covers
-        // registers 8*(q&1)..+7 of the wave's feature tile (q>>1), for both lane halves.
-        if (s < 2) {
-            const int q = IT * s + it;
-            const int k = feat_of(wv * IT + (q >> 1), h, 8 * (q & 1) + e);
-            if (i < D_OUT) v = src.w[i * D_HID + k];
+    __attribute__((aligned(16))) T o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = 0.f;
+        if (src.kind == 0) {
+            const int k = s * 16 + h * 8 + e;
+            if (k < D_IN) v = src.w[f_out * D_IN + k];
+        } else if (src.kind == 1) {
+            const int k = s * 16 + h * 8 + e;
+            v = src.w[f_out * C_LAT + k];
+        } else if (src.kind == 2) {
+            // B operand comes from the LDS activation buffer: k-step s reads storage elements
+            // 16s..16s+15 = what half (s&1) of feature tile (s>>1) wrote as registers 8h+e.
+            const int k = feat_of(s >> 1, s & 1, 8 * h + e);
+            v = src.w[f_out * D_HID + k];
+        } else {
+            // lin_out: B operand = the wave's own accumulators; k-step q = IT*s + it covers
+            // registers 8*(q&1)..+7 of the wave's feature tile (q>>1), for both lane halves.
+            if (s < 2) {
+                const int q = IT * s + it;
+                const int k = feat_of(wv * IT + (q >> 1), h, 8 * (q & 1) + e);
+                if (i < D_OUT) v = src.w[i * D_HID + k];
+            }
         }
+        o[e] = LO ? (T)(v - (float)(T)v) : (T)v;
     }
-    out[idx] = LO ? (T)(v - (float)(T)v) : (T)v;
+    *reinterpret_cast<uint4 *>(out + idx8 * 8) = *reinterpret_cast<const uint4 *>(o);
 }
 
 template <bool FOLD>
@@ -228,7 +233,7 @@ extern "C" int pnr_pack_mlp_split(const PnrMlpWeights *w, void *packed, void *st
     using namespace pnr;
     if (!w || !packed) return pnr_fail(PNR_E_INVALID, "pnr_pack_mlp_split: null argument");
     hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)RS_TOTAL_F * IT * FRAG_ELEMS * NW;
+    const size_t n = (size_t)RS_TOTAL_F * IT * (FRAG_ELEMS / 8) * NW;  // one thread per 8 elements
     const int threads = 256;
     const unsigned blocks = (unsigned)((n + threads - 1) / threads);
     hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, false>), dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed);
@@ -247,7 +252,7 @@ static int pack_mlp_impl(const PnrMlpWeights *w, int precision, void *packed, vo
     using namespace pnr;
     if (!w || !packed) return pnr_fail(PNR_E_INVALID, "pnr_pack_mlp: null argument");
     hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)(FOLD ? RS_TOTAL_F : RS_TOTAL) * IT * FRAG_ELEMS * NW;
+    const size_t n = (size_t)(FOLD ? RS_TOTAL_F : RS_TOTAL) * IT * (FRAG_ELEMS / 8) * NW;  // one thread per 8 elements
     const int threads = 256;
     const unsigned blocks = (unsigned)((n + threads - 1) / threads);
     if (precision == PNR_PREC_F16)

@@ -7,8 +7,22 @@ The arithmetic of ResnetFC.forward (resnetfc.py:132-184) runs inside the fused H
 whenever a parameter changed."""
 import torch
 from torch import nn
+from torch.optim.optimizer import register_optimizer_step_post_hook
 
 from .. import ops
+
+# Fused optimizers (torch.optim.Adam(..., fused=True) and friends) update parameters in place WITHOUT bumping
+# tensor._version, so (data_ptr, _version) alone cannot tell that the packed fragment streams / folded tables are stale.
+# A global post-step hook counts optimizer steps; the count is part of every cache key: any optimizer.step() anywhere
+# re-packs on next use (56 us per network -- what a training step pays anyway).
+_OPTIMIZER_STEPS = [0]
+
+
+def _count_optimizer_step(optimizer, args, kwargs):
+    _OPTIMIZER_STEPS[0] += 1
+
+
+register_optimizer_step_post_hook(_count_optimizer_step)
 
 
 class ResnetBlockFC(nn.Module):
@@ -58,7 +72,12 @@ class ResnetFC(nn.Module):
                 and not self.use_spade)
 
     def _fingerprint(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (_OPTIMIZER_STEPS[0],) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def invalidate_packed(self):
+        """Drop the packed streams (for parameter writes that neither bump tensor._version nor go through a
+        torch.optim optimizer, e.g. a custom kernel writing through data_ptr())."""
+        self._packed.clear()
 
     def packed(self, precision="f16", folded=False):
         if not self.supported():

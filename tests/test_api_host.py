@@ -148,3 +148,17 @@ def test_pretrained_encoder_without_weights_warns():
         warnings.simplefilter("always")
         SpatialEncoder(pretrained=False)
     assert not w
+
+
+def test_packed_streams_follow_fused_optimizer_updates(net):
+    """torch's fused optimizers write parameters in place without bumping tensor._version; the cache key of the packed
+    weight streams / folded tables must change anyway (a stale stream would train on frozen weights)."""
+    mlp = net.mlp_coarse
+    for fused in (False, True):
+        opt = torch.optim.Adam(mlp.parameters(), lr=1e-3, fused=fused)
+        before = mlp._fingerprint()
+        for p in mlp.parameters():
+            p.grad = torch.ones_like(p)
+        opt.step()
+        assert mlp._fingerprint() != before, f"fused={fused}"
+        assert mlp._fingerprint() == mlp._fingerprint()

@@ -419,3 +419,44 @@ def test_direct_forward_is_differentiable(dev, scene_name):
         assert rel <= 5e-2 and cos >= 0.998, f"{k}: rel err {rel:.3e}, cos {cos:.6f}"
     with pytest.raises(NotImplementedError):
         net(xyz.to(dev).requires_grad_(True), coarse=True, viewdirs=vd.to(dev))
+
+
+def test_fused_optimizer_updates_reach_the_kernels(dev):
+    """torch.optim.Adam(fused=True) writes the parameters in place without bumping tensor._version: the packed streams
+    must be rebuilt anyway.  Same batch, same frozen noise, six steps with the fused and with the foreach form of Adam:
+    both must lower the loss, along the same trajectory."""
+    from pixelnerf_amd.model import make_model
+    from pixelnerf_amd.render import NeRFRenderer
+    from pixelnerf_amd.util import DotMap
+    from pixelnerf_amd.util.conf import default_model_conf
+    from helpers import mlp_params
+    g, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
+    gt = torch.rand(4, 32, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) * 0.5 + 0.25
+    r = rays.to(dev)
+    traj = {}
+    for fused in (False, True):
+        net = make_model(default_model_conf()).to(dev).train()
+        net.mlp_coarse.load_state_dict(mlp_params(11))
+        net.mlp_fine.load_state_dict(mlp_params(12))
+        net.encoder.latent = scene["latent"].to(dev)
+        ls = torch.tensor([32.0, 32.0], device=dev)
+        net.encoder.latent_scaling = ls / (ls - 1) * 2.0
+        net.poses, net.image_shape = scene["poses"].to(dev), scene["image_shape"].to(dev)
+        net.focal, net.c = scene["focal"].to(dev), scene["c"].to(dev)
+        net.num_objs, net.num_views_per_obj = scene["SB"], scene["NS"]
+        rend = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).to(dev)
+        render_par = rend.bind_parallel(net, None, simple_output=False).train()
+        opt = torch.optim.Adam(list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters()), lr=2e-4, fused=fused)
+        losses = []
+        for it in range(6):
+            torch.manual_seed(123)
+            rd = DotMap(render_par(r, want_weights=True))
+            loss = ((rd.coarse.rgb - gt) ** 2).mean() + ((rd.fine.rgb - gt) ** 2).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        traj[fused] = losses
+        assert losses[-1] < 0.9 * losses[0], (fused, losses)
+    for a, b in zip(traj[False], traj[True]):
+        assert abs(a - b) <= 2e-2 * abs(a), traj

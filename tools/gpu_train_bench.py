@@ -38,7 +38,8 @@ def main():
         rend = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).to(dev)
         render_par = rend.bind_parallel(net, None, simple_output=False).train()
         params = list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters())
-        opt = torch.optim.Adam(params, lr=1e-4)
+        # as bench.py: PyTorch's single-kernel form of the same optimizer (PNR_ADAM_FOREACH=1: the default foreach form)
+        opt = torch.optim.Adam(params, lr=1e-4, fused=not os.environ.get("PNR_ADAM_FOREACH"))
 
         def step():
             rd = DotMap(render_par(rays, want_weights=True))
@@ -49,7 +50,8 @@ def main():
             opt.step()
             return loss
 
-        for _ in range(8):
+        first = step().item()
+        for _ in range(7):
             step()
         torch.cuda.synchronize()
         n = 20
@@ -58,7 +60,7 @@ def main():
             loss = step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print(f"HIP {prec}: {dt*1e3:8.2f} ms/step  {1/dt:7.2f} steps/s  {512/dt:9.0f} rays/s   loss {loss.item():.5f}", flush=True)
+        print(f"HIP {prec}: {dt*1e3:8.2f} ms/step  {1/dt:7.2f} steps/s  {512/dt:9.0f} rays/s   loss {first:.5f} -> {loss.item():.5f}", flush=True)
 
     if quick:
         return
