@@ -203,7 +203,11 @@ typedef struct PnrTrainDumps {
     void *d_a[5];   /* relu(x) in front of blocks[b].fc_0: b<3 (rows_v,512), b>=3 (rows_p,512)   */
     void *d_n[5];   /* relu(net) in front of blocks[b].fc_1, same shapes                         */
     void *d_x5;     /* (rows_p, 512) relu(x) in front of lin_out                                 */
+    void *d_mask;   /* pnr_train_masks_bytes(P, NS) bytes: 1 bit per element of the 11 activation dumps ("was dumped non-zero"
+                       = the relu derivative), 64-bit word per (layer, view, 64-point tile, kernel thread); what the
+                       backward chain reads instead of the 1 KiB dump rows (which only the weight-gradient GEMMs read) */
 } PnrTrainDumps;
+size_t pnr_train_masks_bytes(long long P, int NS);
 
 typedef struct PnrBackwardDumps {
     void *g_fc1[5]; /* dL/d(blocks[b].fc_1 output) = dL/d(residual stream after block b), shapes as d_n */
@@ -245,6 +249,16 @@ int pnr_composite_backward(const float *rays, const float *z, const float *rgbsi
 int pnr_position_backward(const PnrScene *scene /*host*/, const float *rays, const float *z, int R,
                           int rays_per_obj, int K, const float *d_in42, const float *d_zlat,
                           float *d_z, void *stream);
+
+/* The same gradient for the DEPTH samples only -- the only sample positions that carry gradient in the reference (the
+ * importance samples are drawn from detached weights, nerf.py:288; z = clamp(depth_c + n4 * depth_std), nerf.py:157-160,292)
+ * -- pushed through the sort and the clamp towards dL/d(coarse depth): for ray r, depth sample j at sorted position
+ * ranks[r][j] and view v, contrib[v][r][j] = [near < depth_c[r] + n4[r][j] depth_std < far] * (network term of view v
+ * [+ dz_comp[r][ranks[r][j]] for v = 0]); dL/d depth_c[r] = sum over (v, j) -- left to the caller so that the sum has a
+ * fixed order.  dz_comp (R,K) = the compositing dL/dz of pnr_composite_backward (nullable); contrib (NS,R,Kfd) out. */
+int pnr_depth_sample_backward(const PnrScene *scene /*host*/, const float *rays, const float *z, int R, int rays_per_obj,
+                              int K, const int *ranks, const float *n4, int Kfd, const float *depth_c, float depth_std,
+                              const float *d_in42, const float *d_zlat, const float *dz_comp, float *contrib, void *stream);
 
 /* Fused data-gradient chain of one ResnetFC (reverse of src/model/resnetfc.py:132-184).
  * g_out (P,4) = dL/d(lin_out output) (pre sigmoid/relu), grad_scale = power of two the chain is

@@ -49,7 +49,7 @@ class PnrWeightGradJob(ctypes.Structure):
 
 class PnrTrainDumps(ctypes.Structure):
     _fields_ = [("d_in", ctypes.c_void_p), ("d_z", ctypes.c_void_p), ("d_a", ctypes.c_void_p * 5),
-                ("d_n", ctypes.c_void_p * 5), ("d_x5", ctypes.c_void_p)]
+                ("d_n", ctypes.c_void_p * 5), ("d_x5", ctypes.c_void_p), ("d_mask", ctypes.c_void_p)]
 
 
 class PnrBackwardDumps(ctypes.Structure):
@@ -83,6 +83,7 @@ PROTOTYPES = {
     "pnr_eval_epilogue": (_I, [_P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "pnr_resnetfc_forward_f32_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
     "pnr_resnetfc_forward_f32": (_I, [ctypes.POINTER(PnrMlpWeights), _P, ctypes.c_longlong, _I, _I, _P, _P, _SZ, _P]),
+    "pnr_train_masks_bytes": (_SZ, [ctypes.c_longlong, _I]),
     "pnr_eval_f32_workspace_bytes": (_SZ, [_I, ctypes.c_longlong]),
     "pnr_eval_ray_samples_f32": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _I, _I, _P,
                                       _P, _SZ, _P]),
@@ -107,6 +108,7 @@ PROTOTYPES = {
     "pnr_pack_mlp_bwd": (_I, [ctypes.POINTER(PnrMlpWeights), _I, _P, _P]),
     "pnr_composite_backward": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "pnr_position_backward": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "pnr_depth_sample_backward": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _I, _P, _F, _P, _P, _P, _P, _P]),
     "pnr_mlp_backward": (_I, [_P, _I, ctypes.POINTER(PnrTrainDumps), _P, _F, _P, ctypes.c_longlong, _I,
                               ctypes.POINTER(PnrBackwardDumps), _P]),
     "pnr_weight_grad_workspace_bytes": (_SZ, []),

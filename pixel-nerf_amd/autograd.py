@@ -130,13 +130,10 @@ class _RenderFunction(torch.autograd.Function):
             if need_latent:
                 ops.latent_scatter(scene, rays, ps["z"], d_zlat, d_lat)
             if pos:
-                # dL/dz of every fine sample: compositing part (dz) + network-input part
-                ops.position_backward(scene, rays, ps["z"], d_in, d_zlat, dz)
-                # only the depth samples carry gradient: undo the sort, apply the clamp's mask
-                # z = max(min(depth + n*std, far), near)   (nerf.py:157-160)
-                zraw = ps["depth_c"].unsqueeze(1) + ps["n4"] * cfg["depth_std"]
-                live = ((zraw < rays[:, 7:8]) & (zraw > rays[:, 6:7])).float()
-                extra_depth = (dz.gather(1, ps["ranks"].long()) * live).sum(1)
+                # only the depth samples carry position gradient: compositing part (dz) + network-input part at their
+                # sorted positions, through the clamp z = max(min(depth + n*std, far), near)   (nerf.py:157-160,292)
+                extra_depth = ops.depth_sample_backward(scene, rays, ps["z"], ps["ranks"], ps["n4"], ps["depth_c"],
+                                                        cfg["depth_std"], d_in, d_zlat, dz)
         ctx.passes = None  # release the 16-bit operand dumps (~12 KB per point and view) as soon as they are used
         out = [None, None, d_lat.permute(0, 3, 1, 2).contiguous() if need_latent else None]
         n_each = len(PARAM_NAMES)

@@ -76,7 +76,7 @@ __global__ void pack_weights_bwd_kernel(PnrMlpWeights p, T *__restrict__ out) {
 // ---------------------------------------------------------------- fused data-gradient chain
 struct BwdParams {
     const char *wstream;
-    const char *d_a[5], *d_n[5], *d_x5;  // forward dumps: relu masks
+    const unsigned long long *d_mask;    // relu bit masks of the forward (pnr_device.h: nonzero_bits8), [layer][view][tile][thread]
     const float *g_out;                  // (P,4) dL/d(lin_out output)
     float scale;
     const float *scale_dev;  // when set, the chain runs at *scale_dev instead (scale picked on the device)
@@ -87,52 +87,33 @@ struct BwdParams {
     float *d_in;    // (NS*P, 42)  fp32: d(positional code | view direction)             (nullable: skip)
 };
 
-// relu masks: the forward dump holds relu(.) as 16-bit values in storage order; this lane's 16 values per MFMA tile are
-// fetched BEFORE the GEMM whose result they gate (32 registers in flight under it) so that the HBM round trip of the
-// dump -- written a whole forward + compositing pass earlier -- is not exposed behind every GEMM of the chain
-struct MaskRegs {
-    u32x4 m[IT][JT][2];
-};
-__device__ __forceinline__ void load_mask(MaskRegs &mk, const char *dump_lane, const bool *valid) {
+// relu masks: one 64-bit word per thread and layer from the forward kernel (bit (it*JT + jt)*16 + r = register r of the
+// thread's accumulator tile (it, jt) was positive); fetched BEFORE the GEMM whose result it gates.  (Reading the masks
+// from the 1 KiB dump rows instead cost the chain a third of its time: 592 -> 405 us for 49 152 points without them.)
+static_assert(IT * JT * 16 == 64, "one 64-bit mask word per thread");
+
+// acc = bit ? acc : 0
+__device__ __forceinline__ void apply_mask(f32x16 (&acc)[IT][JT], unsigned long long mk) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            mk.m[it][jt][0] = mk.m[it][jt][1] = u32x4{0, 0, 0, 0};
-            if (valid[jt]) {
-                const char *d = dump_lane + (size_t)jt * 32 * (D_HID * 2) + it * 64;
-                mk.m[it][jt][0] = *reinterpret_cast<const u32x4 *>(d);
-                mk.m[it][jt][1] = *reinterpret_cast<const u32x4 *>(d + 16);
-            }
+            const uint32_t m16 = (uint32_t)(mk >> ((it * JT + jt) * 16)) & 0xffffu;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[it][jt][r] = (m16 >> r) & 1u ? acc[it][jt][r] : 0.f;
         }
 }
 
-// acc = (dump element != 0) ? acc : 0
-__device__ __forceinline__ void apply_mask(f32x16 (&acc)[IT][JT], const MaskRegs &mk) {
+// G += bit ? t : 0
+__device__ __forceinline__ void masked_add(f32x16 (&G)[IT][JT], const f32x16 (&t)[IT][JT], unsigned long long mk) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
+        for (int jt = 0; jt < JT; ++jt) {
+            const uint32_t m16 = (uint32_t)(mk >> ((it * JT + jt) * 16)) & 0xffffu;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t word = mk.m[it][jt][r >> 3][(r & 7) >> 1];
-                const uint32_t bits = (r & 1) ? (word >> 16) : (word & 0xffffu);
-                acc[it][jt][r] = bits ? acc[it][jt][r] : 0.f;
-            }
-}
-
-// G += (dump element != 0) ? t : 0
-__device__ __forceinline__ void masked_add(f32x16 (&G)[IT][JT], const f32x16 (&t)[IT][JT], const MaskRegs &mk) {
-#pragma unroll
-    for (int it = 0; it < IT; ++it)
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t word = mk.m[it][jt][r >> 3][(r & 7) >> 1];
-                const uint32_t bits = (r & 1) ? (word >> 16) : (word & 0xffffu);
-                G[it][jt][r] += bits ? t[it][jt][r] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) G[it][jt][r] += (m16 >> r) & 1u ? t[it][jt][r] : 0.f;
+        }
 }
 
 template <typename P>
@@ -163,23 +144,29 @@ __device__ __forceinline__ void zero_acc(f32x16 (&a)[IT][JT]) {
 //   dY(fc_1) = G ;  d net = (fc_1^T G) . [net > 0] = dY(fc_0) ;  G += (fc_0^T d net) . [x > 0]
 template <typename P>
 __device__ __forceinline__ void bwd_block(f32x16 (&G)[IT][JT], char *smem, int b, Ring<P> &R, int NS, const BwdParams &q,
-                                          size_t off, const bool *valid, uint32_t a_rd0, uint32_t a_rd1, uint32_t a_wr) {
+                                          size_t off, const bool *valid, uint32_t a_rd0, uint32_t a_rd1, uint32_t a_wr,
+                                          uint32_t mask_off, size_t mask_layer) {
+#ifdef PNR_EXP_BWD_NODUMP  // experiment (timing only): no gradient dumps
+    constexpr bool DUMP = false;
+#else
+    constexpr bool DUMP = true;
+#endif
     __syncthreads();  // every wave is done reading the gradient image (previous GEMM)
-    write_act<P, false, true>(G, smem, a_wr, q.g_fc1[b] + off, valid);
+    write_act<P, false, DUMP>(G, smem, a_wr, q.g_fc1[b] + off, valid);
     __syncthreads();
     f32x16 t[IT][JT];
-    MaskRegs mk;
-    load_mask(mk, q.d_n[b] + off, valid);
+    // mask_off / mask_layer: this thread's word within a layer of q.d_mask / words per layer (layer 2b: x, 2b+1: net)
+    const unsigned long long mk_n = (q.d_mask + (size_t)(2 * b + 1) * mask_layer)[mask_off];
     zero_acc(t);
     gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
-    apply_mask(t, mk);
+    apply_mask(t, mk_n);
     __syncthreads();
-    write_act<P, false, true>(t, smem, a_wr, q.g_fc0[b] + off, valid);
+    write_act<P, false, DUMP>(t, smem, a_wr, q.g_fc0[b] + off, valid);
     __syncthreads();
-    load_mask(mk, q.d_a[b] + off, valid);
+    const unsigned long long mk_a = (q.d_mask + (size_t)(2 * b) * mask_layer)[mask_off];
     zero_acc(t);
     gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
-    masked_add(G, t, mk);
+    masked_add(G, t, mk_a);
 }
 
 template <int PREC, bool MV>
@@ -223,16 +210,17 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
         }
         __syncthreads();
         f32x16 G[IT][JT];
+        const size_t mask_layer = (size_t)NS * (size_t)q.ntiles * NTHREADS;
+        const uint32_t mask_pooled = (uint32_t)tile * NTHREADS + tid;  // 32 bits: NS * tiles * 512 < 2^32 (host check)
         {
-            MaskRegs mk;
-            load_mask(mk, q.d_x5 + off_pooled, valid);
+            const unsigned long long mk = (q.d_mask + (size_t)10 * mask_layer)[mask_pooled];
             zero_acc(G);
             gemm<P, AdvanceBwd>(G, smem, in_rd0, in_rd1, KS_IN / 4, R, NS);  // lin_out^T g_out
             apply_mask(G, mk);                                                // . [x5 > 0]
         }
 #pragma unroll 1
         for (int b = N_BLOCKS - 1; b >= COMBINE_LAYER; --b)
-            bwd_block<P>(G, smem, b, R, NS, q, off_pooled, valid, a_rd0, a_rd1, a_wr);
+            bwd_block<P>(G, smem, b, R, NS, q, off_pooled, valid, a_rd0, a_rd1, a_wr, mask_pooled, mask_layer);
         f32x16 Gp[MV ? IT : 1][MV ? JT : 1];
         if constexpr (MV) {
             // backward of the view mean (util.py:461-466): every view receives G / NS
@@ -253,8 +241,13 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
             }
 #pragma unroll 1
             for (int b = COMBINE_LAYER - 1; b >= 0; --b)
-                bwd_block<P>(G, smem, b, R, NS, q, off_view, valid, a_rd0, a_rd1, a_wr);
+                bwd_block<P>(G, smem, b, R, NS, q, off_view, valid, a_rd0, a_rd1, a_wr,
+                             mask_pooled + (uint32_t)view * (uint32_t)q.ntiles * NTHREADS, mask_layer);
+#ifdef PNR_EXP_BWD_NOZ  // experiment (timing only): no lin_z^T / lin_in^T section
+            if (true) {
+#else
             if (!q.d_zlat) {
+#endif
                 dump_only<P>(G, q.g_x0 + off_view, valid);  // dY of lin_in and lin_z[0] (and of lin_z[b]: g_fc1[b-1])
                 continue;
             }
@@ -835,14 +828,41 @@ latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat,
 }
 
 // dL/dz through the network inputs; one wavefront per (view, point).
+// ranks == nullptr: every point, the result is accumulated into d_z[point].
+// ranks (R, Kfd): only the depth samples (the ones whose position carries gradient, nerf.py:157-160,292): wave =
+// (view, ray, j), point = ray * K + ranks[ray][j]; the total dL/dz of that sample -- this network term plus the compositing
+// term dz_comp -- goes through the clamp z = max(min(depth + n * std, far), near) into contrib[view][ray][j].
+struct DepthSamples {
+    const int *ranks;        // (R, Kfd) position of each depth sample in the sorted z, or null
+    const float *n4;         // (R, Kfd) the normal draws
+    const float *depth_c;    // (R) coarse depth
+    const float *dz_comp;    // (R, K) compositing dL/dz (nullable)
+    float *contrib;          // (NS, R, Kfd) out: what sample j of ray r sends to d_depth[r] through view v (summed by the caller
+                             // in a fixed order: the result stays bit-reproducible)
+    float depth_std;
+    int Kfd;
+};
+
 __global__ void __launch_bounds__(CW * 64)
 position_bwd_kernel(const EvalParams q, const float *__restrict__ d_in42, const float *__restrict__ d_zlat,
-                    float *__restrict__ d_z) {
+                    float *__restrict__ d_z, const DepthSamples ds) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * CW + wv;  // view * P + point
-    if (idx >= q.P * q.NS) return;
-    const int view = (int)(idx / q.P);
-    const int g = (int)(idx % q.P);
+    const long long widx = (long long)blockIdx.x * CW + wv;
+    int view, g, jd = 0;
+    if (ds.ranks) {  // (view, ray, j)
+        const long long per_view = (long long)(q.P / q.K) * ds.Kfd;
+        if (widx >= per_view * q.NS) return;
+        view = (int)(widx / per_view);
+        const long long rj = widx - (long long)view * per_view;
+        const int ray_i = (int)(rj / ds.Kfd);
+        jd = (int)(rj - (long long)ray_i * ds.Kfd);
+        g = ray_i * q.K + ds.ranks[(size_t)ray_i * ds.Kfd + jd];
+    } else {         // view * P + point
+        if (widx >= q.P * q.NS) return;
+        view = (int)(widx / q.P);
+        g = (int)(widx % q.P);
+    }
+    const long long idx = (long long)view * q.P + g;
     const int r = g / q.K;
     const float *ray = q.rays + (size_t)r * 8;
     const float zz = q.z[g];
@@ -921,8 +941,15 @@ position_bwd_kernel(const EvalParams q, const float *__restrict__ d_in42, const 
         const float wx = pose[0] * g0 + pose[4] * g1 + pose[8] * g2;
         const float wy = pose[1] * g0 + pose[5] * g1 + pose[9] * g2;
         const float wz = pose[2] * g0 + pose[6] * g1 + pose[10] * g2;
-        const float val = ray[3] * wx + ray[4] * wy + ray[5] * wz;
-        if (val == val) atomicAdd(d_z + g, val);
+        float val = ray[3] * wx + ray[4] * wy + ray[5] * wz;
+        if (!ds.ranks) {
+            if (val == val) atomicAdd(d_z + g, val);
+        } else {
+            if (view == 0 && ds.dz_comp) val += ds.dz_comp[g];
+            const float zraw = ds.depth_c[r] + ds.n4[(size_t)r * ds.Kfd + jd] * ds.depth_std;
+            const bool live = zraw < ray[7] && zraw > ray[6];  // inside the clamp: gradient passes (nerf.py:157-160)
+            ds.contrib[widx] = (live && val == val) ? val : 0.f;
+        }
     }
 }
 #pragma clang fp contract(fast)
@@ -1009,6 +1036,11 @@ __global__ void __launch_bounds__(1024) grad_scale_kernel(const float *__restric
     }
 }
 
+extern "C" size_t pnr_train_masks_bytes(long long P, int NS) {
+    if (P <= 0 || NS <= 0) return 0;
+    return (size_t)11 * (size_t)NS * (size_t)((P + MT - 1) / MT) * NTHREADS * sizeof(unsigned long long);
+}
+
 extern "C" int pnr_grad_scale(const float *g, long long n, float *scales, void *stream) {
     if (!g || !scales || n <= 0) return pnr_fail(PNR_E_INVALID, "pnr_grad_scale: bad argument");
     hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, scales);
@@ -1020,18 +1052,19 @@ extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const Pnr
                                 const PnrBackwardDumps *out, void *stream) {
     if (!packed_bwd || !fwd || !g_out || !out || P <= 0 || NS <= 0 || (!grad_scale_dev && !(grad_scale > 0.f)))
         return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: bad argument");
-    if (P > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: too many points");
+    if (P > 0x7fffffc0LL || (P + MT - 1) / MT * NS * NTHREADS > 0xffffffffLL)
+        return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: too many points");
     BwdParams q = {};
     q.wstream = (const char *)packed_bwd;
     q.g_out = g_out; q.scale = grad_scale; q.scale_dev = grad_scale_dev; q.P = P; q.NS = NS; q.ntiles = (int)((P + MT - 1) / MT);
-    q.d_x5 = (const char *)fwd->d_x5; q.g_x0 = (char *)out->g_x0;
+    q.d_mask = (const unsigned long long *)fwd->d_mask; q.g_x0 = (char *)out->g_x0;
     q.d_zlat = out->d_zlat; q.d_in = out->d_in;
     if (q.d_in && !q.d_zlat) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: d_in needs d_zlat (they are produced together)");
-    if (!q.d_x5 || !q.g_x0) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: null dump");
+    if (!q.d_mask) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: the forward dumps carry no relu bit masks (PnrTrainDumps.d_mask)");
+    if (!q.g_x0) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: null dump");
     for (int b = 0; b < 5; ++b) {
-        q.d_a[b] = (const char *)fwd->d_a[b]; q.d_n[b] = (const char *)fwd->d_n[b];
         q.g_fc1[b] = (char *)out->g_fc1[b]; q.g_fc0[b] = (char *)out->g_fc0[b];
-        if (!q.d_a[b] || !q.d_n[b] || !q.g_fc1[b] || !q.g_fc0[b]) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: null dump");
+        if (!q.g_fc1[b] || !q.g_fc0[b]) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: null dump");
     }
     const bool mv = NS > 1;
     const int grid = q.ntiles < bwd_num_cus() ? q.ntiles : bwd_num_cus();
@@ -1198,8 +1231,28 @@ extern "C" int pnr_position_backward(const PnrScene *s, const float *rays, const
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
     const long long n = q.P * q.NS;
     hipLaunchKernelGGL(position_bwd_kernel, dim3((unsigned)((n + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream, q,
-                       d_in42, d_zlat, d_z);
+                       d_in42, d_zlat, d_z, DepthSamples{});
     return pnr_check_launch("pnr_position_backward");
+}
+
+extern "C" int pnr_depth_sample_backward(const PnrScene *s, const float *rays, const float *z, int R, int rays_per_obj, int K,
+                                         const int *ranks, const float *n4, int Kfd, const float *depth_c, float depth_std,
+                                         const float *d_in42, const float *d_zlat, const float *dz_comp, float *contrib,
+                                         void *stream) {
+    if (!s || !rays || !z || !ranks || !n4 || !depth_c || !d_in42 || !d_zlat || !contrib || R <= 0 || K <= 0 || Kfd <= 0 ||
+        Kfd > K || rays_per_obj <= 0)
+        return pnr_fail(PNR_E_INVALID, "pnr_depth_sample_backward: bad argument");
+    if ((long long)rays_per_obj * s->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_depth_sample_backward: R != SB * rays_per_obj");
+    EvalParams q = {};
+    q.latent = s->latent_nhwc; q.poses = s->poses; q.focal = s->focal; q.c = s->c;
+    q.SB = s->SB; q.NS = s->NS; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
+    q.img_w = s->img_w; q.img_h = s->img_h;
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
+    DepthSamples ds = {ranks, n4, depth_c, dz_comp, contrib, depth_std, Kfd};
+    const long long n = (long long)R * Kfd * q.NS;
+    hipLaunchKernelGGL(position_bwd_kernel, dim3((unsigned)((n + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream, q,
+                       d_in42, d_zlat, nullptr, ds);
+    return pnr_check_launch("pnr_depth_sample_backward");
 }
 
 extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const float *z, int R, int rays_per_obj, int K,

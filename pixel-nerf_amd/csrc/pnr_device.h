@@ -66,6 +66,7 @@ struct EvalParams {
     // TRAIN instantiation: 16-bit row-major dumps of every linear layer's input operand
     // (rows = view*P + point for the per-view layers, point for the pooled ones)
     char *d_in;    // (NS*P, 64)   positional code + view direction (natural order, zero padded)
+    unsigned long long *d_mask;  // relu bit masks of the 11 dumped activations, [layer][view][tile][thread] (see relu_bits)
     char *d_z;     // (NS*P, 512)  interpolated latent (natural channel order)
     char *d_a[5];  // relu(x) in front of blocks[b].fc_0, storage order; b<3: (NS*P,512), else (P,512)
     char *d_n[5];  // relu(net) in front of blocks[b].fc_1, same shapes
@@ -252,9 +253,27 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT_], const char *smem, u
 // HBM (training: operands of the weight-gradient GEMMs and relu masks of the backward chain);
 // dump_lane = array + ((first row of the tile + p)*512 + 32*wave*IT + 16h) elements, valid[jt]
 // guards rows beyond the last point.
+// relu bit masks for the backward chain: bit (it*JT + jt)*16 + r of a thread's 64-bit word = "register r of its
+// accumulator tile (it, jt) was dumped as a non-zero 16-bit value" (the raw bits, like the dump itself would be tested).
+// 64 bytes per point and layer instead of re-reading the 1 KiB dump row: the backward kernel spent a third of its time
+// waiting for those rows.  v = the 8 packed 16-bit values of registers 8*half .. 8*half+7.
+template <typename T8>
+__device__ __forceinline__ uint32_t nonzero_bits8(const T8 &v) {
+    const u32x4 w = __builtin_bit_cast(u32x4, v);
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m |= ((w[k] & 0xffffu) ? 1u : 0u) << (2 * k);
+        m |= ((w[k] >> 16) ? 1u : 0u) << (2 * k + 1);
+    }
+    return m;
+}
+
 template <typename P, bool RELU = true, bool DUMP = false, int JT_>
 __device__ __forceinline__ void write_act(const f32x16 (&acc)[IT][JT_], char *smem, uint32_t waddr,
-                                          char *dump_lane = nullptr, const bool *valid = nullptr) {
+                                          char *dump_lane = nullptr, const bool *valid = nullptr,
+                                          unsigned long long *mask_slot = nullptr) {
+    unsigned long long mbits = 0ull;
 #pragma unroll
     for (int it = 0; it < IT; ++it)
 #pragma unroll
@@ -273,8 +292,11 @@ __device__ __forceinline__ void write_act(const f32x16 (&acc)[IT][JT_], char *sm
                     *reinterpret_cast<typename P::T8 *>(d) = lo;
                     *reinterpret_cast<typename P::T8 *>(d + 16) = hi;
                 }
+                if (RELU && mask_slot && IT * JT_ * 16 <= 64)
+                    mbits |= (unsigned long long)(nonzero_bits8(lo) | (nonzero_bits8(hi) << 8)) << ((it * JT_ + jt) * 16);
             }
         }
+    if (DUMP && RELU && mask_slot) *mask_slot = mbits;
 }
 
 template <bool INIT, int JT_>

@@ -194,14 +194,16 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
                                           uint32_t z_rd0, uint32_t z_rd1, uint32_t a_wr, int tid,
                                           unsigned long long *tim, unsigned long long &tlast,
                                           const EvalParams &q, size_t dump_off, const bool *valid, int wv, int lane,
-                                          f32x4 *park = nullptr, bool park_first = true, bool park_last = true, float park_inv = 1.f) {
+                                          uint32_t mask_off = 0, size_t mask_layer = 0, f32x4 *park = nullptr, bool park_first = true, bool park_last = true, float park_inv = 1.f) {
     typedef Advance<0, FOLD ? RS_VIEW_END_F : RS_VIEW_END, FOLD ? RS_TOTAL_F : RS_TOTAL> ADV;
     constexpr int JT = TL::JT;
     // dump_off: byte offset of this lane's 32-byte slot in a (rows,512) 16-bit dump array
+    // mask_off / mask_layer: this thread's word within a layer of q.d_mask / words per layer (layer 2b: x, 2b+1: net)
     // park (multi-view, last per-view block only): this thread's slots of the parked running view sum (see eval_kernel)
     __syncthreads();  // every wave is done reading LDS_A (previous fc_1)
     PNR_T(PH_BAR1);
-    write_act<P, true, TRAIN>(x, smem, a_wr, TRAIN ? q.d_a[b] + dump_off : nullptr, valid);
+    write_act<P, true, TRAIN>(x, smem, a_wr, TRAIN ? q.d_a[b] + dump_off : nullptr, valid,
+                              TRAIN ? q.d_mask + (size_t)(2 * b) * mask_layer + mask_off : nullptr);
     PNR_T(PH_WRITE_X);
     __syncthreads();
     PNR_T(PH_BAR2);
@@ -212,7 +214,8 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
         PNR_T(PH_GEMM_FC0);
         __syncthreads();  // every wave is done reading relu(x)
         PNR_T(PH_BAR3);
-        write_act<P, true, TRAIN>(net, smem, a_wr, TRAIN ? q.d_n[b] + dump_off : nullptr, valid);
+        write_act<P, true, TRAIN>(net, smem, a_wr, TRAIN ? q.d_n[b] + dump_off : nullptr, valid,
+                                  TRAIN ? q.d_mask + (size_t)(2 * b + 1) * mask_layer + mask_off : nullptr);
         PNR_T(PH_WRITE_NET);
     }
     __syncthreads();
@@ -319,9 +322,13 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
         f32x16 xsum[MV ? IT : 1][MV ? JT : 1];
 #endif
         const size_t dump_pooled = (((size_t)tile * MT + pl) * D_HID + (wv * IT) * 32 + h * 16) * 2;
+        // relu bit masks (training): [layer][view][tile][thread] words; pooled layers use view slot 0
+        const size_t mask_layer = (size_t)NS * (size_t)q.ntiles * NTHREADS;
+        const uint32_t mask_pooled = (uint32_t)tile * NTHREADS + tid;  // 32 bits: NS * tiles * 512 < 2^32 (host check)
 #pragma unroll 1
         for (int view = 0; view < NS; ++view) {
             const size_t dump_view = dump_pooled + (size_t)view * (size_t)q.P * (D_HID * 2);
+            const uint32_t mask_view = mask_pooled + (uint32_t)view * (uint32_t)q.ntiles * NTHREADS;
             __syncthreads();  // previous users of LDS_IN / LDS_META / LDS_Z are done
             PNR_T(PH_SYNC_TOP);
 #ifdef PNR_EXP_NO_FEATURE  // experiment: feature phase only for the first tile (stale LDS afterwards; wrong results)
@@ -353,7 +360,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b)
                 res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane);
+                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer);
             if constexpr (MV) {  // mean over source views (util.combine_interleaved, util.py:461-466)
                 const float inv = 1.f / (float)NS;
 #pragma unroll
@@ -370,12 +377,12 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 #pragma unroll 1
                 for (int b = 0; b < COMBINE_LAYER; ++b)
                     res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane);
+                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer);
             } else {
 #pragma unroll 1
             for (int b = 0; b + 1 < COMBINE_LAYER; ++b)
                 res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, true, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane);
+                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer);
             // last per-view block.  Multi-view: mean over source views (util.combine_interleaved, util.py:461-466) -- the
             // running view sum is PARKED in a per-workgroup scratch (q.mv_ws, [slot][thread] layout, each lane re-reads
             // only what it wrote itself: no synchronisation) instead of 64 live registers across three residual blocks;
@@ -383,7 +390,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             // summation order view 0 + view 1 + ...: deterministic.
             f32x4 *ws = MV ? reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid : nullptr;
             res_block<P, TIMING, TRAIN, FOLD, TL, MV>(x, smem, COMBINE_LAYER - 1, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, ws, view == 0,
+                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer, ws, view == 0,
                                                       view + 1 == NS, 1.f / (float)NS);
             }
 #endif
@@ -391,7 +398,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b)
             res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr, tid, tim, tlast,
-                                              q, dump_pooled, valid, wv, lane);
+                                              q, dump_pooled, valid, wv, lane, mask_pooled, mask_layer);
 
         if (q.dbg) {
 #pragma unroll
@@ -412,6 +419,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[jt][r] = 0.f;
             const char *pf = R.wave_base + (size_t)R.pf_rs * (IT * 1024);
+            [[maybe_unused]] unsigned long long x5_bits = 0ull;
 #pragma unroll
             for (int qk = 0; qk < 2 * IT; ++qk) {
                 const int xit = qk >> 1, rr = qk & 1;
@@ -426,6 +434,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                         if (valid[jt])
                             *reinterpret_cast<typename P::T8 *>(q.d_x5 + dump_pooled + (size_t)jt * 32 * (D_HID * 2) +
                                                                 xit * 64 + rr * 16) = bq;
+                        if (IT * JT * 16 <= 64) x5_bits |= (unsigned long long)nonzero_bits8(bq) << ((xit * JT + jt) * 16 + 8 * rr);
                     }
                     o[jt] = P::mfma(a, bq, o[jt]);
                 }
@@ -435,6 +444,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 #pragma unroll
                 for (int it = 0; it < IT; ++it) R.r[j][it] = gload8<P>(pf + j * (IT * 1024) + it * 1024);
             ADV::step4(R, NS);
+            if (TRAIN) {
+                (q.d_mask + (size_t)10 * mask_layer)[mask_pooled] = x5_bits;
+            }
             if (h == 0) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
@@ -669,6 +681,8 @@ extern "C" int pnr_eval_ray_samples_train(const PnrScene *scene, const void *pac
     pnr::EvalParams q = {};
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
     q.d_in = (char *)dumps->d_in; q.d_z = (char *)dumps->d_z; q.d_x5 = (char *)dumps->d_x5;
+    q.d_mask = (unsigned long long *)dumps->d_mask;
+    if (!q.d_mask) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_train: null relu-mask buffer (PnrTrainDumps.d_mask)");
     for (int b = 0; b < 5; ++b) {
         if (!dumps->d_a[b] || !dumps->d_n[b]) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_train: null dump buffer");
         q.d_a[b] = (char *)dumps->d_a[b]; q.d_n[b] = (char *)dumps->d_n[b];

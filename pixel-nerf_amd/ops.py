@@ -669,7 +669,7 @@ def storage_perm(device=None):
 
 
 class TrainDumps:
-    """16-bit dumps of every linear layer's input operand for P points x NS views."""
+    """16-bit dumps of every linear layer's input operand for P points x NS views, plus their relu bit masks."""
 
     def __init__(self, P, NS, precision, device):
         dt = torch.float16 if precision == _lib.PREC_F16 else torch.bfloat16
@@ -680,8 +680,10 @@ class TrainDumps:
         self.d_a = [torch.empty((rv if b < 3 else rp, 512), dtype=dt, device=device) for b in range(5)]
         self.d_n = [torch.empty((rv if b < 3 else rp, 512), dtype=dt, device=device) for b in range(5)]
         self.d_x5 = torch.empty((rp, 512), dtype=dt, device=device)
+        self.d_mask = torch.empty(_lib.load().pnr_train_masks_bytes(P, NS), dtype=torch.uint8, device=device)
         s = _lib.PnrTrainDumps()
         s.d_in, s.d_z, s.d_x5 = self.d_in.data_ptr(), self.d_z.data_ptr(), self.d_x5.data_ptr()
+        s.d_mask = self.d_mask.data_ptr()
         for b in range(5):
             s.d_a[b], s.d_n[b] = self.d_a[b].data_ptr(), self.d_n[b].data_ptr()
         self.struct = s
@@ -759,6 +761,32 @@ def position_backward(scene, rays, z, d_in42, d_zlat, d_z):
         _lib.check(lib.pnr_position_backward(scene.ref, _p(rays), _p(z), R, max(R // scene.SB, 1), K, _p(d_in42),
                                              _p(d_zlat), _p(d_z), _stream()), "pnr_position_backward")
     return d_z
+
+
+def depth_sample_backward(scene, rays, z, ranks, n4, depth_c, depth_std, d_in42, d_zlat, dz_comp):
+    """dL/d(coarse depth) (R,) through the depth samples of the fine pass (nerf.py:157-160,292): network-input term
+    (positional code, projection + lookup) + compositing term dz_comp at the samples' sorted positions `ranks`, through
+    the clamp; the per-(view, ray, sample) terms are summed in a fixed order (bit-reproducible)."""
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z = _f32(z, "z", (R, None))
+    K = z.shape[1]
+    Kfd = ranks.shape[1]
+    if ranks.dtype != torch.int32 or not ranks.is_contiguous() or ranks.shape[0] != R:
+        raise ValueError("ranks must be a contiguous (R, Kfd) int32 tensor (ops.sample_fine(..., want_ranks=True))")
+    rows = scene.NS * R * K
+    n4 = _f32(n4, "n4", (R, Kfd))
+    depth_c = _f32(depth_c, "depth_c", (R,))
+    d_in42 = _f32(d_in42, "d_in42", (rows, 42))
+    d_zlat = _f32(d_zlat, "d_zlat", (rows, 512))
+    dz_comp = None if dz_comp is None else _f32(dz_comp, "dz_comp", (R, K))
+    contrib = torch.empty((scene.NS, R, Kfd), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.pnr_depth_sample_backward(scene.ref, _p(rays), _p(z), R, max(R // scene.SB, 1), K, _p(ranks), _p(n4), Kfd,
+                                                 _p(depth_c), float(depth_std), _p(d_in42), _p(d_zlat), _p(dz_comp), _p(contrib),
+                                                 _stream()), "pnr_depth_sample_backward")
+    return contrib.sum(dim=(0, 2))
 
 
 def grad_scale(g):

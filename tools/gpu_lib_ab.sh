@@ -1,0 +1,12 @@
+#!/bin/bash
+# Generic A/B: run "$@" once with the default library and once per build/libpnr_*.so -> gpurun_out/lib_ab.txt
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+: > gpurun_out/lib_ab.txt
+shopt -s nullglob
+for lib in default build/libpnr_*.so; do
+    if [ "$lib" = default ]; then unset PIXELNERF_HIP_LIB; else export PIXELNERF_HIP_LIB="$PWD/$lib"; fi
+    echo "=== $lib" >> gpurun_out/lib_ab.txt
+    timeout 200 "$@" 2>&1 | grep -v amdgpu.ids >> gpurun_out/lib_ab.txt
+done
+cat gpurun_out/lib_ab.txt
