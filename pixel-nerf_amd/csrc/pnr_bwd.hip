@@ -145,15 +145,18 @@ __device__ __forceinline__ void zero_acc(f32x16 (&a)[IT][JT]) {
 template <typename P>
 __device__ __forceinline__ void bwd_block(f32x16 (&G)[IT][JT], char *smem, int b, Ring<P> &R, int NS, const BwdParams &q,
                                           size_t off, const bool *valid, uint32_t a_rd0, uint32_t a_rd1, uint32_t a_wr,
-                                          uint32_t mask_off, size_t mask_layer) {
+                                          uint32_t mask_off, size_t mask_layer, long long rows_left, int wv, int lane) {
 #ifdef PNR_EXP_BWD_NODUMP  // experiment (timing only): no gradient dumps
     constexpr bool DUMP = false;
 #else
     constexpr bool DUMP = true;
 #endif
+    // gradient dumps (operands of the weight-gradient GEMMs): copied out of the image behind the barrier, whole rows
+    const size_t off_tile = off - (size_t)(((lane & 31) * D_HID + (wv * IT) * 32 + (lane >> 5) * 16) * 2);
     __syncthreads();  // every wave is done reading the gradient image (previous GEMM)
-    write_act<P, false, DUMP>(G, smem, a_wr, q.g_fc1[b] + off, valid);
+    write_act<P, false, false>(G, smem, a_wr);
     __syncthreads();
+    if (DUMP) dump_image<MT>(smem, LDS_A, q.g_fc1[b] + off_tile, rows_left, wv, lane);
     f32x16 t[IT][JT];
     // mask_off / mask_layer: this thread's word within a layer of q.d_mask / words per layer (layer 2b: x, 2b+1: net)
     const unsigned long long mk_n = (q.d_mask + (size_t)(2 * b + 1) * mask_layer)[mask_off];
@@ -161,8 +164,9 @@ __device__ __forceinline__ void bwd_block(f32x16 (&G)[IT][JT], char *smem, int b
     gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
     apply_mask(t, mk_n);
     __syncthreads();
-    write_act<P, false, DUMP>(t, smem, a_wr, q.g_fc0[b] + off, valid);
+    write_act<P, false, false>(t, smem, a_wr);
     __syncthreads();
+    if (DUMP) dump_image<MT>(smem, LDS_A, q.g_fc0[b] + off_tile, rows_left, wv, lane);
     const unsigned long long mk_a = (q.d_mask + (size_t)(2 * b) * mask_layer)[mask_off];
     zero_acc(t);
     gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
@@ -211,6 +215,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
         __syncthreads();
         f32x16 G[IT][JT];
         const size_t mask_layer = (size_t)NS * (size_t)q.ntiles * NTHREADS;
+        const long long rows_left = q.P - (long long)tile * MT;
         const uint32_t mask_pooled = (uint32_t)tile * NTHREADS + tid;  // 32 bits: NS * tiles * 512 < 2^32 (host check)
         {
             const unsigned long long mk = (q.d_mask + (size_t)10 * mask_layer)[mask_pooled];
@@ -220,7 +225,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
         }
 #pragma unroll 1
         for (int b = N_BLOCKS - 1; b >= COMBINE_LAYER; --b)
-            bwd_block<P>(G, smem, b, R, NS, q, off_pooled, valid, a_rd0, a_rd1, a_wr, mask_pooled, mask_layer);
+            bwd_block<P>(G, smem, b, R, NS, q, off_pooled, valid, a_rd0, a_rd1, a_wr, mask_pooled, mask_layer, rows_left, wv, lane);
         f32x16 Gp[MV ? IT : 1][MV ? JT : 1];
         if constexpr (MV) {
             // backward of the view mean (util.py:461-466): every view receives G / NS
@@ -242,7 +247,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
 #pragma unroll 1
             for (int b = COMBINE_LAYER - 1; b >= 0; --b)
                 bwd_block<P>(G, smem, b, R, NS, q, off_view, valid, a_rd0, a_rd1, a_wr,
-                             mask_pooled + (uint32_t)view * (uint32_t)q.ntiles * NTHREADS, mask_layer);
+                             mask_pooled + (uint32_t)view * (uint32_t)q.ntiles * NTHREADS, mask_layer, rows_left, wv, lane);
 #ifdef PNR_EXP_BWD_NOZ  // experiment (timing only): no lin_z^T / lin_in^T section
             if (true) {
 #else
@@ -276,8 +281,10 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
                 gemm<P, AdvanceBwd>(Z, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);  // lin_z[b]^T dY_b
             }
             __syncthreads();
-            write_act<P, false, true>(G, smem, a_wr, q.g_x0 + off_view, valid);  // dY of lin_in and lin_z[0]
+            write_act<P, false, false>(G, smem, a_wr);  // dY of lin_in and lin_z[0]
             __syncthreads();
+            dump_image<MT>(smem, LDS_A, q.g_x0 + (size_t)view * (size_t)q.P * (D_HID * 2) + (size_t)tile * MT * (D_HID * 2), rows_left,
+                           wv, lane);
             gemm<P, AdvanceBwd>(Z, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);      // lin_z[0]^T dY_0
             {   // accumulator (channel 32T + (r&3) + 8(r>>2) + 4h, point) -> fp32 rows, 16-byte pieces
                 float *dst = q.d_zlat + ((size_t)view * (size_t)q.P + (size_t)tile * MT + pl) * C_LAT + (wv * IT) * 32 + 4 * h;

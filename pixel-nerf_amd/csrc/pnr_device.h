@@ -285,7 +285,7 @@ __device__ __forceinline__ void write_act(const f32x16 (&acc)[IT][JT_], char *sm
             *reinterpret_cast<typename P::T8 *>(smem + ad) = lo;
             *reinterpret_cast<typename P::T8 *>(smem + ad + 16) = hi;
             if (DUMP) {
-                if (valid[jt]) {
+                if (dump_lane && valid[jt]) {  // per-lane fragment stores (dump_lane == null: the caller copies the image, dump_image)
                     char *d = dump_lane + (size_t)jt * 32 * (D_HID * 2) + it * 64;
                     // plain stores: streaming (nontemporal) stores for the dumps + loads for the masks measured 5 % SLOWER
                     // on the training step -- the dumps are served to the backward kernels from the Infinity Cache
@@ -297,6 +297,28 @@ __device__ __forceinline__ void write_act(const f32x16 (&acc)[IT][JT_], char *sm
             }
         }
     if (DUMP && RELU && mask_slot) *mask_slot = mbits;
+}
+
+// Cooperative copy of an activation / gradient image (MT rows of 1 KiB, row stride ROW_ACT) to its (rows,512) 16-bit dump:
+// every wave instruction moves one whole row, 1 KiB contiguous in LDS and in HBM (8 full lines), instead of the 64 scattered
+// 16-byte pieces per instruction of the per-lane fragment stores.  Call after the barrier that publishes the image.
+// dst_tile = first row of this tile in the dump; rows_left = rows of the dump from there on.
+template <int MT_>
+__device__ __forceinline__ void dump_image(const char *smem, uint32_t image, char *dst_tile, long long rows_left, int wv, int lane) {
+    constexpr int RPW = MT_ / NW;  // rows per wave
+    static_assert(RPW % 4 == 0, "copied in batches of 4 rows");
+#pragma unroll
+    for (int u0 = 0; u0 < RPW; u0 += 4) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = *reinterpret_cast<const u32x4 *>(smem + image + (wv * RPW + u0 + u) * ROW_ACT + lane * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = wv * RPW + u0 + u;
+            if (row < rows_left) *reinterpret_cast<u32x4 *>(dst_tile + (size_t)row * (D_HID * 2) + lane * 16) = v[u];
+        }
+    }
 }
 
 template <bool INIT, int JT_>

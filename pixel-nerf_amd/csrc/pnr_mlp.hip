@@ -194,7 +194,7 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
                                           uint32_t z_rd0, uint32_t z_rd1, uint32_t a_wr, int tid,
                                           unsigned long long *tim, unsigned long long &tlast,
                                           const EvalParams &q, size_t dump_off, const bool *valid, int wv, int lane,
-                                          uint32_t mask_off = 0, size_t mask_layer = 0, f32x4 *park = nullptr, bool park_first = true, bool park_last = true, float park_inv = 1.f) {
+                                          uint32_t mask_off = 0, size_t mask_layer = 0, long long rows_left = 0, f32x4 *park = nullptr, bool park_first = true, bool park_last = true, float park_inv = 1.f) {
     typedef Advance<0, FOLD ? RS_VIEW_END_F : RS_VIEW_END, FOLD ? RS_TOTAL_F : RS_TOTAL> ADV;
     constexpr int JT = TL::JT;
     // dump_off: byte offset of this lane's 32-byte slot in a (rows,512) 16-bit dump array
@@ -202,11 +202,13 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
     // park (multi-view, last per-view block only): this thread's slots of the parked running view sum (see eval_kernel)
     __syncthreads();  // every wave is done reading LDS_A (previous fc_1)
     PNR_T(PH_BAR1);
-    write_act<P, true, TRAIN>(x, smem, a_wr, TRAIN ? q.d_a[b] + dump_off : nullptr, valid,
-                              TRAIN ? q.d_mask + (size_t)(2 * b) * mask_layer + mask_off : nullptr);
+    // training dumps: relu bit masks from the registers, the rows themselves copied out of the image behind the barrier
+    [[maybe_unused]] const size_t dump_tile = dump_off - (size_t)(((lane & 31) * D_HID + (wv * IT) * 32 + (lane >> 5) * 16) * 2);
+    write_act<P, true, TRAIN>(x, smem, a_wr, nullptr, valid, TRAIN ? q.d_mask + (size_t)(2 * b) * mask_layer + mask_off : nullptr);
     PNR_T(PH_WRITE_X);
     __syncthreads();
     PNR_T(PH_BAR2);
+    if constexpr (TRAIN) dump_image<TL::MT>(smem, TL::LDS_A, q.d_a[b] + dump_tile, rows_left, wv, lane);
     {
         f32x16 net[IT][JT];
         add_bias<true>(net, bias_lane, 1 + 2 * b);
@@ -214,12 +216,12 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
         PNR_T(PH_GEMM_FC0);
         __syncthreads();  // every wave is done reading relu(x)
         PNR_T(PH_BAR3);
-        write_act<P, true, TRAIN>(net, smem, a_wr, TRAIN ? q.d_n[b] + dump_off : nullptr, valid,
-                                  TRAIN ? q.d_mask + (size_t)(2 * b + 1) * mask_layer + mask_off : nullptr);
+        write_act<P, true, TRAIN>(net, smem, a_wr, nullptr, valid, TRAIN ? q.d_mask + (size_t)(2 * b + 1) * mask_layer + mask_off : nullptr);
         PNR_T(PH_WRITE_NET);
     }
     __syncthreads();
     PNR_T(PH_BAR4);
+    if constexpr (TRAIN) dump_image<TL::MT>(smem, TL::LDS_A, q.d_n[b] + dump_tile, rows_left, wv, lane);
     add_bias<false>(x, bias_lane, 2 + 2 * b);
     // multi-view pooling: the running sum of the previous views comes back from its scratch UNDER this GEMM (`net` is dead,
     // its registers hold the loads in flight), so the view boundary costs no exposed memory round trip
@@ -324,6 +326,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
         const size_t dump_pooled = (((size_t)tile * MT + pl) * D_HID + (wv * IT) * 32 + h * 16) * 2;
         // relu bit masks (training): [layer][view][tile][thread] words; pooled layers use view slot 0
         const size_t mask_layer = (size_t)NS * (size_t)q.ntiles * NTHREADS;
+        const long long rows_left = q.P - (long long)tile * MT;
         const uint32_t mask_pooled = (uint32_t)tile * NTHREADS + tid;  // 32 bits: NS * tiles * 512 < 2^32 (host check)
 #pragma unroll 1
         for (int view = 0; view < NS; ++view) {
@@ -360,7 +363,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b)
                 res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer);
+                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer, rows_left);
             if constexpr (MV) {  // mean over source views (util.combine_interleaved, util.py:461-466)
                 const float inv = 1.f / (float)NS;
 #pragma unroll
@@ -377,12 +380,12 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 #pragma unroll 1
                 for (int b = 0; b < COMBINE_LAYER; ++b)
                     res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer);
+                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer, rows_left);
             } else {
 #pragma unroll 1
             for (int b = 0; b + 1 < COMBINE_LAYER; ++b)
                 res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, true, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer);
+                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer, rows_left);
             // last per-view block.  Multi-view: mean over source views (util.combine_interleaved, util.py:461-466) -- the
             // running view sum is PARKED in a per-workgroup scratch (q.mv_ws, [slot][thread] layout, each lane re-reads
             // only what it wrote itself: no synchronisation) instead of 64 live registers across three residual blocks;
@@ -390,7 +393,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             // summation order view 0 + view 1 + ...: deterministic.
             f32x4 *ws = MV ? reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid : nullptr;
             res_block<P, TIMING, TRAIN, FOLD, TL, MV>(x, smem, COMBINE_LAYER - 1, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer, ws, view == 0,
+                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer, rows_left, ws, view == 0,
                                                       view + 1 == NS, 1.f / (float)NS);
             }
 #endif
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b)
             res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1, a_wr, tid, tim, tlast,
-                                              q, dump_pooled, valid, wv, lane, mask_pooled, mask_layer);
+                                              q, dump_pooled, valid, wv, lane, mask_pooled, mask_layer, rows_left);
 
         if (q.dbg) {
 #pragma unroll
