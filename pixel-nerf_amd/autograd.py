@@ -69,6 +69,9 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, rays, latent, *params):
+        # outputs the loss does not use (depths, weights) arrive in backward as None, not as zero tensors torch would
+        # have to fill and the compositing backward would have to read
+        ctx.set_materialize_grads(False)
         net, noise = cfg["net"], cfg["noise"]
         Kc, Kf, Kfd = cfg["n_coarse"], cfg["n_fine"], cfg["n_fine_depth"]
         scene = net.scene()
@@ -151,6 +154,7 @@ class _PointsFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, xyz, viewdirs, latent, *params):
+        ctx.set_materialize_grads(False)
         net, coarse = cfg["net"], cfg["coarse"]
         scene = net.scene()
         R = xyz.shape[0]
@@ -165,6 +169,8 @@ class _PointsFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * (4 + len(PARAM_NAMES))
         (out,) = ctx.saved_tensors
         net, coarse = ctx.cfg["net"], ctx.cfg["coarse"]
         g = g.contiguous().float()

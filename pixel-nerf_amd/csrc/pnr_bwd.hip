@@ -788,10 +788,11 @@ latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat,
         auto flush = [&](int c) {
 #pragma unroll
             for (int e = 0; e < CS; ++e) {
-                const float f = acc[c][e] * scale;
-                // |f| <= 8 * 2^41 for finite inputs; Inf / NaN gradients (a diverged step) are dropped here, they still
-                // poison the weight gradients through the other kernels
-                if (fabsf(f) < 9.0e18f && f != 0.f) atomicAdd(&slab[cur[c] * row + e], (unsigned long long)(long long)f);
+                // |f| <= 8 * 2^41 for finite inputs; Inf is clamped and NaN dropped here (a diverged step still poisons the
+                // weight gradients through the other kernels).  No per-element branch: the adds of a flush go out back to back
+                float f = acc[c][e] * scale;
+                f = f == f ? __builtin_amdgcn_fmed3f(f, -9.0e18f, 9.0e18f) : 0.f;
+                atomicAdd(&slab[cur[c] * row + e], (unsigned long long)(long long)f);
             }
         };
 #pragma unroll
