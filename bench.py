@@ -205,7 +205,7 @@ def extra_render_config(dev, prec, scene_name, n_img, n_oracle=128, n_f32=8192, 
     return out
 
 
-def extra_train_step(dev, prec, steps=20, warmup=8):
+def extra_train_step(dev, prec, steps=40, warmup=8):
     """BASELINE configs[4]: sn64 training step, 4 objects x 128 rays, 64 coarse + 32 fine (16 depth), ResnetFC d=512,
     forward + backward (+ Adam) through NeRFRenderer/_RenderWrapper in train mode (train/train.py:199-215)."""
     from pixelnerf_amd.model import make_model
@@ -244,7 +244,8 @@ def extra_train_step(dev, prec, steps=20, warmup=8):
         opt.step()
         return loss
 
-    for _ in range(warmup):
+    loss_first = float(step().item())
+    for _ in range(warmup - 1):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -254,7 +255,7 @@ def extra_train_step(dev, prec, steps=20, warmup=8):
     dt = (time.perf_counter() - t0) / steps
     out = {"workload": "sn64 training step: 4 objects x 128 rays, 64+32 (16 depth) samples, fwd+bwd+Adam, grads to both "
                        "ResnetFCs and encoder.latent", "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "rays_per_s": 512 / dt,
-           "algorithmic_tflops": 512 / dt * 3.29e9 / 1e12, "loss": float(loss.item()), "steps": steps,
+           "algorithmic_tflops": 512 / dt * 3.29e9 / 1e12, "loss_first_step": loss_first, "loss": float(loss.item()), "steps": steps,
            "launch_mode": "eager launches (one Python-sequenced HIP launch per kernel)"}
     # the same step captured ONCE into a HIP graph (torch.cuda.CUDAGraph: forward, backward and a capturable Adam) and
     # replayed: no per-kernel launch latency, no Python between the ~35 kernels.  Run as a CHILD process

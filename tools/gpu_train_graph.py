@@ -41,7 +41,7 @@ def main():
     rend = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).to(dev)
     render_par = rend.bind_parallel(net, None, simple_output=False).train()
     params = list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters())
-    opt = torch.optim.Adam(params, lr=1e-4, capturable=True)
+    opt = torch.optim.Adam(params, lr=1e-4, capturable=True, fused=True)  # the single-kernel form, as in bench.py
     static_loss = torch.zeros((), device=dev)
 
     def body(stage):
