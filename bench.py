@@ -484,9 +484,9 @@ def main():
         if world == 1 and not args.no_extras:
             # BASELINE configs[2..4] on this one GPU, outside the timed region
             extra = {}
-            for key, fn in (("srn_car", lambda: extra_render_config(dev, args.prec, "srn_car", 4)),
-                            ("dtu", lambda: extra_render_config(dev, args.prec, "dtu", 1)),
-                            ("train_step", lambda: extra_train_step(dev, args.prec))):
+            for key, fn in (("train_step", lambda: extra_train_step(dev, args.prec)),
+                            ("srn_car", lambda: extra_render_config(dev, args.prec, "srn_car", 4)),
+                            ("dtu", lambda: extra_render_config(dev, args.prec, "dtu", 1))):
                 try:
                     extra[key] = fn()
                 except Exception as e:  # an extra must never take the headline line down with it
