@@ -138,3 +138,20 @@ def test_folded_api_errors_and_saturation(ops, dev):
     assert torch.isfinite(tab_big.float()).all()
     out = ops.eval_points(sc, ops.pack_mlp(big, "f16", folded=True), xyz, vd, tables=tab_big)
     assert torch.isfinite(out).all()
+
+
+def test_tile_size_does_not_change_the_result(ops, dev):
+    """The folded single-view kernel runs 96-point tiles for long launches and 64-point tiles when that takes fewer
+    rounds (pnr_mlp.hip: use_tile96): 98 304 points in one launch (96-point tiles) against the same points in chunks of
+    8 192 (64-point tiles) -- a point's output does not depend on the tile it sits in, bit for bit."""
+    from testdata import synthetic
+    s, meta = scene_for("sn64")
+    sc = dscene(ops, dev, "sn64")
+    state = {k: v.to(dev) for k, v in mlp_params(12).items()}
+    pk, tab = ops.pack_mlp(state, "f16", folded=True), ops.fold_latent(sc, state, "f16")
+    rays = synthetic.target_rays(meta).reshape(-1, 8)[:1536].contiguous().to(dev)  # 1536 rays x 64 samples
+    z = ops.sample_coarse(rays, torch.rand(rays.shape[0], 64, device=dev, generator=torch.Generator(device=dev).manual_seed(3)))
+    whole = ops.eval_ray_samples(sc, pk, rays, z, tables=tab)
+    parts = [ops.eval_ray_samples(sc, pk, rays[i:i + 128].contiguous(), z[i:i + 128].contiguous(), tables=tab)
+             for i in range(0, rays.shape[0], 128)]
+    assert torch.equal(whole, torch.cat(parts, dim=0))
