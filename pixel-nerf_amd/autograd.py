@@ -59,7 +59,7 @@ def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS, want_d_in=False):
     grads["lin_out.weight"], grads["lin_out.bias"] = ops.lin_out_grad(g_out, fwd.d_x5, prec)
     # d z_lat = sum_b dY_b W_z[b] and d(code | viewdir) = dY W_in come out of the same fused chain (pnr_mlp_backward:
     # four more transposed-stream GEMMs on gradient images the kernel already holds), fp32, unscaled
-    return grads, bd.d_zlat, (bd.d_in if want_d_in else None)
+    return grads, bd.d_zlat, (bd.d_in if want_d_in else None), bd
 
 
 class _RenderFunction(torch.autograd.Function):
@@ -125,9 +125,7 @@ class _RenderFunction(torch.autograd.Function):
             d_pre, dz = cb if pos else (cb, None)
             g_out = d_pre.reshape(-1, 4)
             mlp = net.mlp_coarse if (ps["coarse"] or shared) else net.mlp_fine
-            state = dict(mlp.named_parameters())
-            grads, d_zlat, d_in = _mlp_grads(state, mlp.packed_bwd(net.precision), ps["dumps"], g_out, scene.NS,
-                                             want_d_in=pos)
+            grads, d_zlat, d_in, bd = _mlp_grads(None, mlp.packed_bwd(net.precision), ps["dumps"], g_out, scene.NS, want_d_in=pos)
             slot = 0 if (ps["coarse"] or shared) else 1
             gsum[slot] = grads if gsum[slot] is None else {k: gsum[slot][k] + v for k, v in grads.items()}
             if need_latent:
@@ -137,6 +135,10 @@ class _RenderFunction(torch.autograd.Function):
                 # sorted positions, through the clamp z = max(min(depth + n*std, far), near)   (nerf.py:157-160,292)
                 extra_depth = ops.depth_sample_backward(scene, rays, ps["z"], ps["ranks"], ps["n4"], ps["depth_c"],
                                                         cfg["depth_std"], d_in, d_zlat, dz)
+            # every consumer of this pass's dumps is enqueued: the sets go back to the pool (same-stream reuse)
+            bd.release()
+            ps["dumps"].release()
+            ps["dumps"] = None
         ctx.passes = None  # release the 16-bit operand dumps (~12 KB per point and view) as soon as they are used
         out = [None, None, d_lat.permute(0, 3, 1, 2).contiguous() if need_latent else None]
         n_each = len(PARAM_NAMES)
@@ -177,13 +179,15 @@ class _PointsFunction(torch.autograd.Function):
         # through the output activations (models.py:260-265): rgb = sigmoid(.), sigma = relu(.)
         d_pre = torch.cat([g[:, :3] * out[:, :3] * (1.0 - out[:, :3]), g[:, 3:] * (out[:, 3:] > 0).float()], dim=1).contiguous()
         mlp = net.mlp_coarse if (coarse or net.mlp_fine is None) else net.mlp_fine
-        grads, d_zlat, _ = _mlp_grads(dict(mlp.named_parameters()), mlp.packed_bwd(net.precision), ctx.dumps, d_pre, ctx.scene.NS)
+        grads, d_zlat, _, bd = _mlp_grads(None, mlp.packed_bwd(net.precision), ctx.dumps, d_pre, ctx.scene.NS)
         d_lat = None
         if ctx.needs_input_grad[3]:
             n, c, hl, wl = ctx.latent_shape
             d_lat = torch.zeros((n, hl, wl, c), dtype=torch.float32, device=g.device)
             ops.latent_scatter(ctx.scene, ctx.rays, ctx.z, d_zlat, d_lat)
             d_lat = d_lat.permute(0, 3, 1, 2).contiguous()
+        bd.release()
+        ctx.dumps.release()
         ctx.dumps = None
         return (None, None, None, d_lat) + tuple(grads[n] for n in PARAM_NAMES)
 
@@ -198,9 +202,8 @@ def points_autograd(net, xyz, viewdirs, coarse):
     if net.stop_encoder_grad:
         latent = latent.detach()
     mlp = net.mlp_coarse if (coarse or net.mlp_fine is None) else net.mlp_fine
-    named = dict(mlp.named_parameters())
     out = _PointsFunction.apply(dict(net=net, coarse=coarse), xyz.reshape(-1, 3).float().contiguous(),
-                                viewdirs.reshape(-1, 3).float().contiguous(), latent, *[named[n] for n in PARAM_NAMES])
+                                viewdirs.reshape(-1, 3).float().contiguous(), latent, *mlp.ordered_params(PARAM_NAMES))
     return out.reshape(SB, B, 4)
 
 
@@ -217,8 +220,7 @@ def render_autograd(renderer, net, rays, noise, want_weights):
     mlps = [net.mlp_coarse] + ([net.mlp_fine] if net.mlp_fine is not None else [])
     params = []
     for m in mlps:
-        named = dict(m.named_parameters())
-        params += [named[n] for n in PARAM_NAMES]
+        params += m.ordered_params(PARAM_NAMES)
     outs = _RenderFunction.apply(cfg, rays, latent, *params)
     res = {"coarse": {"rgb": outs[0], "depth": outs[1], "weights": outs[2]}}
     if Kf > 0:

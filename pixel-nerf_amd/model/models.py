@@ -170,7 +170,8 @@ class PixelNeRFNet(torch.nn.Module):
 
     def _wants_grad(self):
         lat = getattr(self.encoder, "latent", None)
-        return torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+        return torch.is_grad_enabled() and (self.mlp_coarse.any_requires_grad()
+                                            or (self.mlp_fine is not None and self.mlp_fine.any_requires_grad())
                                             or (torch.is_tensor(lat) and lat.requires_grad))
 
     # ------------------------------------------------------------------ forward (HIP)

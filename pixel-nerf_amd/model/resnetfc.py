@@ -71,13 +71,63 @@ class ResnetFC(nn.Module):
                 and self.d_hidden == 512 and self.combine_layer == 3 and self.combine_type == "average"
                 and not self.use_spade)
 
+    _CACHE_KEYS = ("_named_cache", "_ordered_cache", "_wstruct_cache")
+
+    def __getstate__(self):
+        # copies / pickles start with empty caches (the weight struct holds raw device pointers of THIS module's storage)
+        d = dict(self.__dict__)
+        for k in self._CACHE_KEYS:
+            d.pop(k, None)
+        d["_packed"] = {}
+        return d
+
+    # ---- host-side caches.  A training step re-packs both networks twice (forward + transposed streams); walking the
+    # module tree for state_dict() / named_parameters() every time cost more host time than the pack kernels take on the GPU.
+    def _named(self):
+        """[(state_dict key, Parameter)] in registration order, cached (dropped by .to() / .cuda() / ._apply)."""
+        c = self.__dict__.get("_named_cache")
+        if c is None:
+            c = list(self.named_parameters())
+            self.__dict__["_named_cache"] = c
+        return c
+
+    def ordered_params(self, names):
+        """the parameters in the order of `names` (autograd.PARAM_NAMES), cached per name list"""
+        c = self.__dict__.get("_ordered_cache")
+        if c is None or c[0] is not names:
+            d = dict(self._named())
+            c = (names, [d[n] for n in names])
+            self.__dict__["_ordered_cache"] = c
+        return c[1]
+
+    def _apply(self, fn, *args, **kwargs):
+        for k in self._CACHE_KEYS:
+            self.__dict__.pop(k, None)
+        self.__dict__.get("_packed", {}).clear()
+        return super()._apply(fn, *args, **kwargs)
+
+    def any_requires_grad(self):
+        return any(p.requires_grad for _, p in self._named())
+
     def _fingerprint(self):
-        return (_OPTIMIZER_STEPS[0],) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (_OPTIMIZER_STEPS[0],) + tuple((p.data_ptr(), p._version) for _, p in self._named())
+
+    def _wstruct(self):
+        """(PnrMlpWeights, tensors) of the current parameter storage: the struct holds pointers only, so it survives
+        in-place updates and is rebuilt only when a parameter moved."""
+        key = tuple(p.data_ptr() for _, p in self._named())
+        c = self.__dict__.get("_wstruct_cache")
+        if c is None or c[0] != key:
+            c = (key, ops._weights_struct({k: p for k, p in self._named()}))
+            self.__dict__["_wstruct_cache"] = c
+        return c[1]
 
     def invalidate_packed(self):
         """Drop the packed streams (for parameter writes that neither bump tensor._version nor go through a
         torch.optim optimizer, e.g. a custom kernel writing through data_ptr())."""
         self._packed.clear()
+        for k in self._CACHE_KEYS:
+            self.__dict__.pop(k, None)
 
     def packed(self, precision="f16", folded=False):
         if not self.supported():
@@ -88,8 +138,9 @@ class ResnetFC(nn.Module):
         key = (precision, bool(folded))
         hit = self._packed.get(key)
         if hit is None or hit[0] != fp:
-            state = {k: v for k, v in self.state_dict().items()}
-            self._packed[key] = (fp, ops.pack_mlp(state, precision, folded=folded))
+            # the previous stream's buffer is overwritten in place (its users are earlier launches on the same stream)
+            self._packed[key] = (fp, ops.pack_mlp(None, precision, folded=folded, weights=self._wstruct(),
+                                                  out=None if hit is None else hit[1]))
         return self._packed[key][1]
 
     def packed_bwd(self, precision="f16"):
@@ -98,7 +149,8 @@ class ResnetFC(nn.Module):
         key = ("bwd", precision)
         hit = self._packed.get(key)
         if hit is None or hit[0] != fp:
-            self._packed[key] = (fp, ops.pack_mlp(dict(self.state_dict()), precision, backward=True))
+            self._packed[key] = (fp, ops.pack_mlp(None, precision, backward=True, weights=self._wstruct(),
+                                                  out=None if hit is None else hit[1]))
         return self._packed[key][1]
 
     def forward(self, zx, combine_inner_dims=(1,), combine_index=None, dim_size=None):

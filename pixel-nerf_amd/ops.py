@@ -92,14 +92,16 @@ def _weights_struct(state):
     return w, keep
 
 
-def pack_mlp(state, precision="f16", backward=False, folded=False):
+def pack_mlp(state, precision="f16", backward=False, folded=False, weights=None, out=None):
     """state: {reference ResnetFC state_dict key: float32 HIP tensor}
     (src/model/resnetfc.py:66-130: lin_in, lin_out, blocks.N.fc_0/fc_1, lin_z.N).
     backward=True packs the transposed streams of the data-gradient chain instead;
-    folded=True packs the inference stream without the lin_z GEMMs (use with fold_latent)."""
+    folded=True packs the inference stream without the lin_z GEMMs (use with fold_latent).
+    weights: a cached _weights_struct(state) result (the struct only holds pointers: it stays valid while the parameters
+    are updated in place); out: a PackedMLP of the same form whose buffer is overwritten (same stream: ordered)."""
     lib = _lib.load()
     prec = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
-    w, keep = _weights_struct(state)
+    w, keep = weights if weights is not None else _weights_struct(state)
     if prec == _lib.PREC_F32:
         if backward:
             raise _lib.PixelNerfHipError("precision='f32' has no backward path")
@@ -116,7 +118,9 @@ def pack_mlp(state, precision="f16", backward=False, folded=False):
     if backward and folded:
         raise ValueError("the backward streams have no folded form")
     nbytes = lib.pnr_packed_mlp_bwd_bytes() if backward else lib.pnr_packed_mlp_bytes()
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    reuse = (out is not None and out.buf is not None and out.precision == prec and out.folded == bool(folded)
+             and out.buf.numel() == nbytes and out.buf.device == dev)
+    buf = out.buf if reuse else torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         if backward:
             _lib.check(lib.pnr_pack_mlp_bwd(ctypes.byref(w), prec, _p(buf), _stream()), "pnr_pack_mlp_bwd")
@@ -124,7 +128,7 @@ def pack_mlp(state, precision="f16", backward=False, folded=False):
             _lib.check(lib.pnr_pack_mlp_folded(ctypes.byref(w), prec, _p(buf), _stream()), "pnr_pack_mlp_folded")
         else:
             _lib.check(lib.pnr_pack_mlp(ctypes.byref(w), prec, _p(buf), _stream()), "pnr_pack_mlp")
-    return PackedMLP(buf, prec, folded=folded)
+    return out if reuse else PackedMLP(buf, prec, folded=folded)
 
 
 def fold_latent(scene, state, precision="f16"):
@@ -668,8 +672,39 @@ def storage_perm(device=None):
     return torch.tensor(list(arr), dtype=torch.long, device=device)
 
 
+# Dump sets are recycled: a training step allocates the same ~50 tensors (1.2 GB at config-5 sizes) every step, and the
+# host time of those allocations is comparable to the GPU time of a small kernel each.  acquire() hands out a free set of
+# the right shape or builds one; the autograd Functions release() a set once its last consumer is enqueued (same-stream
+# ordering makes the reuse safe).  A set that is never released is simply garbage-collected.
+_DUMP_POOL = {}
+
+
+def _pool_get(key):
+    free = _DUMP_POOL.get(key)
+    return free.pop() if free else None
+
+
+def _pool_put(key, obj, limit=4):
+    free = _DUMP_POOL.setdefault(key, [])
+    if len(free) < limit:
+        free.append(obj)
+
+
 class TrainDumps:
     """16-bit dumps of every linear layer's input operand for P points x NS views, plus their relu bit masks."""
+
+    @classmethod
+    def acquire(cls, P, NS, precision, device):
+        key = ("fwd", int(P), int(NS), int(precision), str(device))
+        obj = _pool_get(key)
+        if obj is None:
+            obj = cls(P, NS, precision, device)
+            obj._pool_key = key
+        return obj
+
+    def release(self):
+        if getattr(self, "_pool_key", None) is not None:
+            _pool_put(self._pool_key, self)
 
     def __init__(self, P, NS, precision, device):
         dt = torch.float16 if precision == _lib.PREC_F16 else torch.bfloat16
@@ -693,6 +728,19 @@ class BackwardDumps:
     """Outputs of the fused data-gradient chain: every layer's dY (16-bit rows, operands of the weight-gradient GEMMs)
     plus, in fp32, d(interpolated latent) = sum_b dY_b W_z[b] and d(code | viewdir) = dY W_in."""
 
+    @classmethod
+    def acquire(cls, fwd, device):
+        key = ("bwd", int(fwd.P), int(fwd.NS), str(fwd.dtype), str(device))
+        obj = _pool_get(key)
+        if obj is None:
+            obj = cls(fwd, device)
+            obj._pool_key = key
+        return obj
+
+    def release(self):
+        if getattr(self, "_pool_key", None) is not None:
+            _pool_put(self._pool_key, self)
+
     def __init__(self, fwd, device):
         self.g_fc1 = [torch.empty_like(t) for t in fwd.d_n]
         self.g_fc0 = [torch.empty_like(t) for t in fwd.d_a]
@@ -715,7 +763,7 @@ def eval_ray_samples_train(scene, packed, rays, z):
     R = rays.shape[0]
     z = _f32(z, "z", (R, None))
     K = z.shape[1]
-    dumps = TrainDumps(R * K, scene.NS, packed.precision, rays.device)
+    dumps = TrainDumps.acquire(R * K, scene.NS, packed.precision, rays.device)
     out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
     with torch.cuda.device(rays.device):
         _lib.check(lib.pnr_eval_ray_samples_train(scene.ref, packed.ptr, packed.precision, _p(rays), _p(z), R,
@@ -804,7 +852,7 @@ def mlp_backward(packed_bwd, fwd_dumps, g_out, grad_scale):
     """grad_scale: python float, or a 1-element device tensor (e.g. ops.grad_scale(g_out)[0:1])."""
     lib = _lib.load()
     g_out = _f32(g_out, "g_out", (fwd_dumps.P, 4))
-    out = BackwardDumps(fwd_dumps, g_out.device)
+    out = BackwardDumps.acquire(fwd_dumps, g_out.device)
     dev_scale = grad_scale if isinstance(grad_scale, torch.Tensor) else None
     with torch.cuda.device(g_out.device):
         _lib.check(lib.pnr_mlp_backward(packed_bwd.ptr, packed_bwd.precision, ctypes.byref(fwd_dumps.struct), _p(g_out),

@@ -178,8 +178,8 @@ class NeRFRenderer(torch.nn.Module):
                 raise NotImplementedError("noise_std > 0 (unused by every shipped config) is not fused")
             model._check_supported()
             needs_grad = torch.is_grad_enabled() and (
-                any(p.requires_grad for p in model.mlp_coarse.parameters())
-                or (model.mlp_fine is not None and any(p.requires_grad for p in model.mlp_fine.parameters()))
+                model.mlp_coarse.any_requires_grad()
+                or (model.mlp_fine is not None and model.mlp_fine.any_requires_grad())
                 or (model.encoder.latent.requires_grad and not model.stop_encoder_grad))
             if needs_grad:  # training: differentiable path (HIP forward with operand dumps + HIP backward)
                 from ..autograd import render_autograd
