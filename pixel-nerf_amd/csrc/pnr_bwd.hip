@@ -4,15 +4,19 @@
 //                         forward kernel (persistent 512-thread workgroup, 64-point tiles, wave w
 //                         owns features 64w..64w+63, gradient of the residual stream resident in
 //                         fp32 accumulators), driven by a TRANSPOSED weight stream
-//                         (lin_out^T, fc_1[b]^T, fc_0[b]^T, b = 4..0).  relu masks come from the
-//                         forward's 16-bit activation dumps; every layer's output gradient dY is
-//                         written as 16-bit rows for the weight-gradient GEMMs dW = dY^T X.
+//                         (lin_out^T, fc_1[b]^T, fc_0[b]^T, b = 4..0, then lin_z[2..0]^T and lin_in^T).
+//                         relu masks = the forward's 1-bit-per-element words; every layer's output
+//                         gradient dY leaves as whole 16-bit rows copied out of the LDS image
+//                         (operands of the weight-gradient GEMMs dW = dY^T X).
+//   dw_kernel             dW = dY^T X for all linears of a network in one launch (MFMA from the dumps
+//                         through transposing LDS reads), dw_reduce_kernel sums the row slices.
 //   composite_bwd_kernel  backward of the alpha compositing (nerf.py:223-249), wavefront per ray.
 //                         also emits dL/dz through the deltas and depth = sum w z.
-//   latent_scatter_kernel d(interpolated latent) -> d(feature grid): bilinear scatter-add.
+//   latent_scatter_*      d(interpolated latent) -> d(feature grid): bilinear scatter-add (small grids: a
+//                         64-bit fixed-point slab in LDS per (image, channel slice); large: global atomics).
 //   position_bwd_kernel   dL/dz through the network inputs (positional code, projection, bilinear
 //                         coordinates): the reference's position gradient through the n_fine_depth
-//                         samples (nerf.py:292).
+//                         samples (nerf.py:292), for all points or for the depth samples only.
 #include <hip/hip_runtime.h>
 
 #include "pnr_common.h"
