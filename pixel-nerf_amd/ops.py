@@ -677,17 +677,30 @@ def storage_perm(device=None):
 # the right shape or builds one; the autograd Functions release() a set once its last consumer is enqueued (same-stream
 # ordering makes the reuse safe).  A set that is never released is simply garbage-collected.
 _DUMP_POOL = {}
+_DUMP_POOL_BYTES = [0]
+DUMP_POOL_MAX_BYTES = 16 << 30  # sets beyond this total are not kept (they go back to torch's allocator)
 
 
 def _pool_get(key):
     free = _DUMP_POOL.get(key)
-    return free.pop() if free else None
+    if not free:
+        return None
+    obj = free.pop()
+    _DUMP_POOL_BYTES[0] -= obj.nbytes
+    return obj
 
 
-def _pool_put(key, obj, limit=4):
-    free = _DUMP_POOL.setdefault(key, [])
-    if len(free) < limit:
-        free.append(obj)
+def _pool_put(key, obj):
+    if _DUMP_POOL_BYTES[0] + obj.nbytes > DUMP_POOL_MAX_BYTES:
+        return
+    _DUMP_POOL.setdefault(key, []).append(obj)
+    _DUMP_POOL_BYTES[0] += obj.nbytes
+
+
+def dump_pool_clear():
+    """Drop the recycled dump sets (e.g. after the last training step of a process that goes on to do something else)."""
+    _DUMP_POOL.clear()
+    _DUMP_POOL_BYTES[0] = 0
 
 
 class TrainDumps:
@@ -700,10 +713,12 @@ class TrainDumps:
         if obj is None:
             obj = cls(P, NS, precision, device)
             obj._pool_key = key
+        obj._free = False
         return obj
 
     def release(self):
-        if getattr(self, "_pool_key", None) is not None:
+        if getattr(self, "_pool_key", None) is not None and not self._free:  # a second release of the same set is a no-op
+            self._free = True
             _pool_put(self._pool_key, self)
 
     def __init__(self, P, NS, precision, device):
@@ -719,6 +734,7 @@ class TrainDumps:
         s = _lib.PnrTrainDumps()
         s.d_in, s.d_z, s.d_x5 = self.d_in.data_ptr(), self.d_z.data_ptr(), self.d_x5.data_ptr()
         s.d_mask = self.d_mask.data_ptr()
+        self.nbytes = sum(t.numel() * t.element_size() for t in [self.d_in, self.d_z, self.d_x5, self.d_mask] + self.d_a + self.d_n)
         for b in range(5):
             s.d_a[b], s.d_n[b] = self.d_a[b].data_ptr(), self.d_n[b].data_ptr()
         self.struct = s
@@ -735,10 +751,12 @@ class BackwardDumps:
         if obj is None:
             obj = cls(fwd, device)
             obj._pool_key = key
+        obj._free = False
         return obj
 
     def release(self):
-        if getattr(self, "_pool_key", None) is not None:
+        if getattr(self, "_pool_key", None) is not None and not self._free:
+            self._free = True
             _pool_put(self._pool_key, self)
 
     def __init__(self, fwd, device):
@@ -748,6 +766,7 @@ class BackwardDumps:
         rows = fwd.d_z.shape[0]
         self.d_zlat = torch.empty((rows, 512), dtype=torch.float32, device=device)
         self.d_in = torch.empty((rows, 42), dtype=torch.float32, device=device)
+        self.nbytes = sum(t.numel() * t.element_size() for t in [self.g_x0, self.d_zlat, self.d_in] + self.g_fc1 + self.g_fc0)
         s = _lib.PnrBackwardDumps()
         s.g_x0 = self.g_x0.data_ptr()
         s.d_zlat, s.d_in = self.d_zlat.data_ptr(), self.d_in.data_ptr()
