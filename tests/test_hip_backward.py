@@ -460,3 +460,31 @@ def test_fused_optimizer_updates_reach_the_kernels(dev):
         assert losses[-1] < 0.9 * losses[0], (fused, losses)
     for a, b in zip(traj[False], traj[True]):
         assert abs(a - b) <= 2e-2 * abs(a), traj
+
+
+@pytest.mark.parametrize("scale", [1e-20, 1.0, 1e20])
+def test_latent_scatter_fixed_point_follows_the_gradient_scale(dev, scale):
+    """The LDS slab of the latent scatter is 64-bit fixed point at 2^40 / (workgroup's max |gradient|): the result must
+    be the same relative to the input scale from 1e-20 to 1e20, zeros stay zeros, and a few huge entries must not wipe
+    out ordinary ones (resolution 2^-40 of the max)."""
+    from helpers import scene_for
+    from pixelnerf_amd import ops
+    from testdata import synthetic
+    scene, meta = scene_for("mv_mini")
+    sc = ops.make_scene(scene["latent"].to(dev), scene["poses"].to(dev), scene["focal"].to(dev), scene["c"].to(dev),
+                        scene["image_shape"], scene["NS"])
+    gen = torch.Generator().manual_seed(5)
+    r = synthetic.target_rays(meta, n_rays=40).reshape(-1, 8)
+    z = O.sample_coarse(r, torch.rand(r.shape[0], 12, generator=gen), 12)
+    rows = scene["NS"] * r.shape[0] * 12
+    d = torch.randn(rows, 512, generator=gen)
+    d[::7] *= 1e4   # a wide dynamic range inside one slab
+    d[3] = 0.0
+    Hl, Wl = scene["latent"].shape[-2:]
+    ref = ops.latent_scatter(sc, r.to(dev), z.to(dev), d.to(dev), torch.zeros(4, Hl, Wl, 512, device=dev))
+    got = ops.latent_scatter(sc, r.to(dev), z.to(dev), (d * scale).to(dev), torch.zeros(4, Hl, Wl, 512, device=dev))
+    assert torch.isfinite(got).all()
+    err = (got / scale - ref).abs().max().item()
+    assert err <= 1e-5 * ref.abs().max().item(), err
+    zero = ops.latent_scatter(sc, r.to(dev), z.to(dev), torch.zeros_like(d).to(dev), torch.zeros(4, Hl, Wl, 512, device=dev))
+    assert not zero.any()
