@@ -193,8 +193,8 @@ int pnr_eval_points_f32(const PnrScene *scene /*host*/, const PnrMlpWeights *w /
  *             pnr_mlp_backward (fused data-gradient chain with transposed weight streams: consumes
  *             d(pre-activation output), writes the per-layer output gradients dY as 16-bit rows),
  *             pnr_latent_scatter (d interpolated latent -> d feature grid, bilinear scatter-add);
- *             the weight gradients dW = dY^T X are plain GEMMs over those dumps (library calls in
- *             the host layer).
+ *             pnr_weight_grad_batched / pnr_lin_out_grad (dW = dY^T X, db = sum dY from those dumps),
+ *             pnr_depth_sample_backward (the position gradient of the depth samples, nerf.py:292).
  * Array shapes: rows_v = NS*P for per-view layers (row = view*P + point), rows_p = P pooled;
  * 512-wide dims of activation dumps / gradients are in "storage order" (pnr_storage_perm). */
 typedef struct PnrTrainDumps {
@@ -305,8 +305,10 @@ int pnr_lin_out_grad(const float *g_out, const void *x5, long long P, int precis
                      float *db, void *workspace, void *stream);
 
 /* d(encoder.latent) += bilinear scatter of d_zlat (rows_v,512) fp32 (natural channel order) to
- * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (caller zero-initialises; accumulates).  Grids of up to 4608
- * texels per image are accumulated in LDS slabs (no global atomics), larger ones with global atomics. */
+ * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (caller zero-initialises; accumulates).  Grids of up to 5120
+ * texels per image (64 x 64 and smaller) are accumulated in LDS slabs -- 64-bit fixed point at 2^-40 of the
+ * workgroup's largest |gradient|, order-independent -- and reach HBM with one atomic per touched element and
+ * workgroup; larger grids use global fp32 atomics throughout.  (encoder.py:96-109 backward) */
 int pnr_latent_scatter(const PnrScene *scene /*host*/, const float *rays, const float *z, int R,
                        int rays_per_obj, int K, const float *d_zlat, float *d_latent_nhwc, void *stream);
 
