@@ -2,29 +2,39 @@
 """
 bench.py -- rays/sec of the pixelNeRF volume-rendering hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--prec f16|bf16] [--rays R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--prec f16x3|f16] [--rays R]
+                    [--workload sn64|dtu] [--bcast tree|flat]
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): sn64 NMR
-geometry, 64x64 target views, 1 source view, 64 coarse + 128 fine samples (112 importance +
-16 depth), separate coarse / fine ResnetFC (d_hidden 512, 5 blocks), synthetic feature grid
-and random-init weights (no datasets / checkpoints offline).  One step = one
-`render_par(rays)` call, exactly what eval/eval.py:277 times in the reference: R = 65536 rays
-(16 target views) per GPU, through NeRFRenderer/_RenderWrapper (noise draws included).
+Headline workload (BASELINE.json configs[1], the configuration the metric is quoted on): sn64 NMR geometry, 64x64 target
+views, 1 source view, 64 coarse + 128 fine samples (112 importance + 16 depth), separate coarse / fine ResnetFC
+(d_hidden 512, 5 blocks), synthetic feature grid and random-init weights (no datasets / checkpoints offline).  One step =
+one `render_par(rays)` call, exactly what eval/eval.py:277 times in the reference: R = 65536 rays (16 target views) per GPU,
+through NeRFRenderer/_RenderWrapper (noise draws included, lin_z re-folded into the grid inside every step).
 `value` = rays rendered by all ranks / wall time of the K timed steps (inputs resident in HBM).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling -- every rank
-renders its own R rays; each timed step also contains the single feature-grid broadcast from
-rank 0 and the final gather of (rgb, depth) to rank 0.
+PRECISION.  The reference computes in fp32 (nn.Linear, no autocast: src/model/resnetfc.py:147,175-180,55-62).  The timed
+headline therefore runs `precision="f16x3"` -- the fp32-CLASS fused kernel (pnr_split.hip: every operand a (head, tail)
+pair of fp16, three f16 MFMAs per product, fp32 accumulation and tables; per-point |rgb| <= 2e-5 against the reference's
+goldens, tests/test_hip_split.py) -- and `dtype` says so.  The 16-bit-operand kernel (`precision="f16"`, PSNR >= 52 dB
+against the reference) is timed in a second region of the same length and reported as a PEER block `f16_path`
+with its own roofline: faster, but narrower arithmetic than the reference, so it is not `value`.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling -- every rank renders its own R rays; each
+timed step also contains the single feature-grid broadcast from rank 0 and the final gather of (rgb, depth) to rank 0
+(SURVEY.md 8e).  The same run then times BASELINE configs[3] in its strong-scaling form (`extra.strong_dtu`: ONE DTU
+400x300 image, 3 source views, 176 MiB grid, its 120 000 rays sharded contiguously over the N ranks; step = grid broadcast
++ render + gather).  `--workload dtu` makes that form the headline instead (`scaling: "strong"`).
 
 The JSON line also carries
-  roofline     : the fused network kernel (>= 99 % of the work) against the dense MFMA peak:
-                 algorithmic FLOP of the launches in the timed region / their HIP-event time;
-  cpu_baseline : the CPU oracle (restatement of the reference, kind "port") timed on this
-                 host's cores on a bounded sample of the same workload, rank 0 / N=1 only;
-  psnr_db      : PSNR of the HIP render vs that CPU render on the sample (identical rays,
-                 weights, grid and noise) -- the "matched PSNR" of the metric;
-  psnr_db_full_size_vs_f32_hip : PSNR of one full step (all R rays) vs the exact-fp32 HIP path
-                 (precision "f32", ~1e-6 from the reference), outside the timed region.
+  roofline     : the fused network kernel (>= 99 % of the work) against the dense f16 MFMA peak: algorithmic FLOP of the
+                 launches in the timed region / their HIP-event time on the launch stream; executed_mfma_tflops counts the
+                 MFMAs really issued (3 per product for f16x3, lin_z folded away); traffic from the committed PMC passes;
+  cpu_baseline : the CPU restatement of the reference (oracle, kind "port", F.grid_sample like the reference) timed on this
+                 host's cores on a bounded sample of the same workload, rank 0 / N=1 only; cpu_baseline_config1 =
+                 BASELINE configs[0] verbatim (32 coarse, no fine pass, one 4096-ray call, CPU);
+  psnr_db      : PSNR of the timed path's render vs that CPU render on the sample (identical rays, weights, grid, noise);
+  latency_4096_rays_ms, encode_ms : SURVEY 8d's single-image latency and the encoder time (ResNet-34 trunk in
+                 PyTorch-ROCm + pnr_pyramid_to_latent), both outside `value`.
 """
 import argparse
 import json
@@ -37,10 +47,20 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_POINT_VIEW = 4.7616e6   # lin_in + 3 lin_z + 3 blocks, per (point, view)   SURVEY.md §8a
+FLOP_PER_POINT_VIEW = 4.7616e6   # lin_in + 3 lin_z + 3 blocks, per (point, view)   SURVEY.md 8a
 FLOP_PER_POINT_POOLED = 2.1012e6  # 2 blocks + lin_out, per point
-FLOP_LIN_Z_PER_POINT_VIEW = 3 * 2 * 512 * 512  # the three lin_z layers (folded into per-texel tables by default)
-PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0}  # dense MFMA peak, MI355X_MICROARCH.md
+FLOP_LIN_Z_PER_POINT_VIEW = 3 * 2 * 512 * 512  # the three lin_z layers (folded into per-texel tables at inference)
+PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak, MI355X_MICROARCH.md (both kernels issue v_mfma_f32_32x32x16_f16)
+MFMAS_PER_PRODUCT = {"f16": 1, "bf16": 1, "f16x3": 3}
+KERNEL_OF = {"f16": "pnr::eval_kernel", "bf16": "pnr::eval_kernel", "f16x3": "pnr::eval_split_kernel"}
+KERNEL_SOURCES = {"f16": ["pnr_mlp.hip", "pnr_device.h", "pnr_layout.h"], "bf16": ["pnr_mlp.hip", "pnr_device.h", "pnr_layout.h"],
+                  "f16x3": ["pnr_split.hip", "pnr_device.h", "pnr_layout.h"]}
+PMC_PROFILE = {"f16": os.path.join("profiles", "r03_bench_f16_pmc_eval_kernel.json"),
+               "f16x3": os.path.join("profiles", "r03_bench_f16x3_pmc_eval_split_kernel.json")}
+DTYPE_NOTE = {"f16x3": "fp32-class: (head, tail) fp16 operand pairs, 3 f16 MFMAs per product, fp32 accumulate, fp32 tables; "
+                       "per-point |rgb| <= 2e-5 vs the reference (the reference's own arithmetic class)",
+              "f16": "fp16 MFMA operands, fp32 accumulate: narrower than the reference's fp32 (PSNR >= 52 dB bar)",
+              "bf16": "bf16 MFMA operands (experiment flag)"}
 
 
 def build(dev, prec, scene_name="sn64"):
@@ -76,49 +96,89 @@ def make_rays(meta, R, rank):
     return rays.reshape(-1, 8)[:R].contiguous()
 
 
-def cpu_baseline(scene, mlps, rays_sample, noise, threads=None):
-    """Oracle (CPU restatement of the reference) on a bounded sample; returns rays/s + render."""
+def flop_per_ray(NS, n_coarse=64, n_fine=128):
+    evals = n_coarse + ((n_coarse + n_fine) if n_fine > 0 else 0)
+    return evals * (FLOP_PER_POINT_VIEW * NS + FLOP_PER_POINT_POOLED)
+
+
+def executed_fraction(NS, fold):
+    """share of the algorithmic FLOP that is issued as per-sample GEMMs (lin_z leaves the stream when folded)"""
+    per_pt = FLOP_PER_POINT_VIEW * NS + FLOP_PER_POINT_POOLED
+    return 1.0 - (NS * FLOP_LIN_Z_PER_POINT_VIEW) / per_pt if fold else 1.0
+
+
+def cpu_baseline(scene, mlps, rays_sample, noise, threads=None, n_coarse=64, n_fine=128, n_fine_depth=16):
+    """Oracle (CPU restatement of the reference, F.grid_sample like the reference) on a bounded sample; rays/s + render."""
     from oracle import pnr_oracle as O
     if threads:
         torch.set_num_threads(threads)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        out = O.render(scene, mlps[0], mlps[1], rays_sample[None], noise, 64, 128, 16, white_bkgd=True)
-        dt = time.perf_counter() - t0
+    prev, O.USE_GRID_SAMPLE = O.USE_GRID_SAMPLE, True  # the reference's op (src/model/encoder.py:96-109)
+    try:
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            out = O.render(scene, mlps[0], mlps[1], rays_sample[None], noise, n_coarse, n_fine, n_fine_depth, white_bkgd=True)
+            dt = time.perf_counter() - t0
+    finally:
+        O.USE_GRID_SAMPLE = prev
     return rays_sample.shape[0] / dt, dt, out
 
 
-KERNEL_SOURCES = ["pnr_mlp.hip", "pnr_device.h", "pnr_layout.h"]
-PMC_PROFILE = os.path.join("profiles", "r02_bench_f16_pmc_eval_kernel.json")
-
-
-def kernel_source_sha16():
-    """Identity of the fused network kernel: hash of the sources it is compiled from."""
+def kernel_source_sha16(prec="f16"):
+    """Identity of a fused network kernel: hash of the sources it is compiled from."""
     import hashlib
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in KERNEL_SOURCES[prec]:
         h.update(open(os.path.join(ROOT, "pixel-nerf_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic_per_launch():
+def pmc_traffic_per_launch(prec):
     """HBM-side bytes per fused-kernel launch from the committed rocprofv3 PMC passes of THIS command
     (tools/collect_pmc.sh: separate --pmc runs for FETCH_SIZE and WRITE_SIZE, KiB units, FETCH_SIZE doubled per
     MI355X_MICROARCH.md's gfx950 correction; average over the coarse and fine launches, like `achieved`).
     The profile carries the hash of the kernel sources it was measured on; a profile of a different kernel is
     refused (-> (None, reason)) instead of silently going stale."""
-    path = os.path.join(ROOT, PMC_PROFILE)
+    rel = PMC_PROFILE.get(prec)
+    if rel is None:
+        return None, "no PMC profile for precision %s" % prec, None
     try:
-        d = json.load(open(path))
+        d = json.load(open(os.path.join(ROOT, rel)))
     except Exception:
-        return None, "no PMC profile committed for this kernel (%s absent)" % PMC_PROFILE
-    if d.get("_kernel_source_sha16") != kernel_source_sha16():
+        return None, "no PMC profile committed for this kernel (%s absent)" % rel, None
+    if d.get("_kernel_source_sha16") != kernel_source_sha16(prec):
         return None, "%s was measured on kernel sources %s, this build is %s: refused as stale" % (
-            PMC_PROFILE, d.get("_kernel_source_sha16"), kernel_source_sha16())
-    return (2.0 * d["FETCH_SIZE"]["avg_per_launch"] + d["WRITE_SIZE"]["avg_per_launch"]) * 1024.0, None
+            rel, d.get("_kernel_source_sha16"), kernel_source_sha16(prec)), None
+    return (2.0 * d["FETCH_SIZE"]["avg_per_launch"] + d["WRITE_SIZE"]["avg_per_launch"]) * 1024.0, None, d.get("_derived")
 
 
-def eager_gpu_baseline(scene, mlps, rays, dev, n=16384):
+def roofline_block(prec, rays_rank0, steps, kern_ms, n_launch, NS, fold, elapsed, default_shape):
+    """roofline of the dominant kernel: ALGORITHMIC flop of rank 0's launches in the timed region / their HIP-event time"""
+    fpr = flop_per_ray(NS)
+    ach = (rays_rank0 * steps * fpr) / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    traffic, why, derived = pmc_traffic_per_launch(prec) if default_shape else (None, "the committed profile is for 65536 sn64 rays, folded", None)
+    ex = ach * executed_fraction(NS, fold) * MFMAS_PER_PRODUCT[prec]
+    blk = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS,
+           "traffic": traffic,
+           "traffic_note": "bytes per launch at the L2<->fabric interface (Infinity-Cache hits included): 2*FETCH_SIZE + WRITE_SIZE "
+                           "from %s (tools/collect_pmc.sh, stamped with the kernel-source hash %s); algorithmic HBM bytes per launch "
+                           "are ~0.18 GB (z in, rgb-sigma out, weights + tables once); the excess is the weight stream (> 4 MB L2 per "
+                           "XCD) re-fetched from the Infinity Cache once per tile pass and XCD%s" % (
+                               PMC_PROFILE.get(prec), kernel_source_sha16(prec), "" if why is None else "; NULL because " + why),
+           "kernel": KERNEL_OF[prec] + " (fused per-point network)", "launches": n_launch,
+           "avg_launch_ms": kern_ms / max(n_launch, 1), "flop_per_ray": fpr,
+           "kernel_time_frac_of_step": kern_ms * 1e-3 / elapsed,
+           "executed_mfma_tflops": ex, "executed_mfma_frac_of_peak": ex / PEAK_TFLOPS,
+           "mfmas_per_product": MFMAS_PER_PRODUCT[prec],
+           "note": "achieved = ALGORITHMIC FLOP (SURVEY 8d: 1.757 GFLOP/ray at NS=1) / kernel time, against the dense f16 MFMA peak "
+                   "(the pipe both kernels run on).  lin_z (22.9 % of the algorithmic FLOP at NS=1) is applied to the feature grid "
+                   "once per scene (per-texel tables, re-done inside every timed step) and reaches the samples by bilinear lookup; "
+                   "executed_mfma_tflops = the GEMM work really issued per sample x MFMAs per product (3 for f16x3)"}
+    if derived:
+        blk["pmc_derived"] = derived
+    return blk
+
+
+def eager_gpu_baseline(scene, mlps, rays, dev, n=16384, calls=3):
     """The north_star's "reference single-GPU" comparison point: the same eager PyTorch fp32
     code path (the oracle restatement of the reference, with F.grid_sample like the reference
     and its 50 000-ray eval chunking irrelevant at this size) on THIS GPU through PyTorch-ROCm.
@@ -131,101 +191,123 @@ def eager_gpu_baseline(scene, mlps, rays, dev, n=16384):
     r = rays[:n]
     noise = {k: v.to(dev) for k, v in synthetic.make_noise(r.shape[0], 64, 128, 16, seed=7).items()}
     with torch.no_grad():
-        # warm-up at the SAME shapes (GEMM heuristics, caching-allocator growth), then the steady-state call is timed:
-        # the fairest reading of "the reference on this GPU"
+        # warm-up at the SAME shapes (GEMM heuristics, caching-allocator growth), then steady-state calls are timed
         O.render(sc, ms[0], ms[1], r[None], noise, 64, 128, 16, white_bkgd=True)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        O.render(sc, ms[0], ms[1], r[None], noise, 64, 128, 16, white_bkgd=True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            O.render(sc, ms[0], ms[1], r[None], noise, 64, 128, 16, white_bkgd=True)
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
     O.USE_GRID_SAMPLE = False
+    dt = sum(dts) / len(dts)
     return {"value": r.shape[0] / dt, "unit": "rays/s", "kind": "port (oracle restatement, torch fp32 eager on the same MI355X)",
-            "sample": "%d rays, one steady-state call (after a same-shape warm-up), %.2f s" % (r.shape[0], dt)}
+            "sample": "%d rays per call, mean of %d steady-state calls (after a same-shape warm-up): %s s" % (
+                r.shape[0], calls, ", ".join("%.3f" % d for d in dts))}
 
 
-def extra_render_config(dev, prec, scene_name, n_img, n_oracle=128, n_f32=8192, steps=3):
+def encode_timing(dev, n_img=16, reps=5):
+    """encode time reported separately.  SpatialEncoder (ResNet-34 trunk in PyTorch-ROCm, random init, eval
+    mode) + pnr_pyramid_to_latent on sn64-shaped inputs (64x64 images, use_first_pool=False -> 512 x 32 x 32 grid)."""
+    from pixelnerf_amd.model import make_model
+    from pixelnerf_amd.util.conf import default_model_conf
+    conf = default_model_conf()
+    net = make_model(conf, precision="f16x3").to(dev).eval()
+    out = {}
+    with torch.no_grad():
+        for n in (1, n_img):
+            img = torch.rand(n, 3, 64, 64, device=dev) * 2 - 1
+            net.encoder(img)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                lat = net.encoder(img)
+            torch.cuda.synchronize()
+            out["%d_images_ms" % n] = (time.perf_counter() - t0) / reps * 1e3
+            out["latent_shape"] = list(lat.shape)
+    out["what"] = ("SpatialEncoder.forward on (n,3,64,64): plain-torch ResNet-34 trunk (PyTorch-ROCm, fp32, eval) + "
+                   "pnr_pyramid_to_latent; excluded from `value` (SURVEY 8d)")
+    return out
+
+
+def extra_render_config(dev, scene_name, n_img, n_oracle=128, n_f32=8192, steps=3):
     """One of BASELINE configs[2] (srn_car 128x128, 2 views) / configs[3] on one GPU (DTU 400x300, 3 views, 176 MiB
-    grid): rays/s through render_par(rays) at 64+128, PSNR of a ray sample spread over the whole image (border
-    pixels included) vs the CPU oracle and vs the exact-fp32 HIP path.  Untimed extras: not part of `value`."""
+    grid): rays/s through render_par(rays) at 64+128 for the fp32-class path and the f16 path, PSNR of a ray sample spread
+    over the whole image (border pixels included) vs the CPU oracle and vs the exact-fp32 HIP path.  Untimed extras."""
     from oracle import pnr_oracle as O
     from testdata import synthetic
-    scene, meta, net, renderer, mlps = build(dev, prec, scene_name)
+    scene, meta, net, renderer, mlps = build(dev, "f16x3", scene_name)
     NS = scene["NS"]
     rays1 = synthetic.target_rays(meta).reshape(-1, 8)
     rays = rays1.repeat(n_img, 1).contiguous().to(dev)
     R = rays.shape[0]
     render_par = renderer.bind_parallel(net, None, simple_output=True).eval()
+    out = {"workload": "%s %dx%d, %d source views, grid %s, 64+128, %d rays per call" % (
+        scene_name, meta["W"], meta["H"], NS, "x".join(str(v) for v in scene["latent"].shape), R)}
+    g = torch.Generator().manual_seed(3)
+    n_pix = rays1.shape[0]
+    idx = torch.randperm(n_pix, generator=g)[:n_f32]
+    W = meta["W"]
+    border = torch.cat([torch.arange(0, W, max(W // 16, 1)), n_pix - 1 - torch.arange(0, W, max(W // 16, 1))])  # first / last rows
+    idx[:border.numel()] = border
+    rs = rays1[idx]
+    noise = synthetic.make_noise(rs.shape[0], 64, 128, 16, seed=5)
+    nz = {k: v.to(dev) for k, v in noise.items()}
+    span = float(meta["z_far"] - meta["z_near"])
     with torch.no_grad():
-        render_par(rays[None])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            net._tables.clear()  # a freshly encoded scene per step: the lin_z fold is inside the time
-            render_par(rays[None])
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        g = torch.Generator().manual_seed(3)
-        n_pix = rays1.shape[0]
-        idx = torch.randperm(n_pix, generator=g)[:n_f32]
-        W = meta["W"]
-        border = torch.cat([torch.arange(0, W, max(W // 16, 1)), n_pix - 1 - torch.arange(0, W, max(W // 16, 1))])  # first / last rows
-        idx[:border.numel()] = border
-        rs = rays1[idx]
-        noise = synthetic.make_noise(rs.shape[0], 64, 128, 16, seed=5)
-        nz = {k: v.to(dev) for k, v in noise.items()}
-        fast = renderer(net, rs.to(dev)[None], _noise=nz)
         net.precision = "f32"
         exact = renderer(net, rs.to(dev)[None], _noise=nz)
-        # the fp32-class fast path (split f16 operands, 32-point tiles for multi-view scenes) on the same rays
-        net.precision = "f16x3"
-        split = renderer(net, rs.to(dev)[None], _noise=nz)
-        render_par(rays[None])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        render_par(rays[None])
-        torch.cuda.synchronize()
-        dt_split = time.perf_counter() - t0
-        net.precision = prec
         no = min(n_oracle, rs.shape[0])
         ref = O.render(scene, mlps[0], mlps[1], rs[None, :no], {k: v[:no] for k, v in noise.items()}, 64, 128, 16,
                        white_bkgd=meta["white_bkgd"])
-    span = float(meta["z_far"] - meta["z_near"])
-    out = {"workload": "%s %dx%d, %d source views, grid %s, 64+128, %d rays per call" % (
-               scene_name, meta["W"], meta["H"], NS, "x".join(str(v) for v in scene["latent"].shape), R),
-           "rays_per_s": R / dt, "ms_per_call": dt * 1e3,
-           "algorithmic_tflops": R / dt * 256 * (FLOP_PER_POINT_VIEW * NS + FLOP_PER_POINT_POOLED) / 1e12,
-           "psnr_db_vs_cpu_oracle": O.psnr(fast.fine.rgb[0, :no].cpu(), ref["fine"]["rgb"][0]), "oracle_rays": no,
-           "psnr_db_vs_f32_hip": O.psnr(fast.fine.rgb.cpu(), exact.fine.rgb.cpu()), "f32_rays": int(rs.shape[0]),
-           "depth_abs_err_p99_over_span_vs_f32_hip": float(torch.quantile((fast.fine.depth - exact.fine.depth).abs().flatten(), 0.99)) / span,
-           "f16x3": {"rays_per_s": R / dt_split, "psnr_db_vs_f32_hip": O.psnr(split.fine.rgb.cpu(), exact.fine.rgb.cpu()),
-                     "rgb_max_abs_err_vs_f32_hip": float((split.coarse.rgb - exact.coarse.rgb).abs().max())}}
+        for prec in ("f16x3", "f16"):
+            net.precision = prec
+            render_par(rays[None])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                net._tables.clear()  # a freshly encoded scene per step: the lin_z fold is inside the time
+                render_par(rays[None])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            fast = renderer(net, rs.to(dev)[None], _noise=nz)
+            alg = R / dt * flop_per_ray(NS) / 1e12
+            out[prec] = {"rays_per_s": R / dt, "ms_per_call": dt * 1e3, "algorithmic_tflops": alg,
+                         "frac_of_f16_mfma_peak": alg / PEAK_TFLOPS,
+                         "executed_mfma_tflops": alg * executed_fraction(NS, True) * MFMAS_PER_PRODUCT[prec],
+                         "psnr_db_vs_cpu_oracle": O.psnr(fast.fine.rgb[0, :no].cpu(), ref["fine"]["rgb"][0]), "oracle_rays": no,
+                         "psnr_db_vs_f32_hip": O.psnr(fast.fine.rgb.cpu(), exact.fine.rgb.cpu()), "f32_rays": int(rs.shape[0]),
+                         "rgb_max_abs_err_vs_f32_hip_coarse": float((fast.coarse.rgb - exact.coarse.rgb).abs().max()),
+                         "depth_abs_err_p99_over_span_vs_f32_hip": float(torch.quantile((fast.fine.depth - exact.fine.depth).abs().flatten(), 0.99)) / span}
     del net, renderer
     torch.cuda.empty_cache()
     return out
 
 
-def extra_train_step(dev, prec, steps=40, warmup=8):
+def extra_train_step(dev, prec, scene_name="train", steps=40, warmup=8, with_graph=True):
     """BASELINE configs[4]: sn64 training step, 4 objects x 128 rays, 64 coarse + 32 fine (16 depth), ResnetFC d=512,
-    forward + backward (+ Adam) through NeRFRenderer/_RenderWrapper in train mode (train/train.py:199-215)."""
+    forward + backward (+ Adam) through NeRFRenderer/_RenderWrapper in train mode (train/train.py:199-215).
+    scene_name "train_mv": the same step on a 2-object x 2-source-view scene (multi-view pooling in forward and backward)."""
     from pixelnerf_amd.model import make_model
     from pixelnerf_amd.render import NeRFRenderer
     from pixelnerf_amd.util import DotMap
     from pixelnerf_amd.util.conf import default_model_conf
     from testdata import synthetic
-    scene, meta = synthetic.make_scene("train")
-    rays = synthetic.target_rays(meta, n_rays=128).to(dev)  # (4,128,8)
-    gt = torch.rand(4, 128, 3, device=dev)
+    scene, meta = synthetic.make_scene(scene_name)
+    SB, NS = scene["SB"], scene["NS"]
+    rays = synthetic.target_rays(meta, n_rays=128).to(dev)  # (SB,128,8)
+    gt = torch.rand(SB, 128, 3, device=dev)
     net = make_model(default_model_conf(), precision=prec).to(dev).train()
     net.mlp_coarse.load_state_dict(synthetic.make_mlp_params(11))
     net.mlp_fine.load_state_dict(synthetic.make_mlp_params(12))
     lat = scene["latent"].to(dev).clone().requires_grad_(True)
     net.encoder.latent = lat
-    ls = torch.tensor([32.0, 32.0], device=dev)
+    ls = torch.tensor([float(lat.shape[-1]), float(lat.shape[-2])], device=dev)
     net.encoder.latent_scaling = ls / (ls - 1) * 2.0
     net.poses, net.image_shape = scene["poses"].to(dev), scene["image_shape"].to(dev)
     net.focal, net.c = scene["focal"].to(dev), scene["c"].to(dev)
-    net.num_objs, net.num_views_per_obj = scene["SB"], scene["NS"]
+    net.num_objs, net.num_views_per_obj = SB, NS
     rend = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).to(dev)
     render_par = rend.bind_parallel(net, None, simple_output=False).train()
     # the reference's optimizer (train/trainer.py: torch.optim.Adam); `fused=True` is PyTorch's single-kernel form of the
@@ -253,27 +335,34 @@ def extra_train_step(dev, prec, steps=40, warmup=8):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    out = {"workload": "sn64 training step: 4 objects x 128 rays, 64+32 (16 depth) samples, fwd+bwd+Adam, grads to both "
-                       "ResnetFCs and encoder.latent", "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "rays_per_s": 512 / dt,
-           "algorithmic_tflops": 512 / dt * 3.29e9 / 1e12, "loss_first_step": loss_first, "loss": float(loss.item()), "steps": steps,
+    n_rays = SB * 128
+    flop_ray = 3.0 * flop_per_ray(NS, 64, 32)  # fwd + dX + dW
+    out = {"workload": "%s: %d objects x 128 rays, %d source view(s), 64+32 (16 depth) samples, fwd+bwd+Adam, grads to both "
+                       "ResnetFCs and encoder.latent" % (scene_name, SB, NS), "precision": prec,
+           "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "rays_per_s": n_rays / dt,
+           "algorithmic_tflops": n_rays / dt * flop_ray / 1e12, "frac_of_f16_mfma_peak": n_rays / dt * flop_ray / 1e12 / PEAK_TFLOPS,
+           "loss_first_step": loss_first, "loss": float(loss.item()), "steps": steps,
            "launch_mode": "eager launches (one Python-sequenced HIP launch per kernel)"}
-    # the same step captured ONCE into a HIP graph (torch.cuda.CUDAGraph: forward, backward and a capturable Adam) and
-    # replayed: no per-kernel launch latency, no Python between the ~35 kernels.  Run as a CHILD process
-    # (tools/gpu_train_graph.py): a failure inside graph capture must never take this benchmark line down.
-    import subprocess
-    try:
-        child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_train_graph.py"), "step"], capture_output=True,
-                               text=True, timeout=300)
-        line = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
-        if child.returncode == 0 and line:
-            r = json.loads(line[-1])["step"]
-            out["hip_graph"] = {"ms_per_step": r["graph_ms"], "steps_per_s": 1e3 / r["graph_ms"], "rays_per_s": 512e3 / r["graph_ms"],
-                                "algorithmic_tflops": 512e3 / r["graph_ms"] * 3.29e9 / 1e12, "eager_ms_per_step_same_process": r["eager_ms"],
-                                "loss": r["loss"]}
-        else:
-            out["hip_graph"] = {"error": "child rc=%d: %s" % (child.returncode, child.stderr[-300:])}
-    except Exception as e:
-        out["hip_graph"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    if with_graph:
+        # the same step captured ONCE into a HIP graph (torch.cuda.CUDAGraph: forward, backward and a capturable Adam) and
+        # replayed: no per-kernel launch latency, no Python between the ~35 kernels.  Run as a CHILD process
+        # (tools/gpu_train_graph.py): a failure inside graph capture must never take this benchmark line down.
+        import subprocess
+        try:
+            child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_train_graph.py"), "step"], capture_output=True,
+                                   text=True, timeout=300)
+            line = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+            if child.returncode == 0 and line:
+                r = json.loads(line[-1])["step"]
+                out["hip_graph"] = {"ms_per_step": r["graph_ms"], "steps_per_s": 1e3 / r["graph_ms"], "rays_per_s": 512e3 / r["graph_ms"],
+                                    "algorithmic_tflops": 512e3 / r["graph_ms"] * 3.29e9 / 1e12, "eager_ms_per_step_same_process": r["eager_ms"],
+                                    "loss": r["loss"]}
+            else:
+                out["hip_graph"] = {"error": "child rc=%d: %s" % (child.returncode, child.stderr[-300:])}
+        except Exception as e:
+            out["hip_graph"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    del net, rend
+    torch.cuda.empty_cache()
     return out
 
 
@@ -293,18 +382,94 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def timed_region(step, fence, steps, warmup):
+    """W untimed warm-ups, then exactly K steps bracketed by fence() (synchronize [+ barrier + synchronize]); HIP events of the
+    network-kernel launches on their stream are collected over the same K steps.  -> (elapsed s, kernel ms, launches)"""
+    from pixelnerf_amd import ops
+    for _ in range(warmup):
+        step()
+    fence()
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms, n_launch = ops.profile_read()
+    ops.profile_enable(False)
+    return elapsed, kern_ms, n_launch
+
+
+def strong_dtu(dev, prec, world, rank, steps, warmup, bcast, fence):
+    """BASELINE configs[3]: ONE DTU 400x300 image (120 000 rays, 3 source views, 176 MiB grid) sharded contiguously over
+    the ranks.  step = [the single feature-grid broadcast from rank 0] + render of this rank's rays + [gather of
+    (rgb | depth) to rank 0]; returns the rank-local timings (the caller max-reduces `elapsed`)."""
+    import torch.distributed as dist
+    from pixelnerf_amd.dist import broadcast_encoded, shard_bounds
+    from testdata import synthetic
+    scene, meta, net, renderer, _ = build(dev, prec, "dtu")
+    lat_shape = tuple(scene["latent"].shape)
+    rays_all = synthetic.target_rays(meta).reshape(-1, 8)
+    R = rays_all.shape[0]
+    lo, hi = shard_bounds(R, rank, world)
+    rays = rays_all[lo:hi].contiguous().to(dev)
+    render_par = renderer.bind_parallel(net, None, simple_output=True).eval()
+    renderer.ray_id_offset, renderer.ray_id_stride = lo, R  # the sharded image equals the unsharded one
+    tb, tg = [0.0], [0.0]
+
+    def step():
+        net._tables.clear()
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            broadcast_encoded(net, src=0, latent_shape=lat_shape, algo=bcast)
+            e1.record()
+        with torch.no_grad():
+            rgb, depth = render_par(rays[None])
+        if world > 1:
+            e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            out = torch.cat([rgb[0], depth[0].unsqueeze(-1)], dim=-1)  # 16 B/ray
+            sizes = [shard_bounds(R, r, world)[1] - shard_bounds(R, r, world)[0] for r in range(world)]
+            if out.shape[0] < max(sizes):
+                out = torch.cat([out, out.new_zeros(max(sizes) - out.shape[0], 4)])
+            bufs = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
+            e2.record()
+            dist.gather(out, bufs, dst=0)
+            e3.record()
+            evs.append((e0, e1, e2, e3))
+        return rgb
+
+    evs = []
+    torch.manual_seed(4321)
+    elapsed, kern_ms, n_launch = timed_region(step, fence, steps, warmup)
+    for e0, e1, e2, e3 in evs[-steps:]:
+        tb[0] += e0.elapsed_time(e1)
+        tg[0] += e2.elapsed_time(e3)
+    NS = scene["NS"]
+    res = {"elapsed": elapsed, "kern_ms": kern_ms, "n_launch": n_launch, "R": R, "rays_this_rank": hi - lo, "NS": NS,
+           "bcast_ms": tb[0] / steps, "gather_ms": tg[0] / steps, "grid_bytes": int(scene["latent"].numel() * 4)}
+    del net, renderer
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--prec", default="f16", choices=["f16", "bf16"])
-    ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step")
+    ap.add_argument("--prec", default="f16x3", choices=["f16x3", "f16", "bf16"],
+                    help="precision of the timed headline (default: the fp32-class path, the reference's arithmetic class)")
+    ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step (sn64 workload)")
+    ap.add_argument("--workload", default="sn64", choices=["sn64", "dtu"],
+                    help="sn64: BASELINE configs[1], weak scaling (default).  dtu: configs[3], ONE 120 000-ray image sharded over the ranks (strong)")
+    ap.add_argument("--bcast", default="tree", choices=["tree", "flat"],
+                    help="feature-grid broadcast: RCCL's broadcast, or a flat 1->(N-1) fan-out of point-to-point sends (one xGMI link each)")
     ap.add_argument("--cpu-rays", type=int, default=0, help="CPU-baseline sample size (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--no-f32-check", action="store_true")
-    ap.add_argument("--no-fold", action="store_true", help="run the lin_z GEMMs per sample instead of folding them into the grid")
+    ap.add_argument("--no-peer", action="store_true", help="skip the second timed region (the f16 peer block)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: functional test on one GPU)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed BASELINE configs 3/4/5 section (extra.configs)")
     args = ap.parse_args()
@@ -332,31 +497,11 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from pixelnerf_amd import _lib, ops
+    from pixelnerf_amd import _lib
     from testdata import synthetic
     from pixelnerf_amd.dist import broadcast_encoded
 
     _lib.ensure_built()  # normally a no-op: the .so built by __graft_entry__.build() travels with the tree
-    scene, meta, net, renderer, mlps = build(dev, args.prec)
-    net.fold = not args.no_fold
-    lat_shape = tuple(scene["latent"].shape)
-    R = args.rays
-    rays = make_rays(meta, R, rank).to(dev)
-    render_par = renderer.bind_parallel(net, None, simple_output=True).eval()
-
-    def step():
-        # every step stands for a freshly encoded object: the per-scene folding of lin_z into the feature grid
-        # (PixelNeRFNet.tables -> pnr_fold_latent, both networks) is redone INSIDE the timed step
-        net._tables.clear()
-        if world > 1:
-            broadcast_encoded(net, src=0, latent_shape=lat_shape)  # THE single feature-grid broadcast (2 MiB for sn64)
-        with torch.no_grad():
-            rgb, depth = render_par(rays[None])
-        if world > 1:
-            out = torch.cat([rgb[0], depth[0].unsqueeze(-1)], dim=-1)  # 16 B/ray
-            bufs = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
-            dist.gather(out, bufs, dst=0)
-        return rgb
 
     def fence():
         torch.cuda.synchronize()
@@ -364,137 +509,258 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    torch.manual_seed(1234 + rank)
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ops.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kern_ms, n_launch = ops.profile_read()
-    ops.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
+    strong = args.workload == "dtu"
+    res = None
+    if strong:
+        # ---- BASELINE configs[3] as the headline: one DTU image over N ranks
+        st = strong_dtu(dev, args.prec, world, rank, args.steps, args.warmup, args.bcast, fence)
+        elapsed = max_over_ranks(st["elapsed"])
+        if rank == 0:
+            rays_per_s = st["R"] * args.steps / elapsed
+            res = {"metric": "rays/sec (64 coarse + 128 fine samples) at matched PSNR vs reference",
+                   "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+                   "vs_baseline": None, "dtype": args.prec, "dtype_note": DTYPE_NOTE[args.prec], "data": "synthetic",
+                   "config": {"workload": "DTU 400x300, 3 input views, 64+128 samples, ONE full-res image (120000 rays) sharded "
+                                          "contiguously over %d rank(s) (BASELINE configs[3]); synthetic 3x512x150x200 feature grid "
+                                          "(176 MiB), random-init ResnetFC coarse+fine; step = grid broadcast + render + gather" % world,
+                              "rays_per_image": st["R"], "rays_rank0": st["rays_this_rank"], "source_views": st["NS"],
+                              "rccl_ranks": world, "backend": args.backend, "bcast_algo": args.bcast},
+                   "comm": {"bcast_ms_rank0": st["bcast_ms"], "gather_ms_rank0": st["gather_ms"], "grid_bytes": st["grid_bytes"]},
+                   "roofline": roofline_block(args.prec, st["rays_this_rank"], args.steps, st["kern_ms"], st["n_launch"], st["NS"], True,
+                                              elapsed, False)}
+        if res is not None:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    # ---- BASELINE configs[1]: sn64, weak scaling
+    scene, meta, net, renderer, mlps = build(dev, args.prec)
+    lat_shape = tuple(scene["latent"].shape)
+    R = args.rays
+    rays = make_rays(meta, R, rank).to(dev)
+    render_par = renderer.bind_parallel(net, None, simple_output=True).eval()
+    comm_ev = []
+
+    def step():
+        # every step stands for a freshly encoded object: the per-scene folding of lin_z into the feature grid
+        # (PixelNeRFNet.tables -> pnr_fold_latent[_f32], both networks) is redone INSIDE the timed step
+        net._tables.clear()
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            broadcast_encoded(net, src=0, latent_shape=lat_shape, algo=args.bcast)  # THE single feature-grid broadcast (2 MiB for sn64)
+            e1.record()
+        with torch.no_grad():
+            rgb, depth = render_par(rays[None])
+        if world > 1:
+            out = torch.cat([rgb[0], depth[0].unsqueeze(-1)], dim=-1)  # 16 B/ray
+            bufs = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
+            e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e2.record()
+            dist.gather(out, bufs, dst=0)
+            e3.record()
+            comm_ev.append((e0, e1, e2, e3))
+        return rgb
+
+    torch.manual_seed(1234 + rank)
+    net.precision = args.prec
+    elapsed, kern_ms, n_launch = timed_region(step, fence, args.steps, args.warmup)
+    elapsed = max_over_ranks(elapsed)
+    comm = None
+    if world > 1:
+        ev = comm_ev[-args.steps:]
+        comm = {"bcast_ms_rank0": sum(a.elapsed_time(b) for a, b, _, _ in ev) / len(ev),
+                "gather_ms_rank0": sum(c.elapsed_time(d) for _, _, c, d in ev) / len(ev),
+                "grid_bytes": int(scene["latent"].numel() * 4), "bcast_algo": args.bcast}
+
+    peer = None
+    if world == 1 and not args.no_peer:
+        peer_prec = "f16" if args.prec == "f16x3" else "f16x3"
+        net.precision = peer_prec
+        torch.manual_seed(1234 + rank)
+        pe, pk, pn = timed_region(step, fence, args.steps, args.warmup)
+        net.precision = args.prec
+        peer = (peer_prec, pe, pk, pn)
+
+    NS = scene["NS"]
+    default_shape = R == 65536
     if rank == 0:
-        NS = scene["NS"]
-        flop_per_ray = (64 + 192) * (FLOP_PER_POINT_VIEW * NS + FLOP_PER_POINT_POOLED)
         rays_per_s = world * R * args.steps / elapsed
-        # roofline of the dominant kernel: algorithmic FLOP of rank 0's launches / their HIP-event time
-        ach = (R * args.steps * flop_per_ray) / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-        traffic, traffic_why = pmc_traffic_per_launch() if (args.prec == "f16" and R == 65536 and net.fold) else (None, "profile is for f16, 65536 rays, folded")
         res = {
             "metric": "rays/sec (64 coarse + 128 fine samples) at matched PSNR vs reference",
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.prec, "dtype_note": DTYPE_NOTE[args.prec], "data": "synthetic",
             "config": {"workload": "sn64 NMR 64x64, 1 input view, 64+128 samples (BASELINE configs[1]); "
                                    "%d rays (%d target views) per GPU per step; synthetic 1x512x32x32 feature grid, "
                                    "random-init ResnetFC coarse+fine (d_hidden 512, 5 blocks)" % (R, R // 4096),
                        "rays_per_gpu_per_step": R, "n_coarse": 64, "n_fine": 128, "n_fine_depth": 16,
                        "source_views": NS, "api": "NeRFRenderer.bind_parallel(net, simple_output=True)(rays)",
-                       "lin_z_folded_into_grid": bool(net.fold)},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.prec], "unit": "TFLOP/s",
-                         "frac": ach / PEAK_TFLOPS[args.prec],
-                         "traffic": traffic,
-                         "traffic_note": "bytes per launch at the L2<->fabric interface (Infinity-Cache hits included): "
-                                         "2*FETCH_SIZE + WRITE_SIZE from %s (tools/collect_pmc.sh, stamped with the kernel-source "
-                                         "hash %s); algorithmic HBM bytes per launch are ~0.18 GB (z in, rgb-sigma out, weights+tables "
-                                         "once); the excess is the 5.4 MB weight stream (> 4 MB L2 per XCD) re-fetched from the Infinity "
-                                         "Cache once per tile pass and XCD%s" % (PMC_PROFILE, kernel_source_sha16(),
-                                                                                  "" if traffic_why is None else "; NULL because " + traffic_why),
-                         "kernel": "pnr::eval_kernel (fused per-point network)", "launches": n_launch,
-                         "avg_launch_ms": kern_ms / max(n_launch, 1),
-                         "flop_per_ray": flop_per_ray, "kernel_time_frac_of_step": kern_ms * 1e-3 / elapsed,
-                         "executed_mfma_tflops": ach * (1.0 - (256 * NS * FLOP_LIN_Z_PER_POINT_VIEW) / flop_per_ray) if net.fold else ach,
-                         "note": "achieved = ALGORITHMIC FLOP (SURVEY 8d: 1.757 GFLOP/ray) / kernel time.  With fold=True (default) "
-                                 "the three lin_z layers (1.573 MFLOP per point and view, 22.9 % of the algorithmic FLOP at NS=1) are "
-                                 "applied to the feature grid once per scene (per-texel tables, re-done inside every timed step) and "
-                                 "reach the samples by bilinear lookup; executed_mfma_tflops counts only the GEMMs actually run per sample"},
+                       "precision": args.prec, "lin_z_folded_into_grid": True, "rccl_ranks": world, "backend": args.backend if world > 1 else None},
+            "roofline": roofline_block(args.prec, R, args.steps, kern_ms, n_launch, NS, True, elapsed, default_shape),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            # bounded CPU sample of the same workload; also yields the matched-PSNR figure
-            # torch's intra-op pool does not scale to every core of a many-socket host on 512-wide
-            # GEMMs: pick the thread count that is FASTEST on a 64-ray probe (fair to the CPU), then
-            # time the real sample with it.  `cores` reports the threads actually used.
-            n0 = 64
-            rs = rays[:4096].cpu()
-            noise0 = synthetic.make_noise(n0, 64, 128, 16, seed=99)
-            ncpu = os.cpu_count() or 1
-            cpu_baseline(scene, mlps, rs[:n0], noise0, threads=min(ncpu, 16))  # warm-up
-            best = (0.0, 1)
-            for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, ncpu)}):
-                rate_t, _, _ = cpu_baseline(scene, mlps, rs[:n0], noise0, threads=th)
-                if rate_t > best[0]:
-                    best = (rate_t, th)
-            rate0 = best[0]
-            torch.set_num_threads(best[1])
-            n = args.cpu_rays or int(min(4096, max(256, rate0 * 15.0)) // 64 * 64)
-            noise = synthetic.make_noise(n, 64, 128, 16, seed=100)
-            rate, dt, ref = cpu_baseline(scene, mlps, rs[:n], noise, threads=best[1])
+        if comm:
+            res["comm"] = comm
+        if peer:
+            pp, pe, pk, pn = peer
+            res[pp + "_path"] = {
+                "what": "the same workload, same steps / warm-up, timed in a second region right after the headline: " + DTYPE_NOTE[pp],
+                "value": R * args.steps / pe, "unit": "rays/s", "ms_per_step": pe / args.steps * 1e3, "dtype": pp,
+                "roofline": roofline_block(pp, R, args.steps, pk, pn, NS, True, pe, default_shape)}
+    if world == 1 and not args.no_cpu_baseline:
+        # bounded CPU sample of the same workload; also yields the matched-PSNR figure.  torch's intra-op pool does not
+        # scale to every core of a many-socket host on 512-wide GEMMs: pick the thread count that is FASTEST on a 64-ray
+        # probe (fair to the CPU), then time the real sample with it.  `cores` reports the threads actually used.
+        from oracle import pnr_oracle as O
+        n0 = 64
+        rs = rays[:4096].cpu()
+        noise0 = synthetic.make_noise(n0, 64, 128, 16, seed=99)
+        ncpu = os.cpu_count() or 1
+        cpu_baseline(scene, mlps, rs[:n0], noise0, threads=min(ncpu, 16))  # warm-up
+        best = (0.0, 1)
+        for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, ncpu)}):
+            rate_t, _, _ = cpu_baseline(scene, mlps, rs[:n0], noise0, threads=th)
+            if rate_t > best[0]:
+                best = (rate_t, th)
+        rate0 = best[0]
+        torch.set_num_threads(best[1])
+        n = args.cpu_rays or int(min(4096, max(256, rate0 * 12.0)) // 64 * 64)
+        noise = synthetic.make_noise(n, 64, 128, 16, seed=100)
+        rate, dt, ref = cpu_baseline(scene, mlps, rs[:n], noise, threads=best[1])
+        nzd = {k: v.to(dev) for k, v in noise.items()}
+        with torch.no_grad():
+            out = renderer(net, rs[:n].to(dev)[None], _noise=nzd)
+        res["psnr_db"] = O.psnr(out.fine.rgb.cpu(), ref["fine"]["rgb"])
+        res["rgb_max_abs_err_vs_cpu"] = float((out.fine.rgb.cpu() - ref["fine"]["rgb"]).abs().max())
+        res["depth_abs_err_p99"] = float(torch.quantile((out.fine.depth.cpu() - ref["fine"]["depth"]).abs().flatten(), 0.99))
+        if peer:
+            net.precision = peer[0]
             with torch.no_grad():
-                out = renderer(net, rs[:n].to(dev)[None], _noise={k: v.to(dev) for k, v in noise.items()})
-            from oracle import pnr_oracle as O
-            res["psnr_db"] = O.psnr(out.fine.rgb.cpu(), ref["fine"]["rgb"])
-            res["depth_abs_err_p99"] = float(torch.quantile((out.fine.depth.cpu() - ref["fine"]["depth"]).abs().flatten(), 0.99))
-            res["cpu_baseline"] = {"value": rate, "unit": "rays/s", "cores": best[1], "host_cpus": ncpu, "kind": "port",
-                                   "sample": "%d rays of the same workload (64+128, same weights/grid), %.1f s, "
-                                             "oracle/pnr_oracle.py (torch CPU fp32 restatement of the reference)" % (n, dt)}
-            res["speedup_vs_cpu_baseline"] = rays_per_s / rate
-        if world == 1 and not args.no_f32_check:
-            # full-size cross-checks on the GPU, outside the timed region, all R rays of the step with the same noise:
-            #   "f32"   : the exact, unfused fp32-MFMA validation path (agrees with the reference to ~1e-6)
-            #   "f16x3" : the fp32-CLASS fast path -- the fused kernel with (head, tail) fp16 operand pairs, 3 MFMAs per
-            #             product, fp32 tables (pnr_split.hip); held to the exact path's bars by tests/test_hip_split.py
-            from oracle import pnr_oracle as O
-            noise = {k: v.to(dev) for k, v in synthetic.make_noise(R, 64, 128, 16, seed=101).items()}
-
-            def timed_render(prec):
-                net.precision = prec
-                with torch.no_grad():
-                    renderer(net, rays[None, :4096], _noise={k: v[:4096] for k, v in noise.items()})  # pack / fold / warm
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    o = renderer(net, rays[None], _noise=noise)
-                    torch.cuda.synchronize()
-                return o, time.perf_counter() - t1
-
-            fast, _ = timed_render(args.prec)
-            exact, dt32 = timed_render("f32")
-            split, dtx3 = timed_render("f16x3")
+                outp = renderer(net, rs[:n].to(dev)[None], _noise=nzd)
             net.precision = args.prec
-            res["psnr_db_full_size_vs_f32_hip"] = O.psnr(fast.fine.rgb.cpu(), exact.fine.rgb.cpu())
-            res["f32_hip_path_rays_per_s"] = R / dtx3
-            res["f32_hip_path"] = {
-                "what": "fp32-class fast path, precision='f16x3': fused kernel, fp16 (head, tail) operand pairs, 3 f16 MFMAs per "
-                        "product, fp32 accumulate, fp32 tables; per-point |rgb| <= 2e-5 vs the reference (tests/test_hip_split.py)",
-                "rays_per_s": R / dtx3, "psnr_db_vs_exact_fp32_path": O.psnr(split.fine.rgb.cpu(), exact.fine.rgb.cpu()),
-                "max_abs_rgb_diff_vs_exact_fp32_path_coarse": float((split.coarse.rgb - exact.coarse.rgb).abs().max()),
-                "algorithmic_tflops": R / dtx3 * flop_per_ray / 1e12,
-                "frac_of_fp32_mfma_peak_157": R / dtx3 * flop_per_ray / 1e12 / 157.3}
-            res["f32_unfused_validation_path_rays_per_s"] = R / dt32
-        if world == 1 and not args.no_eager_baseline:
-            res["torch_eager_gpu_baseline"] = eager_gpu_baseline(scene, mlps, rays, dev)
-            res["speedup_vs_torch_eager_gpu"] = rays_per_s / res["torch_eager_gpu_baseline"]["value"]
-        if world == 1 and not args.no_extras:
+            res[peer[0] + "_path"]["psnr_db"] = O.psnr(outp.fine.rgb.cpu(), ref["fine"]["rgb"])
+        res["cpu_baseline"] = {"value": rate, "unit": "rays/s", "cores": best[1], "host_cpus": ncpu, "kind": "port",
+                               "sample": "%d rays of the same workload (64+128, same weights/grid), %.1f s, oracle/pnr_oracle.py "
+                                         "(torch CPU fp32 restatement of the reference, F.grid_sample as in encoder.py:96-109)" % (n, dt)}
+        res["speedup_vs_cpu_baseline"] = res["value"] / rate
+        # BASELINE configs[0] verbatim: 32 coarse samples, no fine pass, ONE call with all 4096 rays of a view, CPU
+        noise1 = synthetic.make_noise(4096, 32, 0, 0, seed=102)
+        cpu_baseline(scene, mlps, rs[:256], {k: v[:256] for k, v in noise1.items()}, threads=best[1], n_coarse=32, n_fine=0, n_fine_depth=0)
+        rate1, dt1, ref1 = cpu_baseline(scene, mlps, rs, noise1, threads=best[1], n_coarse=32, n_fine=0, n_fine_depth=0)
+        from pixelnerf_amd.render import NeRFRenderer
+        rend1 = NeRFRenderer(n_coarse=32, n_fine=0, n_fine_depth=0, white_bkgd=True).to(dev).eval()
+        with torch.no_grad():
+            nz1 = {k: v.to(dev) for k, v in noise1.items()}
+            rend1(net, rs.to(dev)[None], _noise=nz1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                o1 = rend1(net, rs.to(dev)[None], _noise=nz1)
+            torch.cuda.synchronize()
+            dtg = (time.perf_counter() - t1) / 5
+        res["cpu_baseline_config1"] = {
+            "value": rate1, "unit": "rays/s", "cores": best[1], "host_cpus": ncpu, "kind": "port",
+            "sample": "BASELINE configs[0]: sn64, 1 view, 32 coarse samples (no fine pass), ray_batch=4096 in ONE call on the CPU path, %.1f s" % dt1,
+            "hip_same_call_ms": dtg * 1e3, "hip_same_call_rays_per_s": 4096 / dtg, "hip_precision": args.prec,
+            "psnr_db_hip_vs_cpu": O.psnr(o1.coarse.rgb.cpu(), ref1["coarse"]["rgb"])}
+    if world == 1:
+        # single-image latency (one 4096-ray call through render_par, fold included) next to the saturated rate
+        lat_ms = {}
+        with torch.no_grad():
+            for prec in (args.prec,) + ((peer[0],) if peer else ()):
+                net.precision = prec
+                r1 = rays[None, :4096]
+                render_par(r1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    net._tables.clear()
+                    render_par(r1)
+                torch.cuda.synchronize()
+                lat_ms[prec] = (time.perf_counter() - t0) / 10 * 1e3
+        net.precision = args.prec
+        res["latency_4096_rays_ms"] = lat_ms[args.prec]
+        res["latency_4096_rays_ms_by_precision"] = lat_ms
+        try:
+            res["encode_ms"] = encode_timing(dev)
+        except Exception as e:
+            res["encode_ms"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    if world == 1 and not args.no_f32_check:
+        # full-size cross-check on the GPU, outside the timed region: all R rays of the step with the same noise through
+        # the exact, unfused fp32-MFMA validation path (agrees with the reference to ~1e-6)
+        from oracle import pnr_oracle as O
+        noise = {k: v.to(dev) for k, v in synthetic.make_noise(R, 64, 128, 16, seed=101).items()}
+
+        def render_at(prec):
+            net.precision = prec
+            with torch.no_grad():
+                renderer(net, rays[None, :4096], _noise={k: v[:4096] for k, v in noise.items()})  # pack / fold / warm
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                o = renderer(net, rays[None], _noise=noise)
+                torch.cuda.synchronize()
+            return o, time.perf_counter() - t1
+
+        exact, dt32 = render_at("f32")
+        fast, _ = render_at(args.prec)
+        res["psnr_db_full_size_vs_f32_hip"] = O.psnr(fast.fine.rgb.cpu(), exact.fine.rgb.cpu())
+        res["rgb_max_abs_diff_full_size_vs_f32_hip_coarse"] = float((fast.coarse.rgb - exact.coarse.rgb).abs().max())
+        if peer:
+            pfast, _ = render_at(peer[0])
+            res[peer[0] + "_path"]["psnr_db_full_size_vs_f32_hip"] = O.psnr(pfast.fine.rgb.cpu(), exact.fine.rgb.cpu())
+        net.precision = args.prec
+        res["f32_unfused_validation_path_rays_per_s"] = R / dt32
+    if world == 1 and not args.no_eager_baseline:
+        res["torch_eager_gpu_baseline"] = eager_gpu_baseline(scene, mlps, rays, dev)
+        res["speedup_vs_torch_eager_gpu"] = res["value"] / res["torch_eager_gpu_baseline"]["value"]
+        if peer:
+            res[peer[0] + "_path"]["speedup_vs_torch_eager_gpu"] = res[peer[0] + "_path"]["value"] / res["torch_eager_gpu_baseline"]["value"]
+    del net, renderer, render_par
+    torch.cuda.empty_cache()
+    if not args.no_extras:
+        extra = {}
+        if world == 1:
             # BASELINE configs[2..4] on this one GPU, outside the timed region
-            extra = {}
-            for key, fn in (("train_step", lambda: extra_train_step(dev, args.prec)),
-                            ("srn_car", lambda: extra_render_config(dev, args.prec, "srn_car", 4)),
-                            ("dtu", lambda: extra_render_config(dev, args.prec, "dtu", 1))):
+            for key, fn in (("train_step", lambda: extra_train_step(dev, "f16")),
+                            ("train_step_multiview", lambda: extra_train_step(dev, "f16", "train_mv", steps=20, warmup=4, with_graph=False)),
+                            ("srn_car", lambda: extra_render_config(dev, "srn_car", 4)),
+                            ("dtu", lambda: extra_render_config(dev, "dtu", 1))):
                 try:
                     extra[key] = fn()
                 except Exception as e:  # an extra must never take the headline line down with it
                     extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
-            res["extra"] = {"configs": extra}
+            if rank == 0:
+                res["extra"] = {"configs": extra}
+        else:
+            # BASELINE configs[3] in its strong-scaling form on the same N ranks (a few steps, after the headline)
+            try:
+                st = strong_dtu(dev, args.prec, world, rank, max(2, min(args.steps, 5)), 1, args.bcast, fence)
+                st_elapsed = max_over_ranks(st["elapsed"])
+                nst = max(2, min(args.steps, 5))
+                if rank == 0:
+                    res["extra"] = {"strong_dtu": {
+                        "workload": "BASELINE configs[3]: ONE DTU 400x300 image (120000 rays, 3 views, 176 MiB grid) sharded over %d ranks; "
+                                    "step = grid broadcast + render + gather" % world,
+                        "scaling": "strong", "n_gpus": world, "steps": nst, "rays_per_s": st["R"] * nst / st_elapsed,
+                        "ms_per_image": st_elapsed / nst * 1e3, "bcast_ms_rank0": st["bcast_ms"], "gather_ms_rank0": st["gather_ms"],
+                        "grid_bytes": st["grid_bytes"], "bcast_algo": args.bcast, "dtype": args.prec}}
+            except Exception as e:
+                if rank == 0:
+                    res["extra"] = {"strong_dtu": {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}}
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":

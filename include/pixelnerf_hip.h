@@ -70,6 +70,11 @@ const char *pnr_last_error(void);
 
 /* Library / device facts (host out-params may be NULL). */
 int pnr_version(int *major, int *minor);
+/* ABI revision of THIS header: bumped whenever a struct layout or an entry point's argument list changes.  The
+ * library returns the value it was compiled with; a binding must compare it with the header it was written against
+ * before the first call (pixelnerf_amd/_lib.py does, and refuses a stale or foreign .so). */
+#define PNR_ABI_VERSION 3
+int pnr_abi_version(void);
 int pnr_device_info(int *num_cus, int *lds_bytes_per_block);
 
 /* ---- one-time weight repack ------------------------------------------------------------
@@ -214,9 +219,9 @@ typedef struct PnrBackwardDumps {
     void *g_fc0[5]; /* dL/d(blocks[b].fc_0 output), shapes as d_a                                */
     void *g_x0;     /* (rows_v, 512) dL/d(residual stream in front of block 0) = dY of lin_in, lin_z[0] */
     float *d_zlat;  /* (rows_v, 512) fp32, natural channel order: d(interpolated latent) = sum_b dY_b W_z[b]
-                       (resnetfc.py:175-180 backward), unscaled; NULL = not wanted                      */
+                       (resnetfc.py:175-180 backward), unscaled; REQUIRED (pnr_mlp_backward rejects NULL)     */
     float *d_in;    /* (rows_v, 42) fp32: d(positional code | view direction) = dY W_in (resnetfc.py:147
-                       backward), unscaled; NULL = not wanted (needs d_zlat)                              */
+                       backward), unscaled; NULL = not wanted                                            */
 } PnrBackwardDumps;
 
 int pnr_eval_ray_samples_train(const PnrScene *scene /*host*/, const void *packed, int precision,
@@ -411,6 +416,13 @@ int pnr_sample_training_rays(const float *poses, const float *images, const floa
                              const float *c, const float *bboxes, const long long *ids,
                              const float *ux, const float *uy, int SB, int NV, int W, int H, int B,
                              float z_near, float z_far, float *rays, float *rgb_gt, void *stream);
+
+/* The feature phase of the exact-fp32 path on its own -- PositionalEncoding.forward (src/model/code.py:30-42) on the
+ * rotated point + the rotated view direction (src/model/models.py:161-196) and SpatialEncoder.index
+ * (src/model/encoder.py:80-109) -- for B points per object: in42 (NS*SB*B, 64) = [code(39) | R d (3) | zero pad],
+ * zlat (NS*SB*B, 512), rows ordered [view][object][point].  What lin_in / lin_z consume in pnr_eval_points_f32. */
+int pnr_point_features_f32(const PnrScene *scene /*host*/, const float *xyz, const float *viewdirs, int B,
+                           float *in42, float *zlat, void *stream);
 
 /* Timing hook for bench.py: seconds spent in the fused network kernel launches issued on
  * `stream` since the last reset, measured with HIP events recorded around each launch on

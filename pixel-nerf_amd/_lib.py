@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelne
 SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_split.hip", "pnr_bwd.hip", "pnr_f32.hip", "pnr_encode.hip"]
 HEADERS = ["pnr_common.h", "pnr_layout.h", "pnr_device.h", "pnr_raysrc.h", "pnr_internal.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
 
+ABI_VERSION = 3  # PNR_ABI_VERSION of the include/pixelnerf_hip.h this binding (struct layouts, argtypes below) was written against
 PREC_F16, PREC_BF16, PREC_F32, PREC_F16X3 = 0, 1, 2, 3
 PRECISIONS = {"f16": PREC_F16, "fp16": PREC_F16, "bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -62,6 +63,7 @@ _I, _F, _P, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 PROTOTYPES = {
     "pnr_last_error": (ctypes.c_char_p, []),
     "pnr_version": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "pnr_abi_version": (_I, []),
     "pnr_device_info": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pnr_packed_mlp_bytes": (_SZ, []),
     "pnr_pack_mlp": (_I, [ctypes.POINTER(PnrMlpWeights), _I, _P, _P]),
@@ -124,12 +126,14 @@ PROTOTYPES = {
     "pnr_render_forward": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I,
                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pnr_gen_rays": (_I, [_P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "pnr_point_features_f32": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _P, _P]),
     "pnr_profile_enable": (_I, [_I]),
     "pnr_profile_read": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),
 }
 # test hook exported by the library but not part of the public header
 _EXTRA = {"pnr_debug_set_x_dump": (_I, [_P]),
-          "pnr_debug_phase_timing": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, _P])}
+          "pnr_debug_phase_timing": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+          "pnr_debug_phase_timing_split": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, _P, _P])}
 
 _lib = None
 
@@ -199,6 +203,16 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(pixelnerf_amd has no non-HIP fallback)")
     lib = ctypes.CDLL(LIB_PATH)
+    # struct layouts and argument lists are positional: a library built from another revision of the header (a stale
+    # build, an A/B variant selected with PIXELNERF_HIP_LIB) would bind silently and read fields at wrong offsets
+    try:
+        lib.pnr_abi_version.restype = ctypes.c_int
+        abi = lib.pnr_abi_version()
+    except AttributeError:
+        abi = None
+    if abi != ABI_VERSION:
+        raise PixelNerfHipError(f"{LIB_PATH} implements ABI revision {abi}, this binding was written against {ABI_VERSION} "
+                                "(include/pixelnerf_hip.h PNR_ABI_VERSION): rebuild it (__graft_entry__.build())")
     for name, (res, args) in list(PROTOTYPES.items()) + list(_EXTRA.items()):
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res

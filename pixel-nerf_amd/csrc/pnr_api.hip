@@ -30,6 +30,8 @@ extern "C" int pnr_version(int *major, int *minor) {
     return PNR_OK;
 }
 
+extern "C" int pnr_abi_version(void) { return PNR_ABI_VERSION; }
+
 extern "C" int pnr_device_info(int *num_cus, int *lds_bytes_per_block) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

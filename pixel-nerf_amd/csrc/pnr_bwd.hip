@@ -252,14 +252,12 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
             for (int b = COMBINE_LAYER - 1; b >= 0; --b)
                 bwd_block<P>(G, smem, b, R, NS, q, off_view, valid, a_rd0, a_rd1, a_wr,
                              mask_pooled + (uint32_t)view * (uint32_t)q.ntiles * NTHREADS, mask_layer, rows_left, wv, lane);
-#ifdef PNR_EXP_BWD_NOZ  // experiment (timing only): no lin_z^T / lin_in^T section
-            if (true) {
-#else
-            if (!q.d_zlat) {
-#endif
-                dump_only<P>(G, q.g_x0 + off_view, valid);  // dY of lin_in and lin_z[0] (and of lin_z[b]: g_fc1[b-1])
+#ifdef PNR_EXP_BWD_NOZ  // experiment (TIMING ONLY, wrong results: the weight ring falls out of step with the stream)
+            {
+                dump_only<P>(G, q.g_x0 + off_view, valid);
                 continue;
             }
+#endif
             // ---- d z_lat = sum_b dY_b W_z[b] and d(code) = dY_0 W_in (resnetfc.py:147,175-180 backward): four more
             // transposed-stream GEMMs on gradient images this tile has just produced.  dY_2, dY_1 (= g_fc1[1], g_fc1[0])
             // come back from their dumps (written by this workgroup a moment ago, L2-resident), dY_0 = G is in registers.
@@ -1042,7 +1040,9 @@ __global__ void __launch_bounds__(1024) grad_scale_kernel(const float *__restric
         const float mx = red[0];
         float sc = 1.f;
         if (!(mx <= 3.0e38f)) sc = __builtin_nanf("");
-        else if (mx > 0.f) sc = exp2f(6.f - ceilf(log2f(mx)));
+        // exponent clamped to +-100: scale and 1/scale stay finite normal numbers for vanishing (denormal-range) or huge
+        // gradients -- an unclamped 2^(6 - log2 mx) overflows to inf for mx < 2^-121 and poisons the step with 0 * inf
+        else if (mx > 0.f) sc = exp2f(fminf(fmaxf(6.f - ceilf(log2f(mx)), -100.f), 100.f));
         scales[0] = sc;
         scales[1] = 1.f / sc;
     }
@@ -1071,7 +1071,10 @@ extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const Pnr
     q.g_out = g_out; q.scale = grad_scale; q.scale_dev = grad_scale_dev; q.P = P; q.NS = NS; q.ntiles = (int)((P + MT - 1) / MT);
     q.d_mask = (const unsigned long long *)fwd->d_mask; q.g_x0 = (char *)out->g_x0;
     q.d_zlat = out->d_zlat; q.d_in = out->d_in;
-    if (q.d_in && !q.d_zlat) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: d_in needs d_zlat (they are produced together)");
+    // d_zlat is REQUIRED: the lin_z^T / lin_in^T GEMMs sit inside the per-view segment of the transposed weight stream, and
+    // the prefetch ring only stays in step with that stream when they run (skipping them made every later view / tile
+    // multiply by the wrong fragments)
+    if (!q.d_zlat) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: PnrBackwardDumps.d_zlat is required (d_in alone is optional)");
     if (!q.d_mask) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: the forward dumps carry no relu bit masks (PnrTrainDumps.d_mask)");
     if (!q.g_x0) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward: null dump");
     for (int b = 0; b < 5; ++b) {

@@ -284,3 +284,24 @@ extern "C" int pnr_eval_points_f32(const PnrScene *scene, const PnrMlpWeights *w
     q.P = scene ? (long long)scene->SB * B : 0; q.out = rgbsigma;
     return pnr::eval_f32(scene, w, q, false, (float *)workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+// The feature phase alone (SURVEY rows R7 + R8 in isolation): lin_in operand rows [code(39) | R d (3) | 0-pad] and the
+// bilinearly interpolated latent rows of B points per object, rows ordered [view][object][point] like the dumps.
+extern "C" int pnr_point_features_f32(const PnrScene *s, const float *xyz, const float *viewdirs, int B, float *in42,
+                                      float *zlat, void *stream) {
+    using namespace pnr;
+    if (!s || B < 0 || !in42 || !zlat) return pnr_fail(PNR_E_INVALID, "pnr_point_features_f32: bad argument");
+    if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_point_features_f32: bad scene shape");
+    if (B == 0) return PNR_OK;
+    if (!xyz || !viewdirs) return pnr_fail(PNR_E_INVALID, "pnr_point_features_f32: null xyz/viewdirs");
+    EvalParams q = {};
+    q.xyz = xyz; q.viewdirs = viewdirs; q.K = 1; q.per_obj = B; q.P = (long long)s->SB * B;
+    if (q.P * s->NS > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_point_features_f32: too many points");
+    q.latent = s->latent_nhwc; q.poses = s->poses; q.focal = s->focal; q.c = s->c;
+    q.SB = s->SB; q.NS = s->NS; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
+    q.img_w = s->img_w; q.img_h = s->img_h;
+    const long long rows = q.P * s->NS;
+    hipLaunchKernelGGL(feat_f32_kernel<false>, dim3((unsigned)((rows + FW - 1) / FW)), dim3(FW * 64), 0, (hipStream_t)stream, q, 0LL,
+                       (int)q.P, in42, zlat);
+    return pnr_check_launch("pnr_point_features_f32");
+}

@@ -15,4 +15,17 @@ int eval_samples_src(const PnrScene *scene, const void *packed, const void *tabl
 int eval_samples_split_src(const PnrScene *scene, const void *packed_split, const void *tables_f32, const RaySrc &src,
                            const float *z, int R, int rays_per_obj, int K, float *rgbsigma, hipStream_t stream);
 
+// per (device, stream) scratch for the parked view sum of multi-view launches (one tile of fp32 accumulators per workgroup),
+// allocated at the first multi-view launch on a stream and kept; NULL on allocation failure.  Defined in pnr_mlp.hip.
+float *mv_scratch(hipStream_t st, size_t bytes);
+
+// HIP events around one network-kernel launch, recorded on the launch's own stream while pnr_profile_enable(1) is
+// active (pnr_profile_read sums them): the live kernel-time figure of bench.py's roofline block.  Defined in pnr_mlp.hip.
+struct ProfileScope {
+    hipEvent_t e0 = nullptr;
+    hipStream_t st;
+    explicit ProfileScope(hipStream_t s);
+    ~ProfileScope();
+};
+
 }  // namespace pnr

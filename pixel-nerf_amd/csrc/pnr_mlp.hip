@@ -481,6 +481,19 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
 
 static int num_cus();
 
+ProfileScope::ProfileScope(hipStream_t s) : st(s) {
+    if (!g_profile) return;
+    if (hipEventCreate(&e0) != hipSuccess) { e0 = nullptr; return; }
+    hipEventRecord(e0, st);
+}
+ProfileScope::~ProfileScope() {
+    if (!e0) return;
+    hipEvent_t e1 = nullptr;
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return; }
+    hipEventRecord(e1, st);
+    g_events.emplace_back(e0, e1);
+}
+
 // tile size by instantiation: the folded single-view inference form runs 96-point tiles (one LDS image), everything
 // else (unfolded, multi-view, training dumps) the 64-point two-image tile.  Small launches are a whole number of rounds
 // of one tile per CU: a 96-point tile costs 1.37 x a 64-point one (per point it is 9-10 % cheaper), so the 64-point form
@@ -502,9 +515,9 @@ static inline bool use_tile96(const EvalParams &q, bool mv) {
 #endif
 }
 
-// (-DPNR_MV_PARK builds only) per (device, stream) scratch of the multi-view instantiations: the parked view sum, one tile
+// per (device, stream) scratch of the multi-view instantiations (the split-operand kernel, and -DPNR_MV_PARK builds of this one): the parked view sum, one tile
 // of fp32 accumulators per workgroup (256 x 192 KiB = 48 MiB), allocated at the first multi-view launch on a stream.
-[[maybe_unused]] static float *mv_scratch(hipStream_t st, size_t bytes) {
+float *mv_scratch(hipStream_t st, size_t bytes) {
     struct Slot { int dev; hipStream_t st; float *p; size_t bytes; };
     static std::vector<Slot> slots;
     int dev = 0;
@@ -550,15 +563,9 @@ static int launch(EvalParams &q, bool mv, hipStream_t st) {
 #endif
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_kernel)");
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (g_profile) {
-        hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0, st);
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, q);
-    if (g_profile) {
-        hipEventRecord(e1, st);
-        g_events.emplace_back(e0, e1);
+    {
+        ProfileScope prof(st);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, q);
     }
     return pnr_check_launch("eval_kernel");
 }

@@ -30,7 +30,7 @@ typedef PH::T8 h8;
 // The fp32 table rows (2 KiB + 16 B pad per point) are looked up into the space of the two activation images
 // while those are free (tile start, and after fc_1 of blocks 0-1 has finished reading).
 template <int MT_> struct SplitTileT {
-    static_assert(MT_ == 64 || MT_ == 32, "64 points (single view) or 32 points (multi-view: the view sum needs the registers)");
+    static_assert(MT_ == 64 || MT_ == 32, "64-point tiles (the 32-point form, view sum in registers, is kept for A/B: -DPNR_SPLIT_MV32)");
     static constexpr int MT = MT_, JT = MT_ / 32;
     static constexpr int A_HI = 0;
     static constexpr int A_LO = MT * ROW_ACT;             // 66,560 (64)
@@ -98,18 +98,23 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
             for (int it = 0; it < IT; ++it)
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(al[it], bh[cur][jt], acc[it][jt]);
+#ifndef PNR_EXP_NO_WLOAD  // experiment: never refill the ring (no weight traffic at all); results are wrong
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
                 R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
             }
+#endif
         }
         bhi0 += 128;
         ring_advance(R, NS);
     }
 }
 
-// head / tail of 8 fp32 values (optionally through relu); MODE.FP16_OVFL is set: heads saturate at 65504
+// head / tail of 8 fp32 values (optionally through relu); MODE.FP16_OVFL is set: heads saturate at 65504.
+// tail = f16(v - head): one v_fma_mix{lo,hi}_f16 per value (fp32 FMA of the f16 head taken straight out of its packed
+// register, times -1, plus v; result rounded once to f16) -- the same bits as convert-back + subtract + convert
+// (v - head is exact in fp32), 5 VALU operations per pair instead of 8.
 template <bool RELU>
 __device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo) {
     u32x4 uh, ul;
@@ -118,10 +123,17 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo) {
         f32x2 p = {v[2 * k], v[2 * k + 1]};
         if (RELU) { p[0] = fmaxf(p[0], 0.f); p[1] = fmaxf(p[1], 0.f); }
         const f16x2 h = __builtin_convertvector(p, f16x2);
+        uh[k] = __builtin_bit_cast(uint32_t, h);
+#ifdef PNR_SPLIT_NO_MIX
         const f32x2 back = __builtin_convertvector(h, f32x2);
         const f16x2 l = __builtin_convertvector(p - back, f16x2);
-        uh[k] = __builtin_bit_cast(uint32_t, h);
         ul[k] = __builtin_bit_cast(uint32_t, l);
+#else
+        uint32_t l;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(uh[k]), "v"(p[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(uh[k]), "v"(p[1]));
+        ul[k] = l;
+#endif
     }
     hi = __builtin_bit_cast(h8, uh);
     lo = __builtin_bit_cast(h8, ul);
@@ -202,13 +214,22 @@ __device__ __forceinline__ void add_from_table(f32x16 (&x)[IT][JT], const char *
         }
 }
 
-// MV: multi-view scenes run 32-point tiles (JT = 1): x + net + the running view sum are 3 x 32 accumulator registers next to
-// the 64-register head/tail ring, like the 64-point single-view form (x + net = 128).  Views go through blocks 0-2 one after
-// the other, the mean is formed in registers before block 3 (util.combine_interleaved, util.py:461-466).
-template <bool RAYS, bool MV>
+// MV: views go through blocks 0-2 one after the other on the same 64 points; the running view sum (util.combine_interleaved,
+// util.py:461-466) does not fit the registers next to x + net + the 64-register head/tail ring, so it is PARKED in a
+// per-workgroup scratch (q.mv_ws, [slot][thread] layout: every lane re-reads only what it wrote itself, no synchronisation;
+// 128 KiB per workgroup, L2-resident) and read-modify-written once per view and tile -- 256 KiB of traffic against the 6.6 MB
+// of weights the same view streams.  (Round 2 ran multi-view scenes on 32-point tiles with the sum in registers: twice the
+// weight stream per point, 105-147 k rays/s; -DPNR_SPLIT_MV32 rebuilds that form.)  Fixed summation order
+// (view 0 + view 1) + ...: bit-identical to the in-register form.
+#ifdef PNR_SPLIT_MV32
+constexpr int SPLIT_MV_TILE = 32;
+#else
+constexpr int SPLIT_MV_TILE = 64;
+#endif
+template <bool RAYS, bool MV, bool TIMING = false>
 __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const EvalParams q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef SplitTileT<MV ? 32 : 64> ST;
+    typedef SplitTileT<MV ? SPLIT_MV_TILE : 64> ST;
     constexpr int JT = ST::JT, MT = ST::MT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -234,46 +255,64 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         }
     R.pf_rs = 4;
     R.pf_view = 0;
+    [[maybe_unused]] unsigned long long *tim = q.tim;
+    [[maybe_unused]] unsigned long long tlast = TIMING ? __builtin_readcyclecounter() : 0ull;
 
     // one residual block on x (resnetfc.py:66-88); lookup: lin_z[b+1] via table b+1 behind it
     auto block = [&](f32x16 (&x)[IT][JT], int b, bool lookup) {
         __syncthreads();  // table rows / previous operand images are no longer read
+        PNR_T(PH_BAR1);
         write_split<ST>(x, smem, a_wr);
+        PNR_T(PH_WRITE_X);
         __syncthreads();
+        PNR_T(PH_BAR2);
         {
             f32x16 net[IT][JT];
             add_bias<true>(net, bias_lane, 1 + 2 * b);
             gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);  // fc_0
+            PNR_T(PH_GEMM_FC0);
             __syncthreads();
+            PNR_T(PH_BAR3);
             write_split<ST>(net, smem, a_wr);
+            PNR_T(PH_WRITE_NET);
         }
         __syncthreads();
+        PNR_T(PH_BAR4);
         add_bias<false>(x, bias_lane, 2 + 2 * b);
         gemm_split(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);        // fc_1
+        PNR_T(PH_GEMM_FC1_Z);
         if (lookup) {
+#ifndef PNR_EXP_NO_LOOKUP12  // experiment: upper bound of hiding the block-1/2 lookups entirely (wrong results)
             __syncthreads();
             gather_table_f32<2, ST>(q, smem, wv, lane, b + 1);
             __syncthreads();
             add_from_table<ST>(x, smem, pl, h, wv);
+#endif
+            PNR_T(PH_TABLE);
         }
     };
 
     for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
         f32x16 x[IT][JT];
-        f32x16 xsum[MV ? IT : 1][MV ? JT : 1];
+        constexpr bool MV_REGS = MV && SPLIT_MV_TILE == 32;
+        [[maybe_unused]] f32x16 xsum[MV_REGS ? IT : 1][MV_REGS ? JT : 1];
 #pragma unroll 1
         for (int view = 0; view < NS; ++view) {
             __syncthreads();  // previous tile / view: every reader of the images / IN / META is done
+            PNR_T(PH_SYNC_TOP);
             if (MT == 64 || tid < MT * 8) geometry_item<PH, RAYS, ST>(q, smem, tile, view, tid % MT, tid / MT);
             __syncthreads();
+            PNR_T(PH_GEOMETRY);
             gather_table_f32<2, ST>(q, smem, wv, lane, 0);
+            PNR_T(PH_GATHER);
             add_bias<true>(x, bias_lane, B_IN_Z0);
             gemm_split(x, smem, in_rd0, 32 * ROW_IN, ST::IN_LO_DELTA, KS_IN / 4, R, NS);  // lin_in   resnetfc.py:147
             __syncthreads();  // table rows of every wave are in place
             add_from_table<ST>(x, smem, pl, h, wv);                                           // lin_z[0] via table 0
+            PNR_T(PH_GEMM_IN_Z0);
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b) block(x, b, b + 1 < COMBINE_LAYER);
-            if constexpr (MV) {  // fixed summation order view 0 + view 1 + ...: deterministic
+            if constexpr (MV_REGS) {  // fixed summation order view 0 + view 1 + ...: deterministic
                 const float inv = 1.f / (float)NS;
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
@@ -282,6 +321,25 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
                         if (view == 0) xsum[it][jt] = x[it][jt];
                         else xsum[it][jt] += x[it][jt];
                         if (view + 1 == NS) x[it][jt] = xsum[it][jt] * inv;
+                    }
+            } else if constexpr (MV) {
+                f32x4 *ws = reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid;
+                const float inv = 1.f / (float)NS;
+                const bool first = view == 0, last = view + 1 == NS;
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        __builtin_amdgcn_sched_barrier(0);  // one accumulator tile (4 loads) in flight at a time: no register spike
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int i = (it * JT + jt) * 4 + k;
+                            f32x4 v = {x[it][jt][4 * k], x[it][jt][4 * k + 1], x[it][jt][4 * k + 2], x[it][jt][4 * k + 3]};
+                            if (!first) v = ws[i * NTHREADS] + v;  // 1 KiB per wave-instruction
+                            if (!last) ws[i * NTHREADS] = v;
+                            else v *= inv;
+                            x[it][jt][4 * k] = v[0]; x[it][jt][4 * k + 1] = v[1]; x[it][jt][4 * k + 2] = v[2]; x[it][jt][4 * k + 3] = v[3];
+                        }
                     }
             }
         }
@@ -328,7 +386,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
                 }
             }
         }
+        PNR_T(PH_LIN_OUT);
         __syncthreads();
+        PNR_T(PH_BAR_OUT);
         if (tid < MT) {
             const long long g = (long long)tile * MT + tid;
             f32x4 s = *reinterpret_cast<const f32x4 *>(q.bout);
@@ -338,6 +398,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             f32x4 res = {1.f / (1.f + expf(-s[0])), 1.f / (1.f + expf(-s[1])), 1.f / (1.f + expf(-s[2])), fmaxf(s[3], 0.f)};
             if (g < q.P) *reinterpret_cast<f32x4 *>(q.out + g * 4) = res;
         }
+        PNR_T(PH_FINAL);
     }
 }
 
@@ -360,8 +421,8 @@ static int split_launch(const PnrScene *s, const void *packed, const void *table
     q.tables = (const char *)tables;
     q.table_stride = (long long)s->SB * s->NS * s->Hl * s->Wl * C_LAT;
     const bool mv = s->NS > 1;
-    const int MT = mv ? SplitTileT<32>::MT : SplitTileT<64>::MT;
-    const int lds = mv ? SplitTileT<32>::LDS_TOTAL : SplitTileT<64>::LDS_TOTAL;
+    const int MT = mv ? SplitTileT<SPLIT_MV_TILE>::MT : SplitTileT<64>::MT;
+    const int lds = mv ? SplitTileT<SPLIT_MV_TILE>::LDS_TOTAL : SplitTileT<64>::LDS_TOTAL;
     const long long nt = (q.P + MT - 1) / MT;
     q.ntiles = (int)nt;
     int dev = 0, ncu = 256;
@@ -369,11 +430,22 @@ static int split_launch(const PnrScene *s, const void *packed, const void *table
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         ncu = prop.multiProcessorCount;
     const int grid = (int)(nt < ncu ? nt : ncu);
+    if (mv && SPLIT_MV_TILE == 64) {
+        q.mv_ws = mv_scratch(st, (size_t)ncu * 64 * D_HID * sizeof(float));
+        if (!q.mv_ws) return pnr_fail(PNR_E_HIP, "pnr_eval_split: cannot allocate the multi-view pooling scratch (32 MiB)");
+    }
     auto k = mv ? (rays ? eval_split_kernel<true, true> : eval_split_kernel<false, true>)
                 : (rays ? eval_split_kernel<true, false> : eval_split_kernel<false, false>);
+    if (q.tim) {  // diagnostic instantiation (pnr_debug_phase_timing_split): single view, rays
+        if (mv || !rays) return pnr_fail(PNR_E_INVALID, "phase timing: single-view ray launches only");
+        k = eval_split_kernel<true, false, true>;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_split_kernel)");
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, q);
+    {
+        ProfileScope prof(st);  // HIP events around the launch on ITS stream when pnr_profile_enable(1) is active
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, q);
+    }
     return pnr_check_launch("eval_split_kernel");
 }
 
@@ -398,6 +470,16 @@ extern "C" int pnr_eval_ray_samples_split(const PnrScene *scene, const void *pac
     pnr::RaySrc src = {};
     src.rays = rays;
     return pnr::eval_samples_split_src(scene, packed_split, tables_f32, src, z, R, rays_per_obj, K, rgbsigma, (hipStream_t)stream);
+}
+
+// test/diagnostic hook (not in the public header): per-phase cycle totals of every wave of workgroup 0, one single-view launch
+extern "C" int pnr_debug_phase_timing_split(const PnrScene *scene, const void *packed_split, const void *tables_f32, const float *rays,
+                                            const float *z, int R, int rays_per_obj, int K, float *rgbsigma, unsigned long long *tim,
+                                            void *stream) {
+    if (!tim || !rays || !z) return pnr_fail(PNR_E_INVALID, "pnr_debug_phase_timing_split: null argument");
+    pnr::EvalParams q = {};
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma; q.tim = tim;
+    return pnr::split_launch(scene, packed_split, tables_f32, q, true, (hipStream_t)stream);
 }
 
 extern "C" int pnr_eval_points_split(const PnrScene *scene, const void *packed_split, const void *tables_f32, const float *xyz,

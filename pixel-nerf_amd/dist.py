@@ -30,12 +30,32 @@ def shard_bounds(n, rank, world):
 _HDR = 8  # int64 header words, carried as exact small floats in front of the metadata
 
 
-def broadcast_encoded(net, src=0, group=None, latent_shape=None):
+def _flat_fanout(buf, src, group):
+    """`buf` from rank src to every other rank as ONE group of point-to-point transfers (RCCL send/recv fused by
+    batch_isend_irecv): on MI355X's fully connected xGMI every receiver has its own link to the source, so the
+    7 transfers of an 8-GPU node run concurrently at link rate and each link carries the buffer exactly once
+     -- unlike a ring/tree broadcast that relays it.  Which form wins is a measurement
+    (`bench.py --bcast flat|tree`)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if rank == src:
+        ops = [dist.P2POp(dist.isend, buf, dist.get_global_rank(group, r) if group is not None else r, group=group)
+               for r in range(world) if r != src]
+    else:
+        ops = [dist.P2POp(dist.irecv, buf, dist.get_global_rank(group, src) if group is not None else src, group=group)]
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+
+
+def broadcast_encoded(net, src=0, group=None, latent_shape=None, algo="tree"):
     """Make rank `src`'s encode() state current on every rank with ONE collective when the receivers know the
     grid shape (`latent_shape=(NV,512,Hl,Wl)`, the normal case: every rank knows the dataset's image size and view
     count): a single flat broadcast of [header | poses, focal, c, image_shape, latent_scaling | feature grid].
     Without `latent_shape` a first 8-word broadcast announces the shapes (two collectives in total).  No host
-    synchronisation on the sending side; receivers read the header back only in the shape-discovery form."""
+    synchronisation on the sending side; receivers read the header back only in the shape-discovery form.
+    algo: "tree" = dist.broadcast (RCCL picks ring / tree), "flat" = one point-to-point transfer per receiver
+    (_flat_fanout)."""
+    if algo not in ("tree", "flat"):
+        raise ValueError("broadcast_encoded: algo must be 'tree' or 'flat'")
     dev = net.poses.device
     is_src = dist.get_rank(group) == src
     if is_src:
@@ -68,7 +88,10 @@ def broadcast_encoded(net, src=0, group=None, latent_shape=None):
             meta[o:o + t.numel()] = t.to(dev)
         buf[:n_meta] = meta
         buf[n_meta:] = net.encoder.latent.reshape(-1)
-    dist.broadcast(buf, src, group=group)      # THE feature-grid broadcast (metadata rides in front of it)
+    if algo == "flat":
+        _flat_fanout(buf, src, group)          # THE feature-grid transfer as a 1 -> (N-1) fan-out
+    else:
+        dist.broadcast(buf, src, group=group)  # THE feature-grid broadcast (metadata rides in front of it)
     if not is_src:
         h = buf[:_HDR].tolist()
         NS, SB, nf, nc = int(h[4]), int(h[5]), int(h[6]), int(h[7])

@@ -351,6 +351,21 @@ def eval_points(scene, packed, xyz, viewdirs, tables=None):
     return out
 
 
+def point_features(scene, xyz, viewdirs):
+    """The fp32 feature phase alone: xyz, viewdirs (SB,B,3) -> (in42 (NS,SB,B,64) = [positional code(39) | rotated
+    viewdir(3) | 0 pad], zlat (NS,SB,B,512) = SpatialEncoder.index of the projected points)."""
+    lib = _lib.load()
+    xyz = _f32(xyz, "xyz", (scene.SB, None, 3))
+    B = xyz.shape[1]
+    viewdirs = _f32(viewdirs, "viewdirs", (scene.SB, B, 3))
+    in42 = torch.empty((scene.NS, scene.SB, B, 64), dtype=torch.float32, device=xyz.device)
+    zlat = torch.empty((scene.NS, scene.SB, B, 512), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(lib.pnr_point_features_f32(scene.ref, _p(xyz), _p(viewdirs), B, _p(in42), _p(zlat), _stream()),
+                   "pnr_point_features_f32")
+    return in42, zlat
+
+
 def composite(rays, z, rgbsigma, white_bkgd=False, want_weights=True):
     lib = _lib.load()
     rays = _f32(rays, "rays", (None, 8))
@@ -660,6 +675,21 @@ def debug_phase_timing(scene, packed, rays, z, tables=None):
     torch.cuda.synchronize()
     t = tim.cpu().reshape(8, len(PHASES))
     return {p: t[:, i].tolist() for i, p in enumerate(PHASES)}  # per wave
+
+
+def debug_phase_timing_split(scene, packed, rays, z, tables):
+    """diagnostic: {phase: [cycles of wave 0..7]} of workgroup 0, one f16x3 single-view launch."""
+    lib = _lib.load()
+    rays, z = _f32(rays, "rays", (None, 8)), _f32(z, "z")
+    _check_split_tables(tables)
+    tim = torch.zeros(8 * len(PHASES), dtype=torch.int64, device=rays.device)
+    out = torch.empty((rays.shape[0], z.shape[1], 4), dtype=torch.float32, device=rays.device)
+    _lib.check(lib.pnr_debug_phase_timing_split(scene.ref, packed.ptr, _p(tables), _p(rays), _p(z), rays.shape[0],
+                                                max(rays.shape[0] // scene.SB, 1), z.shape[1], _p(out), _p(tim), _stream()),
+               "pnr_debug_phase_timing_split")
+    torch.cuda.synchronize()
+    t = tim.cpu().reshape(8, len(PHASES))
+    return {p: t[:, i].tolist() for i, p in enumerate(PHASES)}
 
 
 # ------------------------------------------------------------------ training support

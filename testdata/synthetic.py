@@ -165,6 +165,11 @@ SCENES = {
                   z_near=1.2, z_far=4.0, radius=2.732,
                   src=[(30.0, -20.0), (100.0, -30.0), (200.0, -10.0), (300.0, -25.0)],
                   tgt=(75.0, -20.0), white_bkgd=True, blender=False),
+    # config (5)'s step on a multi-view scene: 2 objects x 2 source views (view pooling in forward AND backward)
+    "train_mv": dict(W=64, H=64, NS=2, SB=2, Hl=32, Wl=32, focal=(119.4256, 119.4256), c=(32.0, 32.0),
+                     z_near=1.2, z_far=4.0, radius=2.732,
+                     src=[(30.0, -20.0), (100.0, -30.0), (200.0, -10.0), (300.0, -25.0)],
+                     tgt=(75.0, -20.0), white_bkgd=True, blender=False),
     # one axis-aligned source camera (pose entries exactly 0 / +-1, so points with camera-space z == 0 can be written
     # down exactly in fp32) + one ordinary view: the "on / behind the camera plane" fixtures
     "plane_mini": dict(W=32, H=32, NS=2, SB=1, Hl=16, Wl=16, focal=(59.7, 59.7), c=(16.0, 16.0),

@@ -88,6 +88,32 @@ def _worker(rank, world, port, B):
         assert torch.equal(net.focal, ref["focal"]) and torch.equal(net.c, ref["c"])
         assert torch.equal(net.image_shape, ref["image_shape"]) and torch.equal(enc.latent_scaling, ref["ls"])
         assert (net.num_views_per_obj, net.num_objs) == (2, 2)
+        # the flat 1 -> (N-1) fan-out form of the same transfer (bench.py --bcast flat): point-to-point only,
+        # NO collective, same state on the receivers
+        if rank != 0:
+            enc.latent, net.poses, net.num_views_per_obj = torch.zeros(1, 1, 1, 1), torch.zeros(1, 3, 4), 1
+        calls["broadcast"] = 0
+        dist.broadcast = lambda *a, **k: (calls.__setitem__("broadcast", calls["broadcast"] + 1), real_b(*a, **k))[1]
+        try:
+            broadcast_encoded(net, src=0, latent_shape=(4, 6, 5, 7), algo="flat")
+        finally:
+            dist.broadcast = real_b
+        assert calls["broadcast"] == 0
+        assert torch.equal(enc.latent, ref["latent"]) and torch.equal(net.poses, ref["poses"])
+        assert torch.equal(net.focal, ref["focal"]) and (net.num_views_per_obj, net.num_objs) == (2, 2)
+        # strong-scaling placement (bench.py --workload dtu): contiguous shards of ONE image, gathered with padding, give
+        # back the image in ray order
+        Rimg = 11
+        img = torch.arange(Rimg * 4, dtype=torch.float32).reshape(Rimg, 4)
+        lo, hi = shard_bounds(Rimg, rank, world)
+        sizes = [shard_bounds(Rimg, r, world)[1] - shard_bounds(Rimg, r, world)[0] for r in range(world)]
+        part = img[lo:hi]
+        if part.shape[0] < max(sizes):
+            part = torch.cat([part, part.new_zeros(max(sizes) - part.shape[0], 4)])
+        bufs = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
+        dist.gather(part.contiguous(), bufs, dst=0)
+        if rank == 0:
+            assert torch.equal(torch.cat([b[:n] for b, n in zip(bufs, sizes)]), img)
     finally:
         dist.destroy_process_group()
 

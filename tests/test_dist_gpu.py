@@ -82,10 +82,31 @@ def test_bench_self_launches_two_ranks(repo_root):
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     res = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
-                          "--warmup", "1", "--rays", "8192"], capture_output=True, text=True, timeout=600, env=env)
+                          "--warmup", "1", "--rays", "8192", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["roofline"]["frac"] > 0
+    assert d["dtype"] == "f16x3" and d["roofline"]["frac"] > 0 and d["roofline"]["mfmas_per_product"] == 3
+    assert d["comm"]["bcast_ms_rank0"] >= 0 and d["comm"]["grid_bytes"] == 512 * 32 * 32 * 4
+
+
+@pytest.mark.parametrize("bcast", ["tree", "flat"])
+def test_bench_strong_dtu_two_ranks(repo_root, bcast):
+    """BASELINE configs[3] in its strong-scaling form: ONE DTU image (120 000 rays, 176 MiB grid) sharded over two ranks
+    (gloo, both on the one device): grid broadcast (RCCL-style broadcast or the flat point-to-point fan-out) + render + gather."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1",
+                          "--warmup", "1", "--workload", "dtu", "--prec", "f16", "--bcast", bcast], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["rays_per_image"] == 120000 and d["config"]["rays_rank0"] == 60000
+    assert d["comm"]["grid_bytes"] == 3 * 512 * 150 * 200 * 4 and d["comm"]["bcast_ms_rank0"] > 0

@@ -1,0 +1,88 @@
+"""
+GPU tests (-m gpu) of the feature phase IN ISOLATION (SURVEY.md 8a rows R7 + R8), against goldens frozen from the
+reference's own modules (tests/golden/stages.npz, oracle/make_goldens.py):
+  * PositionalEncoding.forward (src/model/code.py:30-42): `posenc_x` -> `posenc_out`, through pnr_point_features_f32
+    (the exact-fp32 path's feature kernel, libm sinf) with an identity source camera, and through the fused 16-bit
+    kernel's feature phase (hardware sine, code rounded to f16 on its way to LDS) read back from the training dump d_in;
+  * SpatialEncoder.index (src/model/encoder.py:80-109): `<scene>_uv` -> `<scene>_index`, through the same entry with points
+    constructed to project onto those pixel coordinates.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, mlp_params, scene_for
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pixelnerf_amd import ops as _ops
+    return _ops
+
+
+def identity_scene(ops, dev, name="sn64"):
+    """the named scene's grid seen by ONE source camera at the origin looking down -z (world == camera frame)"""
+    s, meta = scene_for(name)
+    pose = torch.eye(4)[:3].reshape(1, 3, 4).contiguous()
+    return s, ops.make_scene(s["latent"][:1].to(dev), pose.to(dev), s["focal"].to(dev), s["c"].to(dev), s["image_shape"], 1)
+
+
+def test_positional_encoding_fp32_matches_reference(ops, dev):
+    g = load_golden("stages")
+    _, sc = identity_scene(ops, dev)
+    x = torch.from_numpy(g["posenc_x"]).to(dev)[None]  # (1, 257, 3)
+    d = torch.nn.functional.normalize(torch.randn(1, x.shape[1], 3, generator=torch.Generator().manual_seed(0)), dim=-1).to(dev)
+    in42, _ = ops.point_features(sc, x, d)
+    got = in42[0, 0].cpu().numpy()
+    # code.py:37-41: [x, sin(f_k x), sin(f_k x + pi/2)]; device libm sinf vs the reference's CPU sin: a few ulp
+    np.testing.assert_allclose(got[:, :39], g["posenc_out"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got[:, 39:42], d[0].cpu().numpy(), rtol=0, atol=1e-7)  # identity rotation of the view direction
+    assert (got[:, 42:] == 0).all()
+
+
+def test_positional_encoding_of_the_fused_kernel_matches_reference(ops, dev):
+    """the 16-bit kernels' feature phase (v_sin_f32, values rounded to f16): read from the training dump of lin_in's operand"""
+    g = load_golden("stages")
+    _, sc = identity_scene(ops, dev)
+    x = torch.from_numpy(g["posenc_x"]).to(dev)
+    R = x.shape[0]
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=torch.Generator().manual_seed(0)), dim=-1).to(dev)
+    rays = torch.cat([x, d, torch.zeros(R, 2, device=dev)], dim=1).contiguous()  # origin = point, z = 0 (autograd._PointsFunction)
+    z = torch.zeros(R, 1, device=dev)
+    state = {k: v.to(dev) for k, v in mlp_params(11).items()}
+    _, dumps = ops.eval_ray_samples_train(sc, ops.pack_mlp(state, "f16"), rays, z)
+    got = dumps.d_in.float().cpu().numpy()
+    ref = g["posenc_out"]
+    # f16 rounding of values in [-1,1] U the identity part: half an f16 ulp of max(|x|, 1) + the hardware sine's 1e-5
+    tol = 2.0 ** -11 * np.maximum(1.0, np.abs(ref)) + 2e-5
+    assert (np.abs(got[:, :39] - ref) <= tol).all(), float(np.abs(got[:, :39] - ref).max())
+    dumps.release()
+
+
+@pytest.mark.parametrize("name", ["sn64", "dtu_mini", "mv_mini"])
+def test_spatial_encoder_index_matches_reference(ops, dev, name):
+    g = load_golden("stages")
+    s, meta = scene_for(name)
+    uv = torch.from_numpy(g[name + "_uv"])        # (NV, 64, 2) pixel coordinates, some outside the image (border clamp)
+    ref = torch.from_numpy(g[name + "_index"])    # (NV, 512, 64)
+    fx, fy = float(s["focal"][0, 0]), float(-s["focal"][0, 1])
+    cx, cy = float(s["c"][0, 0]), float(s["c"][0, 1])
+    pose = torch.eye(4)[:3].reshape(1, 3, 4).contiguous()
+    for v in range(uv.shape[0]):
+        sc = ops.make_scene(s["latent"][v:v + 1].to(dev), pose.to(dev), s["focal"].to(dev), s["c"].to(dev), s["image_shape"], 1)
+        # camera at the origin, depth -1: u = x fx + cx, v = -y fy + cy  (models.py:206-212 with focal stored as (fx, -fy))
+        x = (uv[v, :, 0] - cx) / fx
+        y = -(uv[v, :, 1] - cy) / fy
+        pts = torch.stack([x, y, -torch.ones_like(x)], dim=-1)[None].contiguous().to(dev)
+        _, zlat = ops.point_features(sc, pts, torch.zeros_like(pts))
+        got = zlat[0, 0].cpu().t()  # (512, 64)
+        # reconstructing uv from (x, y) costs ~1e-5 px; the grid is O(1) per texel step
+        assert (got - ref[v]).abs().max() <= 1e-4, float((got - ref[v]).abs().max())

@@ -36,6 +36,21 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.PnrMlpWeights) == 30 * 8
 
 
+def test_abi_revision_header_library_binding_agree(lib, repo_root):
+    """include/pixelnerf_hip.h, the built library and the ctypes binding carry the same ABI revision; load() refuses
+    a library of another revision (a stale build or an A/B variant) instead of binding structs at wrong offsets."""
+    src = open(os.path.join(repo_root, "include", "pixelnerf_hip.h")).read()
+    hdr = int(re.search(r"#define\s+PNR_ABI_VERSION\s+(\d+)", src).group(1))
+    assert hdr == _lib.ABI_VERSION == lib.pnr_abi_version()
+    saved, saved_lib = _lib.ABI_VERSION, _lib._lib
+    try:
+        _lib.ABI_VERSION, _lib._lib = saved + 1, None
+        with pytest.raises(_lib.PixelNerfHipError, match="ABI revision"):
+            _lib.load()
+    finally:
+        _lib.ABI_VERSION, _lib._lib = saved, saved_lib
+
+
 def test_host_only_entry_points(lib):
     major, minor = ctypes.c_int(-1), ctypes.c_int(-1)
     assert lib.pnr_version(ctypes.byref(major), ctypes.byref(minor)) == 0
@@ -67,6 +82,14 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pnr_pack_mlp_bwd(None, 0, None, None) == -1
     assert lib.pnr_composite_backward(None, None, None, 3, 8, 0, None, None, None, None, None, 0, None) == -1
     assert lib.pnr_mlp_backward(None, 0, None, None, 1.0, None, 10, 1, None, None) == -1
+    # d_zlat is required: the chain's weight ring only stays in step with the transposed stream when the lin_z^T GEMMs run
+    dumps, bd = _lib.PnrTrainDumps(), _lib.PnrBackwardDumps()
+    dumps.d_mask = 64
+    for b in range(5):
+        bd.g_fc1[b], bd.g_fc0[b] = 64, 64
+    bd.g_x0 = 64
+    assert lib.pnr_mlp_backward(64, 0, ctypes.byref(dumps), 64, 1.0, None, 10, 1, ctypes.byref(bd), None) == -1
+    assert b"d_zlat is required" in lib.pnr_last_error()
     assert lib.pnr_grad_scale(None, 10, None, None) == -1
     assert lib.pnr_weight_grad(None, None, 10, 0, 1.0, 0, 0, None, None, None, None) == -1
     assert lib.pnr_position_backward(None, None, None, 1, 1, 1, None, None, None, None) == -1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Reduce the rocprofv3 --pmc CSVs written by tools/collect_pmc.sh to one JSON: per counter the values of every
-launch of the fused network kernel (pnr::eval_kernel) and their average, plus derived figures.  FETCH_SIZE and
+launch of the fused network kernel (pnr::eval_kernel, or pnr::eval_split_kernel for f16x3) and their average, plus derived figures.  FETCH_SIZE and
 WRITE_SIZE are in KiB; per MI355X_MICROARCH.md FETCH_SIZE is doubled on gfx950."""
 import csv
 import glob
@@ -11,12 +11,14 @@ import sys
 
 def main():
     out_dir, cmd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
+    kname = sys.argv[3] if len(sys.argv) > 3 else "eval_kernel"  # substring of the kernel name
+    prec = sys.argv[4] if len(sys.argv) > 4 else "f16"
     res = {}
     kern = {}
     for path in sorted(glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)):
         per = {}
         for row in csv.DictReader(open(path)):
-            if "eval_kernel" not in row["Kernel_Name"]:
+            if kname + "<" not in row["Kernel_Name"] and kname + "I" not in row["Kernel_Name"]:
                 continue
             per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
             per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
@@ -32,6 +34,8 @@ def main():
         der["L2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
     if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None and g("SQ_BUSY_CU_CYCLES") is not None:
         der["mfma_busy_frac"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * g("SQ_BUSY_CU_CYCLES"))  # 4 SIMDs per CU
+    if g("GRBM_GUI_ACTIVE") is not None:
+        der["gpu_active_cycles_per_launch"] = g("GRBM_GUI_ACTIVE")  # / kernel duration = the average shader clock
     if g("FETCH_SIZE") is not None:
         der["fabric_read_bytes_per_launch"] = 2.0 * g("FETCH_SIZE") * 1024.0
     if g("WRITE_SIZE") is not None:
@@ -41,10 +45,10 @@ def main():
     res["_kernel"], res["_derived"] = kern, der
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    res["_kernel_source_sha16"] = bench.kernel_source_sha16()  # bench.py refuses this profile once the kernel sources change
+    res["_kernel_source_sha16"] = bench.kernel_source_sha16(prec)  # bench.py refuses this profile once the kernel sources change
     res["_note"] = ("fused network kernel launches of `%s`; one rocprofv3 --pmc pass per counter group; FETCH_SIZE/WRITE_SIZE in KiB, "
                     "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)" % cmd)
-    json.dump(res, open(os.path.join(out_dir, "pmc_eval_kernel.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(out_dir, "pmc_%s.json" % kname), "w"), indent=1)
     print(json.dumps({"derived": der, "kernel": kern, "counters": {k: v["avg_per_launch"] for k, v in res.items() if not k.startswith("_")}}, indent=1))
 
 
