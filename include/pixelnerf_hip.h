@@ -417,6 +417,29 @@ int pnr_sample_training_rays(const float *poses, const float *images, const floa
                              const float *ux, const float *uy, int SB, int NV, int W, int H, int B,
                              float z_near, float z_far, float *rays, float *rgb_gt, void *stream);
 
+/* ---- exact-fp32 TRAINING path (validation grade; precision "f32" under autograd).  The unfused fp32 chain of
+ * pnr_eval_ray_samples_f32 with every activation the backward needs kept in fp32, and its backward on fp32 MFMA:
+ * the fp32 yardstick of the 16-bit training kernels (ResnetFC.forward / autograd through it, src/model/resnetfc.py:132-184;
+ * train/train.py:199-215).  rows_v = NS * P ordered [view][point], rows_p = P. */
+typedef struct PnrF32Saved {
+    float *in42;    /* (rows_v, 64)  lin_in operand: positional code | rotated view direction | 0 pad   */
+    float *zlat;    /* (rows_v, 512) interpolated latent (operand of lin_z[0..2])                      */
+    float *xin[5];  /* residual stream entering blocks[b] (after + lin_z[b]): b < 3 (rows_v,512), else (rows_p,512) */
+    float *net[5];  /* blocks[b].fc_0 output (pre-relu), same shapes                                   */
+    float *x5;      /* (rows_p, 512) residual stream in front of lin_out                               */
+    float *pool_in; /* (rows_v, 512) residual stream after block 2, in front of the view mean; NS == 1: unused, may be NULL */
+} PnrF32Saved;
+int pnr_eval_ray_samples_f32_train(const PnrScene *scene /*host*/, const PnrMlpWeights *w /*host*/, const float *rays,
+                                   const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
+                                   const PnrF32Saved *saved /*host*/, void *stream);
+/* All parameter gradients of one ResnetFC + d(interpolated latent) [+ d(lin_in operand)] from g_out (P,4) =
+ * dL/d(lin_out output): `grads` holds device pointers of the 30 gradient tensors in PnrMlpWeights' layout (same shapes as
+ * the parameters, overwritten); d_zlat (rows_v,512), d_in (rows_v,42) or NULL. */
+size_t pnr_mlp_backward_f32_workspace_bytes(long long P, int NS);
+int pnr_mlp_backward_f32(const PnrMlpWeights *w /*host*/, const PnrF32Saved *saved /*host*/, const float *g_out, long long P,
+                         int NS, const PnrMlpWeights *grads /*host*/, float *d_zlat, float *d_in, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 /* The feature phase of the exact-fp32 path on its own -- PositionalEncoding.forward (src/model/code.py:30-42) on the
  * rotated point + the rotated view direction (src/model/models.py:161-196) and SpatialEncoder.index
  * (src/model/encoder.py:80-109) -- for B points per object: in42 (NS*SB*B, 64) = [code(39) | R d (3) | zero pad],

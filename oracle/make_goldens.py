@@ -340,7 +340,9 @@ def neighbour_goldens():
     return rec
 
 
-GRAD_SCENARIOS = ("train_64_32", "srn_mini_64_128")  # SB=4 x NS=1 (BASELINE config 5 shapes) and NS=2 pooling
+GRAD_SCENARIOS = ("train_64_32", "srn_mini_64_128", "train_cfg5")  # SB=4 x NS=1 (config 5 shapes), NS=2 pooling, config 5 at FULL size
+# gradient-only scenarios (no render fixture: rays and noise are regenerated from their seeds by the tests, exactly as below)
+GRAD_ONLY = {"train_cfg5": ("train", 64, 32, 16, 128, False, True)}  # BASELINE configs[4]: 4 objects x 128 rays, 64+32(16)
 
 def gradient_goldens():
     """Gradients of the UNMODIFIED reference (torch autograd through NeRFRenderer.forward, train/train.py:199-215:
@@ -350,7 +352,7 @@ def gradient_goldens():
 
     rec = {}
     for name in GRAD_SCENARIOS:
-        scene_name, Kc, Kf, Kfd, n_rays, lindisp, use_fine = SCENARIOS[name]
+        scene_name, Kc, Kf, Kfd, n_rays, lindisp, use_fine = SCENARIOS[name] if name in SCENARIOS else GRAD_ONLY[name]
         scene, meta = synthetic.make_scene(scene_name, seed=SCENE_SEED)
         rays = synthetic.target_rays(meta, n_rays=n_rays)
         SB = rays.shape[0]

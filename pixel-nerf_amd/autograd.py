@@ -31,6 +31,28 @@ def _param_names():
 PARAM_NAMES = _param_names()
 
 
+class _NoRelease:
+    @staticmethod
+    def release():
+        pass
+
+
+def _train_eval(net, scene, coarse, rays, z):
+    """network forward of one training pass -> (rgbsigma (R,K,4), saved operands).  precision 'f32': the exact, unfused fp32
+    chain (validation grade); 'f16' / 'bf16': the fused kernel's training instantiation (16-bit operand dumps)."""
+    if net.precision == "f32":
+        return ops.eval_ray_samples_f32_train(scene, net.packed(coarse, folded=False), rays, z)
+    return ops.eval_ray_samples_train(scene, net.packed(coarse, folded=False), rays, z)
+
+
+def _pass_grads(net, mlp, dumps, g_out, scene_NS, want_d_in):
+    """-> (grads, d_zlat, d_in, releasable) of one pass at the network's precision"""
+    if net.precision == "f32":
+        grads, d_zlat, d_in = ops.mlp_backward_f32(mlp.packed("f32"), dumps, g_out, want_d_in=want_d_in)
+        return grads, d_zlat, d_in, _NoRelease
+    return _mlp_grads(None, mlp.packed_bwd(net.precision), dumps, g_out, scene_NS, want_d_in=want_d_in)
+
+
 def _mlp_grads(mlp_state, packed_bwd, fwd, g_out, scene_NS, want_d_in=False):
     """All parameter gradients of one ResnetFC + d(interpolated latent) [+ d(lin_in operand)] from
     one backward pass.  fwd: ops.TrainDumps of the forward; g_out (P,4) fp32 = dL/d(lin_out output)."""
@@ -75,11 +97,9 @@ class _RenderFunction(torch.autograd.Function):
         net, noise = cfg["net"], cfg["noise"]
         Kc, Kf, Kfd = cfg["n_coarse"], cfg["n_fine"], cfg["n_fine_depth"]
         scene = net.scene()
-        pc = net.packed(True, folded=False)  # the training instantiation keeps the lin_z GEMMs (operands are dumped)
-        pf = net.packed(False, folded=False) if Kf > 0 else None
         passes = []
         z_c = ops.sample_coarse(rays, noise["u1"], cfg["lindisp"])
-        rgbs_c, dumps_c = ops.eval_ray_samples_train(scene, pc, rays, z_c)
+        rgbs_c, dumps_c = _train_eval(net, scene, True, rays, z_c)  # the training instantiation keeps the lin_z GEMMs (operands are dumped)
         w_c, rgb_c, depth_c = ops.composite(rays, z_c, rgbs_c, cfg["white_bkgd"], want_weights=True)
         passes.append(dict(z=z_c, rgbs=rgbs_c, dumps=dumps_c, coarse=True))
         outs = [rgb_c, depth_c, w_c]
@@ -87,7 +107,7 @@ class _RenderFunction(torch.autograd.Function):
             n4 = noise.get("n4") if Kfd > 0 else None
             z_f, ranks = ops.sample_fine(rays, w_c, depth_c, z_c, noise.get("u2"), noise.get("u3"), n4,
                                          cfg["depth_std"], cfg["lindisp"], want_ranks=True)
-            rgbs_f, dumps_f = ops.eval_ray_samples_train(scene, pf, rays, z_f)
+            rgbs_f, dumps_f = _train_eval(net, scene, False, rays, z_f)
             w_f, rgb_f, depth_f = ops.composite(rays, z_f, rgbs_f, cfg["white_bkgd"], want_weights=True)
             # depth_c is an OUTPUT of this Function: keeping the tensor itself in ctx would close the cycle
             # output -> grad_fn -> ctx -> output and pin every dump of the step until the cyclic GC runs
@@ -125,7 +145,7 @@ class _RenderFunction(torch.autograd.Function):
             d_pre, dz = cb if pos else (cb, None)
             g_out = d_pre.reshape(-1, 4)
             mlp = net.mlp_coarse if (ps["coarse"] or shared) else net.mlp_fine
-            grads, d_zlat, d_in, bd = _mlp_grads(None, mlp.packed_bwd(net.precision), ps["dumps"], g_out, scene.NS, want_d_in=pos)
+            grads, d_zlat, d_in, bd = _pass_grads(net, mlp, ps["dumps"], g_out, scene.NS, pos)
             slot = 0 if (ps["coarse"] or shared) else 1
             gsum[slot] = grads if gsum[slot] is None else {k: gsum[slot][k] + v for k, v in grads.items()}
             if need_latent:
@@ -162,7 +182,7 @@ class _PointsFunction(torch.autograd.Function):
         R = xyz.shape[0]
         rays = torch.cat([xyz, viewdirs, torch.zeros((R, 2), dtype=torch.float32, device=xyz.device)], dim=1).contiguous()
         z = torch.zeros((R, 1), dtype=torch.float32, device=xyz.device)
-        rgbs, dumps = ops.eval_ray_samples_train(scene, net.packed(coarse, folded=False), rays, z)
+        rgbs, dumps = _train_eval(net, scene, coarse, rays, z)
         ctx.cfg, ctx.scene, ctx.rays, ctx.z, ctx.dumps = cfg, scene, rays, z, dumps
         ctx.latent_shape = latent.shape
         out = rgbs.reshape(R, 4)
@@ -179,7 +199,7 @@ class _PointsFunction(torch.autograd.Function):
         # through the output activations (models.py:260-265): rgb = sigmoid(.), sigma = relu(.)
         d_pre = torch.cat([g[:, :3] * out[:, :3] * (1.0 - out[:, :3]), g[:, 3:] * (out[:, 3:] > 0).float()], dim=1).contiguous()
         mlp = net.mlp_coarse if (coarse or net.mlp_fine is None) else net.mlp_fine
-        grads, d_zlat, _, bd = _mlp_grads(None, mlp.packed_bwd(net.precision), ctx.dumps, d_pre, ctx.scene.NS)
+        grads, d_zlat, _, bd = _pass_grads(net, mlp, ctx.dumps, d_pre, ctx.scene.NS, False)
         d_lat = None
         if ctx.needs_input_grad[3]:
             n, c, hl, wl = ctx.latent_shape

@@ -929,7 +929,7 @@ position_bwd_kernel(const EvalParams q, const float *__restrict__ d_in42, const 
             float term;
             if (k < 6) {
                 const float f = 1.5f * (float)(1 << k), a = xc * f;
-                term = f * (cosf(a) * gi[3 + 6 * k + c] + cosf(a + HALF_PI) * gi[3 + 6 * k + 3 + c]);
+                term = f * (cosf(a) * gi[3 + 6 * k + c] + cosf(__builtin_fmaf(xc, f, HALF_PI)) * gi[3 + 6 * k + 3 + c]);
             } else {
                 term = gi[c];
             }

@@ -453,8 +453,11 @@ __device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, i
         // keeps the precise one.
         auto sn = [](float a) { return TL::IN_LO_DELTA != 0 ? sinf(a) : __sinf(a); };
         put(o + 0, valid ? sn(a0) : 0.f); put(o + 1, valid ? sn(a1) : 0.f); put(o + 2, valid ? sn(a2) : 0.f);
-        put(o + 3, valid ? sn(a0 + HALF_PI) : 0.f); put(o + 4, valid ? sn(a1 + HALF_PI) : 0.f);
-        put(o + 5, valid ? sn(a2 + HALF_PI) : 0.f);
+        // the phase-shifted terms: ATen's addcmul(phases, x, freqs) (code.py:39) is ONE fused multiply-add per element -- x f
+        // + pi/2 rounded once -- so the argument is formed with fmaf here as well (separately rounded it differs by up to an ulp
+        // of the argument, 1.5e-5 at f = 48: found by tests/test_hip_features.py against the reference's own output)
+        put(o + 3, valid ? sn(__builtin_fmaf(xr0, f, HALF_PI)) : 0.f); put(o + 4, valid ? sn(__builtin_fmaf(xr1, f, HALF_PI)) : 0.f);
+        put(o + 5, valid ? sn(__builtin_fmaf(xr2, f, HALF_PI)) : 0.f);
     } else {
         // zero the K padding 42..63 (+ the 8-element row pad read by the last B prefetch)
         for (int i = D_IN; i < D_IN_PAD + 8; ++i) put(i, 0.f);

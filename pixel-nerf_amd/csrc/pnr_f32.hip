@@ -58,7 +58,8 @@ feat_f32_kernel(const EvalParams q, long long p0, int np, float *__restrict__ in
         const int t = lane - 3, k = t / 6, rem = t % 6, c = rem % 3;
         const float f = 1.5f * (float)(1 << k);
         const float a = xr[c] * f;
-        v = rem < 3 ? sinf(a) : sinf(a + 1.57079637050628662109375f);
+        // code.py:39 addcmul(phases, x, freqs) = one fused multiply-add (see geometry_item)
+        v = rem < 3 ? sinf(a) : sinf(__builtin_fmaf(xr[c], f, 1.57079637050628662109375f));
     } else if (lane < 42) {
         const int c = lane - 39;
         v = pose[4 * c + 0] * dx + pose[4 * c + 1] * dy + pose[4 * c + 2] * dz;
@@ -80,11 +81,16 @@ feat_f32_kernel(const EvalParams q, long long p0, int np, float *__restrict__ in
     *reinterpret_cast<f32x4 *>(dst + 4) = acc1;
 }
 
-// Y (M,N) = [Y +] [relu](X (M,K)) W^T (W is (N,K)) + b.   Block 256 threads = 4 waves, 64x64 tile,
-// K in chunks of 32 through LDS, v_mfma_f32_32x32x2_f32 (A: X[i][k], B: W[j][k], one float each).
+// Y (M,N) = [Yin +] mask( [relu](X (M,K)) W'^T + b ).   Block 256 threads = 4 waves, 64x64 tile, K in chunks of 32
+// through LDS, v_mfma_f32_32x32x2_f32 (A: X[i][k], B: W'[j][k], one float each).
+//   W' element (n, k) = W[n * ldw + k]  (w_trans == 0: an nn.Linear weight (N,K), the forward)
+//                     = W[k * ldw + n]  (w_trans == 1: the SAME tensor read transposed -- the backward's dX = dY W)
+//   mask (nullable, leading dimension ldy): the product is kept where mask > 0, zeroed elsewhere (relu' of a saved activation)
+//   Yin (nullable, leading dimension ldy, may alias Y): residual / accumulation operand, added after the mask
 __global__ void __launch_bounds__(256)
-linear_f32_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W, const float *__restrict__ b,
-                  float *__restrict__ Y, int ldy, long long M, int N, int K, int relu_in, int accumulate) {
+linear_f32_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W, int ldw, int w_trans, const float *__restrict__ b,
+                  const float *Yin, float *Y, int ldy, long long M, int N, int K, int relu_in, const float *__restrict__ mask,
+                  float out_scale) {
     __shared__ float sX[64][33], sW[64][33];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const long long m0 = (long long)blockIdx.x * 64;
@@ -95,14 +101,21 @@ linear_f32_kernel(const float *__restrict__ X, int ldx, const float *__restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     for (int k0 = 0; k0 < K; k0 += 32) {
-        // stage 64x32 of X and of W: 2048 floats each, 8 per thread
+        // stage 64x32 of X and of W': 2048 floats each, 8 per thread
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = t + u * 256, row = e >> 5, col = e & 31;
-            float xv = 0.f, wv_ = 0.f;
-            if (m0 + row < M && k0 + col < K) xv = X[(m0 + row) * ldx + k0 + col];
-            if (n0 + row < N && k0 + col < K) wv_ = W[(size_t)(n0 + row) * K + k0 + col];
-            sX[row][col] = relu_in ? fmaxf(xv, 0.f) : xv;
+            const int e = t + u * 256;
+            {
+                const int row = e >> 5, col = e & 31;
+                float xv = 0.f;
+                if (m0 + row < M && k0 + col < K) xv = X[(m0 + row) * ldx + k0 + col];
+                sX[row][col] = relu_in ? fmaxf(xv, 0.f) : xv;
+            }
+            // W': consecutive threads walk the tensor's fast dimension in either orientation
+            const int row = w_trans ? (e & 63) : (e >> 5), col = w_trans ? (e >> 6) : (e & 31);
+            float wv_ = 0.f;
+            if (n0 + row < N && k0 + col < K)
+                wv_ = w_trans ? W[(size_t)(k0 + col) * ldw + n0 + row] : W[(size_t)(n0 + row) * ldw + k0 + col];
             sW[row][col] = wv_;
         }
         __syncthreads();
@@ -119,12 +132,88 @@ linear_f32_kernel(const float *__restrict__ X, int ldx, const float *__restrict_
         for (int r = 0; r < 16; ++r) {
             const long long m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (m < M) {
-                float *y = Y + m * ldy + n;
-                const float v = acc[r] + bias;
-                *y = accumulate ? *y + v : v;
+                float v = (acc[r] + bias) * out_scale;
+                if (mask && !(mask[m * ldy + n] > 0.f)) v = 0.f;
+                if (Yin) v += Yin[m * ldy + n];
+                Y[m * ldy + n] = v;
             }
         }
     }
+}
+
+// Weight gradient of one linear:  dW (N,Kd) = dY^T (N x M) [relu](X) (M x Kd),  db (N) = sum_m dY[m][.]   -- exact fp32
+// (v_mfma_f32_32x32x2_f32), the reduction over the M rows split over blockIdx.z with a fixed-order second pass
+// (wgrad_reduce_f32_kernel): bit-reproducible, no atomics.  Block = 64 x 64 tile of dW, 4 waves.
+__global__ void __launch_bounds__(256)
+wgrad_f32_kernel(const float *__restrict__ dY, int lddy, const float *__restrict__ X, int ldx, int relu_x, long long M, int N, int Kd,
+                 float *__restrict__ part, float *__restrict__ bpart) {
+    __shared__ float sA[32][65], sB[32][65];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int nsplit = gridDim.z, split = blockIdx.z;
+    long long per = (M + nsplit - 1) / nsplit;
+    per = (per + 31) / 32 * 32;
+    const long long r0 = (long long)split * per, r1 = r0 + per < M ? r0 + per : M;
+    const int wn = (w >> 1) * 32, wk = (w & 1) * 32;
+    const int i = lane & 31, kh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    for (long long m0 = r0; m0 < r1; m0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = t + u * 256, row = e >> 6, col = e & 63;
+            float a = 0.f, x = 0.f;
+            if (m0 + row < r1) {
+                if (n0 + col < N) a = dY[(m0 + row) * lddy + n0 + col];
+                if (k0 + col < Kd) x = X[(m0 + row) * ldx + k0 + col];
+            }
+            sA[row][col] = a;
+            sB[row][col] = relu_x ? fmaxf(x, 0.f) : x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[2 * kk + kh][wn + i], sB[2 * kk + kh][wk + i], acc, 0, 0, 0);
+        if (blockIdx.y == 0 && t < 64) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) bsum += sA[r][t];
+        }
+        __syncthreads();
+    }
+    // D: column j = lane&31 -> kd, row (r&3)+8(r>>2)+4kh -> n
+    float *pz = part + (size_t)split * N * Kd;
+    const int kd = k0 + wk + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (n < N && kd < Kd) pz[(size_t)n * Kd + kd] = acc[r];
+    }
+    if (blockIdx.y == 0 && t < 64 && n0 + t < N) bpart[(size_t)split * N + n0 + t] = bsum;
+}
+
+__global__ void wgrad_reduce_f32_kernel(const float *__restrict__ part, const float *__restrict__ bpart, int nsplit, int N, int Kd,
+                                        float *__restrict__ dW, float *__restrict__ db) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < N * Kd) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * N * Kd + idx];
+        dW[idx] = s;
+    }
+    if (db && idx < N) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += bpart[(size_t)z * N + idx];
+        db[idx] = s;
+    }
+}
+
+// Gv[v*np + p][f] = Gp[p][f] * inv   (backward of the view mean, util.py:461-466)
+__global__ void unpool_f32_kernel(const float *__restrict__ gp, float *__restrict__ gv, long long np, int NS, float inv) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= np * D_HID) return;
+    const float v = gp[idx] * inv;
+    for (int s = 0; s < NS; ++s) gv[(size_t)s * np * D_HID + idx] = v;
 }
 
 // xp[p][f] = mean_v x[v*np + p][f]
@@ -146,7 +235,7 @@ __global__ void pool_interleaved_f32_kernel(const float *__restrict__ x, float *
     xp[idx] = s / (float)NS;
 }
 
-__global__ void out_f32_kernel(const float *__restrict__ o, float *__restrict__ rgbs, int np) {
+__global__ void out_f32_kernel(const float *o, float *rgbs, int np) {  // o may alias rgbs (training forward)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= np) return;
     const f32x4 s = *reinterpret_cast<const f32x4 *>(o + (size_t)idx * 4);
@@ -155,10 +244,29 @@ __global__ void out_f32_kernel(const float *__restrict__ o, float *__restrict__ 
 }
 
 static void linear(hipStream_t st, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, long long M,
-                   int N, int K, bool relu_in, bool accumulate) {
+                   int N, int K, bool relu_in, bool accumulate, const float *Yin = nullptr) {
     dim3 grid((unsigned)((M + 63) / 64), (N + 63) / 64);
-    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, st, X, ldx, W, b, Y, ldy, M, N, K, relu_in ? 1 : 0,
-                       accumulate ? 1 : 0);
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, st, X, ldx, W, K, 0, b, accumulate ? (Yin ? Yin : Y) : nullptr, Y, ldy, M,
+                       N, K, relu_in ? 1 : 0, (const float *)nullptr, 1.f);
+}
+
+// backward data product: Out (M,J) = [Out +] ((dY (M,N) W (N,J)) * scale) . [mask > 0]   (W = the nn.Linear weight (N,J) as stored)
+static void linear_bwd(hipStream_t st, const float *dY, int lddy, const float *W, int J, int N, float *Out, int ldo, long long M,
+                       const float *mask, bool accumulate, float scale = 1.f) {
+    dim3 grid((unsigned)((M + 63) / 64), (J + 63) / 64);
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, st, dY, lddy, W, J, 1, (const float *)nullptr,
+                       accumulate ? Out : (const float *)nullptr, Out, ldo, M, J, N, 0, mask, scale);
+}
+
+constexpr int WG_SPLIT = 32;  // row slices of the weight-gradient reduction
+
+// dW (N,Kd), db (N) from dY (M,N) and X (M,Kd); part / bpart: WG_SPLIT * (N*Kd + N) floats of workspace
+static void wgrad(hipStream_t st, const float *dY, int lddy, const float *X, int ldx, bool relu_x, long long M, int N, int Kd,
+                  float *dW, float *db, float *part) {
+    float *bpart = part + (size_t)WG_SPLIT * N * Kd;
+    dim3 grid((N + 63) / 64, (Kd + 63) / 64, WG_SPLIT);
+    hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, dY, lddy, X, ldx, relu_x ? 1 : 0, M, N, Kd, part, bpart);
+    hipLaunchKernelGGL(wgrad_reduce_f32_kernel, dim3((N * Kd + 255) / 256), dim3(256), 0, st, part, bpart, WG_SPLIT, N, Kd, dW, db);
 }
 
 // floats of workspace per point of a chunk
@@ -214,7 +322,115 @@ static int eval_f32(const PnrScene *s, const PnrMlpWeights *w, EvalParams q, boo
     return pnr_check_launch("pnr_eval_f32");
 }
 
+// ---------------------------------------------------------------- exact-fp32 training path (validation grade)
+// The same unfused fp32 chain with every activation the backward needs KEPT (PnrF32Saved), and its backward: data gradients
+// dX = (dY W) . relu', weight gradients dW = dY^T relu(X), all on v_mfma_f32_32x32x2_f32 -- the fp32 reference of the
+// 16-bit training kernels (pnr_bwd.hip), held to 1e-3 against the reference's own autograd (tests/test_hip_backward_f32.py).
+static int check_saved(const PnrF32Saved *sv, int NS) {
+    if (!sv || !sv->in42 || !sv->zlat || !sv->x5) return 0;
+    for (int b = 0; b < 5; ++b)
+        if (!sv->xin[b] || !sv->net[b]) return 0;
+    return NS == 1 || sv->pool_in != nullptr;
+}
+
+static int eval_f32_train(const PnrScene *s, const PnrMlpWeights *w, EvalParams q, const PnrF32Saved *sv, hipStream_t st) {
+    if (!s || !w || !q.out) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: null argument");
+    if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: bad scene shape");
+    if (!check_saved(sv, s->NS)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: null activation buffer in PnrF32Saved");
+    if (q.P == 0) return PNR_OK;
+    if (q.P * s->NS > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: too many points");
+    q.latent = s->latent_nhwc; q.poses = s->poses; q.focal = s->focal; q.c = s->c;
+    q.SB = s->SB; q.NS = s->NS; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
+    q.img_w = s->img_w; q.img_h = s->img_h;
+    const int NS = s->NS;
+    const int np = (int)q.P;
+    const long long rows = (long long)np * NS;
+    hipLaunchKernelGGL(feat_f32_kernel<true>, dim3((unsigned)((rows + FW - 1) / FW)), dim3(FW * 64), 0, st, q, 0LL, np, sv->in42, sv->zlat);
+    linear(st, sv->in42, D_IN_PAD, w->lin_in_w, w->lin_in_b, sv->xin[0], D_HID, rows, D_HID, D_IN, false, false);  // resnetfc.py:147
+    for (int b = 0; b < COMBINE_LAYER; ++b) {
+        linear(st, sv->zlat, C_LAT, w->lin_z_w[b], w->lin_z_b[b], sv->xin[b], D_HID, rows, D_HID, C_LAT, false, true);       // :175-180
+        linear(st, sv->xin[b], D_HID, w->fc0_w[b], w->fc0_b[b], sv->net[b], D_HID, rows, D_HID, D_HID, true, false);         // :55-57
+        float *next = b + 1 < COMBINE_LAYER ? sv->xin[b + 1] : (NS > 1 ? sv->pool_in : sv->xin[COMBINE_LAYER]);
+        linear(st, sv->net[b], D_HID, w->fc1_w[b], w->fc1_b[b], next, D_HID, rows, D_HID, D_HID, true, true, sv->xin[b]);    // :58-62
+    }
+    if (NS > 1) {  // util.combine_interleaved
+        const long long n = (long long)np * D_HID;
+        hipLaunchKernelGGL(pool_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sv->pool_in, sv->xin[COMBINE_LAYER], np, NS);
+    }
+    for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b) {
+        linear(st, sv->xin[b], D_HID, w->fc0_w[b], w->fc0_b[b], sv->net[b], D_HID, np, D_HID, D_HID, true, false);
+        float *next = b + 1 < N_BLOCKS ? sv->xin[b + 1] : sv->x5;
+        linear(st, sv->net[b], D_HID, w->fc1_w[b], w->fc1_b[b], next, D_HID, np, D_HID, D_HID, true, true, sv->xin[b]);
+    }
+    // lin_out's raw output goes through the caller's rgbsigma buffer in place (4 floats per point either way)
+    linear(st, sv->x5, D_HID, w->lin_out_w, w->lin_out_b, q.out, 4, np, D_OUT, D_HID, true, false);  // :183
+    hipLaunchKernelGGL(out_f32_kernel, dim3((np + 255) / 256), dim3(256), 0, st, q.out, q.out, np);
+    return pnr_check_launch("pnr_eval_ray_samples_f32_train");
+}
+
+// reverse of one residual block (resnetfc.py:55-62) on `rows` rows:  G = dL/d(xin + fc_1(relu(fc_0(relu(xin)))))
+//   dW1 = G^T relu(net), db1 = sum G;  T = (G W1) . [net > 0];  dW0 = T^T relu(xin), db0 = sum T;  G += (T W0) . [xin > 0]
+static void block_bwd_f32(hipStream_t st, const PnrMlpWeights *w, const PnrMlpWeights *g, int b, float *G, float *T, const float *xin,
+                          const float *net, long long rows, float *part) {
+    wgrad(st, G, D_HID, net, D_HID, true, rows, D_HID, D_HID, (float *)g->fc1_w[b], (float *)g->fc1_b[b], part);
+    linear_bwd(st, G, D_HID, w->fc1_w[b], D_HID, D_HID, T, D_HID, rows, net, false);
+    wgrad(st, T, D_HID, xin, D_HID, true, rows, D_HID, D_HID, (float *)g->fc0_w[b], (float *)g->fc0_b[b], part);
+    linear_bwd(st, T, D_HID, w->fc0_w[b], D_HID, D_HID, G, D_HID, rows, xin, true);
+}
+
 }  // namespace pnr
+
+extern "C" int pnr_eval_ray_samples_f32_train(const PnrScene *scene, const PnrMlpWeights *w, const float *rays, const float *z, int R,
+                                              int rays_per_obj, int K, float *rgbsigma, const PnrF32Saved *saved, void *stream) {
+    if (R <= 0 || K <= 0 || rays_per_obj <= 0 || !rays || !z) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: bad argument");
+    if (scene && (long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: R != SB * rays_per_obj");
+    pnr::EvalParams q = {};
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
+    return pnr::eval_f32_train(scene, w, q, saved, (hipStream_t)stream);
+}
+
+extern "C" size_t pnr_mlp_backward_f32_workspace_bytes(long long P, int NS) {
+    if (P <= 0 || NS <= 0) return 0;
+    // G and T at (NS*P, 512), the pooled G at (P, 512), the row-slice partials of one weight gradient
+    return ((size_t)P * NS * 2 + (size_t)P) * pnr::D_HID * sizeof(float) +
+           (size_t)pnr::WG_SPLIT * (pnr::D_HID * pnr::D_HID + pnr::D_HID) * sizeof(float);
+}
+
+extern "C" int pnr_mlp_backward_f32(const PnrMlpWeights *w, const PnrF32Saved *sv, const float *g_out, long long P, int NS,
+                                    const PnrMlpWeights *grads, float *d_zlat, float *d_in, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+    using namespace pnr;
+    if (!w || !g_out || !grads || !d_zlat || !workspace || P <= 0 || NS <= 0)
+        return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: bad argument");
+    if (!check_saved(sv, NS)) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: null activation buffer in PnrF32Saved");
+    if (workspace_bytes < pnr_mlp_backward_f32_workspace_bytes(P, NS)) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: workspace too small");
+    if (P * NS > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: too many points");
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = P * NS;
+    float *Gv = (float *)workspace;
+    float *T = Gv + (size_t)rows * D_HID;
+    float *Gp = T + (size_t)rows * D_HID;
+    float *part = Gp + (size_t)P * D_HID;
+    float *G = NS > 1 ? Gp : Gv;  // pooled part of the chain
+    // lin_out (resnetfc.py:183): out = W_out relu(x5) + b
+    wgrad(st, g_out, D_OUT, sv->x5, D_HID, true, P, D_OUT, D_HID, (float *)grads->lin_out_w, (float *)grads->lin_out_b, part);
+    linear_bwd(st, g_out, D_OUT, w->lin_out_w, D_HID, D_OUT, G, D_HID, P, sv->x5, false);
+    for (int b = N_BLOCKS - 1; b >= COMBINE_LAYER; --b) block_bwd_f32(st, w, grads, b, G, T, sv->xin[b], sv->net[b], P, part);
+    if (NS > 1) {  // backward of the view mean: every view receives G / NS
+        const long long n = P * D_HID;
+        hipLaunchKernelGGL(unpool_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Gp, Gv, P, NS, 1.f / (float)NS);
+    }
+    for (int b = COMBINE_LAYER - 1; b >= 0; --b) {
+        block_bwd_f32(st, w, grads, b, Gv, T, sv->xin[b], sv->net[b], rows, part);
+        // xin[b] = (stream in front) + lin_z[b](zlat)   (resnetfc.py:175-180)
+        wgrad(st, Gv, D_HID, sv->zlat, C_LAT, false, rows, D_HID, C_LAT, (float *)grads->lin_z_w[b], (float *)grads->lin_z_b[b], part);
+        linear_bwd(st, Gv, D_HID, w->lin_z_w[b], C_LAT, D_HID, d_zlat, C_LAT, rows, nullptr, b != COMBINE_LAYER - 1);
+    }
+    // lin_in (resnetfc.py:147)
+    wgrad(st, Gv, D_HID, sv->in42, D_IN_PAD, false, rows, D_HID, D_IN, (float *)grads->lin_in_w, (float *)grads->lin_in_b, part);
+    if (d_in) linear_bwd(st, Gv, D_HID, w->lin_in_w, D_IN, D_HID, d_in, D_IN, rows, nullptr, false);
+    return pnr_check_launch("pnr_mlp_backward_f32");
+}
 
 extern "C" size_t pnr_resnetfc_forward_f32_workspace_bytes(long long rows, int NS) {
     if (rows <= 0 || NS <= 0 || rows % NS != 0) return 0;

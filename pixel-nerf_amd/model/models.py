@@ -189,8 +189,9 @@ class PixelNeRFNet(torch.nn.Module):
         if SB != sc.SB:
             raise ValueError(f"xyz has {SB} objects but encode() saw {sc.SB}")
         if self._wants_grad():  # differentiable twin: training kernels + HIP backward (parameters and latent grid)
-            if self._effective_precision() not in ("f16", "bf16"):
-                raise NotImplementedError("training runs on the 16-bit MFMA paths (precision 'f16' / 'bf16')")
+            if self._effective_precision() not in ("f16", "bf16", "f32"):
+                raise NotImplementedError("training runs on the 16-bit MFMA paths (precision 'f16' / 'bf16') or on the exact-fp32 "
+                                          "validation path ('f32'); 'f16x3' is an inference form")
             from .. import autograd
             return autograd.points_autograd(self, xyz, viewdirs.reshape(SB, B, 3), coarse)
         return ops.eval_points(sc, self.packed(coarse), xyz.float(), viewdirs.reshape(SB, B, 3).float(),

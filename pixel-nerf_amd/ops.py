@@ -821,6 +821,63 @@ def eval_ray_samples_train(scene, packed, rays, z):
     return out, dumps
 
 
+class F32Saved:
+    """fp32 activations kept by the exact-fp32 training forward (PnrF32Saved): ~ (NS * 3648 + 2560) floats per point."""
+
+    def __init__(self, P, NS, device):
+        rv, rp = NS * P, P
+        f = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=device)  # noqa: E731
+        self.P, self.NS = P, NS
+        self.in42, self.zlat = f(rv, 64), f(rv, 512)
+        self.xin = [f(rv if b < 3 else rp, 512) for b in range(5)]
+        self.net = [f(rv if b < 3 else rp, 512) for b in range(5)]
+        self.x5 = f(rp, 512)
+        self.pool_in = f(rv, 512) if NS > 1 else None
+        s = _lib.PnrF32Saved()
+        s.in42, s.zlat, s.x5 = self.in42.data_ptr(), self.zlat.data_ptr(), self.x5.data_ptr()
+        s.pool_in = self.pool_in.data_ptr() if self.pool_in is not None else None
+        for b in range(5):
+            s.xin[b], s.net[b] = self.xin[b].data_ptr(), self.net[b].data_ptr()
+        self.struct = s
+
+    def release(self):  # interface twin of TrainDumps.release (the fp32 sets are not pooled)
+        pass
+
+
+def eval_ray_samples_f32_train(scene, weights, rays, z):
+    """exact-fp32 twin of eval_ray_samples_train: weights = PackedMLP of precision 'f32' (raw nn.Linear tensors)."""
+    lib = _lib.load()
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z = _f32(z, "z", (R, None))
+    K = z.shape[1]
+    saved = F32Saved(R * K, scene.NS, rays.device)
+    out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.pnr_eval_ray_samples_f32_train(scene.ref, weights.wref, _p(rays), _p(z), R, max(R // scene.SB, 1), K, _p(out),
+                                                      ctypes.byref(saved.struct), _stream()), "pnr_eval_ray_samples_f32_train")
+    return out, saved
+
+
+def mlp_backward_f32(weights, saved, g_out, want_d_in=False):
+    """-> ({reference state_dict key: fp32 gradient}, d_zlat (rows_v,512), d_in (rows_v,42) | None) of one ResnetFC, exact fp32."""
+    lib = _lib.load()
+    P, NS = saved.P, saved.NS
+    g_out = _f32(g_out, "g_out", (P, 4))
+    dev = g_out.device
+    grads = {k: torch.empty(_MLP_SHAPES.get(k, (512, 512) if k.endswith("weight") else (512,)), dtype=torch.float32, device=dev)
+             for k in _MLP_KEYS}
+    gstruct, _keep = _weights_struct(grads)
+    d_zlat = torch.empty((NS * P, 512), dtype=torch.float32, device=dev)
+    d_in = torch.empty((NS * P, 42), dtype=torch.float32, device=dev) if want_d_in else None
+    nbytes = lib.pnr_mlp_backward_f32_workspace_bytes(P, NS)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_mlp_backward_f32(weights.wref, ctypes.byref(saved.struct), _p(g_out), P, NS, ctypes.byref(gstruct),
+                                            _p(d_zlat), _p(d_in), _p(ws), nbytes, _stream()), "pnr_mlp_backward_f32")
+    return grads, d_zlat, d_in
+
+
 def composite_backward(rays, z, rgbsigma, white_bkgd, d_rgb, d_depth=None, d_weights=None, want_dz=False,
                        pre_activation=False):
     """-> dL/d(rgb sigma) per point (R,K,4) [after the output activations, or in front of them with

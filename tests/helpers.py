@@ -94,3 +94,20 @@ def robust_render_stats(rgb, depth, z_fine, g, span):
         pastfar_frac=float(1.0 - ok.mean()), pastfar_disagree_frac=float(dis.mean()),
         bin_flip_frac=float((np.abs(z - zg) > 1e-4 * span).mean()),
         n_rays=int(rgb.shape[0]))
+
+
+# gradient-only scenarios of tests/golden/gradients.npz (oracle/make_goldens.py GRAD_ONLY): no render fixture -- rays, noise
+# and networks are regenerated from their seeds exactly as the generator does
+GRAD_ONLY = {"train_cfg5": ("train", 64, 32, 16, 128, False, True)}  # BASELINE configs[4] at full size: 4 objects x 128 rays
+
+
+def grad_setup(name):
+    """-> (g-like dict, scene, meta, mlp_coarse, mlp_fine, rays (SB,B,8), noise) for a render golden OR a gradient-only scenario"""
+    if name not in GRAD_ONLY:
+        return golden_setup(name)
+    scene_name, Kc, Kf, Kfd, n_rays, lindisp, _ = GRAD_ONLY[name]
+    scene, meta = scene_for(scene_name, 2)
+    rays = synthetic.target_rays(meta, n_rays=n_rays)
+    noise = synthetic.make_noise(rays.shape[0] * n_rays, Kc, Kf, Kfd)
+    g = dict(n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, white_bkgd=meta["white_bkgd"], lindisp=lindisp)
+    return g, scene, meta, mlp_params(11), mlp_params(12), rays, noise

@@ -171,15 +171,16 @@ def test_bbox_pixels_matches_reference_bbox_sample():
 # ------------------------------------------------------------------ gradients (BASELINE config 5)
 
 
-@pytest.mark.parametrize("name", ["train_64_32", "srn_mini_64_128"])
+@pytest.mark.parametrize("name", ["train_64_32", "srn_mini_64_128", "train_cfg5"])
 def test_oracle_autograd_matches_reference_autograd(name):
     """torch autograd through the oracle vs the UNMODIFIED reference's own backward (tests/golden/gradients.npz:
     per-tensor L2 norm + seeded subsample of every ResnetFC gradient of both networks and of encoder.latent,
     including the position gradient through the depth samples, nerf.py:292).  fp32 on both sides, different
     summation orders: norms within 1e-4, subsamples within 1e-3 relative (measured 1e-6 / 2e-4)."""
     from testdata import synthetic
+    from helpers import grad_setup
     gg = load_golden("gradients")
-    g, scene, meta, mc, mf, rays, noise = golden_setup(name)
+    g, scene, meta, mc, mf, rays, noise = grad_setup(name)  # train_cfg5: BASELINE configs[4] at full size (4 x 128 rays)
     Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])
     sc = dict(scene)
     sc["latent"] = scene["latent"].clone().requires_grad_(True)
