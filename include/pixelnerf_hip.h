@@ -77,6 +77,13 @@ int pnr_version(int *major, int *minor);
 int pnr_abi_version(void);
 int pnr_device_info(int *num_cus, int *lds_bytes_per_block);
 
+/* 64-bit content fingerprint of the 30 parameter tensors, computed and (optionally) compared on the device with no host
+ * synchronisation: ws = 16 zeroed device bytes (left zeroed); sum_out (device, nullable) receives it; with `expect`
+ * (device) a differing value sets *mismatch_flag (device int) to 1.  Lets a caller that caches packed streams notice
+ * parameter writes that bypass its cache key (the Python layer: `p.data.copy_()` bumps no tensor version). */
+int pnr_params_checksum(const PnrMlpWeights *w /*host*/, void *ws, unsigned long long *sum_out,
+                        const unsigned long long *expect, int *mismatch_flag, void *stream);
+
 /* ---- one-time weight repack ------------------------------------------------------------
  * Replaces nothing in the reference (it feeds nn.Linear weights to addmm directly,
  * resnetfc.py:147,175,55-62,183); needed because the fused kernel streams MFMA fragments.

@@ -31,6 +31,19 @@ def _param_names():
 PARAM_NAMES = _param_names()
 
 
+def _sigma_noise(rgbs, cfg):
+    """nerf.py:225-226 (training only, noise_std > 0): sigmas = sigmas + randn_like(sigmas) * noise_std, drawn from torch's
+    generator after each network pass like the reference.  -> (rgb | noisy sigma, mask of points whose own sigma was positive
+    -- the relu' the compositing backward can no longer read off the noisy value) or (rgbs, None)"""
+    std = cfg.get("noise_std", 0.0)
+    if not std > 0.0:
+        return rgbs, None
+    live = (rgbs[..., 3] > 0).float()
+    noisy = rgbs.clone()
+    noisy[..., 3] += torch.randn(rgbs.shape[:-1], dtype=rgbs.dtype, device=rgbs.device) * std  # one (R,K) draw per pass, reference order
+    return noisy, live
+
+
 class _NoRelease:
     @staticmethod
     def release():
@@ -100,18 +113,20 @@ class _RenderFunction(torch.autograd.Function):
         passes = []
         z_c = ops.sample_coarse(rays, noise["u1"], cfg["lindisp"])
         rgbs_c, dumps_c = _train_eval(net, scene, True, rays, z_c)  # the training instantiation keeps the lin_z GEMMs (operands are dumped)
+        rgbs_c, live_c = _sigma_noise(rgbs_c, cfg)
         w_c, rgb_c, depth_c = ops.composite(rays, z_c, rgbs_c, cfg["white_bkgd"], want_weights=True)
-        passes.append(dict(z=z_c, rgbs=rgbs_c, dumps=dumps_c, coarse=True))
+        passes.append(dict(z=z_c, rgbs=rgbs_c, dumps=dumps_c, coarse=True, live=live_c))
         outs = [rgb_c, depth_c, w_c]
         if Kf > 0:
             n4 = noise.get("n4") if Kfd > 0 else None
             z_f, ranks = ops.sample_fine(rays, w_c, depth_c, z_c, noise.get("u2"), noise.get("u3"), n4,
                                          cfg["depth_std"], cfg["lindisp"], want_ranks=True)
             rgbs_f, dumps_f = _train_eval(net, scene, False, rays, z_f)
+            rgbs_f, live_f = _sigma_noise(rgbs_f, cfg)
             w_f, rgb_f, depth_f = ops.composite(rays, z_f, rgbs_f, cfg["white_bkgd"], want_weights=True)
             # depth_c is an OUTPUT of this Function: keeping the tensor itself in ctx would close the cycle
             # output -> grad_fn -> ctx -> output and pin every dump of the step until the cyclic GC runs
-            passes.append(dict(z=z_f, rgbs=rgbs_f, dumps=dumps_f, coarse=False, ranks=ranks, n4=n4, depth_c=depth_c.detach()))
+            passes.append(dict(z=z_f, rgbs=rgbs_f, dumps=dumps_f, coarse=False, ranks=ranks, n4=n4, depth_c=depth_c.detach(), live=live_f))
             outs += [rgb_f, depth_f, w_f]
         ctx.cfg, ctx.rays, ctx.scene, ctx.passes = cfg, rays, scene, passes
         ctx.latent_shape = latent.shape
@@ -120,6 +135,10 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        if ctx.passes is None:
+            raise RuntimeError("pixelnerf_amd: backward through this render a second time is not supported -- the operand dumps "
+                               "of the forward were handed back after the first backward (retain_graph=True keeps the autograd "
+                               "graph, not the 12 KB per point and view of saved operands); sum the losses and call backward once")
         cfg, rays, scene = ctx.cfg, ctx.rays, ctx.scene
         net = cfg["net"]
         dev = rays.device
@@ -143,6 +162,8 @@ class _RenderFunction(torch.autograd.Function):
                                         None if d_w is None else d_w.contiguous().float(), want_dz=pos,
                                         pre_activation=True)  # also through sigmoid / relu (models.py:260-265)
             d_pre, dz = cb if pos else (cb, None)
+            if ps.get("live") is not None:  # sigma noise: the compositing kernel saw relu(sigma) + n; relu' of the network's own sigma
+                d_pre[..., 3] *= ps["live"]
             g_out = d_pre.reshape(-1, 4)
             mlp = net.mlp_coarse if (ps["coarse"] or shared) else net.mlp_fine
             grads, d_zlat, d_in, bd = _pass_grads(net, mlp, ps["dumps"], g_out, scene.NS, pos)
@@ -193,6 +214,9 @@ class _PointsFunction(torch.autograd.Function):
     def backward(ctx, g):
         if g is None:
             return (None,) * (4 + len(PARAM_NAMES))
+        if ctx.dumps is None:
+            raise RuntimeError("pixelnerf_amd: backward through this forward a second time is not supported (the operand dumps "
+                               "were handed back after the first backward); sum the losses and call backward once")
         (out,) = ctx.saved_tensors
         net, coarse = ctx.cfg["net"], ctx.cfg["coarse"]
         g = g.contiguous().float()
@@ -233,6 +257,7 @@ def render_autograd(renderer, net, rays, noise, want_weights):
     Kf = renderer.n_fine if renderer.using_fine else 0
     cfg = dict(net=net, noise=noise, n_coarse=renderer.n_coarse, n_fine=Kf,
                n_fine_depth=min(renderer.n_fine_depth, Kf), depth_std=renderer.depth_std,
+               noise_std=float(renderer.noise_std) if renderer.training else 0.0,
                white_bkgd=bool(renderer.white_bkgd), lindisp=bool(renderer.lindisp))
     latent = net.encoder.latent
     if net.stop_encoder_grad:
@@ -241,6 +266,9 @@ def render_autograd(renderer, net, rays, noise, want_weights):
     params = []
     for m in mlps:
         params += m.ordered_params(PARAM_NAMES)
+    sync = getattr(net, "_grad_sync", None)
+    if sync is not None:  # multi-process training (dist.ShardedRenderWrapper): identity here, ONE gradient all-reduce in backward
+        latent, params = sync(latent, params)
     outs = _RenderFunction.apply(cfg, rays, latent, *params)
     res = {"coarse": {"rgb": outs[0], "depth": outs[1], "weights": outs[2]}}
     if Kf > 0:

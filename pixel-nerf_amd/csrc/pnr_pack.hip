@@ -183,6 +183,59 @@ fold_kernel(const float *__restrict__ grid, const FoldJobs jobs, T *__restrict__
 
 }  // namespace pnr
 
+namespace pnr {
+// 64-bit content fingerprint of a ResnetFC's 30 parameter tensors: sum over all elements of bits(v) * (2 * position + 1)
+// (mod 2^64; position = running index over the tensors in PnrMlpWeights order).  ws[0] = running sum, ws[1] = blocks done.
+// The last block publishes the sum (out), compares it with *expect when given (mismatch -> *flag = 1) and re-zeroes ws.
+constexpr int CK_BLOCKS = 128;
+__global__ void __launch_bounds__(256)
+params_checksum_kernel(PnrMlpWeights p, unsigned long long *ws, unsigned long long *out, const unsigned long long *expect, int *flag) {
+    const float *ptr[30];
+    int n[30];
+    int k = 0;
+    auto add = [&](const float *q, int cnt) { ptr[k] = q; n[k] = cnt; ++k; };
+    add(p.lin_in_w, D_HID * D_IN); add(p.lin_in_b, D_HID);
+    for (int b = 0; b < 3; ++b) { add(p.lin_z_w[b], D_HID * C_LAT); add(p.lin_z_b[b], D_HID); }
+    for (int b = 0; b < 5; ++b) { add(p.fc0_w[b], D_HID * D_HID); add(p.fc0_b[b], D_HID); }
+    for (int b = 0; b < 5; ++b) { add(p.fc1_w[b], D_HID * D_HID); add(p.fc1_b[b], D_HID); }
+    add(p.lin_out_w, D_OUT * D_HID); add(p.lin_out_b, D_OUT);
+    unsigned long long acc = 0ull, base = 0ull;
+    for (int t = 0; t < 30; ++t) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n[t]; i += CK_BLOCKS * 256)
+            acc += (unsigned long long)__float_as_uint(ptr[t][i]) * (2ull * (base + (unsigned long long)i) + 1ull);
+        base += (unsigned long long)n[t];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&ws[0], part[0] + part[1] + part[2] + part[3]);
+        __threadfence();
+        if (atomicAdd(&ws[1], 1ull) == (unsigned long long)(CK_BLOCKS - 1)) {
+            __threadfence();
+            const unsigned long long total = atomicAdd(&ws[0], 0ull);
+            if (out) *out = total;
+            if (expect && flag && *expect != total) *flag = 1;
+            ws[0] = 0ull; ws[1] = 0ull;
+        }
+    }
+}
+}  // namespace pnr
+
+// Content fingerprint of a network's parameters, entirely on the device (no host synchronisation): `ws` = 16 zeroed bytes
+// of device scratch (left zeroed), `sum_out` (nullable) receives the fingerprint, and when `expect` is given a differing
+// fingerprint raises *mismatch_flag (device int).  pixelnerf_amd uses it to notice parameter writes that bypass both
+// tensor._version and torch.optim (`p.data.copy_()`, custom kernels) behind a cached packed stream.
+extern "C" int pnr_params_checksum(const PnrMlpWeights *w, void *ws, unsigned long long *sum_out, const unsigned long long *expect,
+                                   int *mismatch_flag, void *stream) {
+    if (!w || !ws || (!sum_out && !(expect && mismatch_flag))) return pnr_fail(PNR_E_INVALID, "pnr_params_checksum: bad argument");
+    hipLaunchKernelGGL(pnr::params_checksum_kernel, dim3(pnr::CK_BLOCKS), dim3(256), 0, (hipStream_t)stream, *w,
+                       (unsigned long long *)ws, sum_out, expect, mismatch_flag);
+    return pnr_check_launch("pnr_params_checksum");
+}
+
 extern "C" size_t pnr_folded_tables_bytes(const PnrScene *s) {
     if (!s || s->SB <= 0 || s->NS <= 0 || s->Hl <= 0 || s->Wl <= 0) return 0;
     return (size_t)pnr::COMBINE_LAYER * s->SB * s->NS * s->Hl * s->Wl * pnr::D_HID * 2;

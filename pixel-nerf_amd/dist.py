@@ -117,24 +117,68 @@ def _gather_dim1(t, sizes, group):
     return torch.cat([b[:, :s] for b, s in zip(bufs, sizes)], dim=1)
 
 
+class _BucketAllReduce(torch.autograd.Function):
+    """Identity on a list of tensors whose backward sums their gradients over the ranks with ONE all_reduce of one
+    flattened bucket (RCCL ring / tree over xGMI: one large message instead of 61 small ones).  Autograd calls the
+    backward of a multi-output Function once, when the gradients of all its outputs are known -- i.e. at the end of
+    the step's backward through the renderer -- so the reduction needs no hook and no explicit call by the trainer."""
+
+    @staticmethod
+    def forward(ctx, group, stats, *tensors):
+        ctx.group, ctx.stats = group, stats
+        ctx.meta = [(t.shape, t.dtype, t.device) for t in tensors]
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        # every rank must contribute a bucket of the same size: an output the local loss did not touch counts as zeros
+        parts = [(g if g is not None else torch.zeros(sh, dtype=dt, device=dv)).reshape(-1).float()
+                 for g, (sh, dt, dv) in zip(grads, ctx.meta)]
+        flat = torch.cat(parts)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
+        if ctx.stats is not None:
+            ctx.stats["all_reduce_calls"] = ctx.stats.get("all_reduce_calls", 0) + 1
+            ctx.stats["all_reduce_bytes"] = flat.numel() * 4
+        out, o = [], 0
+        for (sh, dt, dv) in ctx.meta:
+            n = 1
+            for d in sh:
+                n *= int(d)
+            out.append(flat[o:o + n].reshape(sh).to(dt))
+            o += n
+        return (None, None) + tuple(out)
+
+
 class ShardedRenderWrapper(torch.nn.Module):
     """Callable like the reference's DataParallel(_RenderWrapper, dim=1): every rank passes the
     same rays (SB,B,8); rank r renders rays[:, lo_r:hi_r]; every rank returns the full result
     (tuple (rgb, depth) for simple_output, else the nested dict).  All outputs of a call travel in ONE
-    all_gather: they are packed along the last axis ((rgb | depth) = 16 B/ray for simple_output)."""
+    all_gather: they are packed along the last axis ((rgb | depth) = 16 B/ray for simple_output).
+
+    Training (grad enabled, as train/train.py:75,199-215 does through DataParallel): the rank's own shard of the outputs
+    keeps its autograd graph inside the gathered result (the other ranks' columns are constants), so the trainer's loss --
+    computed identically on every rank from the full outputs -- back-propagates through the local rays only, and the partial
+    gradients of both ResnetFCs and of `encoder.latent` are summed over the ranks by ONE all_reduce of one flattened bucket
+    (`_BucketAllReduce`, entered by the renderer through `net._grad_sync`).  Every rank ends the step with the full
+    gradient, exactly what a single process would have computed (tests/test_dist_gloo.py), and steps its own optimizer."""
 
     def __init__(self, wrapped, group=None):
         super().__init__()
         self.wrapped = wrapped
         self.group = group
+        self.comm_stats = {}
+
+    def _grad_sync(self, latent, params):
+        ts = list(params) + ([latent] if (latent is not None and latent.requires_grad) else [])
+        out = _BucketAllReduce.apply(self.group, self.comm_stats, *ts)
+        n = len(params)
+        return (out[n] if len(out) > n else latent), list(out[:n])
 
     def forward(self, rays, want_weights=False):
         net = getattr(self.wrapped, "net", None)
-        if net is not None and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
-            raise NotImplementedError(
-                "ShardedRenderWrapper is the inference path (no gradient all-reduce): train with one process per GPU "
-                "on its own ray batch and DistributedDataParallel / an explicit all_reduce of the gradients, or wrap "
-                "the call in torch.no_grad()")
+        training = (net is not None and torch.is_grad_enabled()
+                    and (any(p.requires_grad for p in net.parameters())
+                         or (torch.is_tensor(getattr(getattr(net, "encoder", None), "latent", None)) and net.encoder.latent.requires_grad)))
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         B = rays.shape[1]
         bounds = [shard_bounds(B, r, world) for r in range(world)]
@@ -145,9 +189,13 @@ class ShardedRenderWrapper(torch.nn.Module):
             # counter-based draws are keyed by the GLOBAL ray id: the sharded image equals the unsharded one (every rank
             # must run with the same torch seed; the per-renderer call counter advances in lock-step)
             rend.ray_id_offset, rend.ray_id_stride = lo, B
+        if training:
+            net._grad_sync = self._grad_sync  # render_autograd routes (latent, parameters) through the bucket all-reduce
         try:
             local = self.wrapped(rays[:, lo:hi].contiguous(), want_weights=want_weights)
         finally:
+            if training:
+                net._grad_sync = None
             if rend is not None and hasattr(rend, "ray_id_offset"):
                 rend.ray_id_offset, rend.ray_id_stride = 0, 0
         # flatten the outputs to (SB, b, width) columns, pack, gather once, unpack
@@ -157,7 +205,10 @@ class ShardedRenderWrapper(torch.nn.Module):
             leaves = [(k, kk, vv) for k, v in local.items() for kk, vv in v.items()]
         cols = [t.reshape(t.shape[0], t.shape[1], -1) for _, _, t in leaves]
         widths = [c.shape[-1] for c in cols]
-        full = _gather_dim1(torch.cat(cols, dim=-1), sizes, self.group)
+        packed = torch.cat(cols, dim=-1)
+        full = _gather_dim1(packed.detach(), sizes, self.group)
+        if training and packed.requires_grad:  # this rank's columns keep their graph; the other ranks' are constants
+            full = torch.cat([full[:, :lo], packed, full[:, hi:]], dim=1)
         outs, o = [], 0
         for (_, _, t), w in zip(leaves, widths):
             outs.append(full[..., o:o + w].reshape((t.shape[0], B) + tuple(t.shape[2:])))

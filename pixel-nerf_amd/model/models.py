@@ -71,6 +71,7 @@ class PixelNeRFNet(torch.nn.Module):
         self.fold = bool(fold)
         self._scene = None
         self._tables = {}
+        self._grad_sync = None  # set for the duration of a call by dist.ShardedRenderWrapper (gradient all-reduce across ranks)
 
     # ------------------------------------------------------------------ encode (PyTorch-ROCm)
     def encode(self, images, poses, focal, z_bounds=None, c=None):
@@ -161,6 +162,7 @@ class PixelNeRFNet(torch.nn.Module):
             return None
         mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
         sc = self.scene()
+        mlp.packed(self._effective_precision(), folded=True)  # runs the cache's content check first: a detected silent write bumps the fingerprint
         key = (id(sc), mlp._fingerprint(), self._effective_precision())
         slot = "coarse" if mlp is self.mlp_coarse else "fine"
         hit = self._tables.get(slot)

@@ -706,9 +706,11 @@ def storage_perm(device=None):
 # host time of those allocations is comparable to the GPU time of a small kernel each.  acquire() hands out a free set of
 # the right shape or builds one; the autograd Functions release() a set once its last consumer is enqueued (same-stream
 # ordering makes the reuse safe).  A set that is never released is simply garbage-collected.
-_DUMP_POOL = {}
+_DUMP_POOL = {}  # key -> free sets; insertion order = least recently released first
 _DUMP_POOL_BYTES = [0]
 DUMP_POOL_MAX_BYTES = 16 << 30  # sets beyond this total are not kept (they go back to torch's allocator)
+DUMP_POOL_MAX_PER_KEY = 2       # a step holds at most the coarse and the fine set of a shape at once
+DUMP_POOL_MAX_KEYS = 8          # shapes (ray-batch sizes) remembered: older ones are dropped -> a changing batch size cannot pile up sets
 
 
 def _pool_get(key):
@@ -721,10 +723,15 @@ def _pool_get(key):
 
 
 def _pool_put(key, obj):
-    if _DUMP_POOL_BYTES[0] + obj.nbytes > DUMP_POOL_MAX_BYTES:
-        return
-    _DUMP_POOL.setdefault(key, []).append(obj)
-    _DUMP_POOL_BYTES[0] += obj.nbytes
+    free = _DUMP_POOL.pop(key, [])  # re-inserted below: most recently used last
+    if len(free) < DUMP_POOL_MAX_PER_KEY and _DUMP_POOL_BYTES[0] + obj.nbytes <= DUMP_POOL_MAX_BYTES:
+        free.append(obj)
+        _DUMP_POOL_BYTES[0] += obj.nbytes
+    if free:
+        _DUMP_POOL[key] = free
+    while len(_DUMP_POOL) > DUMP_POOL_MAX_KEYS:  # forget the least recently used shape
+        old = next(iter(_DUMP_POOL))
+        _DUMP_POOL_BYTES[0] -= sum(o.nbytes for o in _DUMP_POOL.pop(old))
 
 
 def dump_pool_clear():

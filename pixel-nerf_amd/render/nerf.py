@@ -174,13 +174,14 @@ class NeRFRenderer(torch.nn.Module):
         Kfd = min(self.n_fine_depth, Kf)
 
         if fused:  # pixelnerf_amd.PixelNeRFNet: one C call
-            if self.training and self.noise_std > 0.0:
-                raise NotImplementedError("noise_std > 0 (unused by every shipped config) is not fused")
             model._check_supported()
             needs_grad = torch.is_grad_enabled() and (
                 model.mlp_coarse.any_requires_grad()
                 or (model.mlp_fine is not None and model.mlp_fine.any_requires_grad())
                 or (model.encoder.latent.requires_grad and not model.stop_encoder_grad))
+            if self.training and self.noise_std > 0.0 and not needs_grad:
+                raise NotImplementedError("noise_std > 0 in train mode is implemented on the differentiable path (grad enabled); "
+                                          "the reference adds the noise only while training (nerf.py:225-226)")
             if needs_grad:  # training: differentiable path (HIP forward with operand dumps + HIP backward)
                 from ..autograd import render_autograd
                 if noise is None:
@@ -279,60 +280,86 @@ class NeRFRenderer(torch.nn.Module):
 class _MultiDeviceRenderWrapper(torch.nn.Module):
     """Single-process counterpart of the reference's DataParallel(_RenderWrapper, gpus, dim=1) (nerf.py:367-371): rays
     are split on dim 1 across the listed devices, every device renders its slice with its own replica of the
-    network (weights copied once and refreshed when they change; the encoded scene -- feature grid, poses, focal, c --
-    is copied per call, as DataParallel's replicate does), results are concatenated on the first device.  Kernel
-    launches are asynchronous, so the slices run concurrently.  Inference only; training across GPUs is one process
-    per GPU (pixelnerf_amd.dist)."""
+    network (weight VALUES copied when they change; the encoded scene -- feature grid, poses, focal, c -- is copied per
+    call, as DataParallel's replicate does), results are concatenated on the first device.  Kernel launches are
+    asynchronous, so the slices run concurrently.
+    Training works as it does through DataParallel (train/train.py:75): under grad, the autograd inputs of a replica's
+    render are the SOURCE network's parameters and `encoder.latent` moved to the replica's device with the
+    differentiable `.to()`, so every shard's gradient flows back across devices and accumulates in the source
+    parameters' `.grad` -- the caller's optimizer steps the source network, the replicas are refreshed on the next call.
+    (Across processes: pixelnerf_amd.dist.ShardedRenderWrapper, one all_reduce per step.)"""
 
     def __init__(self, net, renderer, simple_output, gpus):
         super().__init__()
         self.net, self.renderer, self.simple_output = net, renderer, simple_output
         self.devices = [torch.device("cuda", int(g)) for g in gpus]
-        self._replicas = {}  # device index in the list -> (weights fingerprint, net replica, renderer replica)
+        self._replicas = {}  # device index in the list -> [weights fingerprint, net replica, renderer replica]
+
+    def _weights_key(self):
+        src = self.net
+        mlps = [m for m in (src.mlp_coarse, src.mlp_fine) if m is not None]
+        return tuple(m._fingerprint() for m in mlps) + (src.mlp_fine is None,)
 
     def _replica(self, i):
         import copy
-        fp = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
+        fp = self._weights_key()
         hit = self._replicas.get(i)
-        if hit is None or hit[0] != fp:
+        if hit is None:
             # not parameters: do not drag the grid, the device-side scene descriptor (ctypes) or the packed streams through
             # deepcopy -- the replica rebuilds its own lazily
             src = self.net
-            keep = (src.encoder.latent, src._scene, src._tables, getattr(src.encoder, "_nhwc", None))
-            packs = [(m, m._packed) for m in (src.mlp_coarse, src.mlp_fine) if m is not None]
-            src.encoder.latent, src._scene, src._tables = torch.empty(0), None, {}
+            keep = (src.encoder.latent, src._scene, src._tables, getattr(src.encoder, "_nhwc", None), src._grad_sync)
+            packs = [(m, m._packed, {k: m.__dict__.pop(k) for k in m._CACHE_KEYS if k in m.__dict__})
+                     for m in (src.mlp_coarse, src.mlp_fine) if m is not None]
+            src.encoder.latent, src._scene, src._tables, src._grad_sync = torch.empty(0), None, {}, None
             if hasattr(src.encoder, "_nhwc"):
                 src.encoder._nhwc = None
-            for m, _ in packs:
+            for m, _, _ in packs:
                 m._packed = {}
             try:
                 rep = copy.deepcopy(src).to(self.devices[i])
             finally:
-                src.encoder.latent, src._scene, src._tables = keep[0], keep[1], keep[2]
+                src.encoder.latent, src._scene, src._tables, src._grad_sync = keep[0], keep[1], keep[2], keep[4]
                 if hasattr(src.encoder, "_nhwc"):
                     src.encoder._nhwc = keep[3]
-                for m, pk in packs:
+                for m, pk, caches in packs:
                     m._packed = pk
-            self._replicas[i] = (fp, rep, copy.deepcopy(self.renderer).to(self.devices[i]))
-        _, rep, rend = self._replicas[i]
+                    m.__dict__.update(caches)
+            for p in rep.parameters():
+                p.requires_grad_(False)  # gradients go to the SOURCE parameters (see forward)
+            hit = [fp, rep, copy.deepcopy(self.renderer).to(self.devices[i])]
+            self._replicas[i] = hit
+        elif hit[0] != fp:
+            # the source weights changed (optimizer step, load_state_dict, ...): refresh the VALUES in place, re-pack lazily
+            with torch.no_grad():
+                for rp, sp in zip(hit[1].parameters(), self.net.parameters()):
+                    rp.copy_(sp, non_blocking=True)
+            for m in (hit[1].mlp_coarse, hit[1].mlp_fine):
+                if m is not None:
+                    m.invalidate_packed()
+            hit[0] = fp
+        _, rep, rend = hit
         dev = self.devices[i]
         src = self.net
-        rep.encoder.latent = src.encoder.latent.to(dev, non_blocking=True)
+        rep.encoder.latent = src.encoder.latent.detach().to(dev, non_blocking=True)
         rep.encoder.latent_scaling = src.encoder.latent_scaling.to(dev, non_blocking=True)
         rep.poses, rep.focal, rep.c = src.poses.to(dev, non_blocking=True), src.focal.to(dev, non_blocking=True), src.c.to(dev, non_blocking=True)
         rep.image_shape = src.image_shape.to(dev, non_blocking=True)
         rep.num_objs, rep.num_views_per_obj, rep.mlp_fine = src.num_objs, src.num_views_per_obj, (rep.mlp_fine if src.mlp_fine is not None else None)
-        rep.precision, rep.fold = src.precision, src.fold
-        for k in ("n_coarse", "n_fine", "n_fine_depth", "using_fine", "white_bkgd", "lindisp", "depth_std"):
+        rep.precision, rep.fold, rep.stop_encoder_grad = src.precision, src.fold, src.stop_encoder_grad
+        for k in ("n_coarse", "n_fine", "n_fine_depth", "using_fine", "white_bkgd", "lindisp", "depth_std", "noise_std"):
             setattr(rend, k, getattr(self.renderer, k))
         rend.train(self.renderer.training)
+        rep.train(src.training)
         return rep, rend
 
     def forward(self, rays, want_weights=False):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
-            raise NotImplementedError("bind_parallel(net, gpus) in one process is the inference path; wrap the call in "
-                                      "torch.no_grad(), or train with one process per GPU (pixelnerf_amd.dist)")
+        from ..autograd import PARAM_NAMES
         from ..dist import shard_bounds
+        src = self.net
+        lat = src.encoder.latent
+        training = torch.is_grad_enabled() and (any(p.requires_grad for p in src.parameters())
+                                                or (torch.is_tensor(lat) and lat.requires_grad and not src.stop_encoder_grad))
         B, n = rays.shape[1], len(self.devices)
         seed = self.renderer._next_seed(self.devices[0])  # one key per call, shared by all shards
         outs = []
@@ -342,8 +369,22 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
                 continue
             rep, rend = self._replica(i)
             rend.ray_id_offset, rend.ray_id_stride, rend._seed_override = lo, B, seed  # same draws as one device
-            with torch.cuda.device(dev):
-                part = _RenderWrapper(rep, rend, self.simple_output)(rays[:, lo:hi].to(dev, non_blocking=True), want_weights=want_weights)
+            if training:
+                # autograd inputs of this shard = the source tensors, moved differentiably: the shard's gradients arrive in
+                # the source parameters' .grad (summed over the shards by autograd's accumulation)
+                mlps = [m for m in (src.mlp_coarse, src.mlp_fine) if m is not None]
+                src_params = [p for m in mlps for p in m.ordered_params(PARAM_NAMES)]
+                rep.encoder.latent.requires_grad_(lat.requires_grad)  # the replica's renderer takes the differentiable path
+                for rp, sp in zip([p for m in (rep.mlp_coarse, rep.mlp_fine) if m is not None for p in m.ordered_params(PARAM_NAMES)], src_params):
+                    rp.requires_grad_(sp.requires_grad)
+                rep._grad_sync = (lambda latent, params, _d=dev, _sp=src_params:
+                                  ((lat.to(_d) if lat.requires_grad and not src.stop_encoder_grad else latent), [p.to(_d) for p in _sp]))
+            try:
+                with torch.cuda.device(dev):
+                    part = _RenderWrapper(rep, rend, self.simple_output)(rays[:, lo:hi].to(dev, non_blocking=True), want_weights=want_weights)
+            finally:
+                if training:
+                    rep._grad_sync = None
             outs.append(part)
         home = self.devices[0]
         if self.simple_output:

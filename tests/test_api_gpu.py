@@ -220,3 +220,34 @@ def test_bind_parallel_single_process_multi_device(dev):
     net.mlp_coarse.lin_in.weight.requires_grad_(True)
     with pytest.raises(NotImplementedError):
         par(r)
+
+
+def test_parameter_write_through_data_is_detected_and_repacked(dev):
+    """`p.data.mul_()` bumps neither tensor._version nor an optimizer step: the (steps, ptr, version) cache key cannot see it.
+    The device-side content check behind every cache hit (pnr_params_checksum) does: the call after the write may still
+    render with the old weights, the NEXT call warns (RuntimeWarning), re-packs / re-folds and renders with the new ones;
+    `invalidate_packed()` makes the very first call exact."""
+    import warnings
+    from pixelnerf_amd.render import NeRFRenderer
+    g, scene, meta, mc, mf, rays, noise = golden_setup("sn64_64_128")
+    net = build_net(dev, scene)
+    rend = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=True).to(dev).eval()
+    nz = {k: v.to(dev) for k, v in noise.items()}
+    r = rays.to(dev)
+    with torch.no_grad():
+        base = rend(net, r, _noise=nz).fine.rgb.clone()
+        assert torch.equal(rend(net, r, _noise=nz).fine.rgb, base)  # cache hit, content unchanged: same bits, no warning
+        v0 = net.mlp_fine.lin_out.weight._version
+        net.mlp_fine.lin_out.weight.data.mul_(0.5)
+        assert net.mlp_fine.lin_out.weight._version == v0  # the hole: nothing in the cache key moved
+        rend(net, r, _noise=nz)           # at most this one call may use the old stream; its check raises the device flag
+        torch.cuda.synchronize()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            fixed = rend(net, r, _noise=nz).fine.rgb.clone()
+        assert any("behind the packed-weight cache" in str(x.message) for x in w)
+        assert (fixed - base).abs().max() > 1e-3  # the new weights are in effect (stream AND folded tables)
+        net.mlp_fine.lin_out.weight.data.mul_(2.0)
+        net.mlp_fine.invalidate_packed()  # the documented way: exact from the first call on
+        back = rend(net, r, _noise=nz).fine.rgb
+        assert (back - base).abs().max() <= 1e-6

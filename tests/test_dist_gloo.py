@@ -118,6 +118,82 @@ def _worker(rank, world, port, B):
         dist.destroy_process_group()
 
 
+class FakeTrainNet(torch.nn.Module):
+    """stands in for PixelNeRFNet on the CPU: two "networks" of parameters + an encoder.latent, and the `_grad_sync` protocol
+    the renderer follows (autograd.render_autograd): parameters and latent pass through the hook before they are used"""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.a = torch.nn.Parameter(torch.randn(8, 3, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(3, generator=g))
+        self.c = torch.nn.Parameter(torch.randn(8, generator=g))   # touched by the depth output only
+        self.encoder = SimpleNamespace(latent=torch.randn(4, 5, generator=g).requires_grad_(True))
+        self._grad_sync = None
+
+
+class FakeTrainWrapped(torch.nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, rays, want_weights=False):
+        net = self.net
+        latent, params = net.encoder.latent, [net.a, net.b, net.c]
+        if net._grad_sync is not None:
+            latent, params = net._grad_sync(latent, params)
+        a, b, c = params
+        rgb = torch.tanh(rays @ a + b) * latent.sum()
+        depth = (rays * c).sum(-1) + latent[0, 0] * rays[..., 0]
+        return {"coarse": {"rgb": rgb, "depth": depth}}
+
+
+def _train_worker(rank, world, port, B):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1)
+        rays = torch.randn(2, B, 8)
+        gt = torch.randn(2, B, 3)
+
+        def loss_of(out):  # train/train.py:199-215 shape: a mean over ALL rays, computed from the full outputs
+            return ((out["coarse"]["rgb"] - gt) ** 2).mean() + 0.1 * (out["coarse"]["depth"] ** 2).mean()
+
+        ref_net = FakeTrainNet()
+        loss_of(FakeTrainWrapped(ref_net)(rays)).backward()  # single process: the whole ray batch
+        net = FakeTrainNet()
+        par = ShardedRenderWrapper(FakeTrainWrapped(net))
+        out = par(rays)
+        assert out["coarse"]["rgb"].shape == (2, B, 3)
+        loss = loss_of(out)
+        loss.backward()
+        # ONE all_reduce of one bucket holding every parameter gradient + the latent gradient ...
+        assert par.comm_stats["all_reduce_calls"] == 1
+        assert par.comm_stats["all_reduce_bytes"] == 4 * (8 * 3 + 3 + 8 + 4 * 5)
+        # ... after which EVERY rank holds the single-process gradient
+        for got, ref in ((net.a.grad, ref_net.a.grad), (net.b.grad, ref_net.b.grad), (net.c.grad, ref_net.c.grad),
+                         (net.encoder.latent.grad, ref_net.encoder.latent.grad)):
+            assert torch.allclose(got, ref, rtol=1e-5, atol=1e-7), (got - ref).abs().max()
+        assert net._grad_sync is None  # the hook is only installed for the duration of the call
+        with torch.no_grad():  # inference through the same wrapper: no bucket, no graph
+            o2 = par(rays)
+        assert not o2["coarse"]["rgb"].requires_grad and par.comm_stats["all_reduce_calls"] == 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [7, 64])
+def test_sharded_training_gradients_equal_single_process(B):
+    """the differentiable multi-process path (reference: DataParallel training, train/train.py:75; src/render/nerf.py:367-371):
+    sharded forward, loss on the gathered outputs, ONE bucketed gradient all-reduce -> single-process gradients on every rank"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_train_worker, args=(2, port, B), nprocs=2, join=True)
+
+
 @pytest.mark.parametrize("B", [7, 64])  # uneven and even splits
 def test_sharded_render_and_scene_broadcast_world2(B):
     s = socket.socket()

@@ -1,0 +1,176 @@
+"""
+GPU tests (-m gpu) of the training-side API surface added in round 3:
+  * `noise_std > 0` in train mode (src/render/nerf.py:225-226): sigma noise after each network pass; forward AND gradients
+    against torch autograd through the CPU oracle with the same draws (exact-fp32 HIP path, 1e-3);
+  * `bind_parallel(net, [d0, d1])` in ONE process trains like the reference's DataParallel (train/train.py:75,
+    src/render/nerf.py:367-371): every shard's gradient arrives in the source parameters;
+  * a second backward through the same render raises a clear error instead of a TypeError.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_setup, mlp_params
+from oracle import pnr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def make_train_net(dev, scene, precision):
+    from pixelnerf_amd.model import make_model
+    from pixelnerf_amd.util.conf import default_model_conf
+    net = make_model(default_model_conf(), precision=precision).to(dev).train()
+    net.mlp_coarse.load_state_dict(mlp_params(11))
+    net.mlp_fine.load_state_dict(mlp_params(12))
+    lat = scene["latent"].to(dev).clone().requires_grad_(True)
+    net.encoder.latent = lat
+    ls = torch.tensor([lat.shape[-1], lat.shape[-2]], dtype=torch.float32, device=dev)
+    net.encoder.latent_scaling = ls / (ls - 1) * 2.0
+    net.poses, net.image_shape = scene["poses"].to(dev), scene["image_shape"].to(dev)
+    net.focal, net.c = scene["focal"].to(dev), scene["c"].to(dev)
+    net.num_objs, net.num_views_per_obj = scene["SB"], scene["NS"]
+    return net, lat
+
+
+def all_grads(net, lat):
+    g = {"latent": lat.grad}
+    g.update({"coarse." + k: v.grad for k, v in net.mlp_coarse.named_parameters()})
+    g.update({"fine." + k: v.grad for k, v in net.mlp_fine.named_parameters()})
+    return {k: v.detach().cpu().double() for k, v in g.items()}
+
+
+def test_sigma_noise_matches_oracle_autograd(dev):
+    from pixelnerf_amd.render import NeRFRenderer
+    g, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
+    Kc, Kf, Kfd = int(g["n_coarse"]), int(g["n_fine"]), int(g["n_fine_depth"])
+    std = 0.7
+    net, lat = make_train_net(dev, scene, "f32")
+    rend = NeRFRenderer(n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, noise_std=std, white_bkgd=True).to(dev).train()
+    R = rays.shape[0] * rays.shape[1]
+    gt = torch.rand(rays.shape[0], rays.shape[1], 3, generator=torch.Generator().manual_seed(9))
+    torch.manual_seed(77)
+    out = rend(net, rays.to(dev), want_weights=True, _noise={k: v.to(dev) for k, v in noise.items()})
+    loss = ((out.coarse.rgb - gt.to(dev)) ** 2).mean() + ((out.fine.rgb - gt.to(dev)) ** 2).mean()
+    loss.backward()
+    # the same draws, in the reference's order: one (R, K) normal per network pass
+    torch.manual_seed(77)
+    n_c = torch.randn((R, Kc), device=dev).cpu() * std
+    n_f = torch.randn((R, Kc + Kf), device=dev).cpu() * std
+    sc = dict(scene)
+    sc["latent"] = scene["latent"].clone().requires_grad_(True)
+    pc = {k: v.clone().requires_grad_(True) for k, v in mc.items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in mf.items()}
+    ref = O.render(sc, pc, pf, rays, noise, Kc, Kf, Kfd, white_bkgd=True, sigma_noise=(n_c, n_f))
+    ref_loss = ((ref["coarse"]["rgb"] - gt) ** 2).mean() + ((ref["fine"]["rgb"] - gt) ** 2).mean()
+    ref_loss.backward()
+    clean = O.render(scene, mc, mf, rays, noise, Kc, Kf, Kfd, white_bkgd=True)
+    assert (ref["coarse"]["rgb"] - clean["coarse"]["rgb"]).abs().max() > 1e-3  # the noise matters at this std
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * max(1.0, ref_loss.item())
+    np.testing.assert_allclose(out.coarse.rgb.detach().cpu().numpy(), ref["coarse"]["rgb"].detach().numpy(), rtol=0, atol=2e-5)
+    got = all_grads(net, lat)
+    want = {"latent": sc["latent"].grad, **{"coarse." + k: v.grad for k, v in pc.items()}, **{"fine." + k: v.grad for k, v in pf.items()}}
+    for k, w in want.items():
+        w = w.double()
+        rel = float((got[k] - w).norm() / w.norm())
+        assert rel <= 1e-3, (k, rel)
+
+
+def test_eval_mode_and_default_noise_std_are_unchanged(dev):
+    """noise_std only acts while training (nerf.py:225): an eval-mode renderer with noise_std > 0 renders the noise-free image"""
+    from pixelnerf_amd.render import NeRFRenderer
+    g, scene, meta, mc, mf, rays, noise = golden_setup("sn64_64_128")
+    net, _ = make_train_net(dev, scene, "f16")
+    net.eval()
+    nz = {k: v.to(dev) for k, v in noise.items()}
+    with torch.no_grad():
+        a = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, noise_std=0.5, white_bkgd=True).to(dev).eval()(net, rays.to(dev), _noise=nz)
+        b = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, noise_std=0.0, white_bkgd=True).to(dev).eval()(net, rays.to(dev), _noise=nz)
+    assert torch.equal(a.fine.rgb, b.fine.rgb)
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("f16", 2e-3)])
+def test_single_process_multi_device_training(dev, precision, tol):
+    """bind_parallel(net, [0, 0]): two shards (both replicas on the one device of the test box), loss on the concatenated
+    outputs, backward -> the source network's gradients equal the unsharded ones (different dW summation order only)"""
+    from pixelnerf_amd.render import NeRFRenderer
+    from pixelnerf_amd.util import DotMap
+    g, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
+    gt = torch.rand(rays.shape[0], rays.shape[1], 3, generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def run(gpus):
+        net, lat = make_train_net(dev, scene, precision)
+        rend = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True, rng="torch").to(dev).train()
+        par = rend.bind_parallel(net, gpus, simple_output=False).train()
+        torch.manual_seed(5)
+        rd = DotMap(par(rays.to(dev), want_weights=True))
+        loss = ((rd.coarse.rgb - gt) ** 2).mean() + ((rd.fine.rgb - gt) ** 2).mean()
+        loss.backward()
+        return par, net, lat, all_grads(net, lat)
+
+    _, _, _, single = run(None)
+    par, net, lat, multi = run([0, 0])
+    assert type(par).__name__ == "_MultiDeviceRenderWrapper"
+    # the shards draw their own noise (torch generator, different call sequence): compare on a noise-independent footing --
+    # every tensor received a gradient of the right size and scale, and an optimizer step on the SOURCE network changes the render
+    for k in single:
+        assert multi[k].shape == single[k].shape and torch.isfinite(multi[k]).all()
+        ratio = float(multi[k].norm() / single[k].norm())
+        assert 0.5 < ratio < 2.0, (k, ratio)
+    opt = torch.optim.SGD(list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters()), lr=1e-2)
+    before = float(net.mlp_coarse.lin_out.weight.detach().abs().sum())
+    opt.step()
+    assert float(net.mlp_coarse.lin_out.weight.detach().abs().sum()) != before
+    with torch.no_grad():
+        par.eval()
+        o1 = par(rays.to(dev))
+    assert torch.isfinite(o1["fine"]["rgb"]).all()  # replicas were refreshed from the stepped source weights without error
+
+
+def test_multi_device_gradients_equal_single_device_with_fixed_noise(dev):
+    """same as above but noise-free sampling differences removed: n_fine = 0 and a zero jitter make the render a
+    deterministic function of the rays, so sharded and unsharded gradients must agree to summation order"""
+    from pixelnerf_amd.render import NeRFRenderer
+    from pixelnerf_amd.util import DotMap
+    g, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
+    gt = torch.rand(rays.shape[0], rays.shape[1], 3, generator=torch.Generator().manual_seed(9)).to(dev)
+    real_rand = torch.rand
+
+    def run(gpus):
+        net, lat = make_train_net(dev, scene, "f32")
+        rend = NeRFRenderer(n_coarse=64, n_fine=0, n_fine_depth=0, white_bkgd=True, rng="torch").to(dev).train()
+        par = rend.bind_parallel(net, gpus, simple_output=False).train()
+        torch.rand = lambda *a, **k: real_rand(*a, **k) * 0 + 0.5  # mid-bin samples: no dependence on the draw sequence
+        try:
+            rd = DotMap(par(rays.to(dev), want_weights=True))
+        finally:
+            torch.rand = real_rand
+        loss = ((rd.coarse.rgb - gt) ** 2).mean()
+        loss.backward()
+        g = {"latent": lat.grad}
+        g.update({"coarse." + k: v.grad for k, v in net.mlp_coarse.named_parameters()})
+        return loss.item(), {k: v.detach().cpu().double() for k, v in g.items()}
+
+    l1, single = run(None)
+    l2, multi = run([0, 0])
+    assert abs(l1 - l2) <= 1e-6 * max(1.0, abs(l1))
+    for k in single:
+        rel = float((multi[k] - single[k]).norm() / single[k].norm())
+        assert rel <= 1e-4, (k, rel)
+
+
+def test_second_backward_raises_a_clear_error(dev):
+    from pixelnerf_amd.render import NeRFRenderer
+    g, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
+    net, lat = make_train_net(dev, scene, "f16")
+    rend = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).to(dev).train()
+    out = rend(net, rays.to(dev), want_weights=True, _noise={k: v.to(dev) for k, v in noise.items()})
+    loss = out.coarse.rgb.sum() + out.fine.rgb.sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time is not supported"):
+        loss.backward()
