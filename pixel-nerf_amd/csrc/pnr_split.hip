@@ -161,11 +161,13 @@ __device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][JT], char *s
         }
 }
 
-// fp32 bilinear lookup of table b: wave handles points wave*8..+7, lane handles storage slots 8*lane..+7
-// (two 16-byte loads per corner); rows land in the table image (ROW_TAB stride) at offset 0
+// fp32 bilinear lookup of table b: wave handles points wave*8..+7; lane handles storage slots 4*lane..+3 and 256 + 4*lane..+3
+// (two fully coalesced 1 KiB loads per corner, and two 16-byte LDS writes per point at a 16-byte lane stride -- a 32-byte
+// lane stride put lanes l and l+8 on the same banks: 5.9 % of the LDS cycles of the round-2 kernel were conflicts);
+// rows land in the table image (ROW_TAB stride) at offset 0
 template <int GB, typename ST>
 __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem, int wv, int lane, int b) {
-    const float *tab = reinterpret_cast<const float *>(q.tables) + (size_t)b * q.table_stride + lane * 8;
+    const float *tab = reinterpret_cast<const float *>(q.tables) + (size_t)b * q.table_stride + lane * 4;
     static_assert((ST::MT / NW) % GB == 0, "gather batch");
 #pragma unroll 1
     for (int i = 0; i < ST::MT / NW; i += GB) {
@@ -179,7 +181,7 @@ __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 v[u][c][0] = *reinterpret_cast<const f32x4 *>(tab + off[c]);
-                v[u][c][1] = *reinterpret_cast<const f32x4 *>(tab + off[c] + 4);
+                v[u][c][1] = *reinterpret_cast<const f32x4 *>(tab + off[c] + D_HID / 2);
             }
         }
 #pragma unroll
@@ -191,7 +193,7 @@ __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem
                 r += v[u][1][hh] * w[u][1];
                 r += v[u][2][hh] * w[u][2];
                 r += v[u][3][hh] * w[u][3];
-                *reinterpret_cast<f32x4 *>(smem + p * ST::ROW_TAB + lane * 32 + hh * 16) = r;
+                *reinterpret_cast<f32x4 *>(smem + p * ST::ROW_TAB + hh * (D_HID * 2) + lane * 16) = r;
             }
         }
     }

@@ -217,9 +217,13 @@ def test_bind_parallel_single_process_multi_device(dev):
     with torch.no_grad():
         d = full(r, want_weights=True)
     assert d["fine"]["weights"].shape == (1, r.shape[1], 192) and d["coarse"]["rgb"].shape == (1, r.shape[1], 3)
+    # with grad enabled the same wrapper is differentiable, as DataParallel is for the reference (train/train.py:75): both
+    # shards' gradients arrive in the SOURCE network's parameters (tests/test_hip_training_api.py checks the values)
     net.mlp_coarse.lin_in.weight.requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        par(r)
+    rgb_t, _ = par(r)
+    assert rgb_t.requires_grad
+    rgb_t.sum().backward()
+    assert net.mlp_fine.lin_out.weight.grad is not None and float(net.mlp_fine.lin_out.weight.grad.abs().sum()) > 0
 
 
 def test_parameter_write_through_data_is_detected_and_repacked(dev):
