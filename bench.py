@@ -732,6 +732,7 @@ def main():
             # BASELINE configs[2..4] on this one GPU, outside the timed region
             for key, fn in (("train_step", lambda: extra_train_step(dev, "f16")),
                             ("train_step_multiview", lambda: extra_train_step(dev, "f16", "train_mv", steps=20, warmup=4, with_graph=False)),
+                            ("train_step_fp32_class", lambda: extra_train_step(dev, "f16x3", steps=10, warmup=3, with_graph=False)),
                             ("train_step_fp32_validation_path", lambda: extra_train_step(dev, "f32", steps=5, warmup=2, with_graph=False)),
                             ("srn_car", lambda: extra_render_config(dev, "srn_car", 4)),
                             ("dtu", lambda: extra_render_config(dev, "dtu", 1))):

@@ -436,16 +436,21 @@ typedef struct PnrF32Saved {
     float *x5;      /* (rows_p, 512) residual stream in front of lin_out                               */
     float *pool_in; /* (rows_v, 512) residual stream after block 2, in front of the view mean; NS == 1: unused, may be NULL */
 } PnrF32Saved;
+/* split_gemm = 0: every product on the exact fp32 MFMA (precision "f32": the yardstick).  split_gemm = 1: the same chain with
+ * every product formed from (head, tail) fp16 operand pairs -- 3 f16 MFMAs, fp32 accumulate, the arithmetic of
+ * PNR_PREC_F16X3 -- about 6x faster at fp32-class accuracy (precision "f16x3" under autograd). */
 int pnr_eval_ray_samples_f32_train(const PnrScene *scene /*host*/, const PnrMlpWeights *w /*host*/, const float *rays,
                                    const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
-                                   const PnrF32Saved *saved /*host*/, void *stream);
+                                   const PnrF32Saved *saved /*host*/, int split_gemm, void *stream);
 /* All parameter gradients of one ResnetFC + d(interpolated latent) [+ d(lin_in operand)] from g_out (P,4) =
  * dL/d(lin_out output): `grads` holds device pointers of the 30 gradient tensors in PnrMlpWeights' layout (same shapes as
  * the parameters, overwritten); d_zlat (rows_v,512), d_in (rows_v,42) or NULL. */
 size_t pnr_mlp_backward_f32_workspace_bytes(long long P, int NS);
+/* split_gemm = 1 additionally takes grad_scale = device [s, 1/s] from pnr_grad_scale(g_out): the gradient chain runs at the
+ * power-of-two scale s (fp16 range of the operand heads), results are un-scaled exactly on their way out. */
 int pnr_mlp_backward_f32(const PnrMlpWeights *w /*host*/, const PnrF32Saved *saved /*host*/, const float *g_out, long long P,
-                         int NS, const PnrMlpWeights *grads /*host*/, float *d_zlat, float *d_in, void *workspace,
-                         size_t workspace_bytes, void *stream);
+                         int NS, const PnrMlpWeights *grads /*host*/, float *d_zlat, float *d_in, int split_gemm,
+                         const float *grad_scale, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The feature phase of the exact-fp32 path on its own -- PositionalEncoding.forward (src/model/code.py:30-42) on the
  * rotated point + the rotated view direction (src/model/models.py:161-196) and SpatialEncoder.index

@@ -133,10 +133,10 @@ PROTOTYPES = {
                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pnr_gen_rays": (_I, [_P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P]),
     "pnr_eval_ray_samples_f32_train": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _I, _I, _P,
-                                            ctypes.POINTER(PnrF32Saved), _P]),
+                                            ctypes.POINTER(PnrF32Saved), _I, _P]),
     "pnr_mlp_backward_f32_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
     "pnr_mlp_backward_f32": (_I, [ctypes.POINTER(PnrMlpWeights), ctypes.POINTER(PnrF32Saved), _P, ctypes.c_longlong, _I,
-                                  ctypes.POINTER(PnrMlpWeights), _P, _P, _P, _SZ, _P]),
+                                  ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _P, _P, _SZ, _P]),
     "pnr_point_features_f32": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _P, _P]),
     "pnr_profile_enable": (_I, [_I]),
     "pnr_profile_read": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),

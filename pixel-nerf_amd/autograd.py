@@ -52,15 +52,17 @@ class _NoRelease:
 
 def _train_eval(net, scene, coarse, rays, z):
     """network forward of one training pass -> (rgbsigma (R,K,4), saved operands).  precision 'f32': the exact, unfused fp32
-    chain (validation grade); 'f16' / 'bf16': the fused kernel's training instantiation (16-bit operand dumps)."""
-    if net.precision == "f32":
-        return ops.eval_ray_samples_f32_train(scene, net.packed(coarse, folded=False), rays, z)
+    chain (validation grade); 'f16x3': the same chain with split-operand (fp32-class) GEMMs on the f16 matrix cores;
+    'f16' / 'bf16': the fused kernel's training instantiation (16-bit operand dumps)."""
+    if net.precision in ("f32", "f16x3"):
+        mlp = net.mlp_coarse if (coarse or net.mlp_fine is None) else net.mlp_fine
+        return ops.eval_ray_samples_f32_train(scene, mlp.packed("f32"), rays, z, split=net.precision == "f16x3")
     return ops.eval_ray_samples_train(scene, net.packed(coarse, folded=False), rays, z)
 
 
 def _pass_grads(net, mlp, dumps, g_out, scene_NS, want_d_in):
     """-> (grads, d_zlat, d_in, releasable) of one pass at the network's precision"""
-    if net.precision == "f32":
+    if net.precision in ("f32", "f16x3"):
         grads, d_zlat, d_in = ops.mlp_backward_f32(mlp.packed("f32"), dumps, g_out, want_d_in=want_d_in)
         return grads, d_zlat, d_in, _NoRelease
     return _mlp_grads(None, mlp.packed_bwd(net.precision), dumps, g_out, scene_NS, want_d_in=want_d_in)

@@ -194,19 +194,253 @@ wgrad_f32_kernel(const float *__restrict__ dY, int lddy, const float *__restrict
 }
 
 __global__ void wgrad_reduce_f32_kernel(const float *__restrict__ part, const float *__restrict__ bpart, int nsplit, int N, int Kd,
-                                        float *__restrict__ dW, float *__restrict__ db) {
+                                        float *__restrict__ dW, float *__restrict__ db, const float *__restrict__ scale_dev) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const float sc = scale_dev ? *scale_dev : 1.f;
     if (idx < N * Kd) {
         float s = 0.f;
         for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * N * Kd + idx];
-        dW[idx] = s;
+        dW[idx] = s * sc;
     }
     if (db && idx < N) {
         float s = 0.f;
         for (int z = 0; z < nsplit; ++z) s += bpart[(size_t)z * N + idx];
-        db[idx] = s;
+        db[idx] = s * sc;
     }
 }
+
+// ---------------------------------------------------------------- fp32-CLASS GEMM on the f16 matrix cores (split operands)
+// C[m][n] (+)= sum_k A(m,k) B(n,k) with fp32 operands in HBM, carried through the MFMA as (head, tail) fp16 pairs:
+// a b ~= ah bh + ah bl + al bh (fp32 accumulate; the dropped al bl is 2^-22 of the product) -- the arithmetic of
+// pnr_split.hip as a plain tiled GEMM, ~6x the rate of the fp32-MFMA kernels above.  It serves all three products of the
+// fp32-class TRAINING path (precision "f16x3" under autograd):
+//     forward   Y  = relu(X) W^T + b        A = X (k contiguous),      B = W (k contiguous)
+//     data grad dX = (dY W) . relu'         A = dY (k contiguous),     B(n,k) = W[k][n]      (row index contiguous)
+//     weights   dW = dY^T relu(X)           A(n,m) = dY[m][n], B(kd,m) = X[m][kd]            (both row-index contiguous;
+//                                           the reduction over the rows m split over blockIdx.z, fixed-order second pass)
+// Operands are split on their way into LDS ([row][k] f16 images, 80-byte rows: conflict-free b128 fragment reads); a device
+// scalar can scale A on load (gradients run at a power-of-two scale that keeps them in the fp16 range) and the result on its way
+// out.  128 x 128 block tile, 4 waves of 64 x 64, K chunks of 32; one LDS stage + register prefetch of the next chunk, three
+// workgroups per CU cover each other's load / convert phases.
+struct Gemm3 {
+    const float *A, *B;
+    long long a_rs, a_ks, b_rs, b_ks;  // element (row, k) at base[row * rs + k * ks]; one of (rs, ks) is 1
+    long long M;                       // rows of A / C
+    int N;                             // rows of B = columns of C
+    long long K;                       // reduction length
+    int relu_a, relu_b;
+    const float *a_scale;              // device scalar multiplied into A on load (nullable)
+    const float *bias, *mask, *Yin;    // epilogue: + bias[n]; keep where mask[m][n] > 0; + Yin[m][n]   (leading dimension ldc)
+    float *C;
+    int ldc;
+    const float *out_scale;            // device scalar multiplied into the product (nullable)
+    float *part, *bpart;               // split-K: partial products part[z][M][N] (raw) and column sums of A bpart[z][M] (nullable)
+    long long k_per_split;
+};
+
+constexpr int G3_ROW = 80;                 // bytes per [row][32 k] f16 row (64 + 16 pad)
+constexpr int G3_IMG = 128 * G3_ROW;       // one 128-row image
+// split 4 fp32 values into head / tail f16 (8 bytes each), MODE.FP16_OVFL set by the caller
+__device__ __forceinline__ void g3_split4(f32x4 v, bool relu, float sc, uint2 &hi, uint2 &lo) {
+    uint32_t h[2], l[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        f32x2 p = {v[2 * k] * sc, v[2 * k + 1] * sc};
+        if (relu) { p[0] = fmaxf(p[0], 0.f); p[1] = fmaxf(p[1], 0.f); }
+        const f16x2 hh = __builtin_convertvector(p, f16x2);
+        h[k] = __builtin_bit_cast(uint32_t, hh);
+        uint32_t t;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(h[k]), "v"(p[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t) : "v"(h[k]), "v"(p[1]));
+        l[k] = t;
+    }
+    hi = make_uint2(h[0], h[1]);
+    lo = make_uint2(l[0], l[1]);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256, 3) gemm3_kernel(const Gemm3 g) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * G3_IMG];  // A head, A tail, B head, B tail
+    typedef Prec<PNR_PREC_F16> PH;
+    typedef PH::T8 h8;
+    f16_ovfl_mode<PH>();
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const long long m0 = (long long)blockIdx.x * 128;
+    const int n0 = blockIdx.y * 128;
+    const long long k_begin = (long long)blockIdx.z * g.k_per_split;
+    const long long k_end = k_begin + g.k_per_split < g.K ? k_begin + g.k_per_split : g.K;
+    const float asc = g.a_scale ? *g.a_scale : 1.f;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    const int fi = lane & 31, fh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // staging maps.  k-contiguous operand: thread -> (row = t/8 + 32u, k = 4 (t%8) .. +3), one 16-byte load per u.
+    // row-contiguous operand: thread -> (rows 4 (t/8) .. +3, k = 4 (t%8) + u): four 16-byte loads along the rows, transposed
+    // in registers so that every LDS write is again 4 consecutive k of one row (8 bytes of heads + 8 of tails).
+    f32x4 ra[4], rb[4];
+    float colsum[4] = {0.f, 0.f, 0.f, 0.f};  // split-K + bpart: sums over k of this thread's four A rows
+    const int kq = t & 7, rq = t >> 3;
+    auto load = [&](long long kc) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (A_KC) {
+                const long long m = m0 + rq + 32 * u, k = kc + 4 * kq;
+                ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < g.M) {
+                    const float *src = g.A + m * g.a_rs + k;
+                    if (k + 3 < k_end && (g.a_rs & 3) == 0) ra[u] = *reinterpret_cast<const f32x4 *>(src);
+                    else
+                        for (int e = 0; e < 4; ++e)
+                            if (k + e < k_end) ra[u][e] = src[e];
+                }
+            } else {
+                const long long m = m0 + 4 * rq, k = kc + 4 * kq + u;
+                ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (k < k_end) {
+                    const float *src = g.A + k * g.a_ks + m;
+                    if (m + 3 < g.M && (g.a_ks & 3) == 0) ra[u] = *reinterpret_cast<const f32x4 *>(src);
+                    else
+                        for (int e = 0; e < 4; ++e)
+                            if (m + e < g.M) ra[u][e] = src[e];
+                }
+            }
+            if (B_KC) {
+                const int n = n0 + rq + 32 * u;
+                const long long k = kc + 4 * kq;
+                rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (n < g.N) {
+                    const float *src = g.B + (long long)n * g.b_rs + k;
+                    if (k + 3 < k_end && (g.b_rs & 3) == 0) rb[u] = *reinterpret_cast<const f32x4 *>(src);
+                    else
+                        for (int e = 0; e < 4; ++e)
+                            if (k + e < k_end) rb[u][e] = src[e];
+                }
+            } else {
+                const int n = n0 + 4 * rq;
+                const long long k = kc + 4 * kq + u;
+                rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (k < k_end) {
+                    const float *src = g.B + k * g.b_ks + n;
+                    if (n + 3 < g.N && (g.b_ks & 3) == 0) rb[u] = *reinterpret_cast<const f32x4 *>(src);
+                    else
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < g.N) rb[u][e] = src[e];
+                }
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint2 hi, lo;
+            if (A_KC) {
+                g3_split4(ra[u], g.relu_a != 0, asc, hi, lo);
+                const int off = (rq + 32 * u) * G3_ROW + kq * 8;
+                *reinterpret_cast<uint2 *>(lds + off) = hi;
+                *reinterpret_cast<uint2 *>(lds + G3_IMG + off) = lo;
+            } else {
+                const f32x4 col = {ra[0][u], ra[1][u], ra[2][u], ra[3][u]};  // row 4 rq + u, k = 4 kq .. +3
+                g3_split4(col, g.relu_a != 0, asc, hi, lo);
+                const int off = (4 * rq + u) * G3_ROW + kq * 8;
+                *reinterpret_cast<uint2 *>(lds + off) = hi;
+                *reinterpret_cast<uint2 *>(lds + G3_IMG + off) = lo;
+                if (g.bpart) colsum[u] += (col[0] + col[1]) + (col[2] + col[3]);
+            }
+            if (B_KC) {
+                g3_split4(rb[u], g.relu_b != 0, 1.f, hi, lo);
+                const int off = (rq + 32 * u) * G3_ROW + kq * 8;
+                *reinterpret_cast<uint2 *>(lds + 2 * G3_IMG + off) = hi;
+                *reinterpret_cast<uint2 *>(lds + 3 * G3_IMG + off) = lo;
+            } else {
+                const f32x4 col = {rb[0][u], rb[1][u], rb[2][u], rb[3][u]};
+                g3_split4(col, g.relu_b != 0, 1.f, hi, lo);
+                const int off = (4 * rq + u) * G3_ROW + kq * 8;
+                *reinterpret_cast<uint2 *>(lds + 2 * G3_IMG + off) = hi;
+                *reinterpret_cast<uint2 *>(lds + 3 * G3_IMG + off) = lo;
+            }
+        }
+    };
+    if (k_begin < k_end) load(k_begin);
+    for (long long kc = k_begin; kc < k_end; kc += 32) {
+        __syncthreads();  // the previous chunk's fragment reads are done
+        stage();
+        __syncthreads();
+        if (kc + 32 < k_end) load(kc + 32);  // in flight under this chunk's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm + i * 32 + fi) * G3_ROW + ks * 32 + fh * 16;
+                ah[i] = *reinterpret_cast<const h8 *>(lds + off);
+                al[i] = *reinterpret_cast<const h8 *>(lds + G3_IMG + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = (wn + j * 32 + fi) * G3_ROW + ks * 32 + fh * 16;
+                bh[j] = *reinterpret_cast<const h8 *>(lds + 2 * G3_IMG + off);
+                bl[j] = *reinterpret_cast<const h8 *>(lds + 3 * G3_IMG + off);
+            }
+            // D[i][j] += sum_k A-frag(row i, k) B-frag(col j, k): the MFMA's D holds column j = lane&31 of the B rows
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue.  D register r of tile (i, j): row m = wm + 32 i + (r&3) + 8 (r>>2) + 4 fh, column n = wn + 32 j + fi
+    const float osc = g.out_scale ? *g.out_scale : 1.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + j * 32 + fi;
+            if (n >= g.N) continue;
+            const float bias = (g.bias && !g.part) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m >= g.M) continue;
+                if (g.part) {
+                    g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+                } else {
+                    float v = acc[i][j][r] * osc + bias;
+                    const size_t o = (size_t)m * g.ldc + n;
+                    if (g.mask && !(g.mask[o] > 0.f)) v = 0.f;
+                    if (g.Yin) v += g.Yin[o];
+                    g.C[o] = v;
+                }
+            }
+        }
+    if (!A_KC && g.bpart && blockIdx.y == 0) {
+        // column sums of this block's A rows over its k range: 8 threads (kq) per row quad, reduced through LDS
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) red[(4 * rq + u) * 8 + kq] = colsum[u];
+        __syncthreads();
+        if (t < 128 && m0 + t < g.M) {
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += red[t * 8 + e];
+            g.bpart[(size_t)blockIdx.z * g.M + m0 + t] = sum * asc;  // same (scaled) domain as the partial products
+        }
+    }
+}
+
 
 // Gv[v*np + p][f] = Gp[p][f] * inv   (backward of the view mean, util.py:461-466)
 __global__ void unpool_f32_kernel(const float *__restrict__ gp, float *__restrict__ gv, long long np, int NS, float inv) {
@@ -243,30 +477,75 @@ __global__ void out_f32_kernel(const float *o, float *rgbs, int np) {  // o may 
     *reinterpret_cast<f32x4 *>(rgbs + (size_t)idx * 4) = r;
 }
 
-static void linear(hipStream_t st, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, long long M,
-                   int N, int K, bool relu_in, bool accumulate, const float *Yin = nullptr) {
-    dim3 grid((unsigned)((M + 63) / 64), (N + 63) / 64);
-    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, st, X, ldx, W, K, 0, b, accumulate ? (Yin ? Yin : Y) : nullptr, Y, ldy, M,
-                       N, K, relu_in ? 1 : 0, (const float *)nullptr, 1.f);
+// how the fp32-precision products are formed: exact fp32 MFMA (validation grade) or split f16 operands (fp32-class, fast);
+// gs / gi: device scalars [s], [1/s] -- the power-of-two scale the gradients of a fast backward run at (NULL: 1)
+struct Mm {
+    hipStream_t st;
+    bool fast;
+    const float *gs, *gi;
+};
+
+template <bool AK, bool BK> static void launch_g3(const Mm &c, Gemm3 g, int nz) {
+    dim3 grid((unsigned)((g.M + 127) / 128), (g.N + 127) / 128, nz);
+    hipLaunchKernelGGL((gemm3_kernel<AK, BK>), grid, dim3(256), 0, c.st, g);
 }
 
-// backward data product: Out (M,J) = [Out +] ((dY (M,N) W (N,J)) * scale) . [mask > 0]   (W = the nn.Linear weight (N,J) as stored)
-static void linear_bwd(hipStream_t st, const float *dY, int lddy, const float *W, int J, int N, float *Out, int ldo, long long M,
-                       const float *mask, bool accumulate, float scale = 1.f) {
+static void linear(const Mm &c, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, long long M,
+                   int N, int K, bool relu_in, bool accumulate, const float *Yin = nullptr) {
+    if (c.fast) {
+        Gemm3 g = {};
+        g.A = X; g.a_rs = ldx; g.a_ks = 1; g.B = W; g.b_rs = K; g.b_ks = 1; g.M = M; g.N = N; g.K = K; g.relu_a = relu_in;
+        g.bias = b; g.Yin = accumulate ? (Yin ? Yin : Y) : nullptr; g.C = Y; g.ldc = ldy; g.k_per_split = K;
+        launch_g3<true, true>(c, g, 1);
+        return;
+    }
+    dim3 grid((unsigned)((M + 63) / 64), (N + 63) / 64);
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, c.st, X, ldx, W, K, 0, b, accumulate ? (Yin ? Yin : Y) : nullptr, Y, ldy, M,
+                       N, K, relu_in ? 1 : 0, (const float *)nullptr, 1.f);
+}
+static void linear(hipStream_t st, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, long long M,
+                   int N, int K, bool relu_in, bool accumulate, const float *Yin = nullptr) {
+    linear(Mm{st, false, nullptr, nullptr}, X, ldx, W, b, Y, ldy, M, N, K, relu_in, accumulate, Yin);
+}
+
+// backward data product: Out (M,J) = [Out +] (dY (M,N) W (N,J)) [* out scale] . [mask > 0]   (W = the nn.Linear weight (N,J) as stored)
+// in_scaled: dY is still the caller's unscaled gradient (scaled on load in the fast form); out_unscale: the result leaves the
+// scaled domain (d z_lat, d(code)); a_scale / out_scale only act in the fast form
+static void linear_bwd(const Mm &c, const float *dY, int lddy, const float *W, int J, int N, float *Out, int ldo, long long M,
+                       const float *mask, bool accumulate, bool in_unscaled = false, bool out_unscale = false) {
+    if (c.fast) {
+        Gemm3 g = {};
+        g.A = dY; g.a_rs = lddy; g.a_ks = 1; g.B = W; g.b_rs = 1; g.b_ks = J; g.M = M; g.N = J; g.K = N;
+        g.a_scale = in_unscaled ? c.gs : nullptr; g.out_scale = out_unscale ? c.gi : nullptr;
+        g.mask = mask; g.Yin = accumulate ? Out : nullptr; g.C = Out; g.ldc = ldo; g.k_per_split = N;
+        launch_g3<true, false>(c, g, 1);
+        return;
+    }
     dim3 grid((unsigned)((M + 63) / 64), (J + 63) / 64);
-    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, st, dY, lddy, W, J, 1, (const float *)nullptr,
-                       accumulate ? Out : (const float *)nullptr, Out, ldo, M, J, N, 0, mask, scale);
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, c.st, dY, lddy, W, J, 1, (const float *)nullptr,
+                       accumulate ? Out : (const float *)nullptr, Out, ldo, M, J, N, 0, mask, 1.f);
 }
 
 constexpr int WG_SPLIT = 32;  // row slices of the weight-gradient reduction
 
 // dW (N,Kd), db (N) from dY (M,N) and X (M,Kd); part / bpart: WG_SPLIT * (N*Kd + N) floats of workspace
-static void wgrad(hipStream_t st, const float *dY, int lddy, const float *X, int ldx, bool relu_x, long long M, int N, int Kd,
-                  float *dW, float *db, float *part) {
+static void wgrad(const Mm &c, const float *dY, int lddy, const float *X, int ldx, bool relu_x, long long M, int N, int Kd,
+                  float *dW, float *db, float *part, bool in_unscaled = false) {
     float *bpart = part + (size_t)WG_SPLIT * N * Kd;
+    if (c.fast) {
+        Gemm3 g = {};
+        g.A = dY; g.a_rs = 1; g.a_ks = lddy; g.B = X; g.b_rs = 1; g.b_ks = ldx; g.M = N; g.N = Kd; g.K = M; g.relu_b = relu_x;
+        g.a_scale = in_unscaled ? c.gs : nullptr; g.part = part; g.bpart = bpart;
+        long long per = (M + WG_SPLIT - 1) / WG_SPLIT;
+        g.k_per_split = (per + 31) / 32 * 32;
+        launch_g3<false, false>(c, g, WG_SPLIT);
+        hipLaunchKernelGGL(wgrad_reduce_f32_kernel, dim3((N * Kd + 255) / 256), dim3(256), 0, c.st, part, bpart, WG_SPLIT, N, Kd, dW, db, c.gi);
+        return;
+    }
     dim3 grid((N + 63) / 64, (Kd + 63) / 64, WG_SPLIT);
-    hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, dY, lddy, X, ldx, relu_x ? 1 : 0, M, N, Kd, part, bpart);
-    hipLaunchKernelGGL(wgrad_reduce_f32_kernel, dim3((N * Kd + 255) / 256), dim3(256), 0, st, part, bpart, WG_SPLIT, N, Kd, dW, db);
+    hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, c.st, dY, lddy, X, ldx, relu_x ? 1 : 0, M, N, Kd, part, bpart);
+    hipLaunchKernelGGL(wgrad_reduce_f32_kernel, dim3((N * Kd + 255) / 256), dim3(256), 0, c.st, part, bpart, WG_SPLIT, N, Kd, dW, db,
+                       (const float *)nullptr);
 }
 
 // floats of workspace per point of a chunk
@@ -333,7 +612,8 @@ static int check_saved(const PnrF32Saved *sv, int NS) {
     return NS == 1 || sv->pool_in != nullptr;
 }
 
-static int eval_f32_train(const PnrScene *s, const PnrMlpWeights *w, EvalParams q, const PnrF32Saved *sv, hipStream_t st) {
+static int eval_f32_train(const PnrScene *s, const PnrMlpWeights *w, EvalParams q, const PnrF32Saved *sv, hipStream_t stream, bool fast) {
+    const Mm st = {stream, fast, nullptr, nullptr};
     if (!s || !w || !q.out) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: null argument");
     if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: bad scene shape");
     if (!check_saved(sv, s->NS)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: null activation buffer in PnrF32Saved");
@@ -345,7 +625,7 @@ static int eval_f32_train(const PnrScene *s, const PnrMlpWeights *w, EvalParams 
     const int NS = s->NS;
     const int np = (int)q.P;
     const long long rows = (long long)np * NS;
-    hipLaunchKernelGGL(feat_f32_kernel<true>, dim3((unsigned)((rows + FW - 1) / FW)), dim3(FW * 64), 0, st, q, 0LL, np, sv->in42, sv->zlat);
+    hipLaunchKernelGGL(feat_f32_kernel<true>, dim3((unsigned)((rows + FW - 1) / FW)), dim3(FW * 64), 0, stream, q, 0LL, np, sv->in42, sv->zlat);
     linear(st, sv->in42, D_IN_PAD, w->lin_in_w, w->lin_in_b, sv->xin[0], D_HID, rows, D_HID, D_IN, false, false);  // resnetfc.py:147
     for (int b = 0; b < COMBINE_LAYER; ++b) {
         linear(st, sv->zlat, C_LAT, w->lin_z_w[b], w->lin_z_b[b], sv->xin[b], D_HID, rows, D_HID, C_LAT, false, true);       // :175-180
@@ -355,7 +635,7 @@ static int eval_f32_train(const PnrScene *s, const PnrMlpWeights *w, EvalParams 
     }
     if (NS > 1) {  // util.combine_interleaved
         const long long n = (long long)np * D_HID;
-        hipLaunchKernelGGL(pool_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sv->pool_in, sv->xin[COMBINE_LAYER], np, NS);
+        hipLaunchKernelGGL(pool_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sv->pool_in, sv->xin[COMBINE_LAYER], np, NS);
     }
     for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b) {
         linear(st, sv->xin[b], D_HID, w->fc0_w[b], w->fc0_b[b], sv->net[b], D_HID, np, D_HID, D_HID, true, false);
@@ -364,13 +644,13 @@ static int eval_f32_train(const PnrScene *s, const PnrMlpWeights *w, EvalParams 
     }
     // lin_out's raw output goes through the caller's rgbsigma buffer in place (4 floats per point either way)
     linear(st, sv->x5, D_HID, w->lin_out_w, w->lin_out_b, q.out, 4, np, D_OUT, D_HID, true, false);  // :183
-    hipLaunchKernelGGL(out_f32_kernel, dim3((np + 255) / 256), dim3(256), 0, st, q.out, q.out, np);
+    hipLaunchKernelGGL(out_f32_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, q.out, q.out, np);
     return pnr_check_launch("pnr_eval_ray_samples_f32_train");
 }
 
 // reverse of one residual block (resnetfc.py:55-62) on `rows` rows:  G = dL/d(xin + fc_1(relu(fc_0(relu(xin)))))
 //   dW1 = G^T relu(net), db1 = sum G;  T = (G W1) . [net > 0];  dW0 = T^T relu(xin), db0 = sum T;  G += (T W0) . [xin > 0]
-static void block_bwd_f32(hipStream_t st, const PnrMlpWeights *w, const PnrMlpWeights *g, int b, float *G, float *T, const float *xin,
+static void block_bwd_f32(const Mm &st, const PnrMlpWeights *w, const PnrMlpWeights *g, int b, float *G, float *T, const float *xin,
                           const float *net, long long rows, float *part) {
     wgrad(st, G, D_HID, net, D_HID, true, rows, D_HID, D_HID, (float *)g->fc1_w[b], (float *)g->fc1_b[b], part);
     linear_bwd(st, G, D_HID, w->fc1_w[b], D_HID, D_HID, T, D_HID, rows, net, false);
@@ -381,12 +661,13 @@ static void block_bwd_f32(hipStream_t st, const PnrMlpWeights *w, const PnrMlpWe
 }  // namespace pnr
 
 extern "C" int pnr_eval_ray_samples_f32_train(const PnrScene *scene, const PnrMlpWeights *w, const float *rays, const float *z, int R,
-                                              int rays_per_obj, int K, float *rgbsigma, const PnrF32Saved *saved, void *stream) {
+                                              int rays_per_obj, int K, float *rgbsigma, const PnrF32Saved *saved, int split_gemm,
+                                              void *stream) {
     if (R <= 0 || K <= 0 || rays_per_obj <= 0 || !rays || !z) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: bad argument");
     if (scene && (long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: R != SB * rays_per_obj");
     pnr::EvalParams q = {};
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
-    return pnr::eval_f32_train(scene, w, q, saved, (hipStream_t)stream);
+    return pnr::eval_f32_train(scene, w, q, saved, (hipStream_t)stream, split_gemm != 0);
 }
 
 extern "C" size_t pnr_mlp_backward_f32_workspace_bytes(long long P, int NS) {
@@ -397,15 +678,17 @@ extern "C" size_t pnr_mlp_backward_f32_workspace_bytes(long long P, int NS) {
 }
 
 extern "C" int pnr_mlp_backward_f32(const PnrMlpWeights *w, const PnrF32Saved *sv, const float *g_out, long long P, int NS,
-                                    const PnrMlpWeights *grads, float *d_zlat, float *d_in, void *workspace, size_t workspace_bytes,
-                                    void *stream) {
+                                    const PnrMlpWeights *grads, float *d_zlat, float *d_in, int split_gemm, const float *grad_scale,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
     using namespace pnr;
     if (!w || !g_out || !grads || !d_zlat || !workspace || P <= 0 || NS <= 0)
         return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: bad argument");
+    if (split_gemm && !grad_scale)
+        return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: the split-operand form needs grad_scale = device [s, 1/s] (pnr_grad_scale)");
     if (!check_saved(sv, NS)) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: null activation buffer in PnrF32Saved");
     if (workspace_bytes < pnr_mlp_backward_f32_workspace_bytes(P, NS)) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: workspace too small");
     if (P * NS > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: too many points");
-    hipStream_t st = (hipStream_t)stream;
+    const Mm st = {(hipStream_t)stream, split_gemm != 0, split_gemm ? grad_scale : nullptr, split_gemm ? grad_scale + 1 : nullptr};
     const long long rows = P * NS;
     float *Gv = (float *)workspace;
     float *T = Gv + (size_t)rows * D_HID;
@@ -413,22 +696,24 @@ extern "C" int pnr_mlp_backward_f32(const PnrMlpWeights *w, const PnrF32Saved *s
     float *part = Gp + (size_t)P * D_HID;
     float *G = NS > 1 ? Gp : Gv;  // pooled part of the chain
     // lin_out (resnetfc.py:183): out = W_out relu(x5) + b
-    wgrad(st, g_out, D_OUT, sv->x5, D_HID, true, P, D_OUT, D_HID, (float *)grads->lin_out_w, (float *)grads->lin_out_b, part);
-    linear_bwd(st, g_out, D_OUT, w->lin_out_w, D_HID, D_OUT, G, D_HID, P, sv->x5, false);
+    // split-operand form: g_out enters at the power-of-two scale s (fp16 range); every gradient of the chain stays in that
+    // domain and the results that leave it -- dW, db, d z_lat, d(code) -- are multiplied by 1/s on their way out (exact)
+    wgrad(st, g_out, D_OUT, sv->x5, D_HID, true, P, D_OUT, D_HID, (float *)grads->lin_out_w, (float *)grads->lin_out_b, part, true);
+    linear_bwd(st, g_out, D_OUT, w->lin_out_w, D_HID, D_OUT, G, D_HID, P, sv->x5, false, true);
     for (int b = N_BLOCKS - 1; b >= COMBINE_LAYER; --b) block_bwd_f32(st, w, grads, b, G, T, sv->xin[b], sv->net[b], P, part);
     if (NS > 1) {  // backward of the view mean: every view receives G / NS
         const long long n = P * D_HID;
-        hipLaunchKernelGGL(unpool_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Gp, Gv, P, NS, 1.f / (float)NS);
+        hipLaunchKernelGGL(unpool_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.st, Gp, Gv, P, NS, 1.f / (float)NS);
     }
     for (int b = COMBINE_LAYER - 1; b >= 0; --b) {
         block_bwd_f32(st, w, grads, b, Gv, T, sv->xin[b], sv->net[b], rows, part);
         // xin[b] = (stream in front) + lin_z[b](zlat)   (resnetfc.py:175-180)
         wgrad(st, Gv, D_HID, sv->zlat, C_LAT, false, rows, D_HID, C_LAT, (float *)grads->lin_z_w[b], (float *)grads->lin_z_b[b], part);
-        linear_bwd(st, Gv, D_HID, w->lin_z_w[b], C_LAT, D_HID, d_zlat, C_LAT, rows, nullptr, b != COMBINE_LAYER - 1);
+        linear_bwd(st, Gv, D_HID, w->lin_z_w[b], C_LAT, D_HID, d_zlat, C_LAT, rows, nullptr, b != COMBINE_LAYER - 1, false, true);
     }
     // lin_in (resnetfc.py:147)
     wgrad(st, Gv, D_HID, sv->in42, D_IN_PAD, false, rows, D_HID, D_IN, (float *)grads->lin_in_w, (float *)grads->lin_in_b, part);
-    if (d_in) linear_bwd(st, Gv, D_HID, w->lin_in_w, D_IN, D_HID, d_in, D_IN, rows, nullptr, false);
+    if (d_in) linear_bwd(st, Gv, D_HID, w->lin_in_w, D_IN, D_HID, d_in, D_IN, rows, nullptr, false, false, true);
     return pnr_check_launch("pnr_mlp_backward_f32");
 }
 

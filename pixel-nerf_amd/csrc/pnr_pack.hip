@@ -187,24 +187,40 @@ namespace pnr {
 // 64-bit content fingerprint of a ResnetFC's 30 parameter tensors: sum over all elements of bits(v) * (2 * position + 1)
 // (mod 2^64; position = running index over the tensors in PnrMlpWeights order).  ws[0] = running sum, ws[1] = blocks done.
 // The last block publishes the sum (out), compares it with *expect when given (mismatch -> *flag = 1) and re-zeroes ws.
-constexpr int CK_BLOCKS = 128;
+constexpr int CK_BLOCKS = 1024;
 __global__ void __launch_bounds__(256)
 params_checksum_kernel(PnrMlpWeights p, unsigned long long *ws, unsigned long long *out, const unsigned long long *expect, int *flag) {
-    const float *ptr[30];
-    int n[30];
-    int k = 0;
-    auto add = [&](const float *q, int cnt) { ptr[k] = q; n[k] = cnt; ++k; };
-    add(p.lin_in_w, D_HID * D_IN); add(p.lin_in_b, D_HID);
-    for (int b = 0; b < 3; ++b) { add(p.lin_z_w[b], D_HID * C_LAT); add(p.lin_z_b[b], D_HID); }
-    for (int b = 0; b < 5; ++b) { add(p.fc0_w[b], D_HID * D_HID); add(p.fc0_b[b], D_HID); }
-    for (int b = 0; b < 5; ++b) { add(p.fc1_w[b], D_HID * D_HID); add(p.fc1_b[b], D_HID); }
-    add(p.lin_out_w, D_OUT * D_HID); add(p.lin_out_b, D_OUT);
+    // 16-byte loads (every tensor's element count is a multiple of 4 and torch allocations are 16-byte aligned), several
+    // in flight per thread: 13.75 MB in a few microseconds instead of a latency-bound scalar walk
+    auto fold = [&](const float *q, int cnt, unsigned long long base, unsigned long long acc) {
+        const uint4 *v = reinterpret_cast<const uint4 *>(q);
+        const int n4 = cnt >> 2;
+#pragma unroll 4
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += CK_BLOCKS * 256) {
+            const uint4 x = v[i];
+            const unsigned long long pos = 2ull * (base + 4ull * (unsigned long long)i) + 1ull;
+            acc += (unsigned long long)x.x * pos + (unsigned long long)x.y * (pos + 2ull) + (unsigned long long)x.z * (pos + 4ull) +
+                   (unsigned long long)x.w * (pos + 6ull);
+        }
+        return acc;
+    };
     unsigned long long acc = 0ull, base = 0ull;
-    for (int t = 0; t < 30; ++t) {
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < n[t]; i += CK_BLOCKS * 256)
-            acc += (unsigned long long)__float_as_uint(ptr[t][i]) * (2ull * (base + (unsigned long long)i) + 1ull);
-        base += (unsigned long long)n[t];
+    acc = fold(p.lin_in_w, D_HID * D_IN, base, acc); base += D_HID * D_IN;
+    acc = fold(p.lin_in_b, D_HID, base, acc); base += D_HID;
+    for (int b = 0; b < 3; ++b) {
+        acc = fold(p.lin_z_w[b], D_HID * C_LAT, base, acc); base += D_HID * C_LAT;
+        acc = fold(p.lin_z_b[b], D_HID, base, acc); base += D_HID;
     }
+    for (int b = 0; b < 5; ++b) {
+        acc = fold(p.fc0_w[b], D_HID * D_HID, base, acc); base += D_HID * D_HID;
+        acc = fold(p.fc0_b[b], D_HID, base, acc); base += D_HID;
+    }
+    for (int b = 0; b < 5; ++b) {
+        acc = fold(p.fc1_w[b], D_HID * D_HID, base, acc); base += D_HID * D_HID;
+        acc = fold(p.fc1_b[b], D_HID, base, acc); base += D_HID;
+    }
+    acc = fold(p.lin_out_w, D_OUT * D_HID, base, acc); base += D_OUT * D_HID;
+    acc = fold(p.lin_out_b, D_OUT, base, acc);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     __shared__ unsigned long long part[4];

@@ -162,7 +162,8 @@ class PixelNeRFNet(torch.nn.Module):
             return None
         mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
         sc = self.scene()
-        mlp.packed(self._effective_precision(), folded=True)  # runs the cache's content check first: a detected silent write bumps the fingerprint
+        # (callers fetch packed() BEFORE tables(): packed() runs the cache's content check, and a silent parameter write it
+        # detects bumps the fingerprint this key is made of)
         key = (id(sc), mlp._fingerprint(), self._effective_precision())
         slot = "coarse" if mlp is self.mlp_coarse else "fine"
         hit = self._tables.get(slot)
@@ -191,9 +192,9 @@ class PixelNeRFNet(torch.nn.Module):
         if SB != sc.SB:
             raise ValueError(f"xyz has {SB} objects but encode() saw {sc.SB}")
         if self._wants_grad():  # differentiable twin: training kernels + HIP backward (parameters and latent grid)
-            if self._effective_precision() not in ("f16", "bf16", "f32"):
-                raise NotImplementedError("training runs on the 16-bit MFMA paths (precision 'f16' / 'bf16') or on the exact-fp32 "
-                                          "validation path ('f32'); 'f16x3' is an inference form")
+            if self._effective_precision() not in ("f16", "bf16", "f32", "f16x3"):
+                raise NotImplementedError("training precisions: 'f16' / 'bf16' (fused 16-bit kernels), 'f16x3' (fp32-class split-operand "
+                                          "GEMMs) or 'f32' (exact fp32 validation path)")
             from .. import autograd
             return autograd.points_autograd(self, xyz, viewdirs.reshape(SB, B, 3), coarse)
         return ops.eval_points(sc, self.packed(coarse), xyz.float(), viewdirs.reshape(SB, B, 3).float(),

@@ -851,8 +851,10 @@ class F32Saved:
         pass
 
 
-def eval_ray_samples_f32_train(scene, weights, rays, z):
-    """exact-fp32 twin of eval_ray_samples_train: weights = PackedMLP of precision 'f32' (raw nn.Linear tensors)."""
+def eval_ray_samples_f32_train(scene, weights, rays, z, split=False):
+    """fp32-precision twin of eval_ray_samples_train: weights = PackedMLP of precision 'f32' (raw nn.Linear tensors).
+    split=False: exact fp32 MFMA products (validation grade); True: (head, tail) fp16 operand pairs, 3 f16 MFMAs per product
+    (fp32-class, ~6x faster -- precision 'f16x3' under autograd)."""
     lib = _lib.load()
     rays = _f32(rays, "rays", (None, 8))
     R = rays.shape[0]
@@ -862,12 +864,14 @@ def eval_ray_samples_f32_train(scene, weights, rays, z):
     out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
     with torch.cuda.device(rays.device):
         _lib.check(lib.pnr_eval_ray_samples_f32_train(scene.ref, weights.wref, _p(rays), _p(z), R, max(R // scene.SB, 1), K, _p(out),
-                                                      ctypes.byref(saved.struct), _stream()), "pnr_eval_ray_samples_f32_train")
+                                                      ctypes.byref(saved.struct), int(bool(split)), _stream()), "pnr_eval_ray_samples_f32_train")
+    saved.split = bool(split)
     return out, saved
 
 
 def mlp_backward_f32(weights, saved, g_out, want_d_in=False):
-    """-> ({reference state_dict key: fp32 gradient}, d_zlat (rows_v,512), d_in (rows_v,42) | None) of one ResnetFC, exact fp32."""
+    """-> ({reference state_dict key: fp32 gradient}, d_zlat (rows_v,512), d_in (rows_v,42) | None) of one ResnetFC: exact fp32
+    MFMA products, or the split-operand (fp32-class) form when the forward ran with split=True."""
     lib = _lib.load()
     P, NS = saved.P, saved.NS
     g_out = _f32(g_out, "g_out", (P, 4))
@@ -879,9 +883,11 @@ def mlp_backward_f32(weights, saved, g_out, want_d_in=False):
     d_in = torch.empty((NS * P, 42), dtype=torch.float32, device=dev) if want_d_in else None
     nbytes = lib.pnr_mlp_backward_f32_workspace_bytes(P, NS)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    split = bool(getattr(saved, "split", False))
+    sc = grad_scale(g_out) if split else None  # device [s, 1/s]: no host synchronisation
     with torch.cuda.device(dev):
         _lib.check(lib.pnr_mlp_backward_f32(weights.wref, ctypes.byref(saved.struct), _p(g_out), P, NS, ctypes.byref(gstruct),
-                                            _p(d_zlat), _p(d_in), _p(ws), nbytes, _stream()), "pnr_mlp_backward_f32")
+                                            _p(d_zlat), _p(d_in), int(split), _p(sc), _p(ws), nbytes, _stream()), "pnr_mlp_backward_f32")
     return grads, d_zlat, d_in
 
 

@@ -191,8 +191,9 @@ class NeRFRenderer(torch.nn.Module):
                 # mlp_fine is None (eval/eval.py:140): pass no fine network, so the fine pass re-uses the coarse pass's
                 # outputs at the shared sample positions instead of evaluating them again
                 own_fine = Kf > 0 and getattr(model, "mlp_fine", None) is not None
+                pk_c, pk_f = model.packed(True), (model.packed(False) if own_fine else None)  # before tables(): see PixelNeRFNet.tables
                 tc = model.tables(True)
-                res = ops.render_forward(model.scene(), model.packed(True), model.packed(False) if own_fine else None,
+                res = ops.render_forward(model.scene(), pk_c, pk_f,
                                          rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
                                          white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights,
                                          tables=None if tc is None else (tc, model.tables(False) if own_fine else None),

@@ -1,6 +1,7 @@
 """
-GPU tests (-m gpu) of the EXACT-fp32 training path (precision "f32" under autograd; pnr_eval_ray_samples_f32_train +
-pnr_mlp_backward_f32, pixel-nerf_amd/csrc/pnr_f32.hip): every one of the 61 gradient tensors -- both ResnetFCs and
+GPU tests (-m gpu) of the fp32-precision training paths (pnr_eval_ray_samples_f32_train + pnr_mlp_backward_f32,
+pixel-nerf_amd/csrc/pnr_f32.hip) -- precision "f32" (every product on the exact fp32 MFMA: the yardstick) and "f16x3" (the same
+chain with split-operand GEMMs on the f16 matrix cores: fp32-class, ~6x faster): every one of the 61 gradient tensors -- both ResnetFCs and
 encoder.latent, including the position gradient through the depth samples (nerf.py:292) -- against the gradients of the
 UNMODIFIED reference's own backward (tests/golden/gradients.npz, frozen by oracle/make_goldens.py: train/train.py:199-215
 loss, torch autograd through src/render/nerf.py:251-303) at <= 1e-3 relative on the frozen subsample and on the norm.
@@ -59,9 +60,10 @@ def train_grads(dev, name, precision):
     return float(loss.item()), {k: v.detach().reshape(-1).cpu().numpy() for k, v in grads.items()}, gg
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])  # exact fp32 MFMA products / split-operand (fp32-class) GEMMs
 @pytest.mark.parametrize("name", ["train_64_32", "srn_mini_64_128", "train_cfg5"])
-def test_fp32_gradients_match_reference_autograd(dev, name):
-    loss, grads, gg = train_grads(dev, name, "f32")
+def test_fp32_gradients_match_reference_autograd(dev, name, precision):
+    loss, grads, gg = train_grads(dev, name, precision)
     ref_loss = float(gg[f"{name}_loss"])
     assert abs(loss - ref_loss) <= 2e-6 * max(1.0, ref_loss), (loss, ref_loss)
     worst = ("", 0.0)
@@ -73,7 +75,7 @@ def test_fp32_gradients_match_reference_autograd(dev, name):
         e_s = np.linalg.norm(got_s.astype(np.float64) - ref_s) / np.linalg.norm(ref_s.astype(np.float64))
         worst = max(worst, (key, max(e_n, e_s)), key=lambda t: t[1])
         assert e_n <= REL_TOL and e_s <= REL_TOL, f"{name} {key}: norm {e_n:.3e} sample {e_s:.3e}"
-    print(f"{name}: worst relative gradient error vs the reference's autograd {worst[1]:.2e} ({worst[0]})")
+    print(f"{name} {precision}: worst relative gradient error vs the reference's autograd {worst[1]:.2e} ({worst[0]})")
 
 
 def test_f16_gradient_error_is_operand_rounding(dev):
