@@ -21,6 +21,7 @@
 
 #include "pnr_common.h"
 #include "pnr_device.h"
+#include "pnr_internal.h"
 #include "pnr_layout.h"
 
 namespace pnr {
@@ -89,6 +90,7 @@ struct BwdParams {
     char *g_fc1[5], *g_fc0[5], *g_x0;
     float *d_zlat;  // (NS*P, 512) fp32, natural channel order: d(interpolated latent)   (nullable: skip)
     float *d_in;    // (NS*P, 42)  fp32: d(positional code | view direction)             (nullable: skip)
+    float *mv_ws;   // multi-view: per-workgroup scratch for the pooled gradient every view starts from ([slot][thread])
 };
 
 // relu masks: one 64-bit word per thread and layer from the forward kernel (bit (it*JT + jt)*16 + r = register r of the
@@ -230,14 +232,21 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
 #pragma unroll 1
         for (int b = N_BLOCKS - 1; b >= COMBINE_LAYER; --b)
             bwd_block<P>(G, smem, b, R, NS, q, off_pooled, valid, a_rd0, a_rd1, a_wr, mask_pooled, mask_layer, rows_left, wv, lane);
-        f32x16 Gp[MV ? IT : 1][MV ? JT : 1];
+        // backward of the view mean (util.py:461-466): every view starts from G / NS.  That gradient is PARKED in a
+        // per-workgroup scratch ([slot][thread]: every lane re-reads what it wrote, L2-resident) instead of 64 registers held
+        // across the whole per-view loop -- the in-register form spilled 106 registers.
+        [[maybe_unused]] f32x4 *gws = MV ? reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid : nullptr;
         if constexpr (MV) {
-            // backward of the view mean (util.py:461-466): every view receives G / NS
             const float inv = 1.f / (float)NS;
 #pragma unroll
             for (int it = 0; it < IT; ++it)
 #pragma unroll
-                for (int jt = 0; jt < JT; ++jt) Gp[it][jt] = G[it][jt] * inv;
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 v = {G[it][jt][4 * k], G[it][jt][4 * k + 1], G[it][jt][4 * k + 2], G[it][jt][4 * k + 3]};
+                        gws[((it * JT + jt) * 4 + k) * NTHREADS] = v * inv;
+                    }
         }
 #pragma unroll 1
         for (int view = 0; view < NS; ++view) {
@@ -246,7 +255,12 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt) G[it][jt] = Gp[it][jt];
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f32x4 v = gws[((it * JT + jt) * 4 + k) * NTHREADS];
+                            G[it][jt][4 * k] = v[0]; G[it][jt][4 * k + 1] = v[1]; G[it][jt][4 * k + 2] = v[2]; G[it][jt][4 * k + 3] = v[3];
+                        }
             }
 #pragma unroll 1
             for (int b = COMBINE_LAYER - 1; b >= 0; --b)
@@ -1083,6 +1097,10 @@ extern "C" int pnr_mlp_backward(const void *packed_bwd, int precision, const Pnr
     }
     const bool mv = NS > 1;
     const int grid = q.ntiles < bwd_num_cus() ? q.ntiles : bwd_num_cus();
+    if (mv) {
+        q.mv_ws = mv_scratch((hipStream_t)stream, (size_t)bwd_num_cus() * 96 * D_HID * sizeof(float));
+        if (!q.mv_ws) return pnr_fail(PNR_E_HIP, "pnr_mlp_backward: cannot allocate the multi-view scratch (48 MiB)");
+    }
     void (*k)(const BwdParams);
     if (precision == PNR_PREC_F16) k = mv ? bwd_kernel<PNR_PREC_F16, true> : bwd_kernel<PNR_PREC_F16, false>;
     else if (precision == PNR_PREC_BF16) k = mv ? bwd_kernel<PNR_PREC_BF16, true> : bwd_kernel<PNR_PREC_BF16, false>;

@@ -236,6 +236,7 @@ struct Gemm3 {
     const float *out_scale;            // device scalar multiplied into the product (nullable)
     float *part, *bpart;               // split-K: partial products part[z][M][N] (raw) and column sums of A bpart[z][M] (nullable)
     long long k_per_split;
+    int tiles_m, tiles_n, nz;          // 128 x 128 tiles of C and K slices; the 1-D grid is decoded XCD-aware (see the kernel)
 };
 
 constexpr int G3_ROW = 80;                 // bytes per [row][32 k] f16 row (64 + 16 pad)
@@ -265,9 +266,23 @@ __global__ void __launch_bounds__(256, 3) gemm3_kernel(const Gemm3 g) {
     typedef PH::T8 h8;
     f16_ovfl_mode<PH>();
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const long long m0 = (long long)blockIdx.x * 128;
-    const int n0 = blockIdx.y * 128;
-    const long long k_begin = (long long)blockIdx.z * g.k_per_split;
+    // XCD-aware placement (workgroups are dealt to the 8 XCDs round-robin by linear id; each XCD has its own L2).  The blocks
+    // that read the SAME operand rows -- the column tiles of one row tile (A rows re-read per column tile), and all 16 tiles of
+    // one K slice of a weight gradient (both operands) -- get consecutive slots of ONE XCD, so an fp32 operand row (2 KiB)
+    // crosses the fabric once instead of once per tile: these GEMMs are HBM-bound (100 MB per activation tensor).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int tm, tn, bz;
+    if (g.nz == 1) {
+        tn = slot % g.tiles_n; tm = (slot / g.tiles_n) * 8 + xcd; bz = 0;
+        if (tm >= g.tiles_m) return;
+    } else {
+        const int T = g.tiles_m * g.tiles_n, tile = slot % T;
+        bz = (slot / T) * 8 + xcd; tm = tile / g.tiles_n; tn = tile % g.tiles_n;
+        if (bz >= g.nz) return;
+    }
+    const long long m0 = (long long)tm * 128;
+    const int n0 = tn * 128;
+    const long long k_begin = (long long)bz * g.k_per_split;
     const long long k_end = k_begin + g.k_per_split < g.K ? k_begin + g.k_per_split : g.K;
     const float asc = g.a_scale ? *g.a_scale : 1.f;
     const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
@@ -415,7 +430,7 @@ __global__ void __launch_bounds__(256, 3) gemm3_kernel(const Gemm3 g) {
                 const long long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (m >= g.M) continue;
                 if (g.part) {
-                    g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+                    g.part[((size_t)bz * g.M + m) * g.N + n] = acc[i][j][r];
                 } else {
                     float v = acc[i][j][r] * osc + bias;
                     const size_t o = (size_t)m * g.ldc + n;
@@ -425,7 +440,7 @@ __global__ void __launch_bounds__(256, 3) gemm3_kernel(const Gemm3 g) {
                 }
             }
         }
-    if (!A_KC && g.bpart && blockIdx.y == 0) {
+    if (!A_KC && g.bpart && tn == 0) {
         // column sums of this block's A rows over its k range: 8 threads (kq) per row quad, reduced through LDS
         __syncthreads();
         float *red = reinterpret_cast<float *>(lds);
@@ -436,7 +451,7 @@ __global__ void __launch_bounds__(256, 3) gemm3_kernel(const Gemm3 g) {
             float sum = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum += red[t * 8 + e];
-            g.bpart[(size_t)blockIdx.z * g.M + m0 + t] = sum * asc;  // same (scaled) domain as the partial products
+            g.bpart[(size_t)bz * g.M + m0 + t] = sum * asc;  // same (scaled) domain as the partial products
         }
     }
 }
@@ -486,8 +501,10 @@ struct Mm {
 };
 
 template <bool AK, bool BK> static void launch_g3(const Mm &c, Gemm3 g, int nz) {
-    dim3 grid((unsigned)((g.M + 127) / 128), (g.N + 127) / 128, nz);
-    hipLaunchKernelGGL((gemm3_kernel<AK, BK>), grid, dim3(256), 0, c.st, g);
+    g.tiles_m = (int)((g.M + 127) / 128); g.tiles_n = (g.N + 127) / 128; g.nz = nz;
+    const long long groups = nz == 1 ? (g.tiles_m + 7) / 8 : (nz + 7) / 8;  // per XCD: row tiles (x column tiles) or K slices (x all tiles)
+    const long long per = nz == 1 ? g.tiles_n : (long long)g.tiles_m * g.tiles_n;
+    hipLaunchKernelGGL((gemm3_kernel<AK, BK>), dim3((unsigned)(groups * per * 8)), dim3(256), 0, c.st, g);
 }
 
 static void linear(const Mm &c, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, long long M,

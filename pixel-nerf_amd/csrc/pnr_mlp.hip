@@ -316,12 +316,15 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
         bool valid[JT];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) valid[jt] = (long long)tile * MT + jt * 32 + pl < q.P;
+        // training + multi-view: the running view sum is parked (simple read-modify-write at the view boundary, as in
+        // pnr_split.hip) -- with the dump bookkeeping live as well, the in-register form spilled 76 registers
+        [[maybe_unused]] constexpr bool PARK_SUM = MV && TRAIN;
 #ifndef PNR_MV_PARK
         // multi-view: running view sum in 64 live registers.  The instantiation then sits at the 256-register limit and spills
         // 20-40 registers to scratch OUTSIDE the GEMM loops; the spill-free alternatives (-DPNR_MV_PARK: sum parked in an
         // L2-resident scratch, simple or prefetched under the last fc_1) measured 2.7-4 % and 4-8 % SLOWER on the same box
         // (profiles/r02_mv_pooling_ab.txt), so the registers stay.
-        f32x16 xsum[MV ? IT : 1][MV ? JT : 1];
+        [[maybe_unused]] f32x16 xsum[(MV && !PARK_SUM) ? IT : 1][(MV && !PARK_SUM) ? JT : 1];
 #endif
         const size_t dump_pooled = (((size_t)tile * MT + pl) * D_HID + (wv * IT) * 32 + h * 16) * 2;
         // relu bit masks (training): [layer][view][tile][thread] words; pooled layers use view slot 0
@@ -364,7 +367,26 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             for (int b = 0; b < COMBINE_LAYER; ++b)
                 res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
                                                   a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer, rows_left);
-            if constexpr (MV) {  // mean over source views (util.combine_interleaved, util.py:461-466)
+            if constexpr (MV && PARK_SUM) {  // mean over source views, the sum parked in the per-workgroup scratch ([slot][thread])
+                f32x4 *ws = reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid;
+                const float inv = 1.f / (float)NS;
+                const bool first = view == 0, last = view + 1 == NS;
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int i = (it * JT + jt) * 4 + k;
+                            f32x4 v = {x[it][jt][4 * k], x[it][jt][4 * k + 1], x[it][jt][4 * k + 2], x[it][jt][4 * k + 3]};
+                            if (!first) v = ws[i * NTHREADS] + v;  // same association as the in-register form: (v0 + v1) + ...
+                            if (!last) ws[i * NTHREADS] = v;
+                            else v *= inv;
+                            x[it][jt][4 * k] = v[0]; x[it][jt][4 * k + 1] = v[1]; x[it][jt][4 * k + 2] = v[2]; x[it][jt][4 * k + 3] = v[3];
+                        }
+                    }
+            } else if constexpr (MV) {  // mean over source views (util.combine_interleaved, util.py:461-466)
                 const float inv = 1.f / (float)NS;
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
@@ -555,12 +577,15 @@ static int launch(EvalParams &q, bool mv, hipStream_t st) {
     const long long nt = (q.P + mt - 1) / mt;
     q.ntiles = (int)nt;
     const int grid = (int)(nt < num_cus() ? nt : num_cus());
-#ifdef PNR_MV_PARK
-    if (mv) {
+#ifndef PNR_MV_PARK
+    if (mv && RAYS && q.d_z)  // the training instantiation parks its view sum
+#else
+    if (mv)
+#endif
+    {
         q.mv_ws = mv_scratch(st, (size_t)num_cus() * 96 * D_HID * sizeof(float));
         if (!q.mv_ws) return pnr_fail(PNR_E_HIP, "pnr_eval: cannot allocate the multi-view pooling scratch (48 MiB)");
     }
-#endif
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_kernel)");
     {
