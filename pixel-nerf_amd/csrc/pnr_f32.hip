@@ -259,9 +259,16 @@ __device__ __forceinline__ void g3_split4(f32x4 v, bool relu, float sc, uint2 &h
     lo = make_uint2(l[0], l[1]);
 }
 
-template <bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(256, 3) gemm3_kernel(const Gemm3 g) {
-    __shared__ __attribute__((aligned(16))) char lds[4 * G3_IMG];  // A head, A tail, B head, B tail
+// STAGES = 2 (weight gradients: long reductions, 1536 rows per slice): two LDS stages, one barrier per chunk, two workgroups
+// per CU.  STAGES = 1 (forward / data gradients: K = 512, sixteen chunks, epilogue-heavy): one stage + one chunk of register
+// lookahead, 40 KiB and <= 170 registers so that THREE workgroups per CU cover each other (measured: 122 / 179 us per
+// 49152-row GEMM against 141 / 211 us in the two-stage form; the weight gradient 102 against 214 us).
+template <bool A_KC, bool B_KC, int STAGES>
+__global__ void __launch_bounds__(256, STAGES == 2 ? 2 : 3) gemm3_kernel(const Gemm3 g) {
+    // two LDS stages of (A head, A tail, B head, B tail): chunk k+1 is split into the other stage while chunk k is multiplied,
+    // and the global loads of chunk k+2 are issued before that -- every load has a whole iteration to arrive (the round-3
+    // first version, one stage + one chunk of lookahead, spent 50-75 % of its wave cycles parked on s_waitcnt / barriers)
+    __shared__ __attribute__((aligned(16))) char lds_all[STAGES * 4 * G3_IMG];
     typedef Prec<PNR_PREC_F16> PH;
     typedef PH::T8 h8;
     f16_ovfl_mode<PH>();
@@ -349,7 +356,7 @@ __global__ void __launch_bounds__(256, 3) gemm3_kernel(const Gemm3 g) {
             }
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](char *lds) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             uint2 hi, lo;
@@ -380,41 +387,93 @@ __global__ void __launch_bounds__(256, 3) gemm3_kernel(const Gemm3 g) {
             }
         }
     };
-    if (k_begin < k_end) load(k_begin);
-    for (long long kc = k_begin; kc < k_end; kc += 32) {
-        __syncthreads();  // the previous chunk's fragment reads are done
-        stage();
-        __syncthreads();
-        if (kc + 32 < k_end) load(kc + 32);  // in flight under this chunk's MFMAs
+    if constexpr (STAGES == 1) {
+        if (k_begin < k_end) load(k_begin);
+        for (long long kc = k_begin; kc < k_end; kc += 32) {
+            __syncthreads();  // the previous chunk's fragment reads are done
+            stage(lds_all);
+            __syncthreads();
+            if (kc + 32 < k_end) load(kc + 32);  // in flight under this chunk's MFMAs
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int off = (wm + i * 32 + fi) * G3_ROW + ks * 32 + fh * 16;
+                    ah[i] = *reinterpret_cast<const h8 *>(lds_all + off);
+                    al[i] = *reinterpret_cast<const h8 *>(lds_all + G3_IMG + off);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int off = (wn + j * 32 + fi) * G3_ROW + ks * 32 + fh * 16;
+                    bh[j] = *reinterpret_cast<const h8 *>(lds_all + 2 * G3_IMG + off);
+                    bl[j] = *reinterpret_cast<const h8 *>(lds_all + 3 * G3_IMG + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    } else {
+    // prologue: chunk 0 staged, chunk 1 in flight
+    if (k_begin < k_end) {
+        load(k_begin);
+        stage(lds_all);
+        if (k_begin + 32 < k_end) load(k_begin + 32);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (long long kc = k_begin; kc < k_end; kc += 32, buf ^= 1) {
+        const char *lds = lds_all + buf * (4 * G3_IMG);
+        // fragments of this chunk first (LDS), then the split of chunk k+1 into the other stage (its loads were issued one
+        // iteration ago), then the loads of chunk k+2 -- all before / under this chunk's 24 MFMAs
+        h8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            h8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int off = (wm + i * 32 + fi) * G3_ROW + ks * 32 + fh * 16;
-                ah[i] = *reinterpret_cast<const h8 *>(lds + off);
-                al[i] = *reinterpret_cast<const h8 *>(lds + G3_IMG + off);
+                ah[ks][i] = *reinterpret_cast<const h8 *>(lds + off);
+                al[ks][i] = *reinterpret_cast<const h8 *>(lds + G3_IMG + off);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int off = (wn + j * 32 + fi) * G3_ROW + ks * 32 + fh * 16;
-                bh[j] = *reinterpret_cast<const h8 *>(lds + 2 * G3_IMG + off);
-                bl[j] = *reinterpret_cast<const h8 *>(lds + 3 * G3_IMG + off);
+                bh[ks][j] = *reinterpret_cast<const h8 *>(lds + 2 * G3_IMG + off);
+                bl[ks][j] = *reinterpret_cast<const h8 *>(lds + 3 * G3_IMG + off);
             }
+        }
+        if (kc + 32 < k_end) {
+            stage(lds_all + (buf ^ 1) * (4 * G3_IMG));
+            if (kc + 64 < k_end) load(kc + 64);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
             // D[i][j] += sum_k A-frag(row i, k) B-frag(col j, k): the MFMA's D holds column j = lane&31 of the B rows
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();  // stage k+1 is complete for every wave; stage k may be overwritten next iteration
+    }
     }
     // epilogue.  D register r of tile (i, j): row m = wm + 32 i + (r&3) + 8 (r>>2) + 4 fh, column n = wn + 32 j + fi
     const float osc = g.out_scale ? *g.out_scale : 1.f;
@@ -443,7 +502,7 @@ __global__ void __launch_bounds__(256, 3) gemm3_kernel(const Gemm3 g) {
     if (!A_KC && g.bpart && tn == 0) {
         // column sums of this block's A rows over its k range: 8 threads (kq) per row quad, reduced through LDS
         __syncthreads();
-        float *red = reinterpret_cast<float *>(lds);
+        float *red = reinterpret_cast<float *>(lds_all);
 #pragma unroll
         for (int u = 0; u < 4; ++u) red[(4 * rq + u) * 8 + kq] = colsum[u];
         __syncthreads();
@@ -504,7 +563,7 @@ template <bool AK, bool BK> static void launch_g3(const Mm &c, Gemm3 g, int nz) 
     g.tiles_m = (int)((g.M + 127) / 128); g.tiles_n = (g.N + 127) / 128; g.nz = nz;
     const long long groups = nz == 1 ? (g.tiles_m + 7) / 8 : (nz + 7) / 8;  // per XCD: row tiles (x column tiles) or K slices (x all tiles)
     const long long per = nz == 1 ? g.tiles_n : (long long)g.tiles_m * g.tiles_n;
-    hipLaunchKernelGGL((gemm3_kernel<AK, BK>), dim3((unsigned)(groups * per * 8)), dim3(256), 0, c.st, g);
+    hipLaunchKernelGGL((gemm3_kernel<AK, BK, (AK ? 1 : 2)>), dim3((unsigned)(groups * per * 8)), dim3(256), 0, c.st, g);
 }
 
 static void linear(const Mm &c, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, long long M,
