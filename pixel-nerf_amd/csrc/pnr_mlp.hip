@@ -298,6 +298,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
     }
 
     f16_ovfl_mode<P>();
+#ifdef PNR_PRIO  // experiment (pnr_split.hip ships this form): static priority for the second-dispatched half of the workgroup
+    if (wv >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     Ring<P> R;
     R.wave_base = q.wstream + (size_t)wv * ((FOLD ? RS_TOTAL_F : RS_TOTAL) * IT * 1024) + lane * 16;
     R.pf_rs = 0;

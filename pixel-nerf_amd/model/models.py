@@ -24,13 +24,17 @@ from .model_util import make_encoder, make_mlp
 
 
 class PixelNeRFNet(torch.nn.Module):
-    def __init__(self, conf, stop_encoder_grad=False, precision="f16", fold=True):
+    def __init__(self, conf, stop_encoder_grad=False, precision="f16x3", fold=True):
         """:param conf PyHocon-like config subtree 'model' (util.Conf or a real ConfigTree)
-        :param precision operand type of the 512-wide linears on the matrix cores: 'f16'
-        (default; PSNR >= 52 dB vs the fp32 reference), 'bf16' (>= 36 dB), 'f16x3' -- fp32-class accuracy on the
-        f16 matrix cores (head/tail operand pairs, 3 MFMAs per product, ~1/3 of the f16 rate, per-point |rgb| <= 2e-5;
-        inference) -- or 'f32': the exact, unfused validation path (inference only, ~1/25 of the f16 rate, agrees
-        to ~1e-5).
+        :param precision arithmetic of the 512-wide linears:
+        'f16x3' (default) -- fp32-CLASS on the f16 matrix cores: every operand a (head, tail) fp16 pair, 3 MFMAs per product, fp32
+        accumulation (per-point |rgb| <= 2e-5 against the reference: the reference's own arithmetic class; the benchmark
+        headline).  Inference: the fused kernel; training: split-operand GEMMs (gradients <= 1e-3 vs the reference's autograd).
+        'f16' (opt-in, ~2.7x faster at inference, ~4.5x in training) -- fp16 MFMA operands, fp32 accumulation: PSNR >= 52 dB vs the fp32
+        reference; inference and training (gradients <= 3e-2 per tensor).
+        'f32' -- the exact, unfused fp32-MFMA validation path (inference and training, ~1/25 of the f16 rate).
+        'bf16' -- experiment flag only: 8-bit significands are not enough for surface-like densities (33 dB on the
+        adversarial fixtures); not a supported product precision.
         :param fold inference applies lin_z[b] to the encoded grid once per scene (per-texel tables) instead of
         once per sample -- the same function by linearity, 22-28 % fewer FLOPs per sample (ops.fold_latent)."""
         super().__init__()

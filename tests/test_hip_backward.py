@@ -83,7 +83,7 @@ def test_training_step_updates_and_is_deterministic(dev):
     from pixelnerf_amd.util.conf import default_model_conf
     from helpers import mlp_params
     g, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
-    net = make_model(default_model_conf()).to(dev).train()
+    net = make_model(default_model_conf(), precision="f16").to(dev).train()
     net.mlp_coarse.load_state_dict(mlp_params(11))
     net.mlp_fine.load_state_dict(mlp_params(12))
     lat = scene["latent"].to(dev).clone().requires_grad_(True)
@@ -138,7 +138,7 @@ def test_training_converges_on_a_fixed_batch(dev):
     from pixelnerf_amd.util.conf import default_model_conf
     from helpers import mlp_params
     g, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
-    net = make_model(default_model_conf()).to(dev).train()
+    net = make_model(default_model_conf(), precision="f16").to(dev).train()
     net.mlp_coarse.load_state_dict(mlp_params(11))
     net.mlp_fine.load_state_dict(mlp_params(12))
     lat = scene["latent"].to(dev).clone().requires_grad_(True)
@@ -435,7 +435,7 @@ def test_fused_optimizer_updates_reach_the_kernels(dev):
     r = rays.to(dev)
     traj = {}
     for fused in (False, True):
-        net = make_model(default_model_conf()).to(dev).train()
+        net = make_model(default_model_conf(), precision="f16").to(dev).train()
         net.mlp_coarse.load_state_dict(mlp_params(11))
         net.mlp_fine.load_state_dict(mlp_params(12))
         net.encoder.latent = scene["latent"].to(dev)
