@@ -143,6 +143,7 @@ PROTOTYPES = {
 }
 # test hook exported by the library but not part of the public header
 _EXTRA = {"pnr_debug_set_x_dump": (_I, [_P]),
+          "pnr_debug_set_split_tile": (_I, [_I]),
           "pnr_debug_phase_timing": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, _P]),
           "pnr_debug_phase_timing_split": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, _P, _P])}
 

@@ -7,6 +7,9 @@ from pixelnerf_amd import ops
 from testdata import synthetic
 
 dev = torch.device("cuda:0")
+MT = int(os.environ.get("PNR_SPLIT_TILE", "64"))
+from pixelnerf_amd import _lib
+_lib.load().pnr_debug_set_split_tile(MT)
 scene, meta = synthetic.make_scene("sn64")
 sc = ops.make_scene(scene["latent"].to(dev), scene["poses"].to(dev), scene["focal"].to(dev), scene["c"].to(dev), scene["image_shape"], 1)
 R, K = 16384, 192
@@ -28,7 +31,6 @@ print(f"f16x3 sn64 R={R} K={K}: {dt*1e3:.2f} ms  {R*K/dt/1e6:.2f} Mpts/s  {R*K*6
 if "--no-phases" not in sys.argv:
     for it in range(2):
         t = ops.debug_phase_timing_split(sc, pk, rays, z, tab)
-    MT = 64
     ntile = ((R * K + MT - 1) // MT + 255) // 256
     tot = [sum(v[w] for v in t.values()) for w in range(8)]
     print(f"tile {MT} pts; tiles by WG0: {ntile}; per-tile cycles per wave: " + " ".join(f"{x/ntile:8.0f}" for x in tot))
