@@ -162,20 +162,38 @@ __device__ __forceinline__ void bwd_block(f32x16 (&G)[IT][JT], char *smem, int b
     __syncthreads();  // every wave is done reading the gradient image (previous GEMM)
     write_act<P, false, false>(G, smem, a_wr);
     __syncthreads();
+#ifndef PNR_DUMP_IN_GEMM
     if (DUMP) dump_image<MT>(smem, LDS_A, q.g_fc1[b] + off_tile, rows_left, wv, lane);
+#endif
     f32x16 t[IT][JT];
     // mask_off / mask_layer: this thread's word within a layer of q.d_mask / words per layer (layer 2b: x, 2b+1: net)
     const unsigned long long mk_n = (q.d_mask + (size_t)(2 * b + 1) * mask_layer)[mask_off];
     zero_acc(t);
+#ifdef PNR_DUMP_IN_GEMM
+    {
+        const DumpJob dj = {smem + LDS_A, q.g_fc1[b] + off_tile, rows_left, wv, lane};
+        gemm<P, AdvanceBwd, DUMP>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS, &dj);
+    }
+#else
     gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
+#endif
     apply_mask(t, mk_n);
     __syncthreads();
     write_act<P, false, false>(t, smem, a_wr);
     __syncthreads();
+#ifndef PNR_DUMP_IN_GEMM
     if (DUMP) dump_image<MT>(smem, LDS_A, q.g_fc0[b] + off_tile, rows_left, wv, lane);
+#endif
     const unsigned long long mk_a = (q.d_mask + (size_t)(2 * b) * mask_layer)[mask_off];
     zero_acc(t);
+#ifdef PNR_DUMP_IN_GEMM
+    {
+        const DumpJob dj = {smem + LDS_A, q.g_fc0[b] + off_tile, rows_left, wv, lane};
+        gemm<P, AdvanceBwd, DUMP>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS, &dj);
+    }
+#else
     gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
+#endif
     masked_add(G, t, mk_a);
 }
 

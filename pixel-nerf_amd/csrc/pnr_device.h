@@ -169,11 +169,23 @@ template <int LOOP_LO, int LOOP_HI, int TOTAL> struct Advance {
 };
 typedef Advance<0, RS_VIEW_END, RS_TOTAL> AdvanceFwd;
 
+// Training dumps riding inside a GEMM (round 3): the copy of the just-published activation / gradient image to its (rows,512)
+// dump -- one 1 KiB row per wave and loop body, 8 bodies = the wave's 8 rows of a 64-point tile -- is issued from INSIDE the GEMM
+// loop, the LDS read of row b in body b and its global store in body b+1, so both sit in the shadow of that body's MFMAs
+// instead of in front of the GEMM (dump_image: 8 LDS reads + 8 stores per wave before the first MFMA of every dumped GEMM).
+struct DumpJob {
+    const char *src;      // LDS image base (row stride ROW_ACT)
+    char *dst;            // first row of this tile in the dump
+    long long rows_left;  // rows of the dump from there on
+    int wv, lane;
+};
+
 // acc[it][jt] += W-fragments (ring) x B-fragments (LDS rows baddr0/baddr1, 32 B per k-step),
 // nbody*4 k-steps.
-template <typename P, typename ADV = AdvanceFwd, int JT_>
+template <typename P, typename ADV = AdvanceFwd, bool DUMP = false, int JT_>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT_], const char *smem, uint32_t baddr0, uint32_t baddr1,
-                                     int nbody, Ring<P> &R, int NS) {
+                                     int nbody, Ring<P> &R, int NS, const DumpJob *dj = nullptr) {
+    [[maybe_unused]] u32x4 dump_v = {0, 0, 0, 0};
     // column tile jt reads rows baddr0 + jt * (baddr1 - baddr0): 32 point rows further down the image
     const uint32_t jstride = baddr1 - baddr0;
     typename P::T8 b[2][JT_];
@@ -181,6 +193,12 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT_], const char *smem, u
     for (int jt = 0; jt < JT_; ++jt) b[0][jt] = lds8<P>(smem, baddr0 + jt * jstride);
 #pragma unroll 1
     for (int body = 0; body < nbody; ++body) {
+        if constexpr (DUMP) {  // nbody == MT / NW == 8 rows per wave (64-point tiles)
+            const int row = dj->wv * 8 + body;
+            if (body > 0 && row - 1 < dj->rows_left)
+                *reinterpret_cast<u32x4 *>(dj->dst + (size_t)(row - 1) * (D_HID * 2) + dj->lane * 16) = dump_v;
+            dump_v = *reinterpret_cast<const u32x4 *>(dj->src + row * ROW_ACT + dj->lane * 16);
+        }
 
 #ifdef PNR_EXP_FAKE_W  // experiment: refill from a fixed 8 KiB window (no L2 streaming); results are wrong
         const char *pf = R.wave_base + (size_t)(R.pf_rs & 0) * (IT * 1024);
@@ -244,6 +262,10 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT_], const char *smem, u
         }
         baddr0 += 128;
         ADV::step4(R, NS);
+    }
+    if constexpr (DUMP) {
+        const int row = dj->wv * 8 + nbody - 1;
+        if (row < dj->rows_left) *reinterpret_cast<u32x4 *>(dj->dst + (size_t)row * (D_HID * 2) + dj->lane * 16) = dump_v;
     }
 }
 

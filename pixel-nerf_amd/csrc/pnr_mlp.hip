@@ -208,10 +208,19 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
     PNR_T(PH_WRITE_X);
     __syncthreads();
     PNR_T(PH_BAR2);
+#ifndef PNR_DUMP_IN_GEMM
     if constexpr (TRAIN) dump_image<TL::MT>(smem, TL::LDS_A, q.d_a[b] + dump_tile, rows_left, wv, lane);
+#endif
     {
         f32x16 net[IT][JT];
         add_bias<true>(net, bias_lane, 1 + 2 * b);
+#ifdef PNR_DUMP_IN_GEMM
+        if constexpr (TRAIN) {
+            static_assert(TL::MT == 64, "the in-GEMM dump copies 8 rows per wave");
+            const DumpJob dj = {smem + TL::LDS_A, q.d_a[b] + dump_tile, rows_left, wv, lane};
+            gemm<P, ADV, true>(net, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS, &dj);
+        } else
+#endif
         gemm<P, ADV>(net, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
         PNR_T(PH_GEMM_FC0);
         __syncthreads();  // every wave is done reading relu(x)
@@ -221,7 +230,9 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
     }
     __syncthreads();
     PNR_T(PH_BAR4);
+#ifndef PNR_DUMP_IN_GEMM
     if constexpr (TRAIN) dump_image<TL::MT>(smem, TL::LDS_A, q.d_n[b] + dump_tile, rows_left, wv, lane);
+#endif
     add_bias<false>(x, bias_lane, 2 + 2 * b);
     // multi-view pooling: the running sum of the previous views comes back from its scratch UNDER this GEMM (`net` is dead,
     // its registers hold the loads in flight), so the view boundary costs no exposed memory round trip
@@ -232,6 +243,12 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
             for (int i = 0; i < IT * JT * 4; ++i) parked[i] = park[i * NTHREADS];  // [slot][thread]: 1 KiB per wave-instruction
         }
     }
+#ifdef PNR_DUMP_IN_GEMM
+    if constexpr (TRAIN) {
+        const DumpJob dj = {smem + TL::LDS_A, q.d_n[b] + dump_tile, rows_left, wv, lane};
+        gemm<P, ADV, true>(x, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS, &dj);
+    } else
+#endif
     gemm<P, ADV>(x, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
     if constexpr (MV_PARK) {
         if (park) {
