@@ -470,6 +470,8 @@ def main():
     ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--no-f32-check", action="store_true")
     ap.add_argument("--no-peer", action="store_true", help="skip the second timed region (the f16 peer block)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the 4096-ray latency / encode sections (profiling runs: every "
+                    "network-kernel launch of the process then has the timed region's shape)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: functional test on one GPU)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed BASELINE configs 3/4/5 section (extra.configs)")
     args = ap.parse_args()
@@ -672,7 +674,7 @@ def main():
             "sample": "BASELINE configs[0]: sn64, 1 view, 32 coarse samples (no fine pass), ray_batch=4096 in ONE call on the CPU path, %.1f s" % dt1,
             "hip_same_call_ms": dtg * 1e3, "hip_same_call_rays_per_s": 4096 / dtg, "hip_precision": args.prec,
             "psnr_db_hip_vs_cpu": O.psnr(o1.coarse.rgb.cpu(), ref1["coarse"]["rgb"])}
-    if world == 1:
+    if world == 1 and not args.no_latency:
         # single-image latency (one 4096-ray call through render_par, fold included) next to the saturated rate
         lat_ms = {}
         with torch.no_grad():

@@ -73,7 +73,11 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
     }
 #pragma unroll 1
     for (int body = 0; body < nbody; ++body) {
+#ifdef PNR_EXP_WRAP_W  // experiment: the stream wraps inside its first PNR_EXP_WRAP_W ring steps (L2-resident); wrong results
+        const size_t pf = (size_t)(R.pf_rs % PNR_EXP_WRAP_W) * (IT * 1024);
+#else
         const size_t pf = (size_t)R.pf_rs * (IT * 1024);
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cur = j & 1;

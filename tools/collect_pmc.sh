@@ -9,7 +9,7 @@ case "$PREC" in f16x3) KERNEL=eval_split_kernel ;; *) KERNEL=eval_kernel ;; esac
 OUT="$REPO/gpurun_out/pmc_$PREC"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --prec $PREC --steps 2 --warmup 1 --no-peer --no-cpu-baseline --no-eager-baseline --no-f32-check --no-extras $*"
+CMD="python $REPO/bench.py --prec $PREC --steps 2 --warmup 1 --no-peer --no-latency --no-cpu-baseline --no-eager-baseline --no-f32-check --no-extras $*"
 run() {  # name, counters...
     local name=$1; shift
     timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -o "pmc_$name" -- $CMD > "$OUT/$name.log" 2>&1
