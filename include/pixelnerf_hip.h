@@ -78,9 +78,11 @@ int pnr_abi_version(void);
 int pnr_device_info(int *num_cus, int *lds_bytes_per_block);
 
 /* 64-bit content fingerprint of the 30 parameter tensors, computed and (optionally) compared on the device with no host
- * synchronisation: ws = 16 zeroed device bytes (left zeroed); sum_out (device, nullable) receives it; with `expect`
+ * synchronisation: ws = pnr_params_checksum_ws_bytes() of device scratch, first 8 bytes zero (left so); sum_out (device,
+ * nullable) receives it; with `expect`
  * (device) a differing value sets *mismatch_flag (device int) to 1.  Lets a caller that caches packed streams notice
  * parameter writes that bypass its cache key (the Python layer: `p.data.copy_()` bumps no tensor version). */
+size_t pnr_params_checksum_ws_bytes(void);
 int pnr_params_checksum(const PnrMlpWeights *w /*host*/, void *ws, unsigned long long *sum_out,
                         const unsigned long long *expect, int *mismatch_flag, void *stream);
 

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "pnr_version": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pnr_abi_version": (_I, []),
     "pnr_device_info": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "pnr_params_checksum_ws_bytes": (_SZ, []),
     "pnr_params_checksum": (_I, [ctypes.POINTER(PnrMlpWeights), _P, _P, _P, _P, _P]),
     "pnr_packed_mlp_bytes": (_SZ, []),
     "pnr_pack_mlp": (_I, [ctypes.POINTER(PnrMlpWeights), _I, _P, _P]),

@@ -176,7 +176,7 @@ class ResnetFC(nn.Module):
     def _content_state(self, dev):
         st = self.__dict__.get("_content")
         if st is None or st["dev"] != dev:
-            st = dict(dev=dev, ws=torch.zeros(2, dtype=torch.int64, device=dev), sums={},
+            st = dict(dev=dev, ws=torch.zeros(ops._lib.load().pnr_params_checksum_ws_bytes() // 8, dtype=torch.int64, device=dev), sums={},
                       flag=torch.zeros(1, dtype=torch.int32, device=dev), flag_host=torch.zeros(1, dtype=torch.int32).pin_memory())
             self.__dict__["_content"] = st
         return st
