@@ -92,3 +92,36 @@ def test_f16_gradient_error_is_operand_rounding(dev):
         assert cos >= 0.9995, (k, cos)
     print("f16 vs fp32-HIP gradients, config 5: max rel %.2e (%s), median %.2e" % (
         max(rels.values()), max(rels, key=rels.get), float(np.median(list(rels.values())))))
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("scene_name,B", [("train", 96), ("mv_mini", 45)])  # 45: ragged; mv_mini: 2 objects x 2 views (pooling)
+def test_direct_forward_is_differentiable_at_fp32_precision(dev, scene_name, B, precision):
+    """net(xyz, viewdirs) with grad enabled (src/model/models.py:146-266 under autograd) at the fp32-precision paths: outputs and
+    the parameter / latent-grid gradients of a random linear functional against torch autograd through the oracle, 1e-3"""
+    from helpers import mlp_params, scene_for
+    from oracle import pnr_oracle as O
+    from test_api_gpu import build_net
+    scene, meta = scene_for(scene_name)
+    SB = scene["SB"]
+    gen = torch.Generator().manual_seed(13)
+    xyz = (torch.rand(SB, B, 3, generator=gen) - 0.5) * 1.6
+    vd = torch.nn.functional.normalize(torch.randn(SB, B, 3, generator=gen), dim=-1)
+    gw = torch.randn(SB, B, 4, generator=gen)
+    p = {k: v.clone().requires_grad_(True) for k, v in mlp_params(11).items()}
+    sc = dict(scene)
+    sc["latent"] = scene["latent"].clone().requires_grad_(True)
+    ref = O.pixelnerf_forward(sc, p, xyz, vd)
+    (ref * gw).sum().backward()
+    net = build_net(dev, scene, precision=precision).train()
+    lat = scene["latent"].to(dev).clone().requires_grad_(True)
+    net.encoder.latent = lat
+    out = net(xyz.to(dev), coarse=True, viewdirs=vd.to(dev))
+    assert out.shape == (SB, B, 4) and out.requires_grad
+    assert (out.detach().cpu() - ref.detach()).abs().max() <= 2e-5 * max(1.0, float(ref.detach().abs().max()))
+    (out * gw.to(dev)).sum().backward()
+    pairs = [("latent", lat.grad.cpu(), sc["latent"].grad)]
+    pairs += [(k, v.grad.cpu(), p[k].grad) for k, v in net.mlp_coarse.named_parameters()]
+    for k, a, b in pairs:
+        rel = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+        assert rel <= 1e-3, f"{k}: rel err {rel:.3e}"
