@@ -73,7 +73,9 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
     }
 #pragma unroll 1
     for (int body = 0; body < nbody; ++body) {
-#ifdef PNR_EXP_WRAP_W  // experiment: the stream wraps inside its first PNR_EXP_WRAP_W ring steps (L2-resident); wrong results
+#ifdef PNR_EXP_FAKE_W  // experiment: every refill reads the same 16 KiB window (L1-resident: the instruction stream without the L2 -> CU traffic); wrong results
+        const size_t pf = (size_t)(R.pf_rs & 0) * (IT * 1024);
+#elif defined(PNR_EXP_WRAP_W)  // experiment: the stream wraps inside its first PNR_EXP_WRAP_W ring steps (L2-resident); wrong results
         const size_t pf = (size_t)(R.pf_rs % PNR_EXP_WRAP_W) * (IT * 1024);
 #else
         const size_t pf = (size_t)R.pf_rs * (IT * 1024);
@@ -108,6 +110,24 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
                 R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
                 R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
             }
+#endif
+#ifndef PNR_SPLIT_NO_SGB
+            // Issue order of one k-step, pinned (round 3): hipcc batches the 16 refills of a loop body behind its last MFMA and
+            // clusters the LDS reads; here every LDS read of the next step's B fragments follows ONE MFMA and every weight
+            // refill follows TWO -- (M L) x 2JT, (M M G) x 2IT.  Same-box A/B on sn64 / srn_car / DTU: +2.7 ... +6 % in four
+            // runs (profiles/r03_split_kernel_ab.txt, which also lists the eleven other orders tried: -6 ... +4 %; the order
+            // matters here, unlike in the f16 kernel where the same kind of pinning measured -1.9 %).  Results unchanged.
+#pragma unroll
+            for (int i = 0; i < 2 * JT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * IT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+            }
+            if constexpr (3 * IT * JT - 2 * JT - 4 * IT > 0) __builtin_amdgcn_sched_group_barrier(0x008, 3 * IT * JT - 2 * JT - 4 * IT, 0);
 #endif
         }
         bhi0 += 128;
