@@ -247,6 +247,19 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT_], const char *smem, u
             // issue pattern of one k-step: every LDS read of the next step's B fragments and every refill of this
             // step's ring slot sits behind one MFMA (the MFMA pipe is busy 8 passes per instruction; the memory
             // instructions issue in its shadow and the refill gets the full 3-step prefetch distance)
+#if PNR_SGB == 2  // LDS reads behind single MFMAs first, the refills last, two MFMAs apart where the step has enough of them
+#pragma unroll
+            for (int i = 0; i < JT_; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if constexpr (IT * JT_ - JT_ - IT > 0) __builtin_amdgcn_sched_group_barrier(0x008, IT * JT_ - JT_ - IT, 0);
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+#else
 #pragma unroll
             for (int i = 0; i < JT_; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -258,6 +271,7 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT_], const char *smem, u
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
             if constexpr (IT * JT_ - JT_ - IT > 0) __builtin_amdgcn_sched_group_barrier(0x008, IT * JT_ - JT_ - IT, 0);
+#endif
 #endif
         }
         baddr0 += 128;

@@ -92,6 +92,20 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
 #pragma unroll
             for (int it = 0; it < IT; ++it) { ah[it] = R.h[j][it]; al[it] = R.l[j][it]; }
             // the three products of one accumulator are spread over the step so that consecutive MFMAs are independent
+#ifdef PNR_SPLIT_ORDER_JT_OUTER  // experiment: point tile outer, feature tile inner (consecutive MFMAs share the B fragment instead of the A fragment)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) acc[it][jt] = mf(ah[it], bh[cur][jt], acc[it][jt]);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) acc[it][jt] = mf(ah[it], bl[cur][jt], acc[it][jt]);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) acc[it][jt] = mf(al[it], bh[cur][jt], acc[it][jt]);
+#else
 #pragma unroll
             for (int it = 0; it < IT; ++it)
 #pragma unroll
@@ -104,6 +118,7 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
             for (int it = 0; it < IT; ++it)
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(al[it], bh[cur][jt], acc[it][jt]);
+#endif
 #ifndef PNR_EXP_NO_WLOAD  // experiment: never refill the ring (no weight traffic at all); results are wrong
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
