@@ -73,7 +73,7 @@ int pnr_version(int *major, int *minor);
 /* ABI revision of THIS header: bumped whenever a struct layout or an entry point's argument list changes.  The
  * library returns the value it was compiled with; a binding must compare it with the header it was written against
  * before the first call (pixelnerf_amd/_lib.py does, and refuses a stale or foreign .so). */
-#define PNR_ABI_VERSION 3
+#define PNR_ABI_VERSION 4
 int pnr_abi_version(void);
 int pnr_device_info(int *num_cus, int *lds_bytes_per_block);
 
@@ -391,6 +391,21 @@ int pnr_render_views(const PnrScene *scene /*host*/, const void *packed_coarse, 
                      int lindisp, const float *u1, const float *u2, const float *u3, const float *n4,
                      unsigned long long seed, float *rgb_c, float *depth_c, float *weights_c, float *rgb_f,
                      float *depth_f, float *weights_f, void *workspace, void *stream);
+
+/* ---- PositionalEncoding as a stand-alone operator --------------------------------------------
+ * src/model/code.py:30-42 (PositionalEncoding.forward): x (N, d_in) ->
+ * out (N, d_out), d_out = d_in * (2 num_freqs + (include_input ? 1 : 0)):
+ *   out[n] = [x[n]] ++ sin(phases2[j] + x[n][d] * freqs2[j]),  j = 0 .. 2 num_freqs - 1 outer, d inner,
+ * freqs2 / phases2 = DEVICE arrays of 2 num_freqs floats: the module's `_freqs` / `_phases` buffers
+ * (code.py:24-28: every frequency twice, phases 0 and pi/2), so a loaded checkpoint's buffers are
+ * what is evaluated.  The sine argument is one fused multiply-add (ATen's addcmul).  The fused
+ * kernels do not call this: they form the code of their own 3-vectors in registers.
+ * _backward: g_x (N, d_in) = d/dx of sum(out * g_out)  (torch autograd of the same lines). */
+int pnr_positional_encoding(const float *x, long long N, int d_in, int num_freqs, const float *freqs2,
+                            const float *phases2, int include_input, float *out, void *stream);
+int pnr_positional_encoding_backward(const float *x, const float *g_out, long long N, int d_in,
+                                     int num_freqs, const float *freqs2, const float *phases2,
+                                     int include_input, float *g_x, void *stream);
 
 /* ---- next-row helpers: encoder output formatting --------------------
  * src/model/encoder.py:150-163: F.interpolate(bilinear, align_corners=True) of every ResNet stage

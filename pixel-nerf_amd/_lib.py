@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelne
 SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_split.hip", "pnr_bwd.hip", "pnr_f32.hip", "pnr_encode.hip"]
 HEADERS = ["pnr_common.h", "pnr_layout.h", "pnr_device.h", "pnr_raysrc.h", "pnr_internal.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
 
-ABI_VERSION = 3  # PNR_ABI_VERSION of the include/pixelnerf_hip.h this binding (struct layouts, argtypes below) was written against
+ABI_VERSION = 4  # PNR_ABI_VERSION of the include/pixelnerf_hip.h this binding (struct layouts, argtypes below) was written against
 PREC_F16, PREC_BF16, PREC_F32, PREC_F16X3 = 0, 1, 2, 3
 PRECISIONS = {"f16": PREC_F16, "fp16": PREC_F16, "bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -88,6 +88,8 @@ PROTOTYPES = {
                                        ctypes.c_ulonglong, ctypes.c_longlong, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pnr_pyramid_to_latent": (_I, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                    ctypes.POINTER(ctypes.c_int), _I, _I, _P, _P, _P]),
+    "pnr_positional_encoding": (_I, [_P, ctypes.c_longlong, _I, _I, _P, _P, _I, _P, _P]),
+    "pnr_positional_encoding_backward": (_I, [_P, _P, ctypes.c_longlong, _I, _I, _P, _P, _I, _P, _P]),
     "pnr_sample_training_rays": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "pnr_eval_epilogue": (_I, [_P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "pnr_resnetfc_forward_f32_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),

@@ -9,9 +9,14 @@
 // the caller wants the reference's NCHW tensor too (net.encoder.latent stays readable), that as
 // well -- no separate interpolate / cat / transpose passes over up to 176 MiB.
 //
-// HBM-bound: algorithmic bytes = pyramid read once + 4*512 B per output pixel per written layout.
-// 64-channel x 32-pixel x 4-row tiles; interpolation with lanes along x (coalesced source rows and NCHW
-// stores), transposed through LDS, stored with lanes along channels (16-byte NHWC stores).
+// HBM-bound: algorithmic bytes = pyramid read once + 4*C B per output pixel per written layout.  Round 2's kernel fetched the
+// four corners of every output value straight from global memory: 16 B per value through the CU's 64 B/clk vector-memory return
+// path, i.e. as many cycles there as the output stream takes on the HBM side (0.38 of the HBM roofline).  Here a workgroup owns
+// a run of FT_P pixels of one image row x ALL channels and first copies the few source texels the run touches -- for an
+// r-times upsampled stage 2 rows x (FT_P / r + 2) texels per channel -- into LDS, channel-last; the interpolation then reads
+// LDS: lanes along the channels for the channel-last grid (four 16-byte LDS reads and one 16-byte global store per 4 values:
+// every wave instruction writes 1 KiB of ONE pixel's row), and, when the reference's NCHW tensor is wanted too, a second sweep
+// with lanes along the pixels (128-byte runs of a channel plane).
 #include <hip/hip_runtime.h>
 
 #include "pnr_common.h"
@@ -25,64 +30,229 @@ struct Pyramid {
     const float *src[MAX_STAGES];
     int c_begin[MAX_STAGES + 1];  // first output channel of stage s; [n] = total
     int H[MAX_STAGES], W[MAX_STAGES];
+    float sy[MAX_STAGES], sx[MAX_STAGES];  // (in - 1) / (out - 1), 0 when out == 1
+    int same[MAX_STAGES];         // stage at the output resolution: its texels ARE the values
+    int nxw[MAX_STAGES];          // texels per window row the LDS layout reserves (>= what any run touches)
+    int wsh[MAX_STAGES];          // log2 of the lanes a window row is loaded with (2^wsh >= nxw)
+    int win_off[MAX_STAGES + 1];  // float offset of stage s's window in LDS; [n] = total
     int n;
 };
 
-constexpr int FT_C = 64;  // channels per tile
-constexpr int FT_X = 32;  // pixels (along x) per tile
-constexpr int FT_Y = 4;   // rows per workgroup
+constexpr int FT_C = 64;   // stage channel counts are multiples of this
+constexpr int FT_PAD = 4;  // floats of padding per window texel: neighbouring texels sit 4 banks apart (16-byte reads of 8 lanes cover the 32 banks)
+constexpr int FT_U = 8;    // channel steps per thread and stage prefetched in registers (x 2 window rows); covers the shipped shapes
+
+static float axis_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+// texels of a window row that P output pixels can touch: xa(last) - xa(first) <= ceil(sx (P-1)) + 1 (float rounding), + the
+// right neighbour, + 1 for the count
+static int window_texels(int P, int Ws, int W0) {
+    const int n = (int)ceilf(axis_scale(Ws, W0) * (float)(P - 1)) + 3;
+    return n < Ws ? n : Ws;
+}
 
 // ATen upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1); i0 = (int)src;
 // i1 = i0 + (i0 < in-1); l1 = src - i0; l0 = 1 - l1;
 // val = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)     (no FMA contraction)
-// Workgroup = 256 threads: FT_C channels x FT_X pixels x FT_Y rows.  Phase 1 (lanes along x): interpolate,
-// store NCHW, park in LDS; phase 2 (lanes along channels): 16-byte NHWC stores, 256 B contiguous per pixel.
-__global__ void __launch_bounds__(256)
-pyramid_to_latent_kernel(const Pyramid p, int NV, int H0, int W0, float *__restrict__ nhwc, float *__restrict__ nchw) {
+// A stage at the output resolution (the first one) has src == dst, l1 == 0: the value is the texel itself (finite inputs).
+struct StageRun {  // what a run of pixels needs of one stage; every field is uniform over the workgroup
+    int cb, Cs, stride, Ws, nxw, woff, y0, y1, xa0, nx;
+    float h0, h1, sx;
+    bool same;
+};
+
+// One workgroup = one run of P pixels of an image row x all channels:
+//   1. the source texels under the run go global -> LDS, [row][texel][channel]; a window row is loaded with 2^wsh lanes along x so
+//      that the walk over (channel, row) is a pointer increment;
+//   2. channel-last sweep: a thread keeps one group of 4 channels and walks the pixels: four 16-byte LDS reads, the blend, one
+//      16-byte store -- a wave instruction writes 1 KiB of one pixel's row;
+//   3. NCHW sweep (optional): lanes along the pixels, 128-byte runs of a channel plane.
+// Instruction count is what this kernel lives on (rocprofv3: the first LDS-window form issued 1700 VALU + 900 SALU instructions
+// per wave, 60 % of its cycles, most of them 64-bit index arithmetic on per-stage geometry that had spilled into scratch
+// arrays): stage geometry is recomputed in uniform loops (scalar registers), lane-dependent addresses are formed once per stage
+// and then stepped, per-pixel x weights come from a small LDS table.
+template <int P>
+__global__ void __launch_bounds__(256, 3)
+pyramid_to_latent_kernel(const Pyramid p, int H0, int W0, float *__restrict__ nhwc, float *__restrict__ nchw) {
 #pragma clang fp contract(off)
-    __shared__ float tile[FT_C][FT_X + 1];
+    extern __shared__ __attribute__((aligned(16))) float win[];
     const int t = threadIdx.x;
-    const int tx = t & 31, ty = t >> 5;  // phase 1: x, channel group (8)
     const int Ctot = p.c_begin[p.n];
-    const int ctiles = Ctot / FT_C;
-    const int n = blockIdx.z / ctiles, c0 = (blockIdx.z % ctiles) * FT_C;
-    const int x0 = blockIdx.x * FT_X;
-    int s = 0;
-    while (s + 1 < p.n && c0 >= p.c_begin[s + 1]) ++s;
-    const int Hs = p.H[s], Ws = p.W[s], Cs = p.c_begin[s + 1] - p.c_begin[s];
-    const float sy = H0 > 1 ? (float)(Hs - 1) / (float)(H0 - 1) : 0.f;
-    const float sx = W0 > 1 ? (float)(Ws - 1) / (float)(W0 - 1) : 0.f;
-    const int x = x0 + tx;
-    const float fx = sx * (float)x;
-    const int xa = min((int)fx, Ws - 1), xb = xa + (xa < Ws - 1 ? 1 : 0);
-    const float w1 = fx - (float)xa, w0 = 1.f - w1;
-    const int xx2 = t >> 4, c4 = (t & 15) * 4;  // phase 2: pixel (16 per pass), 4 channels
-    for (int yy = 0; yy < FT_Y; ++yy) {
-        const int y = blockIdx.y * FT_Y + yy;
-        if (y >= H0) break;
-        const float fy = sy * (float)y;
-        const int y0 = (int)fy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
-        const float h1 = fy - (float)y0, h0 = 1.f - h1;
-        if (x < W0) {
+    const int n = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * P;
+    const int npx = min(P, W0 - x0);
+    auto stage = [&](int s) {  // s uniform
+        StageRun g;
+        g.cb = p.c_begin[s]; g.Cs = p.c_begin[s + 1] - g.cb; g.stride = g.Cs + FT_PAD; g.Ws = p.W[s]; g.nxw = p.nxw[s]; g.woff = p.win_off[s];
+        g.same = p.same[s] != 0; g.sx = p.sx[s];
+        if (g.same) {
+            g.y0 = g.y1 = y; g.xa0 = x0; g.nx = npx; g.h0 = 1.f; g.h1 = 0.f;
+        } else {
+            const int Hs = p.H[s];
+            const float fy = p.sy[s] * (float)y;
+            g.y0 = __builtin_amdgcn_readfirstlane((int)fy);
+            g.y1 = g.y0 + (g.y0 < Hs - 1 ? 1 : 0);
+            g.h1 = fy - (float)g.y0; g.h0 = 1.f - g.h1;
+            g.xa0 = __builtin_amdgcn_readfirstlane(min((int)(g.sx * (float)x0), g.Ws - 1));
+            const int xl = __builtin_amdgcn_readfirstlane(min((int)(g.sx * (float)(x0 + npx - 1)), g.Ws - 1));
+            g.nx = min(xl + (xl < g.Ws - 1 ? 1 : 0) - g.xa0 + 1, g.nxw);
+        }
+        return g;
+    };
+    f32x4_t *xtab = reinterpret_cast<f32x4_t *>(win + p.win_off[p.n]);
+    const int quads = Ctot / 4;
+    // this thread's constants of the channel-last sweep (its channel group q lies in exactly one stage)
+    const bool fixed_q = 256 % quads == 0 && P % (256 / quads) == 0;  // every ResNet trunk
+    const int q = t % quads;
+    int a_w = 0, a_wb = 0, a_tab = 0;
+    float a_h0 = 1.f, a_h1 = 0.f;
+    bool a_same = true;
+
+    for (int s = 0; s < p.n; ++s) {
+        const StageRun g = stage(s);
+        // ---- 1. window of stage s: lane i = t & (2^wsh - 1) is the texel of a row, j = t >> wsh the first channel, channels step
+        // by 256 >> wsh; FT_U steps (both rows) are loaded before their LDS writes
+        {
+            const int wsh = p.wsh[s];
+            const int i = t & ((1 << wsh) - 1), j = t >> wsh, step = 256 >> wsh;
+            // 32-bit element offsets inside one view of the stage (the host checks Cs Hs Ws < 2^29); only the view base is 64-bit
+            const int plane = p.H[s] * g.Ws;
+            const float *base = p.src[s] + (size_t)n * ((size_t)g.Cs * plane) + (g.y0 * g.Ws + g.xa0);  // uniform
+            const int row1 = (g.y1 - g.y0) * g.Ws;                                                       // uniform
+            const int hop = step * plane;                                                                // uniform
+            const int nsteps = g.Cs / step;  // uniform; step <= 64 divides every stage's channel count (host: wsh >= 2)
+            if (i < g.nx) {
+                const float *r0 = base + (unsigned)(j * plane + i);
+                float *w0 = win + g.woff + i * g.stride + j;
+                const int wrow = g.nxw * g.stride;
+                for (int k = 0; k < nsteps; k += FT_U) {
+                    float v0[FT_U], v1[FT_U];
 #pragma unroll
-            for (int cc = ty; cc < FT_C; cc += 8) {
-                const int c = c0 + cc;
-                const float *plane = p.src[s] + ((size_t)n * Cs + (c - p.c_begin[s])) * Hs * Ws;
-                const float *r0 = plane + (size_t)y0 * Ws, *r1 = plane + (size_t)y1 * Ws;
-                const float v = h0 * (w0 * r0[xa] + w1 * r0[xb]) + h1 * (w0 * r1[xa] + w1 * r1[xb]);
-                tile[cc][tx] = v;
-                if (nchw) nchw[(((size_t)n * Ctot + c) * H0 + y) * W0 + x] = v;
+                    for (int u = 0; u < FT_U; ++u) {
+                        if (k + u >= nsteps) break;  // uniform
+                        v0[u] = r0[u * hop];
+                        if (!g.same) v1[u] = r0[u * hop + row1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < FT_U; ++u) {
+                        if (k + u >= nsteps) break;
+                        w0[u * step] = v0[u];
+                        if (!g.same) w0[u * step + wrow] = v1[u];
+                    }
+                    r0 += (unsigned)(FT_U * hop);
+                    w0 += FT_U * step;
+                }
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int xx = xx2; xx < FT_X; xx += 16)
-            if (x0 + xx < W0) {
-                const f32x4_t v = {tile[c4][xx], tile[c4 + 1][xx], tile[c4 + 2][xx], tile[c4 + 3][xx]};
-                *reinterpret_cast<f32x4_t *>(nhwc + (((size_t)n * H0 + y) * W0 + x0 + xx) * Ctot + c0 + c4) = v;
-            }
-        __syncthreads();
+        // ---- per pixel of the run: float offsets of the two window texels and the x weights -- computed once, read back by every
+        // thread that touches the pixel (one LDS read instead of ~20 VALU operations per output group)
+        if (t < P) {
+            const int x = min(x0 + t, W0 - 1);
+            const float fx = g.sx * (float)x;
+            const int xa = min((int)fx, g.Ws - 1), xb = xa + (xa < g.Ws - 1 ? 1 : 0);
+            const float w1 = fx - (float)xa, w0 = 1.f - w1;
+            int i0 = min(max(xa - g.xa0, 0), g.nxw - 1), i1 = min(max(xb - g.xa0, 0), g.nxw - 1);
+            if (g.same) i0 = i1 = t;
+            xtab[s * P + t] = f32x4_t{__int_as_float(i0 * g.stride), __int_as_float(i1 * g.stride), w0, w1};
+        }
+        if (q * 4 >= g.cb && q * 4 < g.cb + g.Cs) {
+            a_w = g.woff + (q * 4 - g.cb); a_wb = a_w + g.nxw * g.stride; a_tab = s * P; a_h0 = g.h0; a_h1 = g.h1; a_same = g.same;
+        }
     }
+    __syncthreads();
+    auto blend = [&](float h0, float h1, f32x4_t xp, f32x4_t a0, f32x4_t a1, f32x4_t b0, f32x4_t b1) {
+        return h0 * (xp[2] * a0 + xp[3] * a1) + h1 * (xp[2] * b0 + xp[3] * b1);
+    };
+    // ---- 2. channel-last grid: lanes along the channels, 16 bytes per lane
+    {
+        float *dst = nhwc + (((size_t)n * H0 + y) * W0 + x0) * Ctot;  // uniform
+        if (fixed_q) {
+            const int PPG = P / (256 / quads);
+            const float *w = win + a_w, *wb = win + a_wb;
+            const f32x4_t *tab = xtab + a_tab;
+            const int p_begin = (t / quads) * PPG, p_end = min(p_begin + PPG, npx);
+            float *d = dst + ((size_t)p_begin * Ctot + q * 4);
+            for (int px = p_begin; px < p_end; ++px, d += Ctot) {
+                const f32x4_t xp = tab[px];
+                const int o0 = __float_as_int(xp[0]), o1 = __float_as_int(xp[1]);
+                f32x4_t val = *reinterpret_cast<const f32x4_t *>(w + o0);
+                if (!a_same)
+                    val = blend(a_h0, a_h1, xp, val, *reinterpret_cast<const f32x4_t *>(w + o1), *reinterpret_cast<const f32x4_t *>(wb + o0),
+                                *reinterpret_cast<const f32x4_t *>(wb + o1));
+                *reinterpret_cast<f32x4_t *>(d) = val;
+            }
+        } else {  // channel counts that do not tile 256 threads: every (pixel, group) on its own
+            for (int s = 0; s < p.n; ++s) {
+                const StageRun g = stage(s);
+                const float *w = win + g.woff, *wb = w + g.nxw * g.stride;
+                const int sq = g.Cs / 4;
+                for (int k = t; k < npx * sq; k += 256) {
+                    const int px = k / sq, c4 = (k - px * sq) * 4;
+                    const f32x4_t xp = xtab[s * P + px];
+                    const int o0 = __float_as_int(xp[0]), o1 = __float_as_int(xp[1]);
+                    f32x4_t val = *reinterpret_cast<const f32x4_t *>(w + c4 + o0);
+                    if (!g.same)
+                        val = blend(g.h0, g.h1, xp, val, *reinterpret_cast<const f32x4_t *>(w + c4 + o1), *reinterpret_cast<const f32x4_t *>(wb + c4 + o0),
+                                    *reinterpret_cast<const f32x4_t *>(wb + c4 + o1));
+                    *reinterpret_cast<f32x4_t *>(dst + (size_t)px * Ctot + g.cb + c4) = val;
+                }
+            }
+        }
+    }
+    // ---- 3. the reference's NCHW tensor: lanes along the pixels (128-byte runs of a channel plane)
+    if (nchw) {
+        const int px = t % P, grp = t / P;
+        if (px < npx) {
+            const size_t HW = (size_t)H0 * W0;
+            float *dpx = nchw + ((size_t)n * Ctot * H0 + y) * W0 + x0 + px;
+            for (int s = 0; s < p.n; ++s) {
+                const StageRun g = stage(s);
+                const f32x4_t xp = xtab[s * P + px];
+                const int o0 = __float_as_int(xp[0]), o1 = __float_as_int(xp[1]);
+                const float *w = win + g.woff + grp * 4, *wb = w + g.nxw * g.stride;
+                float *d = dpx + (size_t)(g.cb + grp * 4) * HW;
+                const size_t dstep = (size_t)(256 / P) * 4 * HW;
+                for (int c4 = grp * 4; c4 < g.Cs; c4 += (256 / P) * 4, w += (256 / P) * 4, wb += (256 / P) * 4, d += dstep) {
+                    f32x4_t val = *reinterpret_cast<const f32x4_t *>(w + o0);
+                    if (!g.same)
+                        val = blend(g.h0, g.h1, xp, val, *reinterpret_cast<const f32x4_t *>(w + o1), *reinterpret_cast<const f32x4_t *>(wb + o0),
+                                    *reinterpret_cast<const f32x4_t *>(wb + o1));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e * HW] = val[e];
+                }
+            }
+        }
+    }
+}
+
+// PositionalEncoding.forward, src/model/code.py:30-42, for callers that use the module on its own (the fused kernels form the
+// code of their 3-vectors in registers, pnr_device.h):  out[n] = [x[n]] ++ sin(phases[j] + x[n][d] * freqs[j]) with j = 0 .. 2F-1
+// outer and d inner; freqs / phases = the module's `_freqs` / `_phases` buffers (each frequency twice, phases 0, pi/2).  The
+// argument is ONE fused multiply-add like ATen's addcmul.  One thread per output element: lanes along a row's d_out values.
+__global__ void positional_encoding_kernel(const float *__restrict__ x, const float *__restrict__ freqs, const float *__restrict__ phases,
+                                           long long total, int d_in, int d_out, int lead, float *__restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long n = idx / d_out;
+    const int k = (int)(idx - n * d_out);
+    const float *row = x + n * d_in;
+    if (k < lead) { out[idx] = row[k]; return; }
+    const int j = (k - lead) / d_in, d = (k - lead) - j * d_in;
+    out[idx] = sinf(__builtin_fmaf(row[d], freqs[j], phases[j]));
+}
+
+// backward of the above: g_x[n][d] = [g[n][d]] + sum_j g[n][lead + j d_in + d] cos(phases[j] + x[n][d] freqs[j]) freqs[j]
+__global__ void positional_encoding_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ freqs,
+                                               const float *__restrict__ phases, long long total, int d_in, int d_out, int lead,
+                                               int F2, float *__restrict__ gx) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long n = idx / d_in;
+    const int d = (int)(idx - n * d_in);
+    const float v = x[idx];
+    const float *gr = g + n * d_out;
+    float acc = lead ? gr[d] : 0.f;
+    for (int j = 0; j < F2; ++j) acc += gr[lead + j * d_in + d] * (cosf(__builtin_fmaf(v, freqs[j], phases[j])) * freqs[j]);
+    gx[idx] = acc;
 }
 
 // eval/eval.py:283-290,327-329 + util.psnr (util.py:474-481): one workgroup per view.  rgb -> clamp[0,1]
@@ -187,6 +357,34 @@ extern "C" int pnr_eval_epilogue(const float *rgb, const float *depth, int n_vie
     return pnr_check_launch("pnr_eval_epilogue");
 }
 
+extern "C" int pnr_positional_encoding(const float *x, long long N, int d_in, int num_freqs, const float *freqs2, const float *phases2,
+                                       int include_input, float *out, void *stream) {
+    if (N < 0 || d_in <= 0 || num_freqs < 0) return pnr_fail(PNR_E_INVALID, "pnr_positional_encoding: bad sizes");
+    if (N == 0) return PNR_OK;
+    if (!x || !out || (num_freqs > 0 && (!freqs2 || !phases2))) return pnr_fail(PNR_E_INVALID, "pnr_positional_encoding: null argument");
+    const int lead = include_input ? d_in : 0, d_out = lead + 2 * num_freqs * d_in;
+    if (d_out == 0) return PNR_OK;
+    const long long total = N * d_out;
+    if ((total + 255) / 256 > 0x7fffffffLL) return pnr_fail(PNR_E_INVALID, "pnr_positional_encoding: too many rows");
+    hipLaunchKernelGGL(pnr::positional_encoding_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, freqs2,
+                       phases2, total, d_in, d_out, lead, out);
+    return pnr_check_launch("pnr_positional_encoding");
+}
+
+extern "C" int pnr_positional_encoding_backward(const float *x, const float *g_out, long long N, int d_in, int num_freqs,
+                                                const float *freqs2, const float *phases2, int include_input, float *g_x, void *stream) {
+    if (N < 0 || d_in <= 0 || num_freqs < 0) return pnr_fail(PNR_E_INVALID, "pnr_positional_encoding_backward: bad sizes");
+    if (N == 0) return PNR_OK;
+    if (!x || !g_out || !g_x || (num_freqs > 0 && (!freqs2 || !phases2)))
+        return pnr_fail(PNR_E_INVALID, "pnr_positional_encoding_backward: null argument");
+    const int lead = include_input ? d_in : 0, d_out = lead + 2 * num_freqs * d_in;
+    const long long total = N * d_in;
+    if ((total + 255) / 256 > 0x7fffffffLL) return pnr_fail(PNR_E_INVALID, "pnr_positional_encoding_backward: too many rows");
+    hipLaunchKernelGGL(pnr::positional_encoding_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       g_out, freqs2, phases2, total, d_in, d_out, lead, 2 * num_freqs, g_x);
+    return pnr_check_launch("pnr_positional_encoding_backward");
+}
+
 extern "C" int pnr_pyramid_to_latent(const float *const *stages, const int *channels, const int *heights, const int *widths,
                                      int n_stages, int NV, float *latent_nhwc, float *latent_nchw, void *stream) {
     if (n_stages < 1 || n_stages > pnr::MAX_STAGES) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: 1..5 stages");
@@ -198,15 +396,49 @@ extern "C" int pnr_pyramid_to_latent(const float *const *stages, const int *chan
     for (int s = 0; s < n_stages; ++s) {
         if (!stages[s] || channels[s] <= 0 || channels[s] % pnr::FT_C != 0 || heights[s] <= 0 || widths[s] <= 0)
             return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: stage channels must be positive multiples of 64, sizes positive");
+        if ((long long)channels[s] * heights[s] * widths[s] >= (1LL << 29))
+            return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: a stage of one view must stay below 2 GiB");
         p.src[s] = stages[s]; p.c_begin[s] = c; p.H[s] = heights[s]; p.W[s] = widths[s];
         c += channels[s];
     }
     p.c_begin[n_stages] = c;
     if (NV == 0) return PNR_OK;
     const int H0 = heights[0], W0 = widths[0];
-    if ((long long)NV * (c / pnr::FT_C) > 65535) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: grid too large");
-    dim3 grid((W0 + pnr::FT_X - 1) / pnr::FT_X, (H0 + pnr::FT_Y - 1) / pnr::FT_Y, NV * (c / pnr::FT_C));
-    hipLaunchKernelGGL(pnr::pyramid_to_latent_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, NV, H0, W0, latent_nhwc,
-                       latent_nchw);
+    // pixels per workgroup: the longest run whose source windows leave room for >= 3 workgroups per CU (else the shortest)
+    int P = 32;
+    size_t lds = 0;
+    auto layout = [&](int run) {
+        int off = 0;
+        for (int s = 0; s < n_stages; ++s) {
+            p.same[s] = heights[s] == H0 && widths[s] == W0;
+            p.sy[s] = pnr::axis_scale(heights[s], H0); p.sx[s] = pnr::axis_scale(widths[s], W0);
+            p.nxw[s] = p.same[s] ? run : pnr::window_texels(run, widths[s], W0);
+            p.wsh[s] = 2;  // >= 4 lanes per row: the channel step 256 >> wsh is then <= 64 and divides every stage's channel count
+            while ((1 << p.wsh[s]) < p.nxw[s]) ++p.wsh[s];
+            p.win_off[s] = off;
+            off += (p.same[s] ? 1 : 2) * p.nxw[s] * (channels[s] + pnr::FT_PAD);
+        }
+        p.win_off[n_stages] = off;
+        return ((size_t)off + (size_t)n_stages * run * 4) * sizeof(float);  // windows + the per-pixel x table
+    };
+    for (;; P /= 2) {
+        lds = layout(P);
+        if (lds <= 48 * 1024 || P == 8) break;
+    }
+#ifdef PNR_PYR_P
+    P = PNR_PYR_P;  // experiment: fixed run length
+    lds = layout(P);
+#endif
+    if (lds > 160 * 1024) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: source windows do not fit the LDS (too many channels)");
+    for (int s = 0; s < n_stages; ++s)
+        if (p.nxw[s] > 256) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: a stage more than 32x wider than stage 0 is not supported");
+    auto k = P == 32 ? pnr::pyramid_to_latent_kernel<32> : (P == 16 ? pnr::pyramid_to_latent_kernel<16> : pnr::pyramid_to_latent_kernel<8>);
+    if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (not reached by the shipped encoder shapes)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(pyramid_to_latent_kernel)");
+    }
+    const int tiles_x = (W0 + P - 1) / P;
+    if (H0 > 65535 || NV > 65535) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: grid too large");
+    hipLaunchKernelGGL(k, dim3(tiles_x, H0, NV), dim3(256), lds, (hipStream_t)stream, p, H0, W0, latent_nhwc, latent_nchw);
     return pnr_check_launch("pnr_pyramid_to_latent");
 }

@@ -565,6 +565,41 @@ def render_views(scene, packed_coarse, packed_fine, poses_c2w, width, height, fo
     return _render_result(co, fo, Kf, want_weights)
 
 
+def positional_encoding(x, freqs2, phases2, include_input=True):
+    """PositionalEncoding.forward (src/model/code.py:30-42) through pnr_positional_encoding.  x (N, d_in) float32 HIP tensor;
+    freqs2 / phases2: the module's `_freqs` / `_phases` buffers (2 * num_freqs values each).  -> (N, d_out)."""
+    lib = _lib.load()
+    x = _f32(x, "x", (None, None))
+    N, d_in = x.shape
+    freqs2 = _f32(freqs2.reshape(-1), "freqs2", (None,))
+    phases2 = _f32(phases2.reshape(-1), "phases2", (freqs2.shape[0],))
+    if freqs2.shape[0] % 2:
+        raise ValueError("freqs2 holds every frequency twice (sin and cos as a phase-shifted sin)")
+    F = freqs2.shape[0] // 2
+    out = torch.empty((N, d_in * (2 * F + (1 if include_input else 0))), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pnr_positional_encoding(_p(x), N, d_in, F, _p(freqs2), _p(phases2), int(bool(include_input)), _p(out),
+                                               _stream()), "pnr_positional_encoding")
+    return out
+
+
+def positional_encoding_backward(x, g_out, freqs2, phases2, include_input=True):
+    """Gradient of positional_encoding with respect to x (pnr_positional_encoding_backward).  -> (N, d_in)."""
+    lib = _lib.load()
+    x = _f32(x, "x", (None, None))
+    N, d_in = x.shape
+    freqs2 = _f32(freqs2.reshape(-1), "freqs2", (None,))
+    phases2 = _f32(phases2.reshape(-1), "phases2", (freqs2.shape[0],))
+    F = freqs2.shape[0] // 2
+    g_out = _f32(g_out, "g_out", (N, d_in * (2 * F + (1 if include_input else 0))))
+    gx = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pnr_positional_encoding_backward(_p(x), _p(g_out), N, d_in, F, _p(freqs2), _p(phases2),
+                                                        int(bool(include_input)), _p(gx), _stream()),
+                   "pnr_positional_encoding_backward")
+    return gx
+
+
 def pyramid_to_latent(stages, want_nchw=True):
     """Encoder output formatting (src/model/encoder.py:150-163): stages = list of (NV,C_s,H_s,W_s) float32
     HIP tensors (ResNet stage outputs).  -> (latent_nhwc (NV,H0,W0,sum C), latent_nchw (NV,sum C,H0,W0) | None):

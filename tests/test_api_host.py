@@ -56,11 +56,22 @@ def test_mlp_init_follows_reference(net):
     assert sum(p.numel() for p in net.mlp_coarse.parameters()) == 3438596  # SURVEY.md headline facts
 
 
-def test_positional_encoding_module_matches_golden():
-    g = load_golden("stages")
+def test_positional_encoding_module_keeps_the_checkpoint_contract():
+    """`_freqs` / `_phases` are what a reference checkpoint holds (src/model/code.py:17-28, restated here); the forward is a
+    HIP operator (tests/test_hip_features.py) and refuses CPU tensors instead of falling back."""
+    import numpy as np
+    from pixelnerf_amd._lib import PixelNerfHipError
     code = PositionalEncoding(num_freqs=6, d_in=3, freq_factor=1.5, include_input=True)
-    out = code(torch.from_numpy(g["posenc_x"]))
-    assert torch.allclose(out, torch.from_numpy(g["posenc_out"]), atol=1e-6)
+    ref_freqs = torch.repeat_interleave(1.5 * 2.0 ** torch.arange(0, 6), 2).view(1, -1, 1)
+    ref_phases = torch.zeros(12)
+    ref_phases[1::2] = np.pi * 0.5
+    sd = code.state_dict()
+    assert list(sd) == ["_freqs", "_phases"]
+    assert sd["_freqs"].dtype == torch.float32 and torch.equal(sd["_freqs"], ref_freqs)
+    assert torch.equal(sd["_phases"], ref_phases.view(1, -1, 1))
+    assert code.d_out == 39 and PositionalEncoding(4, 2, include_input=False).d_out == 16
+    with pytest.raises(PixelNerfHipError):
+        code(torch.from_numpy(load_golden("stages")["posenc_x"]))
 
 
 def test_encode_state_conventions(net):

@@ -67,6 +67,51 @@ def test_positional_encoding_of_the_fused_kernel_matches_reference(ops, dev):
     dumps.release()
 
 
+def _posenc_restated(x, freqs2, phases2, include_input):
+    """src/model/code.py:30-42 in torch ops (test-side restatement; runs on whatever device x is on)"""
+    if freqs2.numel() == 0:
+        return x if include_input else x.new_zeros(x.shape[0], 0)
+    e = x.unsqueeze(1).repeat(1, freqs2.numel(), 1)
+    e = torch.sin(torch.addcmul(phases2.reshape(1, -1, 1), e, freqs2.reshape(1, -1, 1))).reshape(x.shape[0], -1)
+    return torch.cat((x, e), dim=-1) if include_input else e
+
+
+def test_positional_encoding_module_runs_the_hip_operator(ops, dev):
+    """PositionalEncoding.forward on its own = pnr_positional_encoding, against the reference module's frozen output"""
+    from pixelnerf_amd.model.code import PositionalEncoding
+    g = load_golden("stages")
+    code = PositionalEncoding(num_freqs=6, d_in=3, freq_factor=1.5, include_input=True).to(dev)
+    x = torch.from_numpy(g["posenc_x"]).to(dev)
+    out = code(x)
+    assert out.shape == (x.shape[0], 39) and out.is_cuda
+    np.testing.assert_allclose(out.cpu().numpy(), g["posenc_out"], rtol=0, atol=1e-6)
+    assert torch.equal(out[:, :3], x)
+    assert code(x[:0]).shape == (0, 39)  # empty batch
+    with pytest.raises(ValueError):
+        code(x[:, :2])
+
+
+@pytest.mark.parametrize("d_in,F,include", [(3, 6, True), (2, 4, False), (5, 1, True), (3, 0, True)])
+def test_positional_encoding_operator_forward_backward(ops, dev, d_in, F, include):
+    from pixelnerf_amd.model.code import PositionalEncoding
+    code = PositionalEncoding(num_freqs=F, d_in=d_in, freq_factor=1.5, include_input=include).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(1000, d_in, generator=gen) * 4 - 2).to(dev).requires_grad_(True)
+    gw = torch.randn(1000, code.d_out, generator=gen).to(dev)
+    out = code(x)
+    (out * gw).sum().backward()
+    # the reference lines on the CPU (ATen's CPU addcmul is one fused multiply-add, like the goldens and like the kernel; the
+    # eager GPU addcmul rounds the product first and lands up to an ulp of the ARGUMENT away: 8e-6 at |x f| ~ 100)
+    x2 = x.detach().cpu().requires_grad_(True)
+    ref = _posenc_restated(x2, code._freqs.cpu(), code._phases.cpu(), include)
+    (ref * gw.cpu()).sum().backward()
+    assert out.shape == ref.shape
+    if out.numel():
+        assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 1e-6
+    scale = max(1.0, float(x2.grad.abs().max()))
+    assert (x.grad.cpu() - x2.grad).abs().max().item() <= 2e-5 * scale
+
+
 @pytest.mark.parametrize("name", ["sn64", "dtu_mini", "mv_mini"])
 def test_spatial_encoder_index_matches_reference(ops, dev, name):
     g = load_golden("stages")
