@@ -459,6 +459,13 @@ typedef struct PnrF32Saved {
 int pnr_eval_ray_samples_f32_train(const PnrScene *scene /*host*/, const PnrMlpWeights *w /*host*/, const float *rays,
                                    const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
                                    const PnrF32Saved *saved /*host*/, int split_gemm, void *stream);
+/* The fp32-class training forward through the FUSED split-operand kernel (the inference kernel of PNR_PREC_F16X3 with the
+ * activations of PnrF32Saved written out as fp32 rows): packed_split = pnr_pack_mlp_split(folded) stream, tables_f32 =
+ * pnr_fold_latent_f32 tables of the CURRENT parameters and grid (re-fold after every optimizer step / encode()).  One network
+ * launch instead of 29 GEMM launches; pnr_mlp_backward_f32(split_gemm = 1) runs behind it unchanged.  Same reference lines. */
+int pnr_eval_ray_samples_split_train(const PnrScene *scene /*host*/, const void *packed_split, const void *tables_f32,
+                                     const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
+                                     const PnrF32Saved *saved /*host*/, void *stream);
 /* All parameter gradients of one ResnetFC + d(interpolated latent) [+ d(lin_in operand)] from g_out (P,4) =
  * dL/d(lin_out output): `grads` holds device pointers of the 30 gradient tensors in PnrMlpWeights' layout (same shapes as
  * the parameters, overwritten); d_zlat (rows_v,512), d_in (rows_v,42) or NULL. */

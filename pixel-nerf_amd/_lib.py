@@ -135,6 +135,7 @@ PROTOTYPES = {
     "pnr_render_forward": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I,
                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pnr_gen_rays": (_I, [_P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "pnr_eval_ray_samples_split_train": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, ctypes.POINTER(PnrF32Saved), _P]),
     "pnr_eval_ray_samples_f32_train": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _I, _I, _P,
                                             ctypes.POINTER(PnrF32Saved), _I, _P]),
     "pnr_mlp_backward_f32_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),

@@ -30,6 +30,10 @@ def _param_names():
 
 PARAM_NAMES = _param_names()
 
+# precision "f16x3": the training forward runs the FUSED split-operand kernel (one launch, lin_z through the folded tables) and
+# keeps its activations as fp32 rows; False = the unfused chain of 29 split-operand GEMMs (same arithmetic class, the A/B twin)
+FUSED_SPLIT_FORWARD = True
+
 
 def _sigma_noise(rgbs, cfg):
     """nerf.py:225-226 (training only, noise_std > 0): sigmas = sigmas + randn_like(sigmas) * noise_std, drawn from torch's
@@ -54,6 +58,9 @@ def _train_eval(net, scene, coarse, rays, z):
     """network forward of one training pass -> (rgbsigma (R,K,4), saved operands).  precision 'f32': the exact, unfused fp32
     chain (validation grade); 'f16x3': the same chain with split-operand (fp32-class) GEMMs on the f16 matrix cores;
     'f16' / 'bf16': the fused kernel's training instantiation (16-bit operand dumps)."""
+    if net.precision == "f16x3" and FUSED_SPLIT_FORWARD:
+        pk = net.packed(coarse)  # the folded split stream of inference (before tables(): packed() runs the content check)
+        return ops.eval_ray_samples_split_train(scene, pk, net.tables(coarse), rays, z)
     if net.precision in ("f32", "f16x3"):
         mlp = net.mlp_coarse if (coarse or net.mlp_fine is None) else net.mlp_fine
         return ops.eval_ray_samples_f32_train(scene, mlp.packed("f32"), rays, z, split=net.precision == "f16x3")

@@ -17,6 +17,7 @@
 
 #include "pnr_common.h"
 #include "pnr_device.h"
+#include "pnr_internal.h"
 #include "pnr_layout.h"
 
 namespace pnr {
@@ -744,6 +745,35 @@ extern "C" int pnr_eval_ray_samples_f32_train(const PnrScene *scene, const PnrMl
     pnr::EvalParams q = {};
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
     return pnr::eval_f32_train(scene, w, q, saved, (hipStream_t)stream, split_gemm != 0);
+}
+
+// The same training forward through the FUSED split-operand kernel (pnr_split.hip, TRAIN instantiation): the per-point network
+// runs as one launch (lin_z through the folded fp32 tables, like inference) and leaves the activations of PnrF32Saved as fp32
+// rows; the feature kernel still writes the lin_in operand and the interpolated latent the weight gradients of lin_in / lin_z
+// and the latent scatter need.  29 GEMM launches -> 2 kernels; pnr_mlp_backward_f32(split_gemm = 1) runs behind it unchanged.
+extern "C" int pnr_eval_ray_samples_split_train(const PnrScene *scene, const void *packed_split, const void *tables_f32,
+                                                const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
+                                                const PnrF32Saved *saved, void *stream) {
+    using namespace pnr;
+    if (R <= 0 || K <= 0 || rays_per_obj <= 0 || !rays || !z || !scene || !packed_split || !tables_f32 || !rgbsigma)
+        return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: bad argument");
+    if ((long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: R != SB * rays_per_obj");
+    if (scene->SB <= 0 || scene->NS <= 0 || scene->Hl < 2 || scene->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: bad scene shape");
+    if (!check_saved(saved, scene->NS)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: null activation buffer in PnrF32Saved");
+    EvalParams q = {};
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
+    if (q.P * scene->NS > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: too many points");
+    q.latent = scene->latent_nhwc; q.poses = scene->poses; q.focal = scene->focal; q.c = scene->c;
+    q.SB = scene->SB; q.NS = scene->NS; q.Hl = scene->Hl; q.Wl = scene->Wl; q.n_focal = scene->n_focal; q.n_c = scene->n_c;
+    q.img_w = scene->img_w; q.img_h = scene->img_h;
+    const int np = (int)q.P;
+    const long long rows = (long long)np * scene->NS;
+    hipLaunchKernelGGL(feat_f32_kernel<true>, dim3((unsigned)((rows + FW - 1) / FW)), dim3(FW * 64), 0, (hipStream_t)stream, q, 0LL, np,
+                       saved->in42, saved->zlat);
+    int rc = pnr_check_launch("pnr_eval_ray_samples_split_train (features)");
+    if (rc != PNR_OK) return rc;
+    return eval_samples_split_train(scene, packed_split, tables_f32, rays, z, R, rays_per_obj, K, rgbsigma, saved->xin, saved->net,
+                                    saved->x5, saved->pool_in, (hipStream_t)stream);
 }
 
 extern "C" size_t pnr_mlp_backward_f32_workspace_bytes(long long P, int NS) {

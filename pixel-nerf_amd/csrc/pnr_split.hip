@@ -267,7 +267,7 @@ constexpr int SPLIT_MV_TILE = 32;
 #else
 constexpr int SPLIT_MV_TILE = 64;
 #endif
-template <bool RAYS, bool MV, bool TIMING = false>
+template <bool RAYS, bool MV, bool TIMING = false, bool TRAIN = false>
 __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const EvalParams q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef SplitTileT<MV ? SPLIT_MV_TILE : 64> ST;
@@ -305,8 +305,27 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
     [[maybe_unused]] unsigned long long *tim = q.tim;
     [[maybe_unused]] unsigned long long tlast = TIMING ? __builtin_readcyclecounter() : 0ull;
 
+    // TRAIN: an accumulator tile set leaves as fp32 rows in natural feature order (D register r of tile (it, jt) = feature
+    // 64 wv + 32 it + (r&3) + 8 (r>>2) + 4 h of point 32 jt + pl): 16-byte pieces, `rows` = first row of the tile in dst
+    [[maybe_unused]] auto dump_rows = [&](const f32x16 (&a)[IT][JT], float *dst, long long rows, long long rows_left) {
+        float *d = dst + ((size_t)rows + pl) * D_HID + (wv * IT) * 32 + 4 * h;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            if (jt * 32 + pl >= rows_left) continue;
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 v = {a[it][jt][4 * k], a[it][jt][4 * k + 1], a[it][jt][4 * k + 2], a[it][jt][4 * k + 3]};
+                    *reinterpret_cast<f32x4 *>(d + (size_t)jt * 32 * D_HID + it * 32 + 8 * k) = v;
+                }
+        }
+    };
+    // TRAIN: where the current tile's rows live (set by the tile / view loops; the inference instantiations never touch them)
+    [[maybe_unused]] long long tr_rows_view = 0, tr_rows_pooled = 0, tr_rows_left = 0;
     // one residual block on x (resnetfc.py:66-88); lookup: lin_z[b+1] via table b+1 behind it
     auto block = [&](f32x16 (&x)[IT][JT], int b, bool lookup) {
+        if constexpr (TRAIN) dump_rows(x, q.f_xin[b], b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled, tr_rows_left);
         __syncthreads();  // table rows / previous operand images are no longer read
         PNR_T(PH_BAR1);
         write_split<ST>(x, smem, a_wr);
@@ -318,6 +337,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             add_bias<true>(net, bias_lane, 1 + 2 * b);
             gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);  // fc_0
             PNR_T(PH_GEMM_FC0);
+            if constexpr (TRAIN) dump_rows(net, q.f_net[b], b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled, tr_rows_left);
             __syncthreads();
             PNR_T(PH_BAR3);
             write_split<ST>(net, smem, a_wr);
@@ -357,8 +377,14 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             __syncthreads();  // table rows of every wave are in place
             add_from_table<ST>(x, smem, pl, h, wv);                                           // lin_z[0] via table 0
             PNR_T(PH_GEMM_IN_Z0);
+            if constexpr (TRAIN) {
+                tr_rows_pooled = (long long)tile * MT;
+                tr_rows_view = (long long)view * q.P + tr_rows_pooled;
+                tr_rows_left = q.P - tr_rows_pooled;
+            }
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b) block(x, b, b + 1 < COMBINE_LAYER);
+            if constexpr (TRAIN && MV) dump_rows(x, q.f_pool, tr_rows_view, tr_rows_left);
             if constexpr (MV_REGS) {  // fixed summation order view 0 + view 1 + ...: deterministic
                 const float inv = 1.f / (float)NS;
 #pragma unroll
@@ -392,6 +418,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         }
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b) block(x, b, false);
+        if constexpr (TRAIN) dump_rows(x, q.f_x5, tr_rows_pooled, tr_rows_left);
 
         // lin_out(relu(x)): each wave contracts its own 64 features (the wave's accumulators are the B operand)
         {
@@ -800,7 +827,7 @@ static int split_launch(const PnrScene *s, const void *packed, const void *table
     // tile: 64 points.  The 96-point K-half-staged form (eval_split96_kernel) is correct -- bit-identical, tested -- but
     // MEASURED SLOWER (253 vs 298 k rays/s on one box, profiles/r03_split_kernel_ab.txt): it only runs when a test or an
     // experiment forces it (pnr_debug_set_split_tile(96)).
-    const bool t96 = !mv && g_force_split_tile == 96;
+    const bool t96 = !mv && g_force_split_tile == 96 && !q.f_x5;
     const int MT = t96 ? Split96::MT : (mv ? SplitTileT<SPLIT_MV_TILE>::MT : SplitTileT<64>::MT);
     const int lds = t96 ? Split96::LDS_TOTAL : (mv ? SplitTileT<SPLIT_MV_TILE>::LDS_TOTAL : SplitTileT<64>::LDS_TOTAL);
     const long long nt = (q.P + MT - 1) / MT;
@@ -813,6 +840,10 @@ static int split_launch(const PnrScene *s, const void *packed, const void *table
     auto k = mv ? (rays ? eval_split_kernel<true, true> : eval_split_kernel<false, true>)
                 : (rays ? eval_split_kernel<true, false> : eval_split_kernel<false, false>);
     if (t96) k = rays ? eval_split96_kernel<true> : eval_split96_kernel<false>;
+    if (q.f_x5) {  // training forward: the same kernel + fp32 rows of what the backward keeps
+        if (!rays || t96) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: the training instantiation takes ray samples on 64-point tiles");
+        k = mv ? eval_split_kernel<true, true, false, true> : eval_split_kernel<true, false, false, true>;
+    }
     if (q.tim) {  // diagnostic instantiation (pnr_debug_phase_timing_split): single view, rays
         if (mv || !rays) return pnr_fail(PNR_E_INVALID, "phase timing: single-view ray launches only");
         k = t96 ? eval_split96_kernel<true, true> : eval_split_kernel<true, false, true>;
@@ -845,6 +876,23 @@ int pnr::eval_samples_split_src(const PnrScene *scene, const void *packed_split,
     pnr::EvalParams q = {};
     q.rays = src.rays; q.cam = src; q.cam.rays = nullptr;
     q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
+    return pnr::split_launch(scene, packed_split, tables_f32, q, true, stream);
+}
+
+// training forward of the fp32-class path (pnr_f32.hip, pnr_eval_ray_samples_split_train): outputs + the saved fp32 rows
+int pnr::eval_samples_split_train(const PnrScene *scene, const void *packed_split, const void *tables_f32, const float *rays,
+                                  const float *z, int R, int rays_per_obj, int K, float *rgbsigma, float *const *xin, float *const *net,
+                                  float *x5, float *pool_in, hipStream_t stream) {
+    if (!rays || !z || !xin || !net || !x5) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: null argument");
+    if (scene && scene->NS > 1 && !pool_in) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: pool_in is required with several views");
+    if (SPLIT_MV_TILE != 64) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: built with 32-point multi-view tiles");
+    pnr::EvalParams q = {};
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
+    for (int b = 0; b < 5; ++b) {
+        if (!xin[b] || !net[b]) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: null activation buffer");
+        q.f_xin[b] = xin[b]; q.f_net[b] = net[b];
+    }
+    q.f_x5 = x5; q.f_pool = pool_in;
     return pnr::split_launch(scene, packed_split, tables_f32, q, true, stream);
 }
 

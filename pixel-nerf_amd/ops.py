@@ -904,6 +904,28 @@ def eval_ray_samples_f32_train(scene, weights, rays, z, split=False):
     return out, saved
 
 
+def eval_ray_samples_split_train(scene, packed, tables, rays, z):
+    """fp32-class training forward through the FUSED split-operand kernel (pnr_eval_ray_samples_split_train): packed = folded
+    'f16x3' PackedMLP, tables = fold_latent(scene, state, 'f16x3') of the current parameters.  -> (rgbsigma (R,K,4), F32Saved
+    with split=True) -- what eval_ray_samples_f32_train(split=True) returns, from one network launch."""
+    lib = _lib.load()
+    if packed.precision != _lib.PREC_F16X3 or not packed.folded:
+        raise ValueError("eval_ray_samples_split_train takes the folded 'f16x3' stream")
+    if tables is None:
+        raise ValueError("eval_ray_samples_split_train needs the folded lin_z tables (ops.fold_latent)")
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z = _f32(z, "z", (R, None))
+    K = z.shape[1]
+    saved = F32Saved(R * K, scene.NS, rays.device)
+    out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.pnr_eval_ray_samples_split_train(scene.ref, packed.ptr, _p(tables), _p(rays), _p(z), R, max(R // scene.SB, 1), K,
+                                                        _p(out), ctypes.byref(saved.struct), _stream()), "pnr_eval_ray_samples_split_train")
+    saved.split = True
+    return out, saved
+
+
 def mlp_backward_f32(weights, saved, g_out, want_d_in=False):
     """-> ({reference state_dict key: fp32 gradient}, d_zlat (rows_v,512), d_in (rows_v,42) | None) of one ResnetFC: exact fp32
     MFMA products, or the split-operand (fp32-class) form when the forward ran with split=True."""
