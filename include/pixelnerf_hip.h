@@ -73,7 +73,7 @@ int pnr_version(int *major, int *minor);
 /* ABI revision of THIS header: bumped whenever a struct layout or an entry point's argument list changes.  The
  * library returns the value it was compiled with; a binding must compare it with the header it was written against
  * before the first call (pixelnerf_amd/_lib.py does, and refuses a stale or foreign .so). */
-#define PNR_ABI_VERSION 4
+#define PNR_ABI_VERSION 5
 int pnr_abi_version(void);
 int pnr_device_info(int *num_cus, int *lds_bytes_per_block);
 
@@ -452,6 +452,8 @@ typedef struct PnrF32Saved {
     float *net[5];  /* blocks[b].fc_0 output (pre-relu), same shapes                                   */
     float *x5;      /* (rows_p, 512) residual stream in front of lin_out                               */
     float *pool_in; /* (rows_v, 512) residual stream after block 2, in front of the view mean; NS == 1: unused, may be NULL */
+    void *masks;    /* pnr_train_masks_bytes(P, NS) bytes or NULL: 1-bit relu masks, written by pnr_eval_ray_samples_split_train and
+                     * read by pnr_mlp_backward_split (the fused chain); the unfused entries ignore it */
 } PnrF32Saved;
 /* split_gemm = 0: every product on the exact fp32 MFMA (precision "f32": the yardstick).  split_gemm = 1: the same chain with
  * every product formed from (head, tail) fp16 operand pairs -- 3 f16 MFMAs, fp32 accumulate, the arithmetic of
@@ -466,6 +468,13 @@ int pnr_eval_ray_samples_f32_train(const PnrScene *scene /*host*/, const PnrMlpW
 int pnr_eval_ray_samples_split_train(const PnrScene *scene /*host*/, const void *packed_split, const void *tables_f32,
                                      const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
                                      const PnrF32Saved *saved /*host*/, void *stream);
+/* ... and the backward behind it with the data-gradient chain fused as well (one launch for lin_out^T and the ten fc^T
+ * products; dW and the lin_z^T / lin_in^T products on the split-operand GEMM from the chain's fp32 dY rows): same arguments
+ * and results as pnr_mlp_backward_f32(split_gemm = 1); saved->masks must come from pnr_eval_ray_samples_split_train. */
+size_t pnr_mlp_backward_split_workspace_bytes(long long P, int NS);
+int pnr_mlp_backward_split(const PnrMlpWeights *w /*host*/, const PnrF32Saved *saved /*host*/, const float *g_out, long long P,
+                           int NS, const PnrMlpWeights *grads /*host*/, float *d_zlat, float *d_in /*nullable*/,
+                           const float *grad_scale, void *workspace, size_t workspace_bytes, void *stream);
 /* All parameter gradients of one ResnetFC + d(interpolated latent) [+ d(lin_in operand)] from g_out (P,4) =
  * dL/d(lin_out output): `grads` holds device pointers of the 30 gradient tensors in PnrMlpWeights' layout (same shapes as
  * the parameters, overwritten); d_zlat (rows_v,512), d_in (rows_v,42) or NULL. */

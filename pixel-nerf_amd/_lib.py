@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelne
 SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_split.hip", "pnr_bwd.hip", "pnr_f32.hip", "pnr_encode.hip"]
 HEADERS = ["pnr_common.h", "pnr_layout.h", "pnr_device.h", "pnr_raysrc.h", "pnr_internal.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
 
-ABI_VERSION = 4  # PNR_ABI_VERSION of the include/pixelnerf_hip.h this binding (struct layouts, argtypes below) was written against
+ABI_VERSION = 5  # PNR_ABI_VERSION of the include/pixelnerf_hip.h this binding (struct layouts, argtypes below) was written against
 PREC_F16, PREC_BF16, PREC_F32, PREC_F16X3 = 0, 1, 2, 3
 PRECISIONS = {"f16": PREC_F16, "fp16": PREC_F16, "bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -60,7 +60,7 @@ class PnrBackwardDumps(ctypes.Structure):
 
 class PnrF32Saved(ctypes.Structure):
     _fields_ = [("in42", ctypes.c_void_p), ("zlat", ctypes.c_void_p), ("xin", ctypes.c_void_p * 5), ("net", ctypes.c_void_p * 5),
-                ("x5", ctypes.c_void_p), ("pool_in", ctypes.c_void_p)]
+                ("x5", ctypes.c_void_p), ("pool_in", ctypes.c_void_p), ("masks", ctypes.c_void_p)]
 
 
 # every symbol include/pixelnerf_hip.h declares: name -> (restype, argtypes)
@@ -141,6 +141,9 @@ PROTOTYPES = {
     "pnr_mlp_backward_f32_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
     "pnr_mlp_backward_f32": (_I, [ctypes.POINTER(PnrMlpWeights), ctypes.POINTER(PnrF32Saved), _P, ctypes.c_longlong, _I,
                                   ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _P, _P, _SZ, _P]),
+    "pnr_mlp_backward_split_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
+    "pnr_mlp_backward_split": (_I, [ctypes.POINTER(PnrMlpWeights), ctypes.POINTER(PnrF32Saved), _P, ctypes.c_longlong, _I,
+                                    ctypes.POINTER(PnrMlpWeights), _P, _P, _P, _P, _SZ, _P]),
     "pnr_point_features_f32": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _P, _P]),
     "pnr_profile_enable": (_I, [_I]),
     "pnr_profile_read": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),

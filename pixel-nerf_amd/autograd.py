@@ -33,6 +33,8 @@ PARAM_NAMES = _param_names()
 # precision "f16x3": the training forward runs the FUSED split-operand kernel (one launch, lin_z through the folded tables) and
 # keeps its activations as fp32 rows; False = the unfused chain of 29 split-operand GEMMs (same arithmetic class, the A/B twin)
 FUSED_SPLIT_FORWARD = True
+# ... and its data-gradient chain runs fused too (pnr_mlp_backward_split); False = one split-operand GEMM per transposed product
+FUSED_SPLIT_BACKWARD = True
 
 
 def _sigma_noise(rgbs, cfg):
@@ -70,7 +72,7 @@ def _train_eval(net, scene, coarse, rays, z):
 def _pass_grads(net, mlp, dumps, g_out, scene_NS, want_d_in):
     """-> (grads, d_zlat, d_in, releasable) of one pass at the network's precision"""
     if net.precision in ("f32", "f16x3"):
-        grads, d_zlat, d_in = ops.mlp_backward_f32(mlp.packed("f32"), dumps, g_out, want_d_in=want_d_in)
+        grads, d_zlat, d_in = ops.mlp_backward_f32(mlp.packed("f32"), dumps, g_out, want_d_in=want_d_in, fused_chain=FUSED_SPLIT_BACKWARD)
         return grads, d_zlat, d_in, _NoRelease
     return _mlp_grads(None, mlp.packed_bwd(net.precision), dumps, g_out, scene_NS, want_d_in=want_d_in)
 

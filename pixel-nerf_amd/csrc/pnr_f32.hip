@@ -773,7 +773,63 @@ extern "C" int pnr_eval_ray_samples_split_train(const PnrScene *scene, const voi
     int rc = pnr_check_launch("pnr_eval_ray_samples_split_train (features)");
     if (rc != PNR_OK) return rc;
     return eval_samples_split_train(scene, packed_split, tables_f32, rays, z, R, rays_per_obj, K, rgbsigma, saved->xin, saved->net,
-                                    saved->x5, saved->pool_in, (hipStream_t)stream);
+                                    saved->x5, saved->pool_in, saved->masks, (hipStream_t)stream);
+}
+
+// ---- backward behind it with the data-gradient chain FUSED (bwd_split_kernel, pnr_split.hip): 11 of the 15 transposed products
+// of a network leave the GEMM-per-layer form; the weight gradients and the lin_z^T / lin_in^T products run on gemm3_kernel from
+// the chain's fp32 dY rows.  Same results class as pnr_mlp_backward_f32(split_gemm = 1) (tests hold both to the same bars).
+extern "C" size_t pnr_mlp_backward_split_workspace_bytes(long long P, int NS) {
+    if (P <= 0 || NS <= 0) return 0;
+    // dY rows: g_fc1 / g_fc0 of blocks 0-2 and g_x0 at (NS*P, 512), of blocks 3-4 at (P, 512); the transposed (head, tail) streams;
+    // the row-slice partials of one weight gradient
+    return ((size_t)P * NS * 7 + (size_t)P * 4) * pnr::D_HID * sizeof(float) + pnr::bwd_split_packed_bytes() +
+           (size_t)pnr::WG_SPLIT * (pnr::D_HID * pnr::D_HID + pnr::D_HID) * sizeof(float);
+}
+
+extern "C" int pnr_mlp_backward_split(const PnrMlpWeights *w, const PnrF32Saved *sv, const float *g_out, long long P, int NS,
+                                      const PnrMlpWeights *grads, float *d_zlat, float *d_in, const float *grad_scale, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    using namespace pnr;
+    if (!w || !g_out || !grads || !d_zlat || !workspace || !grad_scale || P <= 0 || NS <= 0)
+        return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: bad argument");
+    if (!check_saved(sv, NS) || !sv->masks)
+        return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: PnrF32Saved needs every activation buffer and the relu masks of pnr_eval_ray_samples_split_train");
+    if (workspace_bytes < pnr_mlp_backward_split_workspace_bytes(P, NS)) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: workspace too small");
+    if (P * NS > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: too many points");
+    hipStream_t hs = (hipStream_t)stream;
+    const Mm st = {hs, true, grad_scale, grad_scale + 1};
+    const long long rows = P * NS;
+    float *cur = (float *)workspace;
+    float *g_fc1[5], *g_fc0[5];
+    for (int b = 0; b < 5; ++b) {
+        const size_t n = (size_t)(b < COMBINE_LAYER ? rows : P) * D_HID;
+        g_fc1[b] = cur; cur += n;
+        g_fc0[b] = cur; cur += n;
+    }
+    float *g_x0 = cur; cur += (size_t)rows * D_HID;
+    void *packed = cur; cur = (float *)((char *)cur + bwd_split_packed_bytes());
+    float *part = cur;
+    int rc = pack_bwd_split(w, packed, hs);
+    if (rc != PNR_OK) return rc;
+    rc = mlp_backward_split_chain(packed, (const unsigned long long *)sv->masks, g_out, grad_scale, P, NS, g_fc1, g_fc0, g_x0, hs);
+    if (rc != PNR_OK) return rc;
+    // weight gradients from the chain's dY rows (scaled domain; wgrad multiplies 1/s on the way out)
+    wgrad(st, g_out, D_OUT, sv->x5, D_HID, true, P, D_OUT, D_HID, (float *)grads->lin_out_w, (float *)grads->lin_out_b, part, true);
+    for (int b = N_BLOCKS - 1; b >= 0; --b) {
+        const long long r = b < COMBINE_LAYER ? rows : P;
+        wgrad(st, g_fc1[b], D_HID, sv->net[b], D_HID, true, r, D_HID, D_HID, (float *)grads->fc1_w[b], (float *)grads->fc1_b[b], part);
+        wgrad(st, g_fc0[b], D_HID, sv->xin[b], D_HID, true, r, D_HID, D_HID, (float *)grads->fc0_w[b], (float *)grads->fc0_b[b], part);
+    }
+    // xin[b] = (stream in front) + lin_z[b](zlat): dY of lin_z[b] = gradient of the stream entering block b (resnetfc.py:175-180)
+    for (int b = COMBINE_LAYER - 1; b >= 0; --b) {
+        const float *gz = b == 0 ? g_x0 : g_fc1[b - 1];
+        wgrad(st, gz, D_HID, sv->zlat, C_LAT, false, rows, D_HID, C_LAT, (float *)grads->lin_z_w[b], (float *)grads->lin_z_b[b], part);
+        linear_bwd(st, gz, D_HID, w->lin_z_w[b], C_LAT, D_HID, d_zlat, C_LAT, rows, nullptr, b != COMBINE_LAYER - 1, false, true);
+    }
+    wgrad(st, g_x0, D_HID, sv->in42, D_IN_PAD, false, rows, D_HID, D_IN, (float *)grads->lin_in_w, (float *)grads->lin_in_b, part);
+    if (d_in) linear_bwd(st, g_x0, D_HID, w->lin_in_w, D_IN, D_HID, d_in, D_IN, rows, nullptr, false, false, true);
+    return pnr_check_launch("pnr_mlp_backward_split");
 }
 
 extern "C" size_t pnr_mlp_backward_f32_workspace_bytes(long long P, int NS) {

@@ -59,10 +59,30 @@ __device__ __forceinline__ void ring_advance(SplitRing &R, int NS) {
     R.pf_rs = rs; R.pf_view = v;
 }
 
+// the fp32-class BACKWARD chain (bwd_split_kernel below) walks a transposed stream: pooled head [0, BRS_HEAD_END) once, then
+// the per-view segment [BRS_HEAD_END, BSRS_TOTAL) NS times, then wrap (lin_out^T, fc_1[4]^T fc_0[4]^T fc_1[3]^T fc_0[3]^T |
+// fc_1[2]^T ... fc_0[0]^T: the layout of pnr_layout.h's backward stream without its lin_z^T / lin_in^T tail)
+constexpr int BSRS_TOTAL = bgemm_offset(BG_Z2);  // 324
+static_assert(BSRS_TOTAL % 4 == 0, "ring depth 4 needs aligned segments");
+constexpr size_t BSPACKED_BYTES = (size_t)BSRS_TOTAL * IT * 1024 * NW;  // one blob (head or tail): 5,308,416 B
+struct SplitAdvFwd {
+    static __device__ __forceinline__ void step(SplitRing &R, int NS) { ring_advance(R, NS); }
+};
+struct SplitAdvBwd {
+    static __device__ __forceinline__ void step(SplitRing &R, int NS) {
+        int rs = R.pf_rs + 4, v = R.pf_view;
+        if (rs == BSRS_TOTAL) {
+            if (v + 1 < NS) { v += 1; rs = BRS_HEAD_END; }
+            else { rs = 0; v = 0; }
+        }
+        R.pf_rs = rs; R.pf_view = v;
+    }
+};
+
 __device__ __forceinline__ f32x16 mf(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // acc[it][jt] += (Wh + Wl)(Xh + Xl) without the tail-tail term; B rows at bhi0 + jt*jstride (+ lo_delta for the tails)
-template <int JT>
+template <int JT, typename ADV = SplitAdvFwd>
 __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *smem, uint32_t bhi0, uint32_t jstride,
                                            uint32_t lo_delta, int nbody, SplitRing &R, int NS) {
     h8 bh[2][JT], bl[2][JT];
@@ -146,7 +166,7 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
 #endif
         }
         bhi0 += 128;
-        ring_advance(R, NS);
+        ADV::step(R, NS);
     }
 }
 
@@ -178,8 +198,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo) {
     lo = __builtin_bit_cast(h8, ul);
 }
 
-// relu(acc) -> head / tail images (storage order, like write_act)
-template <typename ST, int JT>
+// [relu](acc) -> head / tail images (storage order, like write_act)
+template <typename ST, bool RELU = true, int JT>
 __device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][JT], char *smem, uint32_t waddr) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
@@ -193,7 +213,7 @@ __device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][JT], char *s
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = a[8 * half + e];
                 h8 hi, lo;
-                split8<true>(v, hi, lo);
+                split8<RELU>(v, hi, lo);
                 *reinterpret_cast<h8 *>(smem + ST::A_HI + ad + 16 * half) = hi;
                 *reinterpret_cast<h8 *>(smem + ST::A_LO + ad + 16 * half) = lo;
             }
@@ -323,9 +343,30 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
     };
     // TRAIN: where the current tile's rows live (set by the tile / view loops; the inference instantiations never touch them)
     [[maybe_unused]] long long tr_rows_view = 0, tr_rows_pooled = 0, tr_rows_left = 0;
+    // TRAIN: relu masks for the fused backward chain, one 64-bit word per thread and layer in the layout of the 16-bit training
+    // kernels (pnr_device.h: bit (it JT + jt) 16 + r = "register r of accumulator tile (it, jt) is positive"; layer 2b = x
+    // entering block b, 2b + 1 = its fc_0 output, 10 = the stream in front of lin_out; [layer][view][tile][thread])
+    [[maybe_unused]] size_t tr_mask_view = 0, tr_mask_pooled = 0;
+    [[maybe_unused]] const size_t tr_mask_layer = (size_t)NS * (size_t)q.ntiles * NTHREADS;
+    [[maybe_unused]] auto put_mask = [&](const f32x16 (&a)[IT][JT], int layer, size_t word) {
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                uint32_t m16 = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m16 |= (a[it][jt][r] > 0.f ? 1u : 0u) << r;
+                m |= (unsigned long long)m16 << ((it * JT + jt) * 16);
+            }
+        (q.d_mask + (size_t)layer * tr_mask_layer)[word] = m;
+    };
     // one residual block on x (resnetfc.py:66-88); lookup: lin_z[b+1] via table b+1 behind it
     auto block = [&](f32x16 (&x)[IT][JT], int b, bool lookup) {
-        if constexpr (TRAIN) dump_rows(x, q.f_xin[b], b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled, tr_rows_left);
+        if constexpr (TRAIN) {
+            dump_rows(x, q.f_xin[b], b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled, tr_rows_left);
+            if (q.d_mask) put_mask(x, 2 * b, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
+        }
         __syncthreads();  // table rows / previous operand images are no longer read
         PNR_T(PH_BAR1);
         write_split<ST>(x, smem, a_wr);
@@ -337,7 +378,10 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             add_bias<true>(net, bias_lane, 1 + 2 * b);
             gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);  // fc_0
             PNR_T(PH_GEMM_FC0);
-            if constexpr (TRAIN) dump_rows(net, q.f_net[b], b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled, tr_rows_left);
+            if constexpr (TRAIN) {
+                dump_rows(net, q.f_net[b], b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled, tr_rows_left);
+                if (q.d_mask) put_mask(net, 2 * b + 1, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
+            }
             __syncthreads();
             PNR_T(PH_BAR3);
             write_split<ST>(net, smem, a_wr);
@@ -381,6 +425,8 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
                 tr_rows_pooled = (long long)tile * MT;
                 tr_rows_view = (long long)view * q.P + tr_rows_pooled;
                 tr_rows_left = q.P - tr_rows_pooled;
+                tr_mask_pooled = (size_t)tile * NTHREADS + tid;
+                tr_mask_view = tr_mask_pooled + (size_t)view * (size_t)q.ntiles * NTHREADS;
             }
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b) block(x, b, b + 1 < COMBINE_LAYER);
@@ -418,7 +464,10 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         }
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b) block(x, b, false);
-        if constexpr (TRAIN) dump_rows(x, q.f_x5, tr_rows_pooled, tr_rows_left);
+        if constexpr (TRAIN) {
+            dump_rows(x, q.f_x5, tr_rows_pooled, tr_rows_left);
+            if (q.d_mask) put_mask(x, 10, tr_mask_pooled);
+        }
 
         // lin_out(relu(x)): each wave contracts its own 64 features (the wave's accumulators are the B operand)
         {
@@ -798,6 +847,232 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split96_kernel(const Ev
     }
 }
 
+// ================================================================ fp32-class backward chain (training), round 3
+// The data-gradient chain of one ResnetFC at split-operand precision, fused like pnr_bwd.hip's bwd_kernel: same tile geometry as
+// the forward (persistent 512-thread workgroup, 64-point tiles, wave w owns features 64w..64w+63), the gradient G of the residual
+// stream resident in fp32 accumulators, a TRANSPOSED (head, tail) weight stream
+//     lin_out^T | fc_1[4]^T fc_0[4]^T fc_1[3]^T fc_0[3]^T | per source view: fc_1[2]^T fc_0[2]^T ... fc_0[0]^T,
+// gradient images as (head, tail) f16 pairs in LDS, relu masks = the TRAIN forward's 1-bit words.  Every layer's output gradient
+// dY leaves as fp32 rows (natural feature order) at the chain's power-of-two scale: the operands of the weight-gradient GEMMs
+// and of the lin_z^T / lin_in^T products, which stay on the split-operand GEMM kernel of pnr_f32.hip.
+// (reference: torch autograd through src/model/resnetfc.py:132-184, resnetfc.py:55-62 per block.)
+
+// one thread = one lane's 8-element fragment slice of the head AND the tail stream (16-byte stores)
+__global__ void pack_weights_bwd_split_kernel(PnrMlpWeights p, _Float16 *__restrict__ out_h, _Float16 *__restrict__ out_l) {
+    const size_t idx8 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx8 >= (size_t)BSRS_TOTAL * IT * 64 * NW) return;
+    const int lane = idx8 & 63;
+    const int it = (idx8 >> 6) % IT;
+    const size_t rest = idx8 / (64 * IT);
+    const int rs = rest % BSRS_TOTAL;
+    const int wv = rest / BSRS_TOTAL;
+    int g = 0;
+    while (g + 1 < BG_Z2 && rs >= bgemm_offset(g + 1)) ++g;
+    const int st = rs - bgemm_offset(g);
+    const int i = lane & 31, h = lane >> 5;
+    const int f_row = wv * SL + it * 32 + i;  // A-operand row = output row of the transposed GEMM = INPUT feature of the layer
+    __attribute__((aligned(16))) _Float16 oh[8], ol[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = 0.f;
+        if (g == BG_OUT) {
+            const int k = st * 16 + h * 8 + e;  // natural order of the 4 network outputs, zero padded
+            if (k < D_OUT) v = p.lin_out_w[k * D_HID + f_row];
+        } else {
+            const int b = 4 - (g - 1) / 2;       // BG_FC1_4, BG_FC0_4, BG_FC1_3, ... -> block index
+            const float *w = ((g - 1) & 1) == 0 ? p.fc1_w[b] : p.fc0_w[b];
+            const int f_o = feat_of(st >> 1, st & 1, 8 * h + e);  // K index = OUTPUT feature, storage order of the gradient image
+            v = w[f_o * D_HID + f_row];
+        }
+        const _Float16 hh = (_Float16)v;
+        oh[e] = hh;
+        ol[e] = (_Float16)(v - (float)hh);
+    }
+    *reinterpret_cast<uint4 *>(out_h + idx8 * 8) = *reinterpret_cast<const uint4 *>(oh);
+    *reinterpret_cast<uint4 *>(out_l + idx8 * 8) = *reinterpret_cast<const uint4 *>(ol);
+}
+
+struct BwdSplitParams {
+    const char *wstream;                 // head blob; the tail blob follows at + BSPACKED_BYTES
+    const unsigned long long *d_mask;    // relu bit masks of the forward, [layer][view][tile][thread]
+    const float *g_out;                  // (P,4) dL/d(lin_out output), unscaled
+    const float *scale_dev;              // device [s, 1/s]: the chain runs at s (pnr_grad_scale)
+    long long P;
+    int NS, ntiles;
+    float *g_fc1[5], *g_fc0[5], *g_x0;   // fp32 dY rows at scale s: b < 3 (NS*P,512) [view][point], else (P,512); g_x0 (NS*P,512)
+    float *mv_ws;                        // several views: per-workgroup scratch for the pooled gradient every view starts from
+};
+
+template <bool MV>
+__global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSplitParams q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef SplitTileT<64> ST;
+    constexpr int JT = ST::JT, MT = ST::MT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+    const int NS = MV ? q.NS : 1;
+    const uint32_t a_rd0 = ST::A_HI + pl * ROW_ACT + h * 16;
+    const uint32_t in_rd0 = ST::LDS_IN + pl * ROW_IN + h * 16;
+    const uint32_t a_wr = pl * ROW_ACT + (wv * IT) * 64 + h * 32;
+    f16_ovfl_mode<PH>();
+    SplitRing R;
+    R.base_h = q.wstream + (size_t)wv * (BSRS_TOTAL * IT * 1024) + lane * 16;
+    R.base_l = R.base_h + BSPACKED_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            R.h[j][it] = gload8<PH>(R.base_h + j * (IT * 1024) + it * 1024);
+            R.l[j][it] = gload8<PH>(R.base_l + j * (IT * 1024) + it * 1024);
+        }
+    R.pf_rs = 4;
+    R.pf_view = 0;
+    const float scale = q.scale_dev[0];
+    const size_t mask_layer = (size_t)NS * (size_t)q.ntiles * NTHREADS;
+
+    auto zero = [&](f32x16 (&a)[IT][JT]) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[it][jt][r] = 0.f;
+    };
+    // acc = bit ? acc : 0   /   G += bit ? t : 0
+    auto apply_mask = [&](f32x16 (&a)[IT][JT], unsigned long long mk) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const uint32_t m16 = (uint32_t)(mk >> ((it * JT + jt) * 16)) & 0xffffu;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[it][jt][r] = (m16 >> r) & 1u ? a[it][jt][r] : 0.f;
+            }
+    };
+    auto masked_add = [&](f32x16 (&G)[IT][JT], const f32x16 (&t)[IT][JT], unsigned long long mk) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const uint32_t m16 = (uint32_t)(mk >> ((it * JT + jt) * 16)) & 0xffffu;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) G[it][jt][r] += (m16 >> r) & 1u ? t[it][jt][r] : 0.f;
+            }
+    };
+    long long rows_left = 0;
+    auto dump_rows = [&](const f32x16 (&a)[IT][JT], float *dst, long long rows) {
+        float *d = dst + ((size_t)rows + pl) * D_HID + (wv * IT) * 32 + 4 * h;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            if (jt * 32 + pl >= rows_left) continue;
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 v = {a[it][jt][4 * k], a[it][jt][4 * k + 1], a[it][jt][4 * k + 2], a[it][jt][4 * k + 3]};
+                    *reinterpret_cast<f32x4 *>(d + (size_t)jt * 32 * D_HID + it * 32 + 8 * k) = v;
+                }
+        }
+    };
+    // reverse of one residual block (resnetfc.py:55-62):  given G = dL/d(x + fc_1(relu(fc_0(relu(x))))),
+    //   dY(fc_1) = G ;  d net = (fc_1^T G) . [net > 0] = dY(fc_0) ;  G += (fc_0^T d net) . [x > 0]
+    auto bwd_block = [&](f32x16 (&G)[IT][JT], int b, long long rows, size_t mask_off) {
+        dump_rows(G, q.g_fc1[b], rows);
+        __syncthreads();  // every wave is done reading the gradient image (previous GEMM)
+        write_split<ST, false>(G, smem, a_wr);
+        __syncthreads();
+        f32x16 t[IT][JT];
+        const unsigned long long mk_n = (q.d_mask + (size_t)(2 * b + 1) * mask_layer)[mask_off];
+        zero(t);
+        gemm_split<JT, SplitAdvBwd>(t, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
+        apply_mask(t, mk_n);
+        dump_rows(t, q.g_fc0[b], rows);
+        __syncthreads();
+        write_split<ST, false>(t, smem, a_wr);
+        __syncthreads();
+        const unsigned long long mk_a = (q.d_mask + (size_t)(2 * b) * mask_layer)[mask_off];
+        zero(t);
+        gemm_split<JT, SplitAdvBwd>(t, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
+        masked_add(G, t, mk_a);
+    };
+
+    for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
+        rows_left = q.P - (long long)tile * MT;
+        const long long rows_pooled = (long long)tile * MT;
+        const size_t mask_pooled = (size_t)tile * NTHREADS + tid;
+        __syncthreads();  // previous tile: readers of the staging rows / gradient image are done
+        {   // stage s * g_out as (head, tail) operand rows [point][64] (4 real values, zero padded)
+            const int row = tid >> 3, chunk = tid & 7;
+            const long long g = rows_pooled + row;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (chunk == 0 && g < q.P) {
+                const f32x4 gv = *reinterpret_cast<const f32x4 *>(q.g_out + g * 4) * scale;
+                v[0] = gv[0]; v[1] = gv[1]; v[2] = gv[2]; v[3] = gv[3];
+            }
+            h8 hi, lo;
+            split8<false>(v, hi, lo);
+            *reinterpret_cast<h8 *>(smem + ST::LDS_IN + row * ROW_IN + chunk * 16) = hi;
+            *reinterpret_cast<h8 *>(smem + ST::LDS_IN + ST::IN_LO_DELTA + row * ROW_IN + chunk * 16) = lo;
+        }
+        __syncthreads();
+        f32x16 G[IT][JT];
+        {
+            const unsigned long long mk = (q.d_mask + (size_t)10 * mask_layer)[mask_pooled];
+            zero(G);
+            gemm_split<JT, SplitAdvBwd>(G, smem, in_rd0, 32 * ROW_IN, ST::IN_LO_DELTA, KS_IN / 4, R, NS);  // lin_out^T g_out
+            apply_mask(G, mk);                                                                             // . [x5 > 0]
+        }
+#pragma unroll 1
+        for (int b = N_BLOCKS - 1; b >= COMBINE_LAYER; --b) bwd_block(G, b, rows_pooled, mask_pooled);
+        // backward of the view mean (util.py:461-466): every view starts from G / NS, parked in the per-workgroup scratch
+        [[maybe_unused]] f32x4 *gws = MV ? reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid : nullptr;
+        if constexpr (MV) {
+            const float inv = 1.f / (float)NS;
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 v = {G[it][jt][4 * k], G[it][jt][4 * k + 1], G[it][jt][4 * k + 2], G[it][jt][4 * k + 3]};
+                        gws[((it * JT + jt) * 4 + k) * NTHREADS] = v * inv;
+                    }
+        }
+#pragma unroll 1
+        for (int view = 0; view < NS; ++view) {
+            if constexpr (MV) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f32x4 v = gws[((it * JT + jt) * 4 + k) * NTHREADS];
+                            G[it][jt][4 * k] = v[0]; G[it][jt][4 * k + 1] = v[1]; G[it][jt][4 * k + 2] = v[2]; G[it][jt][4 * k + 3] = v[3];
+                        }
+            }
+            const long long rows_view = (long long)view * q.P + rows_pooled;
+            const size_t mask_view = mask_pooled + (size_t)view * (size_t)q.ntiles * NTHREADS;
+#pragma unroll 1
+            for (int b = COMBINE_LAYER - 1; b >= 0; --b) bwd_block(G, b, rows_view, mask_view);
+            dump_rows(G, q.g_x0, rows_view);  // dY of lin_in and lin_z[0]
+        }
+    }
+}
+
+static int bwd_split_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, c = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c = prop.multiProcessorCount;
+        n = c;
+    }
+    return n;
+}
+
 static int g_force_split_tile = 0;  // test hook (pnr_debug_set_split_tile): 0 = automatic, 64 / 96 = forced
 
 
@@ -857,6 +1132,45 @@ static int split_launch(const PnrScene *s, const void *packed, const void *table
     return pnr_check_launch("eval_split_kernel");
 }
 
+size_t bwd_split_packed_bytes() { return 2 * BSPACKED_BYTES; }
+
+int pack_bwd_split(const PnrMlpWeights *w, void *packed, hipStream_t st) {
+    if (!w || !packed) return pnr_fail(PNR_E_INVALID, "pack_bwd_split: null argument");
+    const size_t n8 = (size_t)BSRS_TOTAL * IT * 64 * NW;
+    hipLaunchKernelGGL(pack_weights_bwd_split_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, *w, (_Float16 *)packed,
+                       (_Float16 *)((char *)packed + BSPACKED_BYTES));
+    return pnr_check_launch("pack_weights_bwd_split_kernel");
+}
+
+int mlp_backward_split_chain(const void *packed_bwd_split, const unsigned long long *masks, const float *g_out, const float *scale_dev,
+                             long long P, int NS, float *const *g_fc1, float *const *g_fc0, float *g_x0, hipStream_t st) {
+    if (!packed_bwd_split || !masks || !g_out || !scale_dev || !g_fc1 || !g_fc0 || !g_x0 || P <= 0 || NS <= 0)
+        return pnr_fail(PNR_E_INVALID, "mlp_backward_split_chain: bad argument");
+    BwdSplitParams q = {};
+    q.wstream = (const char *)packed_bwd_split; q.d_mask = masks; q.g_out = g_out; q.scale_dev = scale_dev; q.P = P; q.NS = NS;
+    const long long nt = (P + 63) / 64;
+    if (nt * NTHREADS * NS > 0xffffffffLL) return pnr_fail(PNR_E_INVALID, "mlp_backward_split_chain: too many points");
+    q.ntiles = (int)nt;
+    for (int b = 0; b < 5; ++b) {
+        if (!g_fc1[b] || !g_fc0[b]) return pnr_fail(PNR_E_INVALID, "mlp_backward_split_chain: null gradient buffer");
+        q.g_fc1[b] = g_fc1[b]; q.g_fc0[b] = g_fc0[b];
+    }
+    q.g_x0 = g_x0;
+    const int cus = bwd_split_cus();
+    const int grid = (int)(nt < cus ? nt : cus);
+    const bool mv = NS > 1;
+    if (mv) {
+        q.mv_ws = mv_scratch(st, (size_t)cus * 64 * D_HID * sizeof(float));
+        if (!q.mv_ws) return pnr_fail(PNR_E_HIP, "mlp_backward_split_chain: cannot allocate the multi-view scratch");
+    }
+    auto k = mv ? bwd_split_kernel<true> : bwd_split_kernel<false>;
+    const int lds = SplitTileT<64>::LDS_TOTAL;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(bwd_split_kernel)");
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, q);
+    return pnr_check_launch("bwd_split_kernel");
+}
+
 }  // namespace pnr
 
 // test hook (not in the public header): force the single-view tile of the split-operand kernel (0 = automatic, 64, 96)
@@ -882,7 +1196,7 @@ int pnr::eval_samples_split_src(const PnrScene *scene, const void *packed_split,
 // training forward of the fp32-class path (pnr_f32.hip, pnr_eval_ray_samples_split_train): outputs + the saved fp32 rows
 int pnr::eval_samples_split_train(const PnrScene *scene, const void *packed_split, const void *tables_f32, const float *rays,
                                   const float *z, int R, int rays_per_obj, int K, float *rgbsigma, float *const *xin, float *const *net,
-                                  float *x5, float *pool_in, hipStream_t stream) {
+                                  float *x5, float *pool_in, void *masks, hipStream_t stream) {
     if (!rays || !z || !xin || !net || !x5) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: null argument");
     if (scene && scene->NS > 1 && !pool_in) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: pool_in is required with several views");
     if (SPLIT_MV_TILE != 64) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: built with 32-point multi-view tiles");
@@ -893,6 +1207,7 @@ int pnr::eval_samples_split_train(const PnrScene *scene, const void *packed_spli
         q.f_xin[b] = xin[b]; q.f_net[b] = net[b];
     }
     q.f_x5 = x5; q.f_pool = pool_in;
+    q.d_mask = (unsigned long long *)masks;
     return pnr::split_launch(scene, packed_split, tables_f32, q, true, stream);
 }
 

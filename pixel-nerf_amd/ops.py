@@ -875,12 +875,19 @@ class F32Saved:
         self.net = [f(rv if b < 3 else rp, 512) for b in range(5)]
         self.x5 = f(rp, 512)
         self.pool_in = f(rv, 512) if NS > 1 else None
+        self.masks = None  # relu bit masks: only the fused split-operand forward writes them (with_masks())
         s = _lib.PnrF32Saved()
         s.in42, s.zlat, s.x5 = self.in42.data_ptr(), self.zlat.data_ptr(), self.x5.data_ptr()
         s.pool_in = self.pool_in.data_ptr() if self.pool_in is not None else None
         for b in range(5):
             s.xin[b], s.net[b] = self.xin[b].data_ptr(), self.net[b].data_ptr()
         self.struct = s
+
+    def with_masks(self):
+        if self.masks is None:
+            self.masks = torch.empty(_lib.load().pnr_train_masks_bytes(self.P, self.NS), dtype=torch.uint8, device=self.x5.device)
+            self.struct.masks = self.masks.data_ptr()
+        return self
 
     def release(self):  # interface twin of TrainDumps.release (the fp32 sets are not pooled)
         pass
@@ -917,7 +924,7 @@ def eval_ray_samples_split_train(scene, packed, tables, rays, z):
     R = rays.shape[0]
     z = _f32(z, "z", (R, None))
     K = z.shape[1]
-    saved = F32Saved(R * K, scene.NS, rays.device)
+    saved = F32Saved(R * K, scene.NS, rays.device).with_masks()
     out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
     with torch.cuda.device(rays.device):
         _lib.check(lib.pnr_eval_ray_samples_split_train(scene.ref, packed.ptr, _p(tables), _p(rays), _p(z), R, max(R // scene.SB, 1), K,
@@ -926,9 +933,10 @@ def eval_ray_samples_split_train(scene, packed, tables, rays, z):
     return out, saved
 
 
-def mlp_backward_f32(weights, saved, g_out, want_d_in=False):
+def mlp_backward_f32(weights, saved, g_out, want_d_in=False, fused_chain=True):
     """-> ({reference state_dict key: fp32 gradient}, d_zlat (rows_v,512), d_in (rows_v,42) | None) of one ResnetFC: exact fp32
-    MFMA products, or the split-operand (fp32-class) form when the forward ran with split=True."""
+    MFMA products, or the split-operand (fp32-class) form when the forward ran with split=True -- with the data-gradient chain
+    fused (pnr_mlp_backward_split) when the forward left its relu masks (eval_ray_samples_split_train) and fused_chain is set."""
     lib = _lib.load()
     P, NS = saved.P, saved.NS
     g_out = _f32(g_out, "g_out", (P, 4))
@@ -938,10 +946,17 @@ def mlp_backward_f32(weights, saved, g_out, want_d_in=False):
     gstruct, _keep = _weights_struct(grads)
     d_zlat = torch.empty((NS * P, 512), dtype=torch.float32, device=dev)
     d_in = torch.empty((NS * P, 42), dtype=torch.float32, device=dev) if want_d_in else None
-    nbytes = lib.pnr_mlp_backward_f32_workspace_bytes(P, NS)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     split = bool(getattr(saved, "split", False))
     sc = grad_scale(g_out) if split else None  # device [s, 1/s]: no host synchronisation
+    if split and fused_chain and saved.masks is not None:
+        nbytes = lib.pnr_mlp_backward_split_workspace_bytes(P, NS)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.pnr_mlp_backward_split(weights.wref, ctypes.byref(saved.struct), _p(g_out), P, NS, ctypes.byref(gstruct),
+                                                  _p(d_zlat), _p(d_in), _p(sc), _p(ws), nbytes, _stream()), "pnr_mlp_backward_split")
+        return grads, d_zlat, d_in
+    nbytes = lib.pnr_mlp_backward_f32_workspace_bytes(P, NS)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.pnr_mlp_backward_f32(weights.wref, ctypes.byref(saved.struct), _p(g_out), P, NS, ctypes.byref(gstruct),
                                             _p(d_zlat), _p(d_in), int(split), _p(sc), _p(ws), nbytes, _stream()), "pnr_mlp_backward_f32")
