@@ -776,9 +776,9 @@ extern "C" int pnr_eval_ray_samples_split_train(const PnrScene *scene, const voi
                                     saved->x5, saved->pool_in, saved->masks, (hipStream_t)stream);
 }
 
-// ---- backward behind it with the data-gradient chain FUSED (bwd_split_kernel, pnr_split.hip): 11 of the 15 transposed products
-// of a network leave the GEMM-per-layer form; the weight gradients and the lin_z^T / lin_in^T products run on gemm3_kernel from
-// the chain's fp32 dY rows.  Same results class as pnr_mlp_backward_f32(split_gemm = 1) (tests hold both to the same bars).
+// ---- backward behind it with the data-gradient chain FUSED (bwd_split_kernel, pnr_split.hip): all 15 transposed products of a
+// network -- lin_out^T, ten fc^T, lin_z[2..0]^T, lin_in^T -- in one launch; the weight gradients run on gemm3_kernel from the
+// chain's fp32 dY rows.  Same results class as pnr_mlp_backward_f32(split_gemm = 1) (tests hold both to the same bars).
 extern "C" size_t pnr_mlp_backward_split_workspace_bytes(long long P, int NS) {
     if (P <= 0 || NS <= 0) return 0;
     // dY rows: g_fc1 / g_fc0 of blocks 0-2 and g_x0 at (NS*P, 512), of blocks 3-4 at (P, 512); the transposed (head, tail) streams;
@@ -812,7 +812,7 @@ extern "C" int pnr_mlp_backward_split(const PnrMlpWeights *w, const PnrF32Saved 
     float *part = cur;
     int rc = pack_bwd_split(w, packed, hs);
     if (rc != PNR_OK) return rc;
-    rc = mlp_backward_split_chain(packed, (const unsigned long long *)sv->masks, g_out, grad_scale, P, NS, g_fc1, g_fc0, g_x0, hs);
+    rc = mlp_backward_split_chain(packed, (const unsigned long long *)sv->masks, g_out, grad_scale, P, NS, g_fc1, g_fc0, g_x0, d_zlat, d_in, hs);
     if (rc != PNR_OK) return rc;
     // weight gradients from the chain's dY rows (scaled domain; wgrad multiplies 1/s on the way out)
     wgrad(st, g_out, D_OUT, sv->x5, D_HID, true, P, D_OUT, D_HID, (float *)grads->lin_out_w, (float *)grads->lin_out_b, part, true);
@@ -825,10 +825,8 @@ extern "C" int pnr_mlp_backward_split(const PnrMlpWeights *w, const PnrF32Saved 
     for (int b = COMBINE_LAYER - 1; b >= 0; --b) {
         const float *gz = b == 0 ? g_x0 : g_fc1[b - 1];
         wgrad(st, gz, D_HID, sv->zlat, C_LAT, false, rows, D_HID, C_LAT, (float *)grads->lin_z_w[b], (float *)grads->lin_z_b[b], part);
-        linear_bwd(st, gz, D_HID, w->lin_z_w[b], C_LAT, D_HID, d_zlat, C_LAT, rows, nullptr, b != COMBINE_LAYER - 1, false, true);
     }
     wgrad(st, g_x0, D_HID, sv->in42, D_IN_PAD, false, rows, D_HID, D_IN, (float *)grads->lin_in_w, (float *)grads->lin_in_b, part);
-    if (d_in) linear_bwd(st, g_x0, D_HID, w->lin_in_w, D_IN, D_HID, d_in, D_IN, rows, nullptr, false, false, true);
     return pnr_check_launch("pnr_mlp_backward_split");
 }
 

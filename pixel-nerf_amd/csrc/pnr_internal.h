@@ -25,11 +25,13 @@ int eval_samples_split_train(const PnrScene *scene, const void *packed_split, co
 // fused data-gradient chain of the fp32-class training path (bwd_split_kernel, pnr_split.hip): transposed (head, tail) weight
 // streams packed from the raw parameters, relu masks of the TRAIN forward, g_out (P,4) unscaled + device [s, 1/s]; every layer's
 // output gradient leaves as fp32 rows at scale s (g_fc1[b] = dY of blocks[b].fc_1 = gradient of the stream behind block b,
-// g_fc0[b] = dY of blocks[b].fc_0, g_x0 = gradient of the stream entering block 0; b < 3 and g_x0: [view][point] rows).
+// g_fc0[b] = dY of blocks[b].fc_0, g_x0 = gradient of the stream entering block 0; b < 3 and g_x0: [view][point] rows);
+// d z_lat = sum_b dY_b W_z[b] and d(code) = dY_0 W_in come out of the same launch.
 size_t bwd_split_packed_bytes();
 int pack_bwd_split(const PnrMlpWeights *w, void *packed, hipStream_t st);
 int mlp_backward_split_chain(const void *packed_bwd_split, const unsigned long long *masks, const float *g_out, const float *scale_dev,
-                             long long P, int NS, float *const *g_fc1, float *const *g_fc0, float *g_x0, hipStream_t st);
+                             long long P, int NS, float *const *g_fc1, float *const *g_fc0, float *g_x0, float *d_zlat /* (NS*P,512) unscaled */,
+                             float *d_in /* (NS*P,42) unscaled, nullable */, hipStream_t st);
 
 // per (device, stream) scratch for the parked view sum of multi-view launches (one tile of fp32 accumulators per workgroup),
 // allocated at the first multi-view launch on a stream and kept; NULL on allocation failure.  Defined in pnr_mlp.hip.

@@ -59,10 +59,10 @@ __device__ __forceinline__ void ring_advance(SplitRing &R, int NS) {
     R.pf_rs = rs; R.pf_view = v;
 }
 
-// the fp32-class BACKWARD chain (bwd_split_kernel below) walks a transposed stream: pooled head [0, BRS_HEAD_END) once, then
-// the per-view segment [BRS_HEAD_END, BSRS_TOTAL) NS times, then wrap (lin_out^T, fc_1[4]^T fc_0[4]^T fc_1[3]^T fc_0[3]^T |
-// fc_1[2]^T ... fc_0[0]^T: the layout of pnr_layout.h's backward stream without its lin_z^T / lin_in^T tail)
-constexpr int BSRS_TOTAL = bgemm_offset(BG_Z2);  // 324
+// the fp32-class BACKWARD chain (bwd_split_kernel below) walks a transposed stream in the layout of pnr_layout.h's backward
+// stream: pooled head [0, BRS_HEAD_END) once, then the per-view segment [BRS_HEAD_END, BSRS_TOTAL) NS times, then wrap
+// (lin_out^T, fc_1[4]^T fc_0[4]^T fc_1[3]^T fc_0[3]^T | fc_1[2]^T ... fc_0[0]^T, lin_z[2]^T lin_z[1]^T lin_z[0]^T, lin_in^T)
+constexpr int BSRS_TOTAL = BRS_TOTAL;  // 424
 static_assert(BSRS_TOTAL % 4 == 0, "ring depth 4 needs aligned segments");
 constexpr size_t BSPACKED_BYTES = (size_t)BSRS_TOTAL * IT * 1024 * NW;  // one blob (head or tail): 5,308,416 B
 struct SplitAdvFwd {
@@ -867,7 +867,7 @@ __global__ void pack_weights_bwd_split_kernel(PnrMlpWeights p, _Float16 *__restr
     const int rs = rest % BSRS_TOTAL;
     const int wv = rest / BSRS_TOTAL;
     int g = 0;
-    while (g + 1 < BG_Z2 && rs >= bgemm_offset(g + 1)) ++g;
+    while (g + 1 < NBGEMM && rs >= bgemm_offset(g + 1)) ++g;
     const int st = rs - bgemm_offset(g);
     const int i = lane & 31, h = lane >> 5;
     const int f_row = wv * SL + it * 32 + i;  // A-operand row = output row of the transposed GEMM = INPUT feature of the layer
@@ -875,7 +875,19 @@ __global__ void pack_weights_bwd_split_kernel(PnrMlpWeights p, _Float16 *__restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float v = 0.f;
-        if (g == BG_OUT) {
+        if (g == BG_Z2 || g == BG_Z1 || g == BG_Z0) {
+            // d z_lat[c] += sum_f dY_b[f] W_z[b][f][c]: rows = latent channel c (natural order, wave w owns 64w..64w+63),
+            // K = hidden feature f in the storage order of the gradient image
+            const int b = g == BG_Z2 ? 2 : (g == BG_Z1 ? 1 : 0);
+            const int f_o = feat_of(st >> 1, st & 1, 8 * h + e);
+            v = p.lin_z_w[b][f_o * C_LAT + f_row];
+        } else if (g == BG_IN) {
+            // d(code | viewdir)[k] = sum_f dY[f] W_in[f][k]: every wave holds the FULL 64 (42 real) output rows and contracts
+            // only its own 64 hidden features = storage elements 64w + 16s + 8h + e (K-split, reduced across waves in LDS)
+            const int k_row = it * 32 + i;
+            const int f_o = feat_of(wv * IT + (st >> 1), st & 1, 8 * h + e);
+            if (k_row < D_IN) v = p.lin_in_w[f_o * D_IN + k_row];
+        } else if (g == BG_OUT) {
             const int k = st * 16 + h * 8 + e;  // natural order of the 4 network outputs, zero padded
             if (k < D_OUT) v = p.lin_out_w[k * D_HID + f_row];
         } else {
@@ -900,6 +912,8 @@ struct BwdSplitParams {
     long long P;
     int NS, ntiles;
     float *g_fc1[5], *g_fc0[5], *g_x0;   // fp32 dY rows at scale s: b < 3 (NS*P,512) [view][point], else (P,512); g_x0 (NS*P,512)
+    float *d_zlat;                       // (NS*P, 512) fp32, natural channel order, UNSCALED: d(interpolated latent) = sum_b dY_b W_z[b]
+    float *d_in;                         // (NS*P, 42) fp32, unscaled: d(positional code | view direction)   (nullable: not written)
     float *mv_ws;                        // several views: per-workgroup scratch for the pooled gradient every view starts from
 };
 
@@ -929,7 +943,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
         }
     R.pf_rs = 4;
     R.pf_view = 0;
-    const float scale = q.scale_dev[0];
+    const float scale = q.scale_dev[0], inv_scale = q.scale_dev[1];
     const size_t mask_layer = (size_t)NS * (size_t)q.ntiles * NTHREADS;
 
     auto zero = [&](f32x16 (&a)[IT][JT]) {
@@ -1058,6 +1072,86 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
 #pragma unroll 1
             for (int b = COMBINE_LAYER - 1; b >= 0; --b) bwd_block(G, b, rows_view, mask_view);
             dump_rows(G, q.g_x0, rows_view);  // dY of lin_in and lin_z[0]
+            // ---- d z_lat = sum_b dY_b W_z[b] and d(code) = dY_0 W_in (resnetfc.py:147,175-180 backward): four more transposed-
+            // stream GEMMs on gradients this tile has just produced.  dY_2, dY_1 (= g_fc1[1], g_fc1[0]) come back from their fp32
+            // rows (written by this workgroup a moment ago, L2-resident) and are split into the image in storage order; dY_0 = G
+            // is still in registers.
+            f32x16 Z[IT][JT];
+            zero(Z);
+#pragma unroll 1
+            for (int b = COMBINE_LAYER - 1; b >= 1; --b) {
+                __threadfence_block();
+                __syncthreads();  // the image's readers are done; the rows this tile dumped are visible
+                {
+                    const float *src = q.g_fc1[b - 1] + (size_t)rows_view * D_HID;
+#pragma unroll
+                    for (int u = 0; u < MT * (D_HID / 4) / NTHREADS; ++u) {
+                        const int k = u * NTHREADS + tid, row = k >> 7, f = (k & 127) * 4;  // 4 consecutive features of a row
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        if (row < rows_left) v = *reinterpret_cast<const f32x4 *>(src + (size_t)row * D_HID + f);
+                        // storage slot of feature f (f & 3 == 0): 32 T + 16 h + 4 k'  for f = 32 T + 8 k' + 4 h
+                        const int slot = (f & ~31) + 16 * ((f >> 2) & 1) + 4 * ((f & 31) >> 3);
+                        const f16x2 h01 = __builtin_convertvector(f32x2{v[0], v[1]}, f16x2), h23 = __builtin_convertvector(f32x2{v[2], v[3]}, f16x2);
+                        const f32x2 b01 = __builtin_convertvector(h01, f32x2), b23 = __builtin_convertvector(h23, f32x2);
+                        const f16x2 l01 = __builtin_convertvector(f32x2{v[0] - b01[0], v[1] - b01[1]}, f16x2),
+                                    l23 = __builtin_convertvector(f32x2{v[2] - b23[0], v[3] - b23[1]}, f16x2);
+                        const uint2 hi = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+                        const uint2 lo = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
+                        *reinterpret_cast<uint2 *>(smem + ST::A_HI + row * ROW_ACT + slot * 2) = hi;
+                        *reinterpret_cast<uint2 *>(smem + ST::A_LO + row * ROW_ACT + slot * 2) = lo;
+                    }
+                }
+                __syncthreads();
+                gemm_split<JT, SplitAdvBwd>(Z, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);  // lin_z[b]^T dY_b
+            }
+            __syncthreads();
+            write_split<ST, false>(G, smem, a_wr);  // dY of lin_in and lin_z[0]
+            __syncthreads();
+            gemm_split<JT, SplitAdvBwd>(Z, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);      // lin_z[0]^T dY_0
+            {   // accumulator (channel 64 wv + 32 it + (r&3) + 8(r>>2) + 4h, point) -> fp32 rows, 16-byte pieces, out of the scaled domain
+                float *dst = q.d_zlat + ((size_t)rows_view + pl) * C_LAT + (wv * IT) * 32 + 4 * h;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    if (jt * 32 + pl >= rows_left) continue;
+#pragma unroll
+                    for (int it = 0; it < IT; ++it)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f32x4 v = {Z[it][jt][4 * k], Z[it][jt][4 * k + 1], Z[it][jt][4 * k + 2], Z[it][jt][4 * k + 3]};
+                            *reinterpret_cast<f32x4 *>(dst + (size_t)jt * 32 * C_LAT + it * 32 + 8 * k) = v * inv_scale;
+                        }
+                }
+            }
+            // lin_in^T, K-split: this wave's 64 hidden features = bytes [128 wv, 128 wv + 128) of every image row
+            zero(Z);
+            gemm_split<JT, SplitAdvBwd>(Z, smem, a_rd0 + wv * 128, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_IN / 4, R, NS);
+            __syncthreads();  // every wave is done with the images: their space takes the partials
+            {
+                // partial[w][point][k], 66-float rows: lanes of a half-wave write consecutive points -> distinct banks
+                float *part = reinterpret_cast<float *>(smem) + (size_t)wv * (MT * 66);
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            part[(jt * 32 + pl) * 66 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = Z[it][jt][r];
+            }
+            __syncthreads();
+            if (q.d_in) {
+                const int pnt = tid >> 3, k0 = (tid & 7) * 8;
+                if (pnt < rows_left) {
+#pragma unroll
+                    for (int k = k0; k < k0 + 8; ++k) {
+                        if (k >= D_IN) break;
+                        float sum = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) sum += reinterpret_cast<const float *>(smem)[(size_t)w * (MT * 66) + pnt * 66 + k];
+                        q.d_in[((size_t)rows_view + pnt) * D_IN + k] = sum * inv_scale;
+                    }
+                }
+            }
+            __syncthreads();  // the partials are consumed before the next view / tile reuses the space
         }
     }
 }
@@ -1143,8 +1237,9 @@ int pack_bwd_split(const PnrMlpWeights *w, void *packed, hipStream_t st) {
 }
 
 int mlp_backward_split_chain(const void *packed_bwd_split, const unsigned long long *masks, const float *g_out, const float *scale_dev,
-                             long long P, int NS, float *const *g_fc1, float *const *g_fc0, float *g_x0, hipStream_t st) {
-    if (!packed_bwd_split || !masks || !g_out || !scale_dev || !g_fc1 || !g_fc0 || !g_x0 || P <= 0 || NS <= 0)
+                             long long P, int NS, float *const *g_fc1, float *const *g_fc0, float *g_x0, float *d_zlat, float *d_in,
+                             hipStream_t st) {
+    if (!packed_bwd_split || !masks || !g_out || !scale_dev || !g_fc1 || !g_fc0 || !g_x0 || !d_zlat || P <= 0 || NS <= 0)
         return pnr_fail(PNR_E_INVALID, "mlp_backward_split_chain: bad argument");
     BwdSplitParams q = {};
     q.wstream = (const char *)packed_bwd_split; q.d_mask = masks; q.g_out = g_out; q.scale_dev = scale_dev; q.P = P; q.NS = NS;
@@ -1155,7 +1250,7 @@ int mlp_backward_split_chain(const void *packed_bwd_split, const unsigned long l
         if (!g_fc1[b] || !g_fc0[b]) return pnr_fail(PNR_E_INVALID, "mlp_backward_split_chain: null gradient buffer");
         q.g_fc1[b] = g_fc1[b]; q.g_fc0[b] = g_fc0[b];
     }
-    q.g_x0 = g_x0;
+    q.g_x0 = g_x0; q.d_zlat = d_zlat; q.d_in = d_in;
     const int cus = bwd_split_cus();
     const int grid = (int)(nt < cus ? nt : cus);
     const bool mv = NS > 1;
