@@ -298,7 +298,9 @@ int pnr_weight_grad(const void *dY, const void *X, long long rows, int precision
 
 /* The same for up to 16 linears in ONE launch pair (all 13 512x512 layers of a ResnetFC): fewer, fuller
  * launches and 4-8x fewer split slices to reduce.  jobs: host array.
- * workspace: pnr_weight_grad_batched_workspace_bytes(n_jobs, largest rows of the jobs). */
+ * workspace: pnr_weight_grad_batched_workspace_bytes(n_jobs, largest rows of the jobs).
+ * precision PNR_PREC_F16X3: dY and X are (head | tail) f16 row sets (the tail array behind the head array), three MFMAs per
+ * product -- the fused fp32-class training path. */
 typedef struct PnrWeightGradJob {
     const void *dY, *X;          /* (rows,512) 16-bit row-major dumps                  */
     long long rows;
@@ -452,8 +454,6 @@ typedef struct PnrF32Saved {
     float *net[5];  /* blocks[b].fc_0 output (pre-relu), same shapes                                   */
     float *x5;      /* (rows_p, 512) residual stream in front of lin_out                               */
     float *pool_in; /* (rows_v, 512) residual stream after block 2, in front of the view mean; NS == 1: unused, may be NULL */
-    void *masks;    /* pnr_train_masks_bytes(P, NS) bytes or NULL: 1-bit relu masks, written by pnr_eval_ray_samples_split_train and
-                     * read by pnr_mlp_backward_split (the fused chain); the unfused entries ignore it */
 } PnrF32Saved;
 /* split_gemm = 0: every product on the exact fp32 MFMA (precision "f32": the yardstick).  split_gemm = 1: the same chain with
  * every product formed from (head, tail) fp16 operand pairs -- 3 f16 MFMAs, fp32 accumulate, the arithmetic of
@@ -461,18 +461,30 @@ typedef struct PnrF32Saved {
 int pnr_eval_ray_samples_f32_train(const PnrScene *scene /*host*/, const PnrMlpWeights *w /*host*/, const float *rays,
                                    const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
                                    const PnrF32Saved *saved /*host*/, int split_gemm, void *stream);
-/* The fp32-class training forward through the FUSED split-operand kernel (the inference kernel of PNR_PREC_F16X3 with the
- * activations of PnrF32Saved written out as fp32 rows): packed_split = pnr_pack_mlp_split(folded) stream, tables_f32 =
- * pnr_fold_latent_f32 tables of the CURRENT parameters and grid (re-fold after every optimizer step / encode()).  One network
- * launch instead of 29 GEMM launches; pnr_mlp_backward_f32(split_gemm = 1) runs behind it unchanged.  Same reference lines. */
+/* ---- fp32-class TRAINING, fused (the default of precision "f16x3" under autograd).  Forward: the inference kernel of
+ * PNR_PREC_F16X3 (one launch per network pass, lin_z through the folded fp32 tables) in its training instantiation, which also
+ * keeps what the backward needs -- every 512-wide linear's operand as the (head, tail) f16 images the kernel multiplies from,
+ * copied out of LDS, and 1-bit relu masks.  Backward: one launch for all 15 transposed products of the network (lin_out^T,
+ * ten fc^T, lin_z[2..0]^T, lin_in^T; gradient images copied out the same way), one batched split-operand weight-gradient
+ * launch pair over those images (pnr_weight_grad_batched at PNR_PREC_F16X3) and lin_out's 4 x 512 gradient.  Same reference
+ * lines and the same accuracy class as the GEMM-per-layer entries above (the tests hold both to the same gradient bars).
+ * "(head | tail)": two f16 arrays of the stated shape, the tail array directly behind the head array.  Storage order:
+ * pnr_storage_perm.  packed_split = pnr_pack_mlp_split stream, tables_f32 = pnr_fold_latent_f32 tables of the CURRENT
+ * parameters and grid (re-pack / re-fold after every optimizer step / encode()). */
+typedef struct PnrSplitSaved {
+    void *in_op;   /* (rows_v, 64)  (head | tail), natural order: lin_in operand (code | view direction | 0 pad) */
+    void *zlat;    /* (rows_v, 512) (head | tail), natural channel order: interpolated latent                     */
+    void *a[5];    /* relu(x) entering blocks[b].fc_0, (head | tail) rows in storage order: b < 3 (rows_v,512), else (rows_p,512) */
+    void *n[5];    /* relu(fc_0 output) entering blocks[b].fc_1, same shapes                                       */
+    float *x5;     /* (rows_p, 512) fp32, natural order: residual stream in front of lin_out                       */
+    void *masks;   /* pnr_train_masks_bytes(P, NS) bytes: 1-bit relu masks of the 11 activations                   */
+} PnrSplitSaved;
 int pnr_eval_ray_samples_split_train(const PnrScene *scene /*host*/, const void *packed_split, const void *tables_f32,
                                      const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
-                                     const PnrF32Saved *saved /*host*/, void *stream);
-/* ... and the backward behind it with the data-gradient chain fused as well (one launch for lin_out^T and the ten fc^T
- * products; dW and the lin_z^T / lin_in^T products on the split-operand GEMM from the chain's fp32 dY rows): same arguments
- * and results as pnr_mlp_backward_f32(split_gemm = 1); saved->masks must come from pnr_eval_ray_samples_split_train. */
+                                     const PnrSplitSaved *saved /*host*/, void *stream);
+/* grad_scale = device [s, 1/s] from pnr_grad_scale(g_out); outputs as pnr_mlp_backward_f32 (d_zlat required, d_in nullable). */
 size_t pnr_mlp_backward_split_workspace_bytes(long long P, int NS);
-int pnr_mlp_backward_split(const PnrMlpWeights *w /*host*/, const PnrF32Saved *saved /*host*/, const float *g_out, long long P,
+int pnr_mlp_backward_split(const PnrMlpWeights *w /*host*/, const PnrSplitSaved *saved /*host*/, const float *g_out, long long P,
                            int NS, const PnrMlpWeights *grads /*host*/, float *d_zlat, float *d_in /*nullable*/,
                            const float *grad_scale, void *workspace, size_t workspace_bytes, void *stream);
 /* All parameter gradients of one ResnetFC + d(interpolated latent) [+ d(lin_in operand)] from g_out (P,4) =

@@ -60,7 +60,12 @@ class PnrBackwardDumps(ctypes.Structure):
 
 class PnrF32Saved(ctypes.Structure):
     _fields_ = [("in42", ctypes.c_void_p), ("zlat", ctypes.c_void_p), ("xin", ctypes.c_void_p * 5), ("net", ctypes.c_void_p * 5),
-                ("x5", ctypes.c_void_p), ("pool_in", ctypes.c_void_p), ("masks", ctypes.c_void_p)]
+                ("x5", ctypes.c_void_p), ("pool_in", ctypes.c_void_p)]
+
+
+class PnrSplitSaved(ctypes.Structure):
+    _fields_ = [("in_op", ctypes.c_void_p), ("zlat", ctypes.c_void_p), ("a", ctypes.c_void_p * 5), ("n", ctypes.c_void_p * 5),
+                ("x5", ctypes.c_void_p), ("masks", ctypes.c_void_p)]
 
 
 # every symbol include/pixelnerf_hip.h declares: name -> (restype, argtypes)
@@ -135,14 +140,14 @@ PROTOTYPES = {
     "pnr_render_forward": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I,
                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pnr_gen_rays": (_I, [_P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P]),
-    "pnr_eval_ray_samples_split_train": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, ctypes.POINTER(PnrF32Saved), _P]),
+    "pnr_eval_ray_samples_split_train": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, ctypes.POINTER(PnrSplitSaved), _P]),
     "pnr_eval_ray_samples_f32_train": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _I, _I, _P,
                                             ctypes.POINTER(PnrF32Saved), _I, _P]),
     "pnr_mlp_backward_f32_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
     "pnr_mlp_backward_f32": (_I, [ctypes.POINTER(PnrMlpWeights), ctypes.POINTER(PnrF32Saved), _P, ctypes.c_longlong, _I,
                                   ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _P, _P, _SZ, _P]),
     "pnr_mlp_backward_split_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
-    "pnr_mlp_backward_split": (_I, [ctypes.POINTER(PnrMlpWeights), ctypes.POINTER(PnrF32Saved), _P, ctypes.c_longlong, _I,
+    "pnr_mlp_backward_split": (_I, [ctypes.POINTER(PnrMlpWeights), ctypes.POINTER(PnrSplitSaved), _P, ctypes.c_longlong, _I,
                                     ctypes.POINTER(PnrMlpWeights), _P, _P, _P, _P, _SZ, _P]),
     "pnr_point_features_f32": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _P, _P, _P]),
     "pnr_profile_enable": (_I, [_I]),

@@ -30,11 +30,11 @@ def _param_names():
 
 PARAM_NAMES = _param_names()
 
-# precision "f16x3": the training forward runs the FUSED split-operand kernel (one launch, lin_z through the folded tables) and
-# keeps its activations as fp32 rows; False = the unfused chain of 29 split-operand GEMMs (same arithmetic class, the A/B twin)
-FUSED_SPLIT_FORWARD = True
-# ... and its data-gradient chain runs fused too (pnr_mlp_backward_split); False = one split-operand GEMM per transposed product
-FUSED_SPLIT_BACKWARD = True
+# precision "f16x3": training runs FUSED -- the split-operand inference kernel in its training instantiation (one launch per
+# network pass, operand images + relu masks kept), one launch for all transposed products of the backward, one batched
+# split-operand weight-gradient launch.  False = the GEMM-per-layer form (~120 split-operand GEMM launches per step: same
+# arithmetic class, the A/B twin and the yardstick of the gradient tests)
+FUSED_SPLIT_TRAINING = True
 
 
 def _sigma_noise(rgbs, cfg):
@@ -60,7 +60,7 @@ def _train_eval(net, scene, coarse, rays, z):
     """network forward of one training pass -> (rgbsigma (R,K,4), saved operands).  precision 'f32': the exact, unfused fp32
     chain (validation grade); 'f16x3': the same chain with split-operand (fp32-class) GEMMs on the f16 matrix cores;
     'f16' / 'bf16': the fused kernel's training instantiation (16-bit operand dumps)."""
-    if net.precision == "f16x3" and FUSED_SPLIT_FORWARD:
+    if net.precision == "f16x3" and FUSED_SPLIT_TRAINING:
         pk = net.packed(coarse)  # the folded split stream of inference (before tables(): packed() runs the content check)
         return ops.eval_ray_samples_split_train(scene, pk, net.tables(coarse), rays, z)
     if net.precision in ("f32", "f16x3"):
@@ -71,8 +71,11 @@ def _train_eval(net, scene, coarse, rays, z):
 
 def _pass_grads(net, mlp, dumps, g_out, scene_NS, want_d_in):
     """-> (grads, d_zlat, d_in, releasable) of one pass at the network's precision"""
+    if isinstance(dumps, ops.SplitSaved):
+        grads, d_zlat, d_in = ops.mlp_backward_split(mlp.packed("f32"), dumps, g_out, want_d_in=want_d_in)
+        return grads, d_zlat, d_in, _NoRelease
     if net.precision in ("f32", "f16x3"):
-        grads, d_zlat, d_in = ops.mlp_backward_f32(mlp.packed("f32"), dumps, g_out, want_d_in=want_d_in, fused_chain=FUSED_SPLIT_BACKWARD)
+        grads, d_zlat, d_in = ops.mlp_backward_f32(mlp.packed("f32"), dumps, g_out, want_d_in=want_d_in)
         return grads, d_zlat, d_in, _NoRelease
     return _mlp_grads(None, mlp.packed_bwd(net.precision), dumps, g_out, scene_NS, want_d_in=want_d_in)
 

@@ -521,6 +521,142 @@ dw_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart
     }
 }
 
+// The same weight-gradient GEMM at split-operand (fp32-class) precision: both operands arrive as (head, tail) f16 row sets -- the
+// activation images of the fused split forward and the gradient images of the fused split chain, copied out of LDS as they lie
+// there; the tail array of an operand follows its head array -- and every fragment pair costs three MFMAs (head x head,
+// head x tail, tail x head; fp32 accumulate), the arithmetic of PNR_PREC_F16X3.  Same tiling, placement, slice reduction and
+// storage -> feature order mapping as dw_kernel; four operand slabs (dY / X, head / tail), double-buffered: 147 KiB of LDS, one
+// workgroup of 8 waves per CU -- the kernel is MFMA-bound (3 MFMAs per 2 fragment reads), which 2 waves per SIMD cover.
+__global__ void __launch_bounds__(512)
+dw_split_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart) {
+    typedef Prec<PNR_PREC_F16> P;
+    typedef _Float16 T;
+    constexpr int SR = 32, LDB = 576;
+    extern __shared__ __attribute__((aligned(16))) char dws[];  // [buf][dY head, dY tail, X head, X tail][SR * LDB]
+    constexpr int SLAB = SR * LDB;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int lid = blockIdx.x, ngroups = gridDim.x >> 2, full = (ngroups >> 3) * 32;
+    int grp, tile4;
+    if (lid < full) { const int k = lid >> 3; grp = (k >> 2) * 8 + (lid & 7); tile4 = k & 3; }
+    else { const int rem = lid - full; grp = (full >> 2) + (rem >> 2); tile4 = rem & 3; }
+    const int job = grp / jobs.nsplit, slice = grp - job * jobs.nsplit;
+    const long long rows = jobs.rows[job];
+    const int nx = jobs.nx[job];
+    const T *dYh = reinterpret_cast<const T *>(jobs.dY[job]), *dYl = dYh + (size_t)rows * D_HID;
+    const T *Xh = reinterpret_cast<const T *>(jobs.X[job]), *Xl = Xh + (size_t)rows * nx;
+    long long per = (rows + jobs.nsplit - 1) / jobs.nsplit;
+    per = (per + SR - 1) / SR * SR;
+    const int o0 = (tile4 >> 1) * 256, k0 = (tile4 & 1) * 256;
+    if (k0 >= nx) return;  // narrow X (lin_in): only the first column tile exists
+    const long long r_begin = (long long)slice * per;
+    const long long r_end = r_begin + per < rows ? r_begin + per : rows;
+    const int wo = (w >> 1) * 64, wk = (w & 1) * 128;  // wave tile: 64 (o) x 128 (k) = 2 x 4 MFMA tiles
+    const int i = lane & 31, kh = lane >> 5;
+    f32x16 acc[2][4];
+    float bsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    u32x4 vyh[2], vyl[2], vxh[2], vxl[2];
+    auto load_slab = [&](long long r0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int chunk = t + u * 512;  // consecutive lanes -> consecutive 16-byte chunks of a row
+            const int srow = chunk >> 5, scol = (chunk & 31) * 8;
+            vyh[u] = vyl[u] = vxh[u] = vxl[u] = u32x4{0, 0, 0, 0};
+            if (r0 + srow < r_end) {
+                const size_t oy = (size_t)(r0 + srow) * D_HID + o0 + scol;
+                vyh[u] = *reinterpret_cast<const u32x4 *>(dYh + oy);
+                vyl[u] = *reinterpret_cast<const u32x4 *>(dYl + oy);
+                if (k0 + scol < nx) {
+                    const size_t ox = (size_t)(r0 + srow) * nx + k0 + scol;
+                    vxh[u] = *reinterpret_cast<const u32x4 *>(Xh + ox);
+                    vxl[u] = *reinterpret_cast<const u32x4 *>(Xl + ox);
+                }
+            }
+        }
+    };
+    const int c16 = lane & 15;
+    const int frag_off = (8 * kh + (c16 >> 2)) * LDB + (16 * ((lane >> 4) & 1) + 4 * (c16 & 3)) * 2;
+    auto store_slab = [&](int buf) {
+        char *base = dws + buf * (4 * SLAB);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int chunk = t + u * 512;
+            const int off = (chunk >> 5) * LDB + (chunk & 31) * 16;
+            *reinterpret_cast<u32x4 *>(base + off) = vyh[u];
+            *reinterpret_cast<u32x4 *>(base + SLAB + off) = vyl[u];
+            *reinterpret_cast<u32x4 *>(base + 2 * SLAB + off) = vxh[u];
+            *reinterpret_cast<u32x4 *>(base + 3 * SLAB + off) = vxl[u];
+        }
+    };
+    if (r_begin < r_end) {
+        load_slab(r_begin);
+        store_slab(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (long long r0 = r_begin; r0 < r_end; r0 += SR, cur ^= 1) {
+        const bool more = r0 + SR < r_end;
+        if (more) load_slab(r0 + SR);  // in flight under this slab's MFMAs
+        const char *sYh = dws + cur * (4 * SLAB), *sYl = sYh + SLAB, *sXh = sYh + 2 * SLAB, *sXl = sYh + 3 * SLAB;
+#pragma unroll
+        for (int ks = 0; ks < SR / 16; ++ks) {
+            P::T8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ah[a] = tr_frag<P::T8, LDB>(sYh + ks * 16 * LDB + (wo + a * 32) * 2 + frag_off);
+                al[a] = tr_frag<P::T8, LDB>(sYl + ks * 16 * LDB + (wo + a * 32) * 2 + frag_off);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                bh[b] = tr_frag<P::T8, LDB>(sXh + ks * 16 * LDB + (wk + b * 32) * 2 + frag_off);
+                bl[b] = tr_frag<P::T8, LDB>(sXl + ks * 16 * LDB + (wk + b * 32) * 2 + frag_off);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(ah[a], bh[b], acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(ah[a], bl[b], acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(al[a], bh[b], acc[a][b]);
+            if ((tile4 & 1) == 0 && (w & 1) == 0) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[a] += (float)ah[a][e] + (float)al[a][e];
+            }
+        }
+        if (more) store_slab(cur ^ 1);  // the other buffer: its readers passed the barrier of the previous slab
+        __syncthreads();
+    }
+    float *pz = part + ((size_t)job * jobs.nsplit + slice) * (D_HID * D_HID);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orow = o0 + wo + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                pz[(size_t)orow * D_HID + k0 + wk + b * 32 + i] = acc[a][b][r];
+            }
+    if ((tile4 & 1) == 0 && (w & 1) == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+            if (kh == 0) bpart[((size_t)job * jobs.nsplit + slice) * D_HID + o0 + wo + a * 32 + i] = v;
+        }
+    }
+}
+
 // dW = scale * sum_z part[job][z], db = scale * sum_z bpart[job][z]  (fixed summation order); blockIdx.y = job.
 // rows_st / cols_st: the operand that indexes the rows (dY) / columns (X) of dW was dumped in storage order;
 // the result is written in feature order (row e -> feature feat_of(e/32, (e%32)/16, e%16)).
@@ -1244,7 +1380,13 @@ extern "C" int pnr_weight_grad_batched(const PnrWeightGradJob *jobs, int n_jobs,
         hipLaunchKernelGGL(dw_kernel<PNR_PREC_F16>, grid, dim3(512), 0, st, J, part, bpart);
     else if (precision == PNR_PREC_BF16)
         hipLaunchKernelGGL(dw_kernel<PNR_PREC_BF16>, grid, dim3(512), 0, st, J, part, bpart);
-    else
+    else if (precision == PNR_PREC_F16X3) {
+        // split-operand form: dY / X are (head | tail) f16 row sets, the tail array behind the head array
+        constexpr int lds = 2 * 4 * 32 * 576;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dw_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(dw_split_kernel)");
+        hipLaunchKernelGGL(dw_split_kernel, grid, dim3(512), lds, st, J, part, bpart);
+    } else
         return pnr_fail(PNR_E_INVALID, "pnr_weight_grad_batched: unknown precision");
     hipLaunchKernelGGL(dw_reduce_kernel, dim3(D_HID * D_HID / 256, (unsigned)n_jobs), dim3(256), 0, st, J, part, bpart, out_scale, out_scale_dev);
     return pnr_check_launch("pnr_weight_grad_batched");

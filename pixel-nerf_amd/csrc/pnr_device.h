@@ -71,10 +71,12 @@ struct EvalParams {
     char *d_a[5];  // relu(x) in front of blocks[b].fc_0, storage order; b<3: (NS*P,512), else (P,512)
     char *d_n[5];  // relu(net) in front of blocks[b].fc_1, same shapes
     char *d_x5;    // (P,512) relu(x) in front of lin_out
-    // TRAIN instantiation of the split-operand kernel (pnr_split.hip): fp32 rows in natural feature order of the values the
-    // fp32-precision backward keeps (PnrF32Saved): the residual stream entering block b, each fc_0 output (both before their
-    // relu), the stream in front of lin_out, and -- several views -- each view's stream in front of the view mean
-    float *f_xin[5], *f_net[5], *f_x5, *f_pool;
+    // TRAIN instantiation of the split-operand kernel (pnr_split.hip): the (head, tail) operand images of every linear, copied
+    // out of LDS as 16-bit rows in storage order (s_a[b]: relu(x) entering blocks[b].fc_0, s_n[b]: relu(net) entering fc_1;
+    // b < 3: NS*P rows [view][point], else P rows; the tail array follows the head array), the stream in front of lin_out as
+    // fp32 rows in natural feature order (f_x5), and the relu masks in d_mask
+    char *s_a[5], *s_n[5];
+    float *f_x5;
 };
 
 // phase ids of the TIMING instantiation (wave 0 of workgroup 0, s_memtime ticks)

@@ -25,7 +25,9 @@ namespace pnr {
 constexpr int FW = 4;  // wavefronts per block in the feature kernel
 
 // one wavefront per (view, point) of the chunk [p0, p0+np)
-template <bool RAYS>
+// SPLIT: the two outputs leave as (head | tail) f16 row sets instead (operands of the split-operand weight-gradient GEMM: in42 /
+// zlat then point to the head arrays, the tail arrays follow behind np*NS rows)
+template <bool RAYS, bool SPLIT = false>
 __global__ void __launch_bounds__(FW * 64)
 feat_f32_kernel(const EvalParams q, long long p0, int np, float *__restrict__ in42, float *__restrict__ zlat) {
 #pragma clang fp contract(off)
@@ -65,7 +67,15 @@ feat_f32_kernel(const EvalParams q, long long p0, int np, float *__restrict__ in
         const int c = lane - 39;
         v = pose[4 * c + 0] * dx + pose[4 * c + 1] * dy + pose[4 * c + 2] * dz;
     }
-    in42[(size_t)idx * D_IN_PAD + lane] = v;
+    [[maybe_unused]] const size_t rows_all = (size_t)np * q.NS;
+    if constexpr (SPLIT) {
+        _Float16 *o = reinterpret_cast<_Float16 *>(in42);
+        const _Float16 hh = (_Float16)v;
+        o[(size_t)idx * D_IN_PAD + lane] = hh;
+        o[rows_all * D_IN_PAD + (size_t)idx * D_IN_PAD + lane] = (_Float16)(v - (float)hh);
+    } else {
+        in42[(size_t)idx * D_IN_PAD + lane] = v;
+    }
     // bilinear latent lookup, 8 channels per lane
     const Proj pr = project_point(q, pose, obj, view, xr[0], xr[1], xr[2], true);
     const float *lat = q.latent + lane * 8;
@@ -78,8 +88,21 @@ feat_f32_kernel(const EvalParams q, long long p0, int np, float *__restrict__ in
         if (c == 0) { acc0 = a * pr.w[0]; acc1 = b * pr.w[0]; }
         else { acc0 += a * pr.w[c]; acc1 += b * pr.w[c]; }
     }
-    *reinterpret_cast<f32x4 *>(dst) = acc0;
-    *reinterpret_cast<f32x4 *>(dst + 4) = acc1;
+    if constexpr (SPLIT) {
+        _Float16 *o = reinterpret_cast<_Float16 *>(zlat) + (size_t)idx * C_LAT + lane * 8;
+        __attribute__((aligned(16))) _Float16 hh[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = e < 4 ? acc0[e] : acc1[e - 4];
+            hh[e] = (_Float16)x;
+            ll[e] = (_Float16)(x - (float)hh[e]);
+        }
+        *reinterpret_cast<uint4 *>(o) = *reinterpret_cast<const uint4 *>(hh);
+        *reinterpret_cast<uint4 *>(o + rows_all * C_LAT) = *reinterpret_cast<const uint4 *>(ll);
+    } else {
+        *reinterpret_cast<f32x4 *>(dst) = acc0;
+        *reinterpret_cast<f32x4 *>(dst + 4) = acc1;
+    }
 }
 
 // Y (M,N) = [Yin +] mask( [relu](X (M,K)) W'^T + b ).   Block 256 threads = 4 waves, 64x64 tile, K in chunks of 32
@@ -747,19 +770,27 @@ extern "C" int pnr_eval_ray_samples_f32_train(const PnrScene *scene, const PnrMl
     return pnr::eval_f32_train(scene, w, q, saved, (hipStream_t)stream, split_gemm != 0);
 }
 
-// The same training forward through the FUSED split-operand kernel (pnr_split.hip, TRAIN instantiation): the per-point network
-// runs as one launch (lin_z through the folded fp32 tables, like inference) and leaves the activations of PnrF32Saved as fp32
-// rows; the feature kernel still writes the lin_in operand and the interpolated latent the weight gradients of lin_in / lin_z
-// and the latent scatter need.  29 GEMM launches -> 2 kernels; pnr_mlp_backward_f32(split_gemm = 1) runs behind it unchanged.
+// ---- fp32-class training, FUSED (round 3).  The training forward is the split-operand inference kernel (pnr_split.hip, TRAIN
+// instantiation: one launch, lin_z through the folded fp32 tables) that also copies the (head, tail) operand images of every
+// linear out of LDS and writes 1-bit relu masks; the backward is bwd_split_kernel (all 15 transposed products of a network in
+// one launch, gradient images copied out the same way) + ONE batched split-operand weight-gradient launch (dw_split_kernel,
+// pnr_bwd.hip) straight from those images + lin_out's 4 x 512 gradient.  ~120 launches of the GEMM-per-layer form -> 8.
+static int check_split_saved(const PnrSplitSaved *sv) {
+    if (!sv || !sv->in_op || !sv->zlat || !sv->x5 || !sv->masks) return 0;
+    for (int b = 0; b < 5; ++b)
+        if (!sv->a[b] || !sv->n[b]) return 0;
+    return 1;
+}
+
 extern "C" int pnr_eval_ray_samples_split_train(const PnrScene *scene, const void *packed_split, const void *tables_f32,
                                                 const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
-                                                const PnrF32Saved *saved, void *stream) {
+                                                const PnrSplitSaved *saved, void *stream) {
     using namespace pnr;
     if (R <= 0 || K <= 0 || rays_per_obj <= 0 || !rays || !z || !scene || !packed_split || !tables_f32 || !rgbsigma)
         return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: bad argument");
     if ((long long)rays_per_obj * scene->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: R != SB * rays_per_obj");
     if (scene->SB <= 0 || scene->NS <= 0 || scene->Hl < 2 || scene->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: bad scene shape");
-    if (!check_saved(saved, scene->NS)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: null activation buffer in PnrF32Saved");
+    if (!check_split_saved(saved)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: null buffer in PnrSplitSaved");
     EvalParams q = {};
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
     if (q.P * scene->NS > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: too many points");
@@ -768,65 +799,67 @@ extern "C" int pnr_eval_ray_samples_split_train(const PnrScene *scene, const voi
     q.img_w = scene->img_w; q.img_h = scene->img_h;
     const int np = (int)q.P;
     const long long rows = (long long)np * scene->NS;
-    hipLaunchKernelGGL(feat_f32_kernel<true>, dim3((unsigned)((rows + FW - 1) / FW)), dim3(FW * 64), 0, (hipStream_t)stream, q, 0LL, np,
-                       saved->in42, saved->zlat);
+    // lin_in operand and interpolated latent as (head | tail) rows: operands of the lin_in / lin_z weight gradients
+    hipLaunchKernelGGL((feat_f32_kernel<true, true>), dim3((unsigned)((rows + FW - 1) / FW)), dim3(FW * 64), 0, (hipStream_t)stream, q, 0LL,
+                       np, (float *)saved->in_op, (float *)saved->zlat);
     int rc = pnr_check_launch("pnr_eval_ray_samples_split_train (features)");
     if (rc != PNR_OK) return rc;
-    return eval_samples_split_train(scene, packed_split, tables_f32, rays, z, R, rays_per_obj, K, rgbsigma, saved->xin, saved->net,
-                                    saved->x5, saved->pool_in, saved->masks, (hipStream_t)stream);
+    return eval_samples_split_train(scene, packed_split, tables_f32, rays, z, R, rays_per_obj, K, rgbsigma, saved->a, saved->n,
+                                    saved->x5, saved->masks, (hipStream_t)stream);
 }
 
-// ---- backward behind it with the data-gradient chain FUSED (bwd_split_kernel, pnr_split.hip): all 15 transposed products of a
-// network -- lin_out^T, ten fc^T, lin_z[2..0]^T, lin_in^T -- in one launch; the weight gradients run on gemm3_kernel from the
-// chain's fp32 dY rows.  Same results class as pnr_mlp_backward_f32(split_gemm = 1) (tests hold both to the same bars).
+static size_t split_bwd_images_bytes(long long P, int NS) { return ((size_t)P * NS * 7 + (size_t)P * 4) * pnr::D_HID * 4; }
+
 extern "C" size_t pnr_mlp_backward_split_workspace_bytes(long long P, int NS) {
     if (P <= 0 || NS <= 0) return 0;
-    // dY rows: g_fc1 / g_fc0 of blocks 0-2 and g_x0 at (NS*P, 512), of blocks 3-4 at (P, 512); the transposed (head, tail) streams;
-    // the row-slice partials of one weight gradient
-    return ((size_t)P * NS * 7 + (size_t)P * 4) * pnr::D_HID * sizeof(float) + pnr::bwd_split_packed_bytes() +
+    // gradient images: g_fc1 / g_fc0 of blocks 0-2 and g_x0 at NS*P rows, of blocks 3-4 at P rows, 2 x 1024 B per row; the
+    // transposed (head, tail) streams; the slice partials of the batched weight-gradient launch and of lin_out's
+    return split_bwd_images_bytes(P, NS) + pnr::bwd_split_packed_bytes() + pnr_weight_grad_batched_workspace_bytes(14, P * NS) +
            (size_t)pnr::WG_SPLIT * (pnr::D_HID * pnr::D_HID + pnr::D_HID) * sizeof(float);
 }
 
-extern "C" int pnr_mlp_backward_split(const PnrMlpWeights *w, const PnrF32Saved *sv, const float *g_out, long long P, int NS,
+extern "C" int pnr_mlp_backward_split(const PnrMlpWeights *w, const PnrSplitSaved *sv, const float *g_out, long long P, int NS,
                                       const PnrMlpWeights *grads, float *d_zlat, float *d_in, const float *grad_scale, void *workspace,
                                       size_t workspace_bytes, void *stream) {
     using namespace pnr;
     if (!w || !g_out || !grads || !d_zlat || !workspace || !grad_scale || P <= 0 || NS <= 0)
         return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: bad argument");
-    if (!check_saved(sv, NS) || !sv->masks)
-        return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: PnrF32Saved needs every activation buffer and the relu masks of pnr_eval_ray_samples_split_train");
+    if (!check_split_saved(sv)) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: null buffer in PnrSplitSaved");
     if (workspace_bytes < pnr_mlp_backward_split_workspace_bytes(P, NS)) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: workspace too small");
     if (P * NS > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: too many points");
     hipStream_t hs = (hipStream_t)stream;
-    const Mm st = {hs, true, grad_scale, grad_scale + 1};
     const long long rows = P * NS;
-    float *cur = (float *)workspace;
-    float *g_fc1[5], *g_fc0[5];
+    char *cur = (char *)workspace;
+    void *g_fc1[5], *g_fc0[5];
     for (int b = 0; b < 5; ++b) {
-        const size_t n = (size_t)(b < COMBINE_LAYER ? rows : P) * D_HID;
+        const size_t n = (size_t)(b < COMBINE_LAYER ? rows : P) * D_HID * 4;
         g_fc1[b] = cur; cur += n;
         g_fc0[b] = cur; cur += n;
     }
-    float *g_x0 = cur; cur += (size_t)rows * D_HID;
-    void *packed = cur; cur = (float *)((char *)cur + bwd_split_packed_bytes());
-    float *part = cur;
+    void *g_x0 = cur; cur += (size_t)rows * D_HID * 4;
+    void *packed = cur; cur += bwd_split_packed_bytes();
+    void *dw_ws = cur; cur += pnr_weight_grad_batched_workspace_bytes(14, rows);
+    float *part = (float *)cur;
     int rc = pack_bwd_split(w, packed, hs);
     if (rc != PNR_OK) return rc;
     rc = mlp_backward_split_chain(packed, (const unsigned long long *)sv->masks, g_out, grad_scale, P, NS, g_fc1, g_fc0, g_x0, d_zlat, d_in, hs);
     if (rc != PNR_OK) return rc;
-    // weight gradients from the chain's dY rows (scaled domain; wgrad multiplies 1/s on the way out)
-    wgrad(st, g_out, D_OUT, sv->x5, D_HID, true, P, D_OUT, D_HID, (float *)grads->lin_out_w, (float *)grads->lin_out_b, part, true);
+    // all 14 wide weight gradients in one launch pair, straight from the (head | tail) images; the chain ran at scale s: 1/s on the way out
+    PnrWeightGradJob jobs[14];
+    int nj = 0;
     for (int b = N_BLOCKS - 1; b >= 0; --b) {
         const long long r = b < COMBINE_LAYER ? rows : P;
-        wgrad(st, g_fc1[b], D_HID, sv->net[b], D_HID, true, r, D_HID, D_HID, (float *)grads->fc1_w[b], (float *)grads->fc1_b[b], part);
-        wgrad(st, g_fc0[b], D_HID, sv->xin[b], D_HID, true, r, D_HID, D_HID, (float *)grads->fc0_w[b], (float *)grads->fc0_b[b], part);
+        jobs[nj++] = PnrWeightGradJob{g_fc1[b], sv->n[b], r, 1, 1, (float *)grads->fc1_w[b], (float *)grads->fc1_b[b], 0, 0};
+        jobs[nj++] = PnrWeightGradJob{g_fc0[b], sv->a[b], r, 1, 1, (float *)grads->fc0_w[b], (float *)grads->fc0_b[b], 0, 0};
     }
     // xin[b] = (stream in front) + lin_z[b](zlat): dY of lin_z[b] = gradient of the stream entering block b (resnetfc.py:175-180)
-    for (int b = COMBINE_LAYER - 1; b >= 0; --b) {
-        const float *gz = b == 0 ? g_x0 : g_fc1[b - 1];
-        wgrad(st, gz, D_HID, sv->zlat, C_LAT, false, rows, D_HID, C_LAT, (float *)grads->lin_z_w[b], (float *)grads->lin_z_b[b], part);
-    }
-    wgrad(st, g_x0, D_HID, sv->in42, D_IN_PAD, false, rows, D_HID, D_IN, (float *)grads->lin_in_w, (float *)grads->lin_in_b, part);
+    for (int b = COMBINE_LAYER - 1; b >= 0; --b)
+        jobs[nj++] = PnrWeightGradJob{b == 0 ? g_x0 : g_fc1[b - 1], sv->zlat, rows, 1, 0, (float *)grads->lin_z_w[b], (float *)grads->lin_z_b[b], 0, 0};
+    jobs[nj++] = PnrWeightGradJob{g_x0, sv->in_op, rows, 1, 0, (float *)grads->lin_in_w, (float *)grads->lin_in_b, D_IN_PAD, D_IN};
+    rc = pnr_weight_grad_batched(jobs, nj, PNR_PREC_F16X3, 1.f, grad_scale + 1, dw_ws, stream);
+    if (rc != PNR_OK) return rc;
+    const Mm st = {hs, true, grad_scale, grad_scale + 1};
+    wgrad(st, g_out, D_OUT, sv->x5, D_HID, true, P, D_OUT, D_HID, (float *)grads->lin_out_w, (float *)grads->lin_out_b, part, true);
     return pnr_check_launch("pnr_mlp_backward_split");
 }
 

@@ -15,23 +15,24 @@ int eval_samples_src(const PnrScene *scene, const void *packed, const void *tabl
 int eval_samples_split_src(const PnrScene *scene, const void *packed_split, const void *tables_f32, const RaySrc &src,
                            const float *z, int R, int rays_per_obj, int K, float *rgbsigma, hipStream_t stream);
 
-// training forward of the fp32-class path: the split-operand kernel + fp32 rows (natural feature order) of the residual stream
-// entering each block (xin[5]), each fc_0 output (net[5]), the stream in front of lin_out (x5) and, several views, every view's
-// stream in front of the view mean (pool_in); row = view * P + point for the per-view tensors.  Defined in pnr_split.hip.
+// training forward of the fp32-class path: the split-operand kernel + what the backward keeps -- the (head | tail) 16-bit operand
+// images of every 512-wide linear in storage order (img_a[b]: relu(x) entering blocks[b].fc_0, img_n[b]: relu(net) entering fc_1;
+// b < 3: NS*P rows [view][point], else P rows; 2 x rows x 1024 bytes each), the stream in front of lin_out as fp32 rows (x5) and
+// the relu bit masks (pnr_train_masks_bytes).  Defined in pnr_split.hip.
 int eval_samples_split_train(const PnrScene *scene, const void *packed_split, const void *tables_f32, const float *rays,
-                             const float *z, int R, int rays_per_obj, int K, float *rgbsigma, float *const *xin, float *const *net,
-                             float *x5, float *pool_in, void *masks /* pnr_train_masks_bytes(P, NS), nullable */, hipStream_t stream);
+                             const float *z, int R, int rays_per_obj, int K, float *rgbsigma, void *const *img_a, void *const *img_n,
+                             float *x5, void *masks, hipStream_t stream);
 
 // fused data-gradient chain of the fp32-class training path (bwd_split_kernel, pnr_split.hip): transposed (head, tail) weight
 // streams packed from the raw parameters, relu masks of the TRAIN forward, g_out (P,4) unscaled + device [s, 1/s]; every layer's
-// output gradient leaves as fp32 rows at scale s (g_fc1[b] = dY of blocks[b].fc_1 = gradient of the stream behind block b,
-// g_fc0[b] = dY of blocks[b].fc_0, g_x0 = gradient of the stream entering block 0; b < 3 and g_x0: [view][point] rows);
-// d z_lat = sum_b dY_b W_z[b] and d(code) = dY_0 W_in come out of the same launch.
+// output gradient leaves at scale s as (head | tail) 16-bit rows in storage order (g_fc1[b] = dY of blocks[b].fc_1 = gradient of
+// the stream behind block b, g_fc0[b] = dY of blocks[b].fc_0, g_x0 = gradient of the stream entering block 0; b < 3 and g_x0:
+// [view][point] rows); d z_lat = sum_b dY_b W_z[b] and d(code) = dY_0 W_in come out of the same launch, unscaled fp32.
 size_t bwd_split_packed_bytes();
 int pack_bwd_split(const PnrMlpWeights *w, void *packed, hipStream_t st);
 int mlp_backward_split_chain(const void *packed_bwd_split, const unsigned long long *masks, const float *g_out, const float *scale_dev,
-                             long long P, int NS, float *const *g_fc1, float *const *g_fc0, float *g_x0, float *d_zlat /* (NS*P,512) unscaled */,
-                             float *d_in /* (NS*P,42) unscaled, nullable */, hipStream_t st);
+                             long long P, int NS, void *const *g_fc1, void *const *g_fc0, void *g_x0, float *d_zlat /* (NS*P,512) */,
+                             float *d_in /* (NS*P,42), nullable */, hipStream_t st);
 
 // per (device, stream) scratch for the parked view sum of multi-view launches (one tile of fp32 accumulators per workgroup),
 // allocated at the first multi-view launch on a stream and kept; NULL on allocation failure.  Defined in pnr_mlp.hip.

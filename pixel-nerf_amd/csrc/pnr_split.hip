@@ -361,27 +361,29 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             }
         (q.d_mask + (size_t)layer * tr_mask_layer)[word] = m;
     };
+    // TRAIN: the operand images just published (head, tail) -> their 16-bit row sets, whole 1 KiB rows per wave instruction
+    [[maybe_unused]] auto dump_pair = [&](char *head, int b) {
+        const long long rows = b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled;
+        const size_t total = (size_t)(b < COMBINE_LAYER ? (long long)NS * q.P : q.P) * (D_HID * 2);
+        dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), tr_rows_left, wv, lane);
+        dump_image<MT>(smem, ST::A_LO, head + total + (size_t)rows * (D_HID * 2), tr_rows_left, wv, lane);
+    };
     // one residual block on x (resnetfc.py:66-88); lookup: lin_z[b+1] via table b+1 behind it
     auto block = [&](f32x16 (&x)[IT][JT], int b, bool lookup) {
-        if constexpr (TRAIN) {
-            dump_rows(x, q.f_xin[b], b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled, tr_rows_left);
-            if (q.d_mask) put_mask(x, 2 * b, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
-        }
+        if constexpr (TRAIN) put_mask(x, 2 * b, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
         __syncthreads();  // table rows / previous operand images are no longer read
         PNR_T(PH_BAR1);
         write_split<ST>(x, smem, a_wr);
         PNR_T(PH_WRITE_X);
         __syncthreads();
         PNR_T(PH_BAR2);
+        if constexpr (TRAIN) dump_pair(q.s_a[b], b);
         {
             f32x16 net[IT][JT];
             add_bias<true>(net, bias_lane, 1 + 2 * b);
             gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);  // fc_0
             PNR_T(PH_GEMM_FC0);
-            if constexpr (TRAIN) {
-                dump_rows(net, q.f_net[b], b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled, tr_rows_left);
-                if (q.d_mask) put_mask(net, 2 * b + 1, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
-            }
+            if constexpr (TRAIN) put_mask(net, 2 * b + 1, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
             __syncthreads();
             PNR_T(PH_BAR3);
             write_split<ST>(net, smem, a_wr);
@@ -389,6 +391,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         }
         __syncthreads();
         PNR_T(PH_BAR4);
+        if constexpr (TRAIN) dump_pair(q.s_n[b], b);
         add_bias<false>(x, bias_lane, 2 + 2 * b);
         gemm_split(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);        // fc_1
         PNR_T(PH_GEMM_FC1_Z);
@@ -430,7 +433,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             }
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b) block(x, b, b + 1 < COMBINE_LAYER);
-            if constexpr (TRAIN && MV) dump_rows(x, q.f_pool, tr_rows_view, tr_rows_left);
             if constexpr (MV_REGS) {  // fixed summation order view 0 + view 1 + ...: deterministic
                 const float inv = 1.f / (float)NS;
 #pragma unroll
@@ -466,7 +468,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b) block(x, b, false);
         if constexpr (TRAIN) {
             dump_rows(x, q.f_x5, tr_rows_pooled, tr_rows_left);
-            if (q.d_mask) put_mask(x, 10, tr_mask_pooled);
+            put_mask(x, 10, tr_mask_pooled);
         }
 
         // lin_out(relu(x)): each wave contracts its own 64 features (the wave's accumulators are the B operand)
@@ -911,7 +913,8 @@ struct BwdSplitParams {
     const float *scale_dev;              // device [s, 1/s]: the chain runs at s (pnr_grad_scale)
     long long P;
     int NS, ntiles;
-    float *g_fc1[5], *g_fc0[5], *g_x0;   // fp32 dY rows at scale s: b < 3 (NS*P,512) [view][point], else (P,512); g_x0 (NS*P,512)
+    char *g_fc1[5], *g_fc0[5], *g_x0;    // dY at scale s as (head | tail) 16-bit rows in storage order (copies of the gradient images):
+                                         // b < 3 (NS*P,512) [view][point], else (P,512); g_x0 (NS*P,512); tail array behind the head array
     float *d_zlat;                       // (NS*P, 512) fp32, natural channel order, UNSCALED: d(interpolated latent) = sum_b dY_b W_z[b]
     float *d_in;                         // (NS*P, 42) fp32, unscaled: d(positional code | view direction)   (nullable: not written)
     float *mv_ws;                        // several views: per-workgroup scratch for the pooled gradient every view starts from
@@ -976,36 +979,28 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
             }
     };
     long long rows_left = 0;
-    auto dump_rows = [&](const f32x16 (&a)[IT][JT], float *dst, long long rows) {
-        float *d = dst + ((size_t)rows + pl) * D_HID + (wv * IT) * 32 + 4 * h;
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            if (jt * 32 + pl >= rows_left) continue;
-#pragma unroll
-            for (int it = 0; it < IT; ++it)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x4 v = {a[it][jt][4 * k], a[it][jt][4 * k + 1], a[it][jt][4 * k + 2], a[it][jt][4 * k + 3]};
-                    *reinterpret_cast<f32x4 *>(d + (size_t)jt * 32 * D_HID + it * 32 + 8 * k) = v;
-                }
-        }
+    // the gradient image just published (head, tail) -> its 16-bit row sets (operands of the weight-gradient GEMM), whole rows
+    auto dump_pair = [&](char *head, long long rows, bool per_view) {
+        const size_t total = (size_t)(per_view ? (long long)NS * q.P : q.P) * (D_HID * 2);
+        dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), rows_left, wv, lane);
+        dump_image<MT>(smem, ST::A_LO, head + total + (size_t)rows * (D_HID * 2), rows_left, wv, lane);
     };
     // reverse of one residual block (resnetfc.py:55-62):  given G = dL/d(x + fc_1(relu(fc_0(relu(x))))),
     //   dY(fc_1) = G ;  d net = (fc_1^T G) . [net > 0] = dY(fc_0) ;  G += (fc_0^T d net) . [x > 0]
     auto bwd_block = [&](f32x16 (&G)[IT][JT], int b, long long rows, size_t mask_off) {
-        dump_rows(G, q.g_fc1[b], rows);
         __syncthreads();  // every wave is done reading the gradient image (previous GEMM)
         write_split<ST, false>(G, smem, a_wr);
         __syncthreads();
+        dump_pair(q.g_fc1[b], rows, b < COMBINE_LAYER);
         f32x16 t[IT][JT];
         const unsigned long long mk_n = (q.d_mask + (size_t)(2 * b + 1) * mask_layer)[mask_off];
         zero(t);
         gemm_split<JT, SplitAdvBwd>(t, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
         apply_mask(t, mk_n);
-        dump_rows(t, q.g_fc0[b], rows);
         __syncthreads();
         write_split<ST, false>(t, smem, a_wr);
         __syncthreads();
+        dump_pair(q.g_fc0[b], rows, b < COMBINE_LAYER);
         const unsigned long long mk_a = (q.d_mask + (size_t)(2 * b) * mask_layer)[mask_off];
         zero(t);
         gemm_split<JT, SplitAdvBwd>(t, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
@@ -1071,11 +1066,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
             const size_t mask_view = mask_pooled + (size_t)view * (size_t)q.ntiles * NTHREADS;
 #pragma unroll 1
             for (int b = COMBINE_LAYER - 1; b >= 0; --b) bwd_block(G, b, rows_view, mask_view);
-            dump_rows(G, q.g_x0, rows_view);  // dY of lin_in and lin_z[0]
             // ---- d z_lat = sum_b dY_b W_z[b] and d(code) = dY_0 W_in (resnetfc.py:147,175-180 backward): four more transposed-
-            // stream GEMMs on gradients this tile has just produced.  dY_2, dY_1 (= g_fc1[1], g_fc1[0]) come back from their fp32
-            // rows (written by this workgroup a moment ago, L2-resident) and are split into the image in storage order; dY_0 = G
-            // is still in registers.
+            // stream GEMMs on gradient images this tile has just produced.  dY_2, dY_1 (= g_fc1[1], g_fc1[0]) come back from the
+            // rows this workgroup copied out a moment ago (L2-resident); dY_0 = G is still in registers.
             f32x16 Z[IT][JT];
             zero(Z);
 #pragma unroll 1
@@ -1083,22 +1076,18 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
                 __threadfence_block();
                 __syncthreads();  // the image's readers are done; the rows this tile dumped are visible
                 {
-                    const float *src = q.g_fc1[b - 1] + (size_t)rows_view * D_HID;
+                    const char *src = q.g_fc1[b - 1] + (size_t)rows_view * (D_HID * 2);
+                    const size_t total = (size_t)NS * (size_t)q.P * (D_HID * 2);
 #pragma unroll
-                    for (int u = 0; u < MT * (D_HID / 4) / NTHREADS; ++u) {
-                        const int k = u * NTHREADS + tid, row = k >> 7, f = (k & 127) * 4;  // 4 consecutive features of a row
-                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                        if (row < rows_left) v = *reinterpret_cast<const f32x4 *>(src + (size_t)row * D_HID + f);
-                        // storage slot of feature f (f & 3 == 0): 32 T + 16 h + 4 k'  for f = 32 T + 8 k' + 4 h
-                        const int slot = (f & ~31) + 16 * ((f >> 2) & 1) + 4 * ((f & 31) >> 3);
-                        const f16x2 h01 = __builtin_convertvector(f32x2{v[0], v[1]}, f16x2), h23 = __builtin_convertvector(f32x2{v[2], v[3]}, f16x2);
-                        const f32x2 b01 = __builtin_convertvector(h01, f32x2), b23 = __builtin_convertvector(h23, f32x2);
-                        const f16x2 l01 = __builtin_convertvector(f32x2{v[0] - b01[0], v[1] - b01[1]}, f16x2),
-                                    l23 = __builtin_convertvector(f32x2{v[2] - b23[0], v[3] - b23[1]}, f16x2);
-                        const uint2 hi = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
-                        const uint2 lo = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
-                        *reinterpret_cast<uint2 *>(smem + ST::A_HI + row * ROW_ACT + slot * 2) = hi;
-                        *reinterpret_cast<uint2 *>(smem + ST::A_LO + row * ROW_ACT + slot * 2) = lo;
+                    for (int u = 0; u < MT / NW; ++u) {
+                        const int row = wv * (MT / NW) + u;
+                        u32x4 vh = {0, 0, 0, 0}, vl = vh;
+                        if (row < rows_left) {
+                            vh = *reinterpret_cast<const u32x4 *>(src + (size_t)row * (D_HID * 2) + lane * 16);
+                            vl = *reinterpret_cast<const u32x4 *>(src + total + (size_t)row * (D_HID * 2) + lane * 16);
+                        }
+                        *reinterpret_cast<u32x4 *>(smem + ST::A_HI + row * ROW_ACT + lane * 16) = vh;
+                        *reinterpret_cast<u32x4 *>(smem + ST::A_LO + row * ROW_ACT + lane * 16) = vl;
                     }
                 }
                 __syncthreads();
@@ -1107,6 +1096,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
             __syncthreads();
             write_split<ST, false>(G, smem, a_wr);  // dY of lin_in and lin_z[0]
             __syncthreads();
+            dump_pair(q.g_x0, rows_view, true);
             gemm_split<JT, SplitAdvBwd>(Z, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);      // lin_z[0]^T dY_0
             {   // accumulator (channel 64 wv + 32 it + (r&3) + 8(r>>2) + 4h, point) -> fp32 rows, 16-byte pieces, out of the scaled domain
                 float *dst = q.d_zlat + ((size_t)rows_view + pl) * C_LAT + (wv * IT) * 32 + 4 * h;
@@ -1237,7 +1227,7 @@ int pack_bwd_split(const PnrMlpWeights *w, void *packed, hipStream_t st) {
 }
 
 int mlp_backward_split_chain(const void *packed_bwd_split, const unsigned long long *masks, const float *g_out, const float *scale_dev,
-                             long long P, int NS, float *const *g_fc1, float *const *g_fc0, float *g_x0, float *d_zlat, float *d_in,
+                             long long P, int NS, void *const *g_fc1, void *const *g_fc0, void *g_x0, float *d_zlat, float *d_in,
                              hipStream_t st) {
     if (!packed_bwd_split || !masks || !g_out || !scale_dev || !g_fc1 || !g_fc0 || !g_x0 || !d_zlat || P <= 0 || NS <= 0)
         return pnr_fail(PNR_E_INVALID, "mlp_backward_split_chain: bad argument");
@@ -1248,9 +1238,9 @@ int mlp_backward_split_chain(const void *packed_bwd_split, const unsigned long l
     q.ntiles = (int)nt;
     for (int b = 0; b < 5; ++b) {
         if (!g_fc1[b] || !g_fc0[b]) return pnr_fail(PNR_E_INVALID, "mlp_backward_split_chain: null gradient buffer");
-        q.g_fc1[b] = g_fc1[b]; q.g_fc0[b] = g_fc0[b];
+        q.g_fc1[b] = (char *)g_fc1[b]; q.g_fc0[b] = (char *)g_fc0[b];
     }
-    q.g_x0 = g_x0; q.d_zlat = d_zlat; q.d_in = d_in;
+    q.g_x0 = (char *)g_x0; q.d_zlat = d_zlat; q.d_in = d_in;
     const int cus = bwd_split_cus();
     const int grid = (int)(nt < cus ? nt : cus);
     const bool mv = NS > 1;
@@ -1288,20 +1278,19 @@ int pnr::eval_samples_split_src(const PnrScene *scene, const void *packed_split,
     return pnr::split_launch(scene, packed_split, tables_f32, q, true, stream);
 }
 
-// training forward of the fp32-class path (pnr_f32.hip, pnr_eval_ray_samples_split_train): outputs + the saved fp32 rows
+// training forward of the fp32-class path (pnr_f32.hip, pnr_eval_ray_samples_split_train): outputs + what the backward keeps
 int pnr::eval_samples_split_train(const PnrScene *scene, const void *packed_split, const void *tables_f32, const float *rays,
-                                  const float *z, int R, int rays_per_obj, int K, float *rgbsigma, float *const *xin, float *const *net,
-                                  float *x5, float *pool_in, void *masks, hipStream_t stream) {
-    if (!rays || !z || !xin || !net || !x5) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: null argument");
-    if (scene && scene->NS > 1 && !pool_in) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: pool_in is required with several views");
+                                  const float *z, int R, int rays_per_obj, int K, float *rgbsigma, void *const *img_a, void *const *img_n,
+                                  float *x5, void *masks, hipStream_t stream) {
+    if (!rays || !z || !img_a || !img_n || !x5 || !masks) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: null argument");
     if (SPLIT_MV_TILE != 64) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: built with 32-point multi-view tiles");
     pnr::EvalParams q = {};
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K; q.out = rgbsigma;
     for (int b = 0; b < 5; ++b) {
-        if (!xin[b] || !net[b]) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: null activation buffer");
-        q.f_xin[b] = xin[b]; q.f_net[b] = net[b];
+        if (!img_a[b] || !img_n[b]) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_split_train: null operand buffer");
+        q.s_a[b] = (char *)img_a[b]; q.s_n[b] = (char *)img_n[b];
     }
-    q.f_x5 = x5; q.f_pool = pool_in;
+    q.f_x5 = x5;
     q.d_mask = (unsigned long long *)masks;
     return pnr::split_launch(scene, packed_split, tables_f32, q, true, stream);
 }

@@ -875,19 +875,12 @@ class F32Saved:
         self.net = [f(rv if b < 3 else rp, 512) for b in range(5)]
         self.x5 = f(rp, 512)
         self.pool_in = f(rv, 512) if NS > 1 else None
-        self.masks = None  # relu bit masks: only the fused split-operand forward writes them (with_masks())
         s = _lib.PnrF32Saved()
         s.in42, s.zlat, s.x5 = self.in42.data_ptr(), self.zlat.data_ptr(), self.x5.data_ptr()
         s.pool_in = self.pool_in.data_ptr() if self.pool_in is not None else None
         for b in range(5):
             s.xin[b], s.net[b] = self.xin[b].data_ptr(), self.net[b].data_ptr()
         self.struct = s
-
-    def with_masks(self):
-        if self.masks is None:
-            self.masks = torch.empty(_lib.load().pnr_train_masks_bytes(self.P, self.NS), dtype=torch.uint8, device=self.x5.device)
-            self.struct.masks = self.masks.data_ptr()
-        return self
 
     def release(self):  # interface twin of TrainDumps.release (the fp32 sets are not pooled)
         pass
@@ -911,10 +904,32 @@ def eval_ray_samples_f32_train(scene, weights, rays, z, split=False):
     return out, saved
 
 
+class SplitSaved:
+    """What the fused fp32-class training forward keeps (PnrSplitSaved): every wide linear's operand as (head | tail) f16 rows,
+    the stream in front of lin_out in fp32, 1-bit relu masks: (NS * 7424 + 6144) bytes per point + masks."""
+
+    def __init__(self, P, NS, device):
+        rv, rp = NS * P, P
+        h = lambda r, c: torch.empty((2, r, c), dtype=torch.float16, device=device)  # noqa: E731  [head | tail]
+        self.P, self.NS = P, NS
+        self.in_op, self.zlat = h(rv, 64), h(rv, 512)
+        self.a = [h(rv if b < 3 else rp, 512) for b in range(5)]
+        self.n = [h(rv if b < 3 else rp, 512) for b in range(5)]
+        self.x5 = torch.empty((rp, 512), dtype=torch.float32, device=device)
+        self.masks = torch.empty(_lib.load().pnr_train_masks_bytes(P, NS), dtype=torch.uint8, device=device)
+        s = _lib.PnrSplitSaved()
+        s.in_op, s.zlat, s.x5, s.masks = self.in_op.data_ptr(), self.zlat.data_ptr(), self.x5.data_ptr(), self.masks.data_ptr()
+        for b in range(5):
+            s.a[b], s.n[b] = self.a[b].data_ptr(), self.n[b].data_ptr()
+        self.struct = s
+
+    def release(self):  # interface twin of TrainDumps.release
+        pass
+
+
 def eval_ray_samples_split_train(scene, packed, tables, rays, z):
     """fp32-class training forward through the FUSED split-operand kernel (pnr_eval_ray_samples_split_train): packed = folded
-    'f16x3' PackedMLP, tables = fold_latent(scene, state, 'f16x3') of the current parameters.  -> (rgbsigma (R,K,4), F32Saved
-    with split=True) -- what eval_ray_samples_f32_train(split=True) returns, from one network launch."""
+    'f16x3' PackedMLP, tables = fold_latent(scene, state, 'f16x3') of the current parameters.  -> (rgbsigma (R,K,4), SplitSaved)."""
     lib = _lib.load()
     if packed.precision != _lib.PREC_F16X3 or not packed.folded:
         raise ValueError("eval_ray_samples_split_train takes the folded 'f16x3' stream")
@@ -924,19 +939,38 @@ def eval_ray_samples_split_train(scene, packed, tables, rays, z):
     R = rays.shape[0]
     z = _f32(z, "z", (R, None))
     K = z.shape[1]
-    saved = F32Saved(R * K, scene.NS, rays.device).with_masks()
+    saved = SplitSaved(R * K, scene.NS, rays.device)
     out = torch.empty((R, K, 4), dtype=torch.float32, device=rays.device)
     with torch.cuda.device(rays.device):
         _lib.check(lib.pnr_eval_ray_samples_split_train(scene.ref, packed.ptr, _p(tables), _p(rays), _p(z), R, max(R // scene.SB, 1), K,
                                                         _p(out), ctypes.byref(saved.struct), _stream()), "pnr_eval_ray_samples_split_train")
-    saved.split = True
     return out, saved
 
 
-def mlp_backward_f32(weights, saved, g_out, want_d_in=False, fused_chain=True):
+def mlp_backward_split(weights, saved, g_out, want_d_in=False):
+    """Backward of eval_ray_samples_split_train (pnr_mlp_backward_split): weights = PackedMLP of precision 'f32' (the raw
+    nn.Linear tensors; the transposed streams are packed inside the call).  -> (grads, d_zlat, d_in | None) like mlp_backward_f32."""
+    lib = _lib.load()
+    P, NS = saved.P, saved.NS
+    g_out = _f32(g_out, "g_out", (P, 4))
+    dev = g_out.device
+    grads = {k: torch.empty(_MLP_SHAPES.get(k, (512, 512) if k.endswith("weight") else (512,)), dtype=torch.float32, device=dev)
+             for k in _MLP_KEYS}
+    gstruct, _keep = _weights_struct(grads)
+    d_zlat = torch.empty((NS * P, 512), dtype=torch.float32, device=dev)
+    d_in = torch.empty((NS * P, 42), dtype=torch.float32, device=dev) if want_d_in else None
+    sc = grad_scale(g_out)  # device [s, 1/s]: no host synchronisation
+    nbytes = lib.pnr_mlp_backward_split_workspace_bytes(P, NS)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_mlp_backward_split(weights.wref, ctypes.byref(saved.struct), _p(g_out), P, NS, ctypes.byref(gstruct),
+                                              _p(d_zlat), _p(d_in), _p(sc), _p(ws), nbytes, _stream()), "pnr_mlp_backward_split")
+    return grads, d_zlat, d_in
+
+
+def mlp_backward_f32(weights, saved, g_out, want_d_in=False):
     """-> ({reference state_dict key: fp32 gradient}, d_zlat (rows_v,512), d_in (rows_v,42) | None) of one ResnetFC: exact fp32
-    MFMA products, or the split-operand (fp32-class) form when the forward ran with split=True -- with the data-gradient chain
-    fused (pnr_mlp_backward_split) when the forward left its relu masks (eval_ray_samples_split_train) and fused_chain is set."""
+    MFMA products, or the split-operand (fp32-class) form when the forward ran with split=True."""
     lib = _lib.load()
     P, NS = saved.P, saved.NS
     g_out = _f32(g_out, "g_out", (P, 4))
@@ -948,13 +982,6 @@ def mlp_backward_f32(weights, saved, g_out, want_d_in=False, fused_chain=True):
     d_in = torch.empty((NS * P, 42), dtype=torch.float32, device=dev) if want_d_in else None
     split = bool(getattr(saved, "split", False))
     sc = grad_scale(g_out) if split else None  # device [s, 1/s]: no host synchronisation
-    if split and fused_chain and saved.masks is not None:
-        nbytes = lib.pnr_mlp_backward_split_workspace_bytes(P, NS)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(lib.pnr_mlp_backward_split(weights.wref, ctypes.byref(saved.struct), _p(g_out), P, NS, ctypes.byref(gstruct),
-                                                  _p(d_zlat), _p(d_in), _p(sc), _p(ws), nbytes, _stream()), "pnr_mlp_backward_split")
-        return grads, d_zlat, d_in
     nbytes = lib.pnr_mlp_backward_f32_workspace_bytes(P, NS)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
