@@ -1113,7 +1113,8 @@ def weight_grad(dY, X, precision, out_scale=1.0, want_bias=True, rows_st=False, 
 
 def weight_grad_batched(jobs, precision, out_scale=1.0, out_scale_dev=None):
     """jobs: list of (dY, X, rows_st, cols_st[, x_cols, dw_cols]) with dY (rows,512), X (rows,x_cols=512) 16-bit
-    dumps -> list of (dW (512,dw_cols), db (512)), all computed by ONE pnr_weight_grad_batched call (<= 16 jobs)."""
+    dumps -> list of (dW (512,dw_cols), db (512)), all computed by ONE pnr_weight_grad_batched call (<= 16 jobs).
+    precision 'f16x3' (split-operand, fp32-class): dY (2,rows,512), X (2,rows,x_cols) float16 = [head | tail] row sets."""
     lib = _lib.load()
     n = len(jobs)
     dev = jobs[0][0].device
@@ -1125,8 +1126,12 @@ def weight_grad_batched(jobs, precision, out_scale=1.0, out_scale_dev=None):
     for j, job in enumerate(jobs):
         dY, X, rows_st, cols_st = job[:4]
         x_cols, dw_cols = (job[4], job[5]) if len(job) > 4 else (512, 512)
-        rows = dY.shape[0]
-        assert dY.shape == (rows, 512) and X.shape == (rows, x_cols) and dY.dtype == X.dtype and dY.is_cuda
+        if int(precision) == _lib.PREC_F16X3:
+            rows = dY.shape[1]
+            assert dY.shape == (2, rows, 512) and X.shape == (2, rows, x_cols) and dY.dtype == X.dtype == torch.float16 and dY.is_cuda
+        else:
+            rows = dY.shape[0]
+            assert dY.shape == (rows, 512) and X.shape == (rows, x_cols) and dY.dtype == X.dtype and dY.is_cuda
         dY, X = dY.contiguous(), X.contiguous()
         dW = torch.empty((512, dw_cols), dtype=torch.float32, device=dev)
         db = torch.empty((512,), dtype=torch.float32, device=dev)

@@ -215,6 +215,47 @@ def test_latent_scatter_matches_autograd(dev, Hl, Wl):
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
 
 
+def test_weight_grad_kernel_split_operands(dev):
+    """dW = dY^T X at split-operand precision (pnr_weight_grad_batched at PNR_PREC_F16X3, dw_split_kernel): operands as
+    [head | tail] f16 row sets, three MFMAs per product.  Against an fp64 matmul of the fp32 values the pairs stand for:
+    only the tail x tail term (2^-22 of a product) and the summation order differ.  Ragged rows, both storage orders, the
+    narrow lin_in operand, several jobs in one launch, bit-reproducibility."""
+    from pixelnerf_amd import _lib, ops
+    gen = torch.Generator().manual_seed(9)
+    perm = ops.storage_perm(dev).long()
+    p = _lib.PREC_F16X3
+
+    def pair(v):  # fp32 -> [head | tail] (2, rows, cols) f16, and the fp32 value the pair stands for
+        h = v.to(torch.float16)
+        l = (v - h.float()).to(torch.float16)
+        return torch.stack([h, l]).contiguous(), h.double() + l.double()
+
+    jobs, refs = [], []
+    for rows, cols, rs, cs in ((1000, 512, True, True), (37, 512, False, False), (4096 + 5, 512, True, False), (3000, 64, True, False)):
+        dYp, dYv = pair((torch.randn(rows, 512, generator=gen) * 0.5).to(dev))
+        Xv32 = torch.randn(rows, cols, generator=gen).to(dev)
+        if cols == 64:
+            Xv32[:, 42:] = 0
+        Xp, Xv = pair(Xv32)
+        jobs.append((dYp, Xp, rs, cs, cols, 42 if cols == 64 else 512))
+        dW, db = dYv.t() @ Xv * 0.25, dYv.sum(0) * 0.25
+        if cols == 64:
+            dW = dW[:, :42]
+        if rs:
+            o = torch.empty_like(dW); o[perm] = dW; dW = o
+            b = torch.empty_like(db); b[perm] = db; db = b
+        if cs:
+            o = torch.empty_like(dW); o[:, perm] = dW; dW = o
+        refs.append((dW, db))
+    outs = ops.weight_grad_batched(jobs, p, 0.25)
+    again = ops.weight_grad_batched(jobs, p, 0.25)
+    for (dW, db), (dW2, db2), (rW, rb) in zip(outs, again, refs):
+        assert dW.shape == rW.shape
+        assert (dW.double() - rW).norm() <= 1e-6 * rW.norm() and (db.double() - rb).norm() <= 1e-6 * rb.norm()
+        assert (dW.double() - rW).abs().max() <= 2e-6 * rW.abs().max()
+        assert torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize("prec,dt", [("f16", torch.float16), ("bf16", torch.bfloat16)])
 def test_weight_grad_kernel_single_and_batched(dev, prec, dt):
     """dW = dY^T X / db = column sums from 16-bit row-major dumps (transposing LDS reads, split rows, fixed-order

@@ -1,7 +1,9 @@
 """
-GPU tests (-m gpu) of the fp32-precision training paths (pnr_eval_ray_samples_f32_train + pnr_mlp_backward_f32,
-pixel-nerf_amd/csrc/pnr_f32.hip) -- precision "f32" (every product on the exact fp32 MFMA: the yardstick) and "f16x3" (the same
-chain with split-operand GEMMs on the f16 matrix cores: fp32-class, ~6x faster): every one of the 61 gradient tensors -- both ResnetFCs and
+GPU tests (-m gpu) of the fp32-precision training paths -- precision "f32" (pnr_eval_ray_samples_f32_train + pnr_mlp_backward_f32,
+every product on the exact fp32 MFMA: the yardstick), "f16x3" in its default FUSED form (pnr_eval_ray_samples_split_train +
+pnr_mlp_backward_split: the split-operand inference kernel in its training instantiation, one launch for the transposed
+products, one batched split-operand weight-gradient launch) and "f16x3-gemms" (the same arithmetic as one split-operand GEMM
+per layer, autograd.FUSED_SPLIT_TRAINING = False): every one of the 61 gradient tensors -- both ResnetFCs and
 encoder.latent, including the position gradient through the depth samples (nerf.py:292) -- against the gradients of the
 UNMODIFIED reference's own backward (tests/golden/gradients.npz, frozen by oracle/make_goldens.py: train/train.py:199-215
 loss, torch autograd through src/render/nerf.py:251-303) at <= 1e-3 relative on the frozen subsample and on the norm.
@@ -31,6 +33,17 @@ def dev():
 
 
 def train_grads(dev, name, precision):
+    from pixelnerf_amd import autograd
+    fused = precision != "f16x3-gemms"
+    precision = precision.split("-")[0]
+    saved, autograd.FUSED_SPLIT_TRAINING = autograd.FUSED_SPLIT_TRAINING, fused
+    try:
+        return _train_grads(dev, name, precision)
+    finally:
+        autograd.FUSED_SPLIT_TRAINING = saved
+
+
+def _train_grads(dev, name, precision):
     from pixelnerf_amd.model import make_model
     from pixelnerf_amd.render import NeRFRenderer
     from pixelnerf_amd.util.conf import default_model_conf
@@ -60,7 +73,7 @@ def train_grads(dev, name, precision):
     return float(loss.item()), {k: v.detach().reshape(-1).cpu().numpy() for k, v in grads.items()}, gg
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])  # exact fp32 MFMA products / split-operand (fp32-class) GEMMs
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3-gemms"])  # exact fp32 MFMA / split-operand fused / split-operand GEMM per layer
 @pytest.mark.parametrize("name", ["train_64_32", "srn_mini_64_128", "train_cfg5"])
 def test_fp32_gradients_match_reference_autograd(dev, name, precision):
     loss, grads, gg = train_grads(dev, name, precision)
