@@ -343,6 +343,9 @@ def extra_train_step(dev, prec, scene_name="train", steps=40, warmup=8, with_gra
            "algorithmic_tflops": n_rays / dt * flop_ray / 1e12, "frac_of_f16_mfma_peak": n_rays / dt * flop_ray / 1e12 / PEAK_TFLOPS,
            "loss_first_step": loss_first, "loss": float(loss.item()), "steps": steps,
            "launch_mode": "eager launches (one Python-sequenced HIP launch per kernel)"}
+    if prec == "f16x3":
+        out["form"] = ("fused: split-operand forward kernel in its training instantiation, one launch for the transposed products, "
+                       "one batched split-operand weight-gradient launch (pnr_eval_ray_samples_split_train / pnr_mlp_backward_split)")
     if with_graph:
         # the same step captured ONCE into a HIP graph (torch.cuda.CUDAGraph: forward, backward and a capturable Adam) and
         # replayed: no per-kernel launch latency, no Python between the ~35 kernels.  Run as a CHILD process
@@ -364,6 +367,19 @@ def extra_train_step(dev, prec, scene_name="train", steps=40, warmup=8, with_gra
     del net, rend
     torch.cuda.empty_cache()
     return out
+
+
+def train_step_unfused_twin(dev):
+    """the fp32-class training step in its GEMM-per-layer form (one split-operand GEMM launch per product; the A/B twin of the
+    fused default and the form the round started from)"""
+    from pixelnerf_amd import autograd
+    saved, autograd.FUSED_SPLIT_TRAINING = autograd.FUSED_SPLIT_TRAINING, False
+    try:
+        r = extra_train_step(dev, "f16x3", steps=6, warmup=2, with_graph=False)
+    finally:
+        autograd.FUSED_SPLIT_TRAINING = saved
+    r["form"] = "one split-operand GEMM launch per linear (autograd.FUSED_SPLIT_TRAINING = False)"
+    return r
 
 
 def self_launch(n):
@@ -734,7 +750,9 @@ def main():
             # BASELINE configs[2..4] on this one GPU, outside the timed region
             for key, fn in (("train_step", lambda: extra_train_step(dev, "f16")),
                             ("train_step_multiview", lambda: extra_train_step(dev, "f16", "train_mv", steps=20, warmup=4, with_graph=False)),
-                            ("train_step_fp32_class", lambda: extra_train_step(dev, "f16x3", steps=10, warmup=3, with_graph=False)),
+                            ("train_step_fp32_class", lambda: extra_train_step(dev, "f16x3", steps=16, warmup=4, with_graph=False)),
+                            ("train_step_fp32_class_multiview", lambda: extra_train_step(dev, "f16x3", "train_mv", steps=12, warmup=3, with_graph=False)),
+                            ("train_step_fp32_class_gemm_per_layer", lambda: train_step_unfused_twin(dev)),
                             ("train_step_fp32_validation_path", lambda: extra_train_step(dev, "f32", steps=5, warmup=2, with_graph=False)),
                             ("srn_car", lambda: extra_render_config(dev, "srn_car", 4)),
                             ("dtu", lambda: extra_render_config(dev, "dtu", 1))):

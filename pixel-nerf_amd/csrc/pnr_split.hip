@@ -180,7 +180,17 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         f32x2 p = {v[2 * k], v[2 * k + 1]};
-        if (RELU) { p[0] = fmaxf(p[0], 0.f); p[1] = fmaxf(p[1], 0.f); }
+        if (RELU) {
+#ifdef PNR_SPLIT_RELU_FMAX  // A/B: fmaxf lowers to TWO v_max_f32 per value under IEEE mode (canonicalise the input, then max with 0)
+            p[0] = fmaxf(p[0], 0.f); p[1] = fmaxf(p[1], 0.f);
+#else
+            // one v_med3_f32 per value: median(v, 0, FLT_MAX) = max(v, 0) for every finite v (the head saturates at 65504 anyway;
+            // with +inf as the upper bound LLVM folds the median back into the two-instruction maxnum).  NOT an inline-asm
+            // v_max_f32: the accumulators come straight out of the MFMA pipe and hipcc does not place the MFMA -> VALU wait
+            // states in front of inline asm -- that form read stale registers in the multi-view instantiations.
+            p[0] = __builtin_amdgcn_fmed3f(p[0], 0.f, 3.402823466e38f); p[1] = __builtin_amdgcn_fmed3f(p[1], 0.f, 3.402823466e38f);
+#endif
+        }
         const f16x2 h = __builtin_convertvector(p, f16x2);
         uh[k] = __builtin_bit_cast(uint32_t, h);
 #ifdef PNR_SPLIT_NO_MIX
