@@ -359,6 +359,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
     [[maybe_unused]] size_t tr_mask_view = 0, tr_mask_pooled = 0;
     [[maybe_unused]] const size_t tr_mask_layer = (size_t)NS * (size_t)q.ntiles * NTHREADS;
     [[maybe_unused]] auto put_mask = [&](const f32x16 (&a)[IT][JT], int layer, size_t word) {
+#ifdef PNR_EXP_TRAIN_NOMASK  // experiment (TIMING ONLY, wrong gradients): no relu masks
+        return;
+#endif
         unsigned long long m = 0ull;
 #pragma unroll
         for (int it = 0; it < IT; ++it)
@@ -373,6 +376,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
     };
     // TRAIN: the operand images just published (head, tail) -> their 16-bit row sets, whole 1 KiB rows per wave instruction
     [[maybe_unused]] auto dump_pair = [&](char *head, int b) {
+#ifdef PNR_EXP_TRAIN_NODUMP  // experiment (TIMING ONLY, wrong gradients): no operand image copies
+        return;
+#endif
         const long long rows = b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled;
         const size_t total = (size_t)(b < COMBINE_LAYER ? (long long)NS * q.P : q.P) * (D_HID * 2);
         dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), tr_rows_left, wv, lane);
@@ -991,6 +997,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
     long long rows_left = 0;
     // the gradient image just published (head, tail) -> its 16-bit row sets (operands of the weight-gradient GEMM), whole rows
     auto dump_pair = [&](char *head, long long rows, bool per_view) {
+#ifdef PNR_EXP_BWD_NODUMP  // experiment (TIMING ONLY, wrong gradients): no gradient image copies
+        return;
+#endif
         const size_t total = (size_t)(per_view ? (long long)NS * q.P : q.P) * (D_HID * 2);
         dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), rows_left, wv, lane);
         dump_image<MT>(smem, ST::A_LO, head + total + (size_t)rows * (D_HID * 2), rows_left, wv, lane);
