@@ -12,8 +12,21 @@
 // 3 MFMAs per (weight fragment, activation fragment) instead of 1, 2x the operand bytes: ~1/3 of the f16 kernel's
 // rate, several times the fp32-MFMA ceiling, at the accuracy class of the reference's own fp32 arithmetic
 // (tests/test_hip_split.py holds it to the bars of tests/test_hip_f32.py: per-point |rgb| <= 2e-5).
-// Folded form, inference; 64-point tiles for one source view, 32-point tiles with the view sum in registers for
-// several.  The unfused fp32-MFMA path (pnr_f32.hip) remains the implementation-independent yardstick.
+// Folded form; 64-point tiles (several source views: the view sum parked in a per-workgroup scratch).  The unfused fp32-MFMA
+// path (pnr_f32.hip) remains the implementation-independent yardstick.
+//
+// Kernels of this file:
+//   eval_split_kernel<RAYS, MV, TIMING, TRAIN>   the fused network.  TRAIN = the fp32-class TRAINING forward: the same launch also
+//                                                copies every wide linear's (head, tail) operand image out of LDS (relu(x) /
+//                                                relu(net): the operands of the weight gradients), writes 1-bit relu masks and
+//                                                the stream in front of lin_out; the inference instantiations compile to the
+//                                                code they had before the flag existed.
+//   bwd_split_kernel<MV>                         the fused data-gradient chain behind it: all 15 transposed products of a network
+//                                                (transposed head / tail streams, gradient of the stream in the accumulators,
+//                                                gradient images copied out the same way, d z_lat / d code as fp32 rows).
+//   pack_weights_bwd_split_kernel                its weight streams, from the raw parameters.
+//   eval_split96_kernel                          96-point K-half-staged experiment (measured slower; test hook only).
+// The weight gradients over those images are dw_split_kernel (pnr_bwd.hip); host side: pnr_f32.hip (pnr_*_split_train).
 #include <hip/hip_runtime.h>
 
 #include "pnr_common.h"
@@ -82,9 +95,20 @@ struct SplitAdvBwd {
 __device__ __forceinline__ f32x16 mf(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // acc[it][jt] += (Wh + Wl)(Xh + Xl) without the tail-tail term; B rows at bhi0 + jt*jstride (+ lo_delta for the tails)
-template <int JT, typename ADV = SplitAdvFwd>
+// Training: the copy of the operand / gradient image a GEMM multiplies from -- (head, tail) rows of 1 KiB, the wave's MT / NW = 8
+// rows of a 64-point tile -- can ride INSIDE that GEMM's loop (-DPNR_SPLIT_DUMP_IN_GEMM): body b reads row b of both images
+// from LDS in front of its first MFMA and stores them behind its last, in the shadow of the body's 48 MFMAs, instead of 16 LDS
+// reads + 16 stores per wave in front of the GEMM.
+struct SplitDump {
+    const char *src_hi, *src_lo;  // LDS images + this wave's first row + lane * 16
+    char *dst_hi, *dst_lo;        // the same position in the two row sets
+    long long rows_left;          // rows of the tile that exist
+    int row0;                     // this wave's first row of the tile
+};
+
+template <int JT, typename ADV = SplitAdvFwd, bool DUMP = false>
 __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *smem, uint32_t bhi0, uint32_t jstride,
-                                           uint32_t lo_delta, int nbody, SplitRing &R, int NS) {
+                                           uint32_t lo_delta, int nbody, SplitRing &R, int NS, [[maybe_unused]] const SplitDump *dj = nullptr) {
     h8 bh[2][JT], bl[2][JT];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
@@ -93,6 +117,11 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
     }
 #pragma unroll 1
     for (int body = 0; body < nbody; ++body) {
+        [[maybe_unused]] u32x4 dv_hi, dv_lo;
+        if constexpr (DUMP) {
+            dv_hi = *reinterpret_cast<const u32x4 *>(dj->src_hi + body * ROW_ACT);
+            dv_lo = *reinterpret_cast<const u32x4 *>(dj->src_lo + body * ROW_ACT);
+        }
 #ifdef PNR_EXP_FAKE_W  // experiment: every refill reads the same 16 KiB window (L1-resident: the instruction stream without the L2 -> CU traffic); wrong results
         const size_t pf = (size_t)(R.pf_rs & 0) * (IT * 1024);
 #elif defined(PNR_EXP_WRAP_W)  // experiment: the stream wraps inside its first PNR_EXP_WRAP_W ring steps (L2-resident); wrong results
@@ -167,6 +196,12 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
         }
         bhi0 += 128;
         ADV::step(R, NS);
+        if constexpr (DUMP) {
+            if (dj->row0 + body < dj->rows_left) {
+                *reinterpret_cast<u32x4 *>(dj->dst_hi + (size_t)body * (D_HID * 2)) = dv_hi;
+                *reinterpret_cast<u32x4 *>(dj->dst_lo + (size_t)body * (D_HID * 2)) = dv_lo;
+            }
+        }
     }
 }
 
@@ -374,6 +409,23 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             }
         (q.d_mask + (size_t)layer * tr_mask_layer)[word] = m;
     };
+#ifdef PNR_SPLIT_DUMP_IN_GEMM
+    constexpr bool DUMP_IN_GEMM = TRAIN;
+#else
+    constexpr bool DUMP_IN_GEMM = false;
+#endif
+    [[maybe_unused]] auto dump_job = [&](char *head, int b) {
+        const long long rows = b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled;
+        const size_t total = (size_t)(b < COMBINE_LAYER ? (long long)NS * q.P : q.P) * (D_HID * 2);
+        SplitDump dj;
+        dj.row0 = wv * (MT / NW);
+        dj.src_hi = smem + ST::A_HI + dj.row0 * ROW_ACT + lane * 16;
+        dj.src_lo = dj.src_hi + (ST::A_LO - ST::A_HI);
+        dj.dst_hi = head + ((size_t)rows + dj.row0) * (D_HID * 2) + lane * 16;
+        dj.dst_lo = dj.dst_hi + total;
+        dj.rows_left = tr_rows_left;
+        return dj;
+    };
     // TRAIN: the operand images just published (head, tail) -> their 16-bit row sets, whole 1 KiB rows per wave instruction
     [[maybe_unused]] auto dump_pair = [&](char *head, int b) {
 #ifdef PNR_EXP_TRAIN_NODUMP  // experiment (TIMING ONLY, wrong gradients): no operand image copies
@@ -393,10 +445,14 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         PNR_T(PH_WRITE_X);
         __syncthreads();
         PNR_T(PH_BAR2);
-        if constexpr (TRAIN) dump_pair(q.s_a[b], b);
+        if constexpr (TRAIN && !DUMP_IN_GEMM) dump_pair(q.s_a[b], b);
         {
             f32x16 net[IT][JT];
             add_bias<true>(net, bias_lane, 1 + 2 * b);
+            if constexpr (DUMP_IN_GEMM) {
+                const SplitDump dj = dump_job(q.s_a[b], b);
+                gemm_split<JT, SplitAdvFwd, true>(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS, &dj);
+            } else
             gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);  // fc_0
             PNR_T(PH_GEMM_FC0);
             if constexpr (TRAIN) put_mask(net, 2 * b + 1, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
@@ -407,8 +463,12 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         }
         __syncthreads();
         PNR_T(PH_BAR4);
-        if constexpr (TRAIN) dump_pair(q.s_n[b], b);
+        if constexpr (TRAIN && !DUMP_IN_GEMM) dump_pair(q.s_n[b], b);
         add_bias<false>(x, bias_lane, 2 + 2 * b);
+        if constexpr (DUMP_IN_GEMM) {
+            const SplitDump dj = dump_job(q.s_n[b], b);
+            gemm_split<JT, SplitAdvFwd, true>(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS, &dj);
+        } else
         gemm_split(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);        // fc_1
         PNR_T(PH_GEMM_FC1_Z);
         if (lookup) {
@@ -1004,25 +1064,49 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
         dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), rows_left, wv, lane);
         dump_image<MT>(smem, ST::A_LO, head + total + (size_t)rows * (D_HID * 2), rows_left, wv, lane);
     };
+#ifdef PNR_SPLIT_DUMP_IN_GEMM
+    constexpr bool DUMP_IN_GEMM = true;
+#else
+    constexpr bool DUMP_IN_GEMM = false;
+#endif
+    [[maybe_unused]] auto dump_job = [&](char *head, long long rows, bool per_view) {
+        const size_t total = (size_t)(per_view ? (long long)NS * q.P : q.P) * (D_HID * 2);
+        SplitDump dj;
+        dj.row0 = wv * (MT / NW);
+        dj.src_hi = smem + ST::A_HI + dj.row0 * ROW_ACT + lane * 16;
+        dj.src_lo = dj.src_hi + (ST::A_LO - ST::A_HI);
+        dj.dst_hi = head + ((size_t)rows + dj.row0) * (D_HID * 2) + lane * 16;
+        dj.dst_lo = dj.dst_hi + total;
+        dj.rows_left = rows_left;
+        return dj;
+    };
+    // the GEMM on the image just published, with the image's copy-out in front of it or inside its loop
+    auto gemm_dump = [&](f32x16 (&a)[IT][JT], char *head, long long rows, bool per_view) {
+        if constexpr (DUMP_IN_GEMM) {
+            const SplitDump dj = dump_job(head, rows, per_view);
+            gemm_split<JT, SplitAdvBwd, true>(a, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS, &dj);
+        } else {
+            dump_pair(head, rows, per_view);
+            gemm_split<JT, SplitAdvBwd>(a, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
+        }
+    };
     // reverse of one residual block (resnetfc.py:55-62):  given G = dL/d(x + fc_1(relu(fc_0(relu(x))))),
     //   dY(fc_1) = G ;  d net = (fc_1^T G) . [net > 0] = dY(fc_0) ;  G += (fc_0^T d net) . [x > 0]
     auto bwd_block = [&](f32x16 (&G)[IT][JT], int b, long long rows, size_t mask_off) {
         __syncthreads();  // every wave is done reading the gradient image (previous GEMM)
         write_split<ST, false>(G, smem, a_wr);
         __syncthreads();
-        dump_pair(q.g_fc1[b], rows, b < COMBINE_LAYER);
         f32x16 t[IT][JT];
         const unsigned long long mk_n = (q.d_mask + (size_t)(2 * b + 1) * mask_layer)[mask_off];
         zero(t);
-        gemm_split<JT, SplitAdvBwd>(t, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
+        gemm_dump(t, q.g_fc1[b], rows, b < COMBINE_LAYER);
         apply_mask(t, mk_n);
         __syncthreads();
         write_split<ST, false>(t, smem, a_wr);
         __syncthreads();
-        dump_pair(q.g_fc0[b], rows, b < COMBINE_LAYER);
         const unsigned long long mk_a = (q.d_mask + (size_t)(2 * b) * mask_layer)[mask_off];
         zero(t);
-        gemm_split<JT, SplitAdvBwd>(t, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
+        gemm_dump(t, q.g_fc0[b], rows, b < COMBINE_LAYER);
         masked_add(G, t, mk_a);
     };
 
@@ -1115,8 +1199,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
             __syncthreads();
             write_split<ST, false>(G, smem, a_wr);  // dY of lin_in and lin_z[0]
             __syncthreads();
-            dump_pair(q.g_x0, rows_view, true);
-            gemm_split<JT, SplitAdvBwd>(Z, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);      // lin_z[0]^T dY_0
+            gemm_dump(Z, q.g_x0, rows_view, true);                                                                   // lin_z[0]^T dY_0
             {   // accumulator (channel 64 wv + 32 it + (r&3) + 8(r>>2) + 4h, point) -> fp32 rows, 16-byte pieces, out of the scaled domain
                 float *dst = q.d_zlat + ((size_t)rows_view + pl) * C_LAT + (wv * IT) * 32 + 4 * h;
 #pragma unroll
