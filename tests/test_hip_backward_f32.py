@@ -138,3 +138,68 @@ def test_direct_forward_is_differentiable_at_fp32_precision(dev, scene_name, B, 
     for k, a, b in pairs:
         rel = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
         assert rel <= 1e-3, f"{k}: rel err {rel:.3e}"
+
+
+@pytest.mark.parametrize("scene_name,R,K", [("train", 24, 37), ("mv_mini", 10, 45)])  # 888 / 450 points: ragged last tiles; mv_mini: 2 views
+def test_fused_split_forward_keeps_the_operands_of_the_gemm_form(dev, scene_name, R, K):
+    """What pnr_eval_ray_samples_split_train leaves behind (PnrSplitSaved) against the fp32 activations of the GEMM-per-layer
+    forward on the same inputs: every operand image = relu of the saved pre-activation (head + tail, storage order), the lin_in
+    operand / interpolated latent pairs, the stream in front of lin_out, the outputs, and the 1-bit relu masks bit for bit where
+    the value is clearly away from zero."""
+    from helpers import mlp_params, scene_for
+    from pixelnerf_amd import ops
+    scene, meta = scene_for(scene_name)
+    SB, NS = scene["SB"], scene["NS"]
+    sc = ops.make_scene(scene["latent"].to(dev), scene["poses"].to(dev), scene["focal"].to(dev), scene["c"].to(dev), scene["image_shape"], NS)
+    rays = synthetic.target_rays(meta, n_rays=R).reshape(-1, 8).to(dev)
+    z = torch.sort(ops.sample_coarse(rays, torch.rand(rays.shape[0], K, generator=torch.Generator().manual_seed(2)).to(dev)), dim=-1)[0]
+    state = {k: v.to(dev) for k, v in mlp_params(11).items()}
+    out_g, sv_g = ops.eval_ray_samples_f32_train(sc, ops.pack_mlp(state, "f32"), rays, z, split=True)
+    out_f, sv_f = ops.eval_ray_samples_split_train(sc, ops.pack_mlp(state, "f16x3"), ops.fold_latent(sc, state, "f16x3"), rays, z)
+    P = rays.shape[0] * K
+    assert (out_f - out_g).abs().max() <= 2e-5
+    perm = ops.storage_perm(dev)  # storage position e -> feature
+
+    def value(pair):  # (2, rows, cols) f16 [head | tail] -> fp32 value
+        return pair[0].float() + pair[1].float()
+
+    def close(a, b, what):
+        tol = 4e-6 * max(1.0, float(b.abs().max()))
+        assert (a - b).abs().max() <= tol, (what, float((a - b).abs().max()), tol)
+
+    close(value(sv_f.in_op), sv_g.in42, "lin_in operand")
+    close(value(sv_f.zlat), sv_g.zlat, "interpolated latent")
+    close(sv_f.x5, sv_g.x5, "stream in front of lin_out")
+    for b in range(5):
+        for img, pre, what in ((sv_f.a[b], sv_g.xin[b], f"relu(x) block {b}"), (sv_f.n[b], sv_g.net[b], f"relu(net) block {b}")):
+            nat = torch.empty_like(pre)
+            nat[:, perm] = value(img)  # storage order -> feature order
+            close(nat, torch.relu(pre), what)
+    # masks: [layer][view][tile][thread] 64-bit words, bit (it*2 + jt)*16 + r <-> feature 64 wv + 32 it + (r&3) + 8 (r>>2) + 4 h of
+    # point 32 jt + (lane & 31), thread = 64 wv + lane, h = lane >> 5  (pnr_device.h)
+    ntiles = (P + 63) // 64
+    words = sv_f.masks.view(torch.int64).reshape(11, NS, ntiles, 512).cpu().numpy().astype(np.uint64)
+    layers = []
+    for b in range(5):
+        layers += [sv_g.xin[b], sv_g.net[b]]
+    layers.append(sv_g.x5)
+    t = np.arange(512)
+    wv, lane = t >> 6, t & 63
+    pl, h = lane & 31, lane >> 5
+    checked = 0
+    for li, pre in enumerate(layers):
+        per_view = li < 6
+        v = pre.cpu().numpy().reshape((NS if per_view else 1), P, 512)
+        for view in range(NS if per_view else 1):
+            for it in range(2):
+                for jt in range(2):
+                    for r in range(16):
+                        feat = 64 * wv + 32 * it + (r & 3) + 8 * (r >> 2) + 4 * h
+                        bit = (words[li, view] >> np.uint64((it * 2 + jt) * 16 + r)) & np.uint64(1)  # (ntiles, 512)
+                        pt = np.arange(ntiles)[:, None] * 64 + jt * 32 + pl[None, :]
+                        ok = pt < P
+                        val = v[view][np.minimum(pt, P - 1), feat[None, :]]
+                        sure = ok & (np.abs(val) > 1e-5)  # the two forwards differ by rounding: skip values at the threshold
+                        assert ((bit == 1) == (val > 0))[sure].all(), (li, view, it, jt, r)
+                        checked += int(sure.sum())
+    assert checked > 0.9 * 11 * 0.5 * P * 512
