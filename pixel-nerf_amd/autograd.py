@@ -11,6 +11,12 @@ backward : HIP kernels only (no library GEMM, no torch matmul) --
              pnr_weight_grad_batched  dW = dY^T X, db = sum dY    from the 16-bit dumps (MFMA, fp32 acc), one launch
              pnr_lin_out_grad         lin_out's 4 x 512 weight gradient
              pnr_position_backward    d(network inputs)           -> d(sample positions z)
+At the default precision "f16x3" (fp32-class) the network calls are replaced by their split-operand forms, fused the same way:
+             pnr_eval_ray_samples_split_train   the fp32-class inference kernel in its training instantiation (operand images
+                                                + relu masks kept, lin_z through the folded fp32 tables)
+             pnr_mlp_backward_split             one launch for all transposed products, one batched split-operand
+                                                weight-gradient launch -> all 30 gradients, d z_lat, d(code)
+(FUSED_SPLIT_TRAINING = False: the same arithmetic as one split-operand GEMM per layer; precision "f32": exact fp32 MFMA.)
 Gradients flow to every ResnetFC parameter of both networks and to `encoder.latent` (hence into
 the ResNet-34 through PyTorch autograd), including the reference's one position-gradient path:
 fine loss -> positions of the n_fine_depth samples (compositing deltas/depth, positional code,
