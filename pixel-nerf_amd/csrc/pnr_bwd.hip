@@ -19,6 +19,8 @@
 //                         samples (nerf.py:292), for all points or for the depth samples only.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pnr_common.h"
 #include "pnr_device.h"
 #include "pnr_internal.h"
@@ -1342,6 +1344,10 @@ static int dw_nsplit(int n_jobs, long long max_rows) {
         const double eff = (double)blocks / (double)(rounds * cus);
         if (blocks >= cus && eff > best_eff + 1e-9) { best_eff = eff; best = ns; }
         else if (blocks < cus) best = ns;  // fewer workgroups than CUs: more slices is always better
+    }
+    if (const char *e = getenv("PNR_DW_NSPLIT")) {  // experiment hook: force the slice count
+        const int v = atoi(e);
+        if (v >= 1 && v <= DW_MAX_SPLIT) best = v;
     }
     const long long cap = (max_rows + 255) / 256;
     if (best > cap) best = (int)cap;
