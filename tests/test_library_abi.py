@@ -36,6 +36,33 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.PnrMlpWeights) == 30 * 8
 
 
+def test_struct_layouts_against_the_header_compiled_by_gcc(repo_root, tmp_path):
+    """every struct of include/pixelnerf_hip.h: sizeof and the offset of every field as gcc lays the header out, against the ctypes
+    mirror in pixelnerf_amd/_lib.py (the header is plain C: a reference maintainer's cgo / cffi binding sees the same layout)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    structs = {"PnrScene": _lib.PnrScene, "PnrMlpWeights": _lib.PnrMlpWeights, "PnrTrainDumps": _lib.PnrTrainDumps,
+               "PnrBackwardDumps": _lib.PnrBackwardDumps, "PnrF32Saved": _lib.PnrF32Saved, "PnrSplitSaved": _lib.PnrSplitSaved,
+               "PnrWeightGradJob": _lib.PnrWeightGradJob}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pixelnerf_hip.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(repo_root, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(got[name]) == ctypes.sizeof(cls), name
+        for fname, _ in cls._fields_:
+            assert int(got[f"{name}.{fname}"]) == getattr(cls, fname).offset, f"{name}.{fname}"
+
+
 def test_abi_revision_header_library_binding_agree(lib, repo_root):
     """include/pixelnerf_hip.h, the built library and the ctypes binding carry the same ABI revision; load() refuses
     a library of another revision (a stale build or an A/B variant) instead of binding structs at wrong offsets."""
