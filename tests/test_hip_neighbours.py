@@ -50,6 +50,30 @@ def test_pyramid_to_latent_matches_reference(ops, dev, name):
     assert none is None and torch.equal(only, nhwc)
 
 
+@pytest.mark.parametrize("shapes", [
+    [(64, 9, 11), (64, 5, 6), (64, 3, 3)],                                      # 192 channels: groups do not tile 256 threads (generic sweep)
+    [(64, 12, 40), (64, 6, 20), (128, 3, 10), (256, 2, 5), (512, 1, 3)],        # five stages, 1024 channels: shorter pixel runs (LDS)
+    [(64, 1, 5), (128, 1, 1)],                                                  # a single row, a 1x1 stage
+    [(64, 7, 1), (64, 4, 3)],                                                   # a single column
+    [(64, 6, 8), (64, 13, 29), (128, 6, 8)],                                    # a stage LARGER than stage 0 (downsampled), and an equal-size one
+    [(128, 33, 70)],                                                            # one stage: pure NCHW -> NHWC
+])
+def test_pyramid_to_latent_general_shapes(ops, dev, shapes):
+    """pnr_pyramid_to_latent beyond the ResNet-34 shapes, against torch's own upsample + cat on the same device"""
+    gen = torch.Generator().manual_seed(17)
+    NV = 2
+    stages = [torch.randn(NV, c, h, w, generator=gen).to(dev) for c, h, w in shapes]
+    H0, W0 = shapes[0][1], shapes[0][2]
+    ref = torch.cat([t if t.shape[2:] == (H0, W0) else torch.nn.functional.interpolate(t, (H0, W0), mode="bilinear", align_corners=True)
+                     for t in stages], 1)
+    nhwc, nchw = ops.pyramid_to_latent(stages)
+    assert nchw.shape == ref.shape
+    assert (nchw - ref).abs().max().item() <= 5e-6
+    assert torch.equal(nhwc.permute(0, 3, 1, 2), nchw)
+    only, none = ops.pyramid_to_latent(stages, want_nchw=False)
+    assert none is None and torch.equal(only, nhwc)
+
+
 def test_pyramid_to_latent_full_size_dtu(ops, dev):
     """BASELINE config (4) shapes: 3 views, 150x200 grid, 512 channels = 176 MiB per layout.  Properties:
     stage 0 copied exactly, align_corners => the four image corners of every stage are reproduced exactly,
