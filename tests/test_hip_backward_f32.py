@@ -32,18 +32,18 @@ def dev():
     return torch.device("cuda:0")
 
 
-def train_grads(dev, name, precision):
+def train_grads(dev, name, precision, loss_scale=1.0):
     from pixelnerf_amd import autograd
     fused = precision != "f16x3-gemms"
     precision = precision.split("-")[0]
     saved, autograd.FUSED_SPLIT_TRAINING = autograd.FUSED_SPLIT_TRAINING, fused
     try:
-        return _train_grads(dev, name, precision)
+        return _train_grads(dev, name, precision, loss_scale)
     finally:
         autograd.FUSED_SPLIT_TRAINING = saved
 
 
-def _train_grads(dev, name, precision):
+def _train_grads(dev, name, precision, loss_scale=1.0):
     from pixelnerf_amd.model import make_model
     from pixelnerf_amd.render import NeRFRenderer
     from pixelnerf_amd.util.conf import default_model_conf
@@ -65,7 +65,7 @@ def _train_grads(dev, name, precision):
                         lindisp=bool(g["lindisp"])).to(dev).train()
     out = rend(net, rays.to(dev), want_weights=True, _noise={k: v.to(dev) for k, v in noise.items()})
     loss = ((out.coarse.rgb - gt.to(dev)) ** 2).mean() + ((out.fine.rgb - gt.to(dev)) ** 2).mean()
-    loss.backward()
+    (loss * loss_scale).backward()
     grads = {"latent": lat.grad}
     grads.update({"coarse." + k: v.grad for k, v in net.mlp_coarse.named_parameters()})
     grads.update({"fine." + k: v.grad for k, v in net.mlp_fine.named_parameters()})
@@ -138,6 +138,19 @@ def test_direct_forward_is_differentiable_at_fp32_precision(dev, scene_name, B, 
     for k, a, b in pairs:
         rel = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
         assert rel <= 1e-3, f"{k}: rel err {rel:.3e}"
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3-gemms"])
+def test_split_gradients_follow_the_loss_scale(dev, precision):
+    """the split-operand chains run at a power-of-two scale picked on the device (heads and tails are fp16): the gradients of a
+    loss scaled by 1e-9 / 1e+9 are the scaled gradients, to rounding -- no underflow of small gradient rows, no overflow of large"""
+    _, base, _ = train_grads(dev, "train_64_32", precision)
+    for sc in (1e-9, 1e9):
+        _, g, _ = train_grads(dev, "train_64_32", precision, loss_scale=sc)
+        for k in base:
+            a, b = g[k].astype(np.float64) / sc, base[k].astype(np.float64)
+            assert np.isfinite(a).all(), (k, sc)
+            assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b) + 1e-30, (k, sc, np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
 @pytest.mark.parametrize("scene_name,R,K", [("train", 24, 37), ("mv_mini", 10, 45)])  # 888 / 450 points: ragged last tiles; mv_mini: 2 views
