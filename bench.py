@@ -369,6 +369,45 @@ def extra_train_step(dev, prec, scene_name="train", steps=40, warmup=8, with_gra
     return out
 
 
+def train_step_eager_torch(dev, steps=4):
+    """BASELINE configs[4] in eager PyTorch-ROCm fp32 autograd on THIS GPU: the oracle restatement of the reference (F.grid_sample
+    like the reference) -- forward, loss (train/train.py:199-215), backward, Adam.  A reported baseline, never the product path."""
+    from oracle import pnr_oracle as O
+    from testdata import synthetic
+    O.USE_GRID_SAMPLE = True
+    try:
+        scene, meta = synthetic.make_scene("train")
+        sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+        sc["latent"] = sc["latent"].clone().requires_grad_(True)
+        pc = {k: v.to(dev).requires_grad_(True) for k, v in synthetic.make_mlp_params(11).items()}
+        pf = {k: v.to(dev).requires_grad_(True) for k, v in synthetic.make_mlp_params(12).items()}
+        rays = synthetic.target_rays(meta, n_rays=128).to(dev)
+        gt = torch.rand(scene["SB"], 128, 3, device=dev)
+        noise = {k: v.to(dev) for k, v in synthetic.make_noise(scene["SB"] * 128, 64, 32, 16).items()}
+        opt = torch.optim.Adam(list(pc.values()) + list(pf.values()), lr=1e-4)
+
+        def step():
+            out = O.render(sc, pc, pf, rays, noise, 64, 32, 16, white_bkgd=True)
+            loss = ((out["coarse"]["rgb"] - gt) ** 2).mean() + ((out["fine"]["rgb"] - gt) ** 2).mean()
+            opt.zero_grad(set_to_none=True)
+            sc["latent"].grad = None
+            loss.backward()
+            opt.step()
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        O.USE_GRID_SAMPLE = False
+    return {"ms_per_step": dt * 1e3, "steps": steps, "kind": "port (oracle restatement, torch fp32 eager autograd + Adam on the same MI355X)",
+            "workload": "train: 4 objects x 128 rays, 64+32 (16 depth) samples"}
+
+
 def train_step_unfused_twin(dev):
     """the fp32-class training step in its GEMM-per-layer form (one split-operand GEMM launch per product; the A/B twin of the
     fused default and the form the round started from)"""
@@ -753,13 +792,21 @@ def main():
                             ("train_step_fp32_class", lambda: extra_train_step(dev, "f16x3", steps=16, warmup=4, with_graph=False)),
                             ("train_step_fp32_class_multiview", lambda: extra_train_step(dev, "f16x3", "train_mv", steps=12, warmup=3, with_graph=False)),
                             ("train_step_fp32_class_gemm_per_layer", lambda: train_step_unfused_twin(dev)),
+                            ("train_step_torch_eager_gpu_baseline", lambda: train_step_eager_torch(dev)),
                             ("train_step_fp32_validation_path", lambda: extra_train_step(dev, "f32", steps=5, warmup=2, with_graph=False)),
                             ("srn_car", lambda: extra_render_config(dev, "srn_car", 4)),
                             ("dtu", lambda: extra_render_config(dev, "dtu", 1))):
+                if key == "train_step_torch_eager_gpu_baseline" and args.no_eager_baseline:
+                    continue
                 try:
                     extra[key] = fn()
                 except Exception as e:  # an extra must never take the headline line down with it
                     extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            eager_ms = extra.get("train_step_torch_eager_gpu_baseline", {}).get("ms_per_step")
+            if eager_ms:
+                for key in ("train_step", "train_step_fp32_class"):
+                    if "ms_per_step" in extra.get(key, {}):
+                        extra[key]["speedup_vs_torch_eager_gpu"] = eager_ms / extra[key]["ms_per_step"]
             if rank == 0:
                 res["extra"] = {"configs": extra}
         else:
