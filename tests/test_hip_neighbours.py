@@ -93,6 +93,35 @@ def test_pyramid_to_latent_full_size_dtu(ops, dev):
     assert torch.equal(nhwc.permute(0, 3, 1, 2), nchw)
 
 
+def test_encoder_graph_replay_equals_eager_launches(dev):
+    """eval-mode encodes under no_grad replay a HIP graph of the trunk + formatting pass (captured once per input shape): the
+    eager launches' result, every call returns fresh tensors, a second shape gets its own graph, train mode stays eager"""
+    from pixelnerf_amd.model.encoder import SpatialEncoder
+    torch.manual_seed(5)
+    enc = SpatialEncoder(pretrained=False, use_first_pool=False).to(dev).eval()
+    imgs = [torch.rand(2, 3, 64, 64, device=dev) * 2 - 1 for _ in range(3)] + [torch.rand(1, 3, 48, 80, device=dev)]
+    with torch.no_grad():
+        enc.use_graph = False
+        ref = [(enc(im).clone(), enc.latent_nhwc().clone(), enc.latent_scaling.clone()) for im in imgs]
+        enc.use_graph = True
+        got = []
+        for im in imgs + imgs[:1]:
+            lat = enc(im)
+            got.append((lat, enc.latent_nhwc(), enc.latent_scaling.clone()))
+    assert len(enc._graphs) == 2
+    for (a, an, asc), (b, bn, bsc) in zip(got, ref + ref[:1]):
+        # (the trunk's convolutions may run another MIOpen algorithm inside the capture: rounding-level differences)
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+        assert torch.equal(an.permute(0, 3, 1, 2), a) and torch.equal(asc, bsc)
+    assert got[0][0].data_ptr() != got[1][0].data_ptr()  # fresh outputs: an earlier latent is not overwritten by the next encode
+    enc.train()
+    with torch.no_grad():
+        before = len(enc._graphs)
+        enc(imgs[0])
+        assert len(enc._graphs) == before  # batch-norm statistics move in train mode: never captured
+    type(enc).use_graph = True
+
+
 def test_encoder_forward_uses_fused_formatting(dev):
     """SpatialEncoder.forward under no_grad (HIP formatting) == the torch formatting it replaces."""
     from pixelnerf_amd.model.encoder import SpatialEncoder
