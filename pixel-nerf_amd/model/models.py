@@ -11,7 +11,6 @@ State left by encode() (models.py:111-141) is kept in the same attributes (`pose
 and may be set by hand exactly as with the reference; the device-side scene descriptor is
 rebuilt lazily whenever one of them changes.
 """
-import os
 import os.path as osp
 import warnings
 
@@ -29,7 +28,8 @@ class PixelNeRFNet(torch.nn.Module):
         :param precision arithmetic of the 512-wide linears:
         'f16x3' (default) -- fp32-CLASS on the f16 matrix cores: every operand a (head, tail) fp16 pair, 3 MFMAs per product, fp32
         accumulation (per-point |rgb| <= 2e-5 against the reference: the reference's own arithmetic class; the benchmark
-        headline).  Inference: the fused kernel; training: split-operand GEMMs (gradients <= 1e-3 vs the reference's autograd).
+        headline).  Inference: the fused kernel; training: its training instantiation + a fused backward (gradients <= 1e-3 vs
+        the reference's autograd).
         'f16' (opt-in, ~2.7x faster at inference, ~4.5x in training) -- fp16 MFMA operands, fp32 accumulation: PSNR >= 52 dB vs the fp32
         reference; inference and training (gradients <= 3e-2 per tensor).
         'f32' -- the exact, unfused fp32-MFMA validation path (inference and training, ~1/25 of the f16 rate).
@@ -78,40 +78,40 @@ class PixelNeRFNet(torch.nn.Module):
         self._grad_sync = None  # set for the duration of a call by dist.ShardedRenderWrapper (gradient all-reduce across ranks)
 
     # ------------------------------------------------------------------ encode (PyTorch-ROCm)
+    @staticmethod
+    def _per_view_pair(v, what):
+        """intrinsics in any of the reference's call forms -- scalar, (2), (n) or (n,2) (models.py:116-141) -- as (n|1, 2)"""
+        if v.dim() == 0:
+            return v.reshape(1, 1).expand(1, 2).clone()
+        if v.dim() == 1:
+            return v.reshape(-1, 1).expand(-1, 2).clone()
+        if v.dim() == 2 and v.shape[-1] == 2:
+            return v.clone()
+        raise ValueError(f"{what}: expected a scalar, (n) or (n,2) tensor, got shape {tuple(v.shape)}")
+
     def encode(self, images, poses, focal, z_bounds=None, c=None):
-        """src/model/models.py:89-144, unchanged semantics.
+        """What the reference's encode() leaves behind (src/model/models.py:89-144), same attributes and conventions:
+        `encoder.latent` from the source images, `poses` = world -> camera [R^T | -R^T t] of the camera-to-world inputs,
+        `image_shape` = (W, H), `focal` with the y component negated, `c` (image centre when not given), object / view counts.
         :param images (NS,3,H,W) or (SB,NS,3,H,W); poses (NS,4,4) / (SB,NS,4,4) camera-to-world;
         focal () | (2) | (NS) | (NS,2); c None | () | (2) | (NS) | (NS,2)."""
-        self.num_objs = images.size(0)
-        if len(images.shape) == 5:
-            assert len(poses.shape) == 4
-            assert poses.size(1) == images.size(1)
-            self.num_views_per_obj = images.size(1)
-            images = images.reshape(-1, *images.shape[2:])
-            poses = poses.reshape(-1, 4, 4)
-        else:
-            self.num_views_per_obj = 1
+        batched = images.dim() == 5
+        if batched and (poses.dim() != 4 or poses.shape[1] != images.shape[1]):
+            raise ValueError("encode: (SB,NS,...) images need (SB,NS,4,4) poses")
+        self.num_objs = images.shape[0]
+        self.num_views_per_obj = images.shape[1] if batched else 1
+        if batched:
+            images, poses = images.flatten(0, 1), poses.reshape(-1, 4, 4)
         self.encoder(images)
-        rot = poses[:, :3, :3].transpose(1, 2)
-        trans = -torch.bmm(rot, poses[:, :3, 3:])
-        self.poses = torch.cat((rot, trans), dim=-1)
-        self.image_shape[0] = images.shape[-1]
-        self.image_shape[1] = images.shape[-2]
-        if len(focal.shape) == 0:
-            focal = focal[None, None].repeat((1, 2))
-        elif len(focal.shape) == 1:
-            focal = focal.unsqueeze(-1).repeat((1, 2))
-        else:
-            focal = focal.clone()
-        self.focal = focal.float()
-        self.focal[..., 1] *= -1.0
-        if c is None:
-            c = (self.image_shape * 0.5).unsqueeze(0)
-        elif len(c.shape) == 0:
-            c = c[None, None].repeat((1, 2))
-        elif len(c.shape) == 1:
-            c = c.unsqueeze(-1).repeat((1, 2))
-        self.c = c
+        # camera-to-world (R | t)  ->  world-to-camera (R^T | -R^T t)
+        r_wc = poses[:, :3, :3].transpose(1, 2)
+        self.poses = torch.cat((r_wc, -(r_wc @ poses[:, :3, 3:4])), dim=-1)
+        height, width = images.shape[-2:]
+        self.image_shape[0], self.image_shape[1] = width, height
+        fl = self._per_view_pair(focal, "focal").float()
+        fl[..., 1].neg_()  # image y runs down, camera y up (models.py:129-130)
+        self.focal = fl
+        self.c = (self.image_shape * 0.5).unsqueeze(0) if c is None else self._per_view_pair(c, "c")
 
     # ------------------------------------------------------------------ device scene
     def _check_supported(self):
@@ -205,29 +205,34 @@ class PixelNeRFNet(torch.nn.Module):
                                tables=self.tables(coarse))
 
     # ------------------------------------------------------------------ checkpoints
+    # file layout of the reference's trainer (src/model/models.py:268-316): <checkpoints_path>/<name>/pixel_nerf_{latest,init}
+    # and one backup generation of each
+    @staticmethod
+    def _ckpt_file(args, stem):
+        return osp.join(args.checkpoints_path, args.name, stem)
+
     def load_weights(self, args, opt_init=False, strict=True, device=None):
-        """src/model/models.py:268-298."""
+        """Restore from the experiment's checkpoint like the reference: the `init` file seeds a fresh run (or is asked for with
+        opt_init), `latest` continues one (args.resume).  A missing file leaves the model as it is, with a warning unless the
+        optional init file was the one looked for."""
         if opt_init and not args.resume:
             return
-        ckpt_name = "pixel_nerf_init" if opt_init or not args.resume else "pixel_nerf_latest"
-        model_path = "%s/%s/%s" % (args.checkpoints_path, args.name, ckpt_name)
-        if device is None:
-            device = self.poses.device
-        if os.path.exists(model_path):
-            print("Load", model_path)
-            self.load_state_dict(torch.load(model_path, map_location=device), strict=strict)
+        stem = "pixel_nerf_latest" if (args.resume and not opt_init) else "pixel_nerf_init"
+        path = self._ckpt_file(args, stem)
+        if osp.exists(path):
+            print("Load", path)
+            self.load_state_dict(torch.load(path, map_location=self.poses.device if device is None else device), strict=strict)
         elif not opt_init:
-            warnings.warn("WARNING: {} does not exist, not loaded!! Model will be re-initialized.".format(model_path))
+            warnings.warn(f"{path} does not exist: nothing loaded, the model keeps its initialisation "
+                          "(pretrained weights belong there; pass --resume to continue a run)")
         return self
 
     def save_weights(self, args, opt_init=False):
-        """src/model/models.py:300-316."""
+        """Write the state_dict to the experiment's `latest` (or `init`) file, keeping the previous one as its backup."""
         from shutil import copyfile
-        ckpt_name = "pixel_nerf_init" if opt_init else "pixel_nerf_latest"
-        backup_name = "pixel_nerf_init_backup" if opt_init else "pixel_nerf_backup"
-        ckpt_path = osp.join(args.checkpoints_path, args.name, ckpt_name)
-        ckpt_backup_path = osp.join(args.checkpoints_path, args.name, backup_name)
-        if osp.exists(ckpt_path):
-            copyfile(ckpt_path, ckpt_backup_path)
-        torch.save(self.state_dict(), ckpt_path)
+        stem, backup = ("pixel_nerf_init", "pixel_nerf_init_backup") if opt_init else ("pixel_nerf_latest", "pixel_nerf_backup")
+        path = self._ckpt_file(args, stem)
+        if osp.exists(path):
+            copyfile(path, self._ckpt_file(args, backup))
+        torch.save(self.state_dict(), path)
         return self

@@ -173,3 +173,37 @@ def test_packed_streams_follow_fused_optimizer_updates(net):
         opt.step()
         assert mlp._fingerprint() != before, f"fused={fused}"
         assert mlp._fingerprint() == mlp._fingerprint()
+
+
+def test_checkpoint_helpers_follow_the_reference_layout(tmp_path):
+    """save_weights / load_weights (src/model/models.py:268-316): <checkpoints_path>/<name>/pixel_nerf_latest with one backup
+    generation, pixel_nerf_init for fresh runs, --resume picks latest, a missing file warns and leaves the model alone"""
+    import types
+    import warnings as W
+    net = make_model(default_model_conf())
+    args = types.SimpleNamespace(checkpoints_path=str(tmp_path), name="exp", resume=True)
+    os.makedirs(tmp_path / "exp")
+    with W.catch_warnings(record=True) as caught:
+        W.simplefilter("always")
+        assert net.load_weights(args) is net  # nothing there yet
+    assert any("does not exist" in str(w.message) for w in caught)
+    w0 = net.mlp_coarse.lin_out.weight.detach().clone()
+    net.save_weights(args)
+    assert (tmp_path / "exp" / "pixel_nerf_latest").exists() and not (tmp_path / "exp" / "pixel_nerf_backup").exists()
+    with torch.no_grad():
+        net.mlp_coarse.lin_out.weight.add_(1.0)
+    net.save_weights(args)  # the first file becomes the backup
+    assert (tmp_path / "exp" / "pixel_nerf_backup").exists()
+    other = make_model(default_model_conf())
+    other.load_weights(args)
+    assert torch.equal(other.mlp_coarse.lin_out.weight, w0 + 1.0)
+    backup = torch.load(tmp_path / "exp" / "pixel_nerf_backup", map_location="cpu")
+    assert torch.equal(backup["mlp_coarse.lin_out.weight"], w0)
+    # init checkpoints: written with opt_init, used by a run that does not resume; opt_init without --resume loads nothing
+    net.save_weights(args, opt_init=True)
+    assert (tmp_path / "exp" / "pixel_nerf_init").exists()
+    fresh = types.SimpleNamespace(checkpoints_path=str(tmp_path), name="exp", resume=False)
+    third = make_model(default_model_conf())
+    assert third.load_weights(fresh, opt_init=True) is None
+    third.load_weights(fresh)
+    assert torch.equal(third.mlp_coarse.lin_out.weight, w0 + 1.0)
