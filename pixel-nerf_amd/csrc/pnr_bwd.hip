@@ -10,6 +10,8 @@
 //                         (operands of the weight-gradient GEMMs dW = dY^T X).
 //   dw_kernel             dW = dY^T X for all linears of a network in one launch (MFMA from the dumps
 //                         through transposing LDS reads), dw_reduce_kernel sums the row slices.
+//   dw_split_kernel       the same at split-operand (fp32-class) precision: (head | tail) f16 operand rows, three
+//                         MFMAs per product -- the weight gradients of the fused fp32-class training path.
 //   composite_bwd_kernel  backward of the alpha compositing (nerf.py:223-249), wavefront per ray.
 //                         also emits dL/dz through the deltas and depth = sum w z.
 //   latent_scatter_*      d(interpolated latent) -> d(feature grid): bilinear scatter-add (small grids: a

@@ -13,6 +13,14 @@
 //   pool_f32_kernel   mean over source views                              util.py:461-471
 //   out_f32_kernel    sigmoid / relu                                      models.py:260-265
 // rows are ordered [view][point] like the training dumps.
+//
+// The file also holds the host side of the fp32-precision TRAINING paths:
+//   exact            pnr_eval_ray_samples_f32_train / pnr_mlp_backward_f32 (split_gemm = 0): the chain above with every
+//                    activation kept in fp32, linear_f32_kernel in its transposed form + wgrad_f32_kernel
+//   GEMM per layer   the same entries with split_gemm = 1: every product on gemm3_kernel (128x128-tile GEMM that splits its
+//                    fp32 operands into (head, tail) f16 pairs on the way into LDS, three f16 MFMAs per product)
+//   fused (default)  pnr_eval_ray_samples_split_train / pnr_mlp_backward_split: the launch sequence around the fused
+//                    split-operand kernels of pnr_split.hip (forward, data-gradient chain) and pnr_bwd.hip (weight gradients)
 #include <hip/hip_runtime.h>
 
 #include "pnr_common.h"
