@@ -122,7 +122,8 @@ class SpatialEncoder(nn.Module):
                         self._forward_eager(static_in, scaling=False)
                 torch.cuda.current_stream(x.device).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):  # (latent_scaling is set from host scalars: outside the capture)
+                # thread-local capture mode: other host threads (a DataLoader's pin-memory thread) may keep calling the runtime
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (latent_scaling: host scalars, set outside the capture)
                     out = self._forward_eager(static_in, scaling=False)
                 ent = (g, static_in, out, self._nhwc[1], list(self.latents))
                 self._graphs[key] = ent
