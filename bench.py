@@ -159,6 +159,7 @@ def roofline_block(prec, rays_rank0, steps, kern_ms, n_launch, NS, fold, elapsed
     ex = ach * executed_fraction(NS, fold) * MFMAS_PER_PRODUCT[prec]
     blk = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS,
            "traffic": traffic,
+           "traffic_source": None if traffic is None else "committed profile (%s), not measured in this run" % PMC_PROFILE.get(prec),
            "traffic_note": "bytes per launch at the L2<->fabric interface (Infinity-Cache hits included): 2*FETCH_SIZE + WRITE_SIZE "
                            "from %s (tools/collect_pmc.sh, stamped with the kernel-source hash %s); algorithmic HBM bytes per launch "
                            "are ~0.18 GB (z in, rgb-sigma out, weights + tables once); the excess is the weight stream (> 4 MB L2 per "
@@ -178,10 +179,13 @@ def roofline_block(prec, rays_rank0, steps, kern_ms, n_launch, NS, fold, elapsed
     return blk
 
 
-def eager_gpu_baseline(scene, mlps, rays, dev, n=16384, calls=3):
-    """The north_star's "reference single-GPU" comparison point: the same eager PyTorch fp32
-    code path (the oracle restatement of the reference, with F.grid_sample like the reference
-    and its 50 000-ray eval chunking irrelevant at this size) on THIS GPU through PyTorch-ROCm.
+def eager_gpu_baseline(scene, mlps, rays, dev, n=16384, calls=3, eval_batch_size=None):
+    """The north_star's "reference single-GPU" comparison point: the same eager PyTorch fp32 code path (the oracle
+    restatement of the reference, with F.grid_sample like the reference) on THIS GPU through PyTorch-ROCm.
+    eval_batch_size=None: one model call per pass (no chunk loop).  An integer: the reference's EXECUTION SHAPE --
+    eval/eval.py:264 splits the rays into ray_batch_size = 50 000 per render_par call (util/args.py:19) and eval/eval.py:137
+    hands the same number to the renderer as eval_batch_size, so composite() walks the points in chunks of 50 000 per model
+    call (nerf.py:190-216): 64 model calls for the coarse pass of such a ray batch, 192 for the fine pass.
     A reported baseline only -- never part of the product path."""
     from oracle import pnr_oracle as O
     from testdata import synthetic
@@ -190,19 +194,25 @@ def eager_gpu_baseline(scene, mlps, rays, dev, n=16384, calls=3):
     ms = [{k: v.to(dev) for k, v in m.items()} for m in mlps]
     r = rays[:n]
     noise = {k: v.to(dev) for k, v in synthetic.make_noise(r.shape[0], 64, 128, 16, seed=7).items()}
-    with torch.no_grad():
-        # warm-up at the SAME shapes (GEMM heuristics, caching-allocator growth), then steady-state calls are timed
-        O.render(sc, ms[0], ms[1], r[None], noise, 64, 128, 16, white_bkgd=True)
-        torch.cuda.synchronize()
-        dts = []
-        for _ in range(calls):
-            t0 = time.perf_counter()
-            O.render(sc, ms[0], ms[1], r[None], noise, 64, 128, 16, white_bkgd=True)
+    try:
+        with torch.no_grad():
+            # warm-up at the SAME shapes (GEMM heuristics, caching-allocator growth), then steady-state calls are timed
+            O.render(sc, ms[0], ms[1], r[None], noise, 64, 128, 16, white_bkgd=True, eval_batch_size=eval_batch_size)
             torch.cuda.synchronize()
-            dts.append(time.perf_counter() - t0)
-    O.USE_GRID_SAMPLE = False
+            dts = []
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                O.render(sc, ms[0], ms[1], r[None], noise, 64, 128, 16, white_bkgd=True, eval_batch_size=eval_batch_size)
+                torch.cuda.synchronize()
+                dts.append(time.perf_counter() - t0)
+    finally:
+        O.USE_GRID_SAMPLE = False
     dt = sum(dts) / len(dts)
+    shape = ("one model call per pass (no eval_batch_size chunk loop)" if eval_batch_size is None else
+             "the reference's execution shape: ray batch %d (eval/eval.py:264, util/args.py:19), model calls of %d points "
+             "(eval/eval.py:137 -> nerf.py:190-216)" % (r.shape[0], eval_batch_size))
     return {"value": r.shape[0] / dt, "unit": "rays/s", "kind": "port (oracle restatement, torch fp32 eager on the same MI355X)",
+            "shape": shape,
             "sample": "%d rays per call, mean of %d steady-state calls (after a same-shape warm-up): %s s" % (
                 r.shape[0], calls, ", ".join("%.3f" % d for d in dts))}
 
@@ -455,7 +465,7 @@ def timed_region(step, fence, steps, warmup):
     return elapsed, kern_ms, n_launch
 
 
-def strong_dtu(dev, prec, world, rank, steps, warmup, bcast, fence):
+def strong_dtu(dev, prec, world, rank, steps, warmup, bcast, fence, dist_on=None, layout="nhwc"):
     """BASELINE configs[3]: ONE DTU 400x300 image (120 000 rays, 3 source views, 176 MiB grid) sharded contiguously over
     the ranks.  step = [the single feature-grid broadcast from rank 0] + render of this rank's rays + [gather of
     (rgb | depth) to rank 0]; returns the rank-local timings (the caller max-reduces `elapsed`)."""
@@ -471,17 +481,18 @@ def strong_dtu(dev, prec, world, rank, steps, warmup, bcast, fence):
     render_par = renderer.bind_parallel(net, None, simple_output=True).eval()
     renderer.ray_id_offset, renderer.ray_id_stride = lo, R  # the sharded image equals the unsharded one
     tb, tg = [0.0], [0.0]
+    dist_on = world > 1 if dist_on is None else dist_on
 
     def step():
         net._tables.clear()
-        if world > 1:
+        if dist_on:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            broadcast_encoded(net, src=0, latent_shape=lat_shape, algo=bcast)
+            broadcast_encoded(net, src=0, latent_shape=lat_shape, algo=bcast, layout=layout)
             e1.record()
         with torch.no_grad():
             rgb, depth = render_par(rays[None])
-        if world > 1:
+        if dist_on:
             e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             out = torch.cat([rgb[0], depth[0].unsqueeze(-1)], dim=-1)  # 16 B/ray
             sizes = [shard_bounds(R, r, world)[1] - shard_bounds(R, r, world)[0] for r in range(world)]
@@ -528,6 +539,11 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the 4096-ray latency / encode sections (profiling runs: every "
                     "network-kernel launch of the process then has the timed region's shape)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: functional test on one GPU)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with ONE rank: still create the process group (RCCL communicator) and run every step through the "
+                         "distributed code path (grid broadcast + render + gather; `comm` block in the JSON)")
+    ap.add_argument("--bcast-layout", default="nhwc", choices=["nhwc", "nchw"],
+                    help="layout the feature grid travels in: channel-last (what the kernels read; receivers skip the transpose) or NCHW")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed BASELINE configs 3/4/5 section (extra.configs)")
     args = ap.parse_args()
 
@@ -544,7 +560,14 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     import torch.distributed as dist
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on and world == 1 and "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl" and torch.cuda.device_count() < world:
             raise SystemExit("bench.py --gpus %d: RCCL needs one device per rank and this node has %d (use --backend gloo "
@@ -562,12 +585,12 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not dist_on:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -577,7 +600,7 @@ def main():
     res = None
     if strong:
         # ---- BASELINE configs[3] as the headline: one DTU image over N ranks
-        st = strong_dtu(dev, args.prec, world, rank, args.steps, args.warmup, args.bcast, fence)
+        st = strong_dtu(dev, args.prec, world, rank, args.steps, args.warmup, args.bcast, fence, dist_on, args.bcast_layout)
         elapsed = max_over_ranks(st["elapsed"])
         if rank == 0:
             rays_per_s = st["R"] * args.steps / elapsed
@@ -595,7 +618,7 @@ def main():
                                               elapsed, False)}
         if res is not None:
             print(json.dumps(res), flush=True)
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return 0
 
@@ -611,14 +634,14 @@ def main():
         # every step stands for a freshly encoded object: the per-scene folding of lin_z into the feature grid
         # (PixelNeRFNet.tables -> pnr_fold_latent[_f32], both networks) is redone INSIDE the timed step
         net._tables.clear()
-        if world > 1:
+        if dist_on:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            broadcast_encoded(net, src=0, latent_shape=lat_shape, algo=args.bcast)  # THE single feature-grid broadcast (2 MiB for sn64)
+            broadcast_encoded(net, src=0, latent_shape=lat_shape, algo=args.bcast, layout=args.bcast_layout)  # THE single feature-grid broadcast (2 MiB for sn64)
             e1.record()
         with torch.no_grad():
             rgb, depth = render_par(rays[None])
-        if world > 1:
+        if dist_on:
             out = torch.cat([rgb[0], depth[0].unsqueeze(-1)], dim=-1)  # 16 B/ray
             bufs = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
             e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -633,11 +656,12 @@ def main():
     elapsed, kern_ms, n_launch = timed_region(step, fence, args.steps, args.warmup)
     elapsed = max_over_ranks(elapsed)
     comm = None
-    if world > 1:
+    if dist_on:
         ev = comm_ev[-args.steps:]
         comm = {"bcast_ms_rank0": sum(a.elapsed_time(b) for a, b, _, _ in ev) / len(ev),
                 "gather_ms_rank0": sum(c.elapsed_time(d) for _, _, c, d in ev) / len(ev),
-                "grid_bytes": int(scene["latent"].numel() * 4), "bcast_algo": args.bcast}
+                "grid_bytes": int(scene["latent"].numel() * 4), "bcast_algo": args.bcast, "bcast_layout": args.bcast_layout,
+                "backend": args.backend, "ranks": world}
 
     peer = None
     if world == 1 and not args.no_peer:
@@ -662,7 +686,7 @@ def main():
                                    "random-init ResnetFC coarse+fine (d_hidden 512, 5 blocks)" % (R, R // 4096),
                        "rays_per_gpu_per_step": R, "n_coarse": 64, "n_fine": 128, "n_fine_depth": 16,
                        "source_views": NS, "api": "NeRFRenderer.bind_parallel(net, simple_output=True)(rays)",
-                       "precision": args.prec, "lin_z_folded_into_grid": True, "rccl_ranks": world, "backend": args.backend if world > 1 else None},
+                       "precision": args.prec, "lin_z_folded_into_grid": True, "rccl_ranks": world, "backend": args.backend if dist_on else None},
             "roofline": roofline_block(args.prec, R, args.steps, kern_ms, n_launch, NS, True, elapsed, default_shape),
         }
         if comm:
@@ -777,8 +801,12 @@ def main():
         net.precision = args.prec
         res["f32_unfused_validation_path_rays_per_s"] = R / dt32
     if world == 1 and not args.no_eager_baseline:
-        res["torch_eager_gpu_baseline"] = eager_gpu_baseline(scene, mlps, rays, dev)
+        # the comparison point north_star names, in the shape the reference runs it (50 000-ray calls, 50 000-point model
+        # calls); the unchunked 16 384-ray form earlier rounds quoted stays next to it under its own key
+        res["torch_eager_gpu_baseline"] = eager_gpu_baseline(scene, mlps, rays, dev, n=50000, eval_batch_size=50000)
+        res["torch_eager_gpu_baseline_unchunked_16384"] = eager_gpu_baseline(scene, mlps, rays, dev)
         res["speedup_vs_torch_eager_gpu"] = res["value"] / res["torch_eager_gpu_baseline"]["value"]
+        res["speedup_vs_torch_eager_gpu_unchunked_16384"] = res["value"] / res["torch_eager_gpu_baseline_unchunked_16384"]["value"]
         if peer:
             res[peer[0] + "_path"]["speedup_vs_torch_eager_gpu"] = res[peer[0] + "_path"]["value"] / res["torch_eager_gpu_baseline"]["value"]
     del net, renderer, render_par
@@ -812,7 +840,7 @@ def main():
         else:
             # BASELINE configs[3] in its strong-scaling form on the same N ranks (a few steps, after the headline)
             try:
-                st = strong_dtu(dev, args.prec, world, rank, max(2, min(args.steps, 5)), 1, args.bcast, fence)
+                st = strong_dtu(dev, args.prec, world, rank, max(2, min(args.steps, 5)), 1, args.bcast, fence, dist_on, args.bcast_layout)
                 st_elapsed = max_over_ranks(st["elapsed"])
                 nst = max(2, min(args.steps, 5))
                 if rank == 0:
@@ -827,7 +855,7 @@ def main():
                     res["extra"] = {"strong_dtu": {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}}
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
     return 0
 

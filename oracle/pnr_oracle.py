@@ -255,15 +255,22 @@ def composite_from_rgbsigma(rays, z_samp, out, white_bkgd):
     return weights, rgb_final, depth_final
 
 
-def composite(scene, mlp, rays, z_samp, sb, white_bkgd, sigma_noise=None):
-    """src/render/nerf.py:163-249 without the eval_batch_size chunk loop (chunking does not
-    change results: the model is pointwise).  sigma_noise (R,K), already scaled by noise_std: the training-time
-    `sigmas + randn_like(sigmas) * noise_std` of nerf.py:225-226 with the draw made explicit."""
+def composite(scene, mlp, rays, z_samp, sb, white_bkgd, sigma_noise=None, eval_batch_size=None):
+    """src/render/nerf.py:163-249.  eval_batch_size=None: one model call (chunking does not change results: the model is
+    pointwise); an integer: the reference's chunk loop (nerf.py:190-216: points split along the per-object axis into
+    (eval_batch_size - 1) // sb + 1 points per model call) -- the execution shape bench.py times as the reference's.
+    sigma_noise (R,K), already scaled by noise_std: the training-time `sigmas + randn_like(sigmas) * noise_std` of
+    nerf.py:225-226 with the draw made explicit."""
     R, K = z_samp.shape
     points = rays[:, None, :3] + z_samp.unsqueeze(2) * rays[:, None, 3:6]  # :185
     points = points.reshape(sb, -1, 3)  # :193-195
     viewdirs = rays[:, None, 3:6].expand(-1, K, -1).reshape(sb, -1, 3)  # :204-206
-    out = pixelnerf_forward(scene, mlp, points, viewdirs)
+    if eval_batch_size is None:
+        out = pixelnerf_forward(scene, mlp, points, viewdirs)
+    else:
+        chunk = (int(eval_batch_size) - 1) // sb + 1  # :195
+        out = torch.cat([pixelnerf_forward(scene, mlp, p, d)  # :207-213
+                         for p, d in zip(torch.split(points, chunk, dim=1), torch.split(viewdirs, chunk, dim=1))], dim=1)  # :218
     out = out.reshape(R, K, -1)  # :219
     if sigma_noise is not None:  # :225-226
         out = torch.cat([out[..., :3], out[..., 3:4] + sigma_noise.unsqueeze(-1)], dim=-1)
@@ -271,7 +278,7 @@ def composite(scene, mlp, rays, z_samp, sb, white_bkgd, sigma_noise=None):
 
 
 def render(scene, mlp_coarse, mlp_fine, rays, noise, n_coarse, n_fine, n_fine_depth,
-           depth_std=0.01, white_bkgd=False, lindisp=False, detach_depth=False, sigma_noise=None):
+           depth_std=0.01, white_bkgd=False, lindisp=False, detach_depth=False, sigma_noise=None, eval_batch_size=None):
     """src/render/nerf.py:251-303.  rays (SB, B, 8); noise = dict(u1,u2,u3,n4) (missing keys
     allowed when the corresponding stage is skipped).  Returns a nested dict
     {coarse:{rgb,depth,weights,z,rgbsigma}, fine:{...}}; `fine` absent when n_fine == 0.
@@ -282,7 +289,7 @@ def render(scene, mlp_coarse, mlp_fine, rays, noise, n_coarse, n_fine, n_fine_de
     z_coarse = sample_coarse(rays, noise["u1"], n_coarse, lindisp)  # :273
     # sigma_noise: (noise of the coarse pass (R,Kc), of the fine pass (R,Kc+Kf)), nerf.py:225-226 (training, noise_std > 0)
     wc, rgbc, depthc, outc = composite(scene, mlp_coarse, rays, z_coarse, SB, white_bkgd,
-                                       None if sigma_noise is None else sigma_noise[0])
+                                       None if sigma_noise is None else sigma_noise[0], eval_batch_size)
 
     def fmt(w, rgb, depth, z, out):
         return dict(
@@ -307,7 +314,7 @@ def render(scene, mlp_coarse, mlp_fine, rays, noise, n_coarse, n_fine, n_fine_de
         z_sorted, _ = torch.sort(z_combine, dim=-1)  # :294-295
         mf = mlp_fine if mlp_fine is not None else mlp_coarse
         wf, rgbf, depthf, outf = composite(scene, mf, rays, z_sorted, SB, white_bkgd,
-                                           None if sigma_noise is None else sigma_noise[1])  # :296
+                                           None if sigma_noise is None else sigma_noise[1], eval_batch_size)  # :296
         ret["fine"] = fmt(wf, rgbf, depthf, z_sorted, outf)
     return ret
 

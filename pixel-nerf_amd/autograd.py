@@ -256,6 +256,71 @@ class _PointsFunction(torch.autograd.Function):
         return (None, None, None, d_lat) + tuple(grads[n] for n in PARAM_NAMES)
 
 
+class _CompositeFunction(torch.autograd.Function):
+    """Differentiable alpha compositing around an arbitrary model's per-point (rgb, sigma) (src/render/nerf.py:178-182,
+    223-249): forward = pnr_composite, backward = pnr_composite_backward.  Gradients reach the model through `rgbsigma`
+    (relu' of the raw sigma is applied inside, as nerf.py:228 applies the relu inside) and the sample positions `z`
+    (through the deltas and depth = sum w z) -- the latter is what carries the fine loss back to the coarse depth
+    (nerf.py:157-160,292).  Rays are inputs, like on the fused path."""
+
+    @staticmethod
+    def forward(ctx, rays, z, rgbsigma, white_bkgd):
+        ctx.set_materialize_grads(False)
+        w, rgb, depth = ops.composite(rays, z, rgbsigma, white_bkgd, want_weights=True)
+        ctx.save_for_backward(rays, z, rgbsigma)
+        ctx.white_bkgd = bool(white_bkgd)
+        return w, rgb, depth
+
+    @staticmethod
+    def backward(ctx, d_w, d_rgb, d_depth):
+        rays, z, rgbsigma = ctx.saved_tensors
+        if d_w is None and d_rgb is None and d_depth is None:
+            return None, None, None, None
+        if d_rgb is None:
+            d_rgb = torch.zeros((rays.shape[0], 3), dtype=torch.float32, device=rays.device)
+        want_dz = ctx.needs_input_grad[1]
+        res = ops.composite_backward(rays, z, rgbsigma, ctx.white_bkgd, d_rgb.contiguous().float(),
+                                     None if d_depth is None else d_depth.contiguous().float(),
+                                     None if d_w is None else d_w.contiguous().float(), want_dz=want_dz, pre_activation=False)
+        d_rgbs, dz = res if want_dz else (res, None)
+        return None, dz, (d_rgbs if ctx.needs_input_grad[2] else None), None
+
+
+def composite_autograd(rays, z, rgbsigma, white_bkgd):
+    """-> weights (R,K), rgb (R,3), depth (R), differentiable with respect to `rgbsigma` (R,K,4) and `z` (R,K)."""
+    return _CompositeFunction.apply(rays, z.contiguous().float(), rgbsigma.contiguous().float(), bool(white_bkgd))
+
+
+class _SampleFineFunction(torch.autograd.Function):
+    """The fine pass's merged sample set (nerf.py:285-295: importance samples from the DETACHED coarse weights, depth samples
+    around the coarse depth, sort) with the one gradient the reference has there: z_all -> the depth samples at their sorted
+    positions -> through the clamp max(min(depth + n * std, far), near) -> coarse depth (the coarse depth is not detached,
+    nerf.py:292).  forward = pnr_sample_fine (which also reports the depth samples' sorted positions)."""
+
+    @staticmethod
+    def forward(ctx, rays, weights_c, depth_c, z_coarse, u2, u3, n4, depth_std, lindisp):
+        z_all, ranks = ops.sample_fine(rays, weights_c, depth_c, z_coarse, u2, u3, n4, depth_std, lindisp, want_ranks=True)
+        ctx.save_for_backward(rays, depth_c, n4, ranks)
+        ctx.depth_std = float(depth_std)
+        ctx.mark_non_differentiable(ranks)
+        return z_all, ranks
+
+    @staticmethod
+    def backward(ctx, dz_all, _):
+        rays, depth_c, n4, ranks = ctx.saved_tensors
+        if dz_all is None:
+            return (None,) * 9
+        zraw = depth_c.unsqueeze(1) + n4 * ctx.depth_std
+        live = (zraw < rays[:, 7:8]) & (zraw > rays[:, 6:7])  # inside the clamp: the gradient passes (nerf.py:160)
+        g = torch.gather(dz_all, 1, ranks.long()) * live.to(dz_all.dtype)
+        return None, None, g.sum(dim=1), None, None, None, None, None, None
+
+
+def sample_fine_autograd(rays, weights_c, depth_c, z_coarse, u2, u3, n4, depth_std, lindisp):
+    """ops.sample_fine, differentiable with respect to the coarse depth (only the n_fine_depth samples depend on it)."""
+    return _SampleFineFunction.apply(rays, weights_c, depth_c, z_coarse, u2, u3, n4, float(depth_std), bool(lindisp))[0]
+
+
 def points_autograd(net, xyz, viewdirs, coarse):
     """net(xyz, viewdirs) with autograd: (SB,B,3) x 2 -> (SB,B,4)."""
     if xyz.requires_grad or viewdirs.requires_grad:

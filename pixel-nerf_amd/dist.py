@@ -46,16 +46,22 @@ def _flat_fanout(buf, src, group):
         w.wait()
 
 
-def broadcast_encoded(net, src=0, group=None, latent_shape=None, algo="tree"):
+def broadcast_encoded(net, src=0, group=None, latent_shape=None, algo="tree", layout="nchw"):
     """Make rank `src`'s encode() state current on every rank with ONE collective when the receivers know the
     grid shape (`latent_shape=(NV,512,Hl,Wl)`, the normal case: every rank knows the dataset's image size and view
     count): a single flat broadcast of [header | poses, focal, c, image_shape, latent_scaling | feature grid].
     Without `latent_shape` a first 8-word broadcast announces the shapes (two collectives in total).  No host
     synchronisation on the sending side; receivers read the header back only in the shape-discovery form.
     algo: "tree" = dist.broadcast (RCCL picks ring / tree), "flat" = one point-to-point transfer per receiver
-    (_flat_fanout)."""
+    (_flat_fanout).
+    layout: "nchw" ships `encoder.latent` as the reference holds it; "nhwc" ships the channel-last copy the fused kernels read
+    (`encoder.latent_nhwc()`, which the source already has after an inference encode): the receivers install it as the
+    cached channel-last grid and expose `encoder.latent` as its (N,C,H,W)-shaped permuted VIEW -- same values for
+    `SpatialEncoder.index`, and no per-rank 176 MiB NCHW -> NHWC transpose on the DTU grid after every broadcast."""
     if algo not in ("tree", "flat"):
         raise ValueError("broadcast_encoded: algo must be 'tree' or 'flat'")
+    if layout not in ("nchw", "nhwc"):
+        raise ValueError("broadcast_encoded: layout must be 'nchw' or 'nhwc'")
     dev = net.poses.device
     is_src = dist.get_rank(group) == src
     if is_src:
@@ -87,7 +93,7 @@ def broadcast_encoded(net, src=0, group=None, latent_shape=None, algo="tree"):
         for o, t in zip(offs, parts):
             meta[o:o + t.numel()] = t.to(dev)
         buf[:n_meta] = meta
-        buf[n_meta:] = net.encoder.latent.reshape(-1)
+        buf[n_meta:] = (net.encoder.latent_nhwc() if layout == "nhwc" else net.encoder.latent).reshape(-1)
     if algo == "flat":
         _flat_fanout(buf, src, group)          # THE feature-grid transfer as a 1 -> (N-1) fan-out
     else:
@@ -95,7 +101,13 @@ def broadcast_encoded(net, src=0, group=None, latent_shape=None, algo="tree"):
     if not is_src:
         h = buf[:_HDR].tolist()
         NS, SB, nf, nc = int(h[4]), int(h[5]), int(h[6]), int(h[7])
-        net.encoder.latent = buf[n_meta:].reshape(NV, C, Hl, Wl)
+        if layout == "nhwc":
+            nhwc = buf[n_meta:].reshape(NV, Hl, Wl, C)
+            lat = nhwc.permute(0, 3, 1, 2)  # (NV,C,Hl,Wl) view of the channel-last buffer
+            net.encoder.latent = lat
+            net.encoder._nhwc = ((lat.data_ptr(), lat._version, tuple(lat.shape)), nhwc)  # latent_nhwc() cache: no transpose
+        else:
+            net.encoder.latent = buf[n_meta:].reshape(NV, C, Hl, Wl)
         net.poses = buf[_HDR:_HDR + NV * 12].reshape(NV, 3, 4).clone()
         net.focal = buf[_HDR + NV * 12:_HDR + NV * 12 + nf * 2].reshape(nf, 2).clone()
         net.c = buf[_HDR + NV * 14:_HDR + NV * 14 + nc * 2].reshape(nc, 2).clone()
@@ -174,6 +186,24 @@ class ShardedRenderWrapper(torch.nn.Module):
         n = len(params)
         return (out[n] if len(out) > n else latent), list(out[:n])
 
+    def _empty_outputs(self, rays, rend, want_weights):
+        """what the wrapped module returns for a (SB, 0, 8) ray batch, without launching anything (the kernels reject R = 0)"""
+        SB, dev = rays.shape[0], rays.device
+
+        def part(K):
+            d = {"rgb": torch.zeros(SB, 0, 3, device=dev), "depth": torch.zeros(SB, 0, device=dev)}
+            if want_weights and not getattr(self.wrapped, "simple_output", False):
+                d["weights"] = torch.zeros(SB, 0, K, device=dev)
+            return d
+        Kc = rend.n_coarse
+        res = {"coarse": part(Kc)}
+        if rend.using_fine:
+            res["fine"] = part(Kc + rend.n_fine)
+        if getattr(self.wrapped, "simple_output", False):
+            last = res["fine"] if rend.using_fine else res["coarse"]
+            return last["rgb"], last["depth"]
+        return res
+
     def forward(self, rays, want_weights=False):
         net = getattr(self.wrapped, "net", None)
         training = (net is not None and torch.is_grad_enabled()
@@ -181,6 +211,11 @@ class ShardedRenderWrapper(torch.nn.Module):
                          or (torch.is_tensor(getattr(getattr(net, "encoder", None), "latent", None)) and net.encoder.latent.requires_grad)))
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         B = rays.shape[1]
+        if training and B < world:
+            # a rank without rays would never enter the renderer's autograd Function, i.e. never join the step's one
+            # all_reduce, and its peers would block in it: refuse up front, identically on every rank
+            raise ValueError(f"ShardedRenderWrapper: training needs at least one ray per rank (rays per object B = {B}, "
+                             f"world size = {world}); use a ray batch >= the number of ranks")
         bounds = [shard_bounds(B, r, world) for r in range(world)]
         sizes = [hi - lo for lo, hi in bounds]
         lo, hi = bounds[rank]
@@ -192,7 +227,10 @@ class ShardedRenderWrapper(torch.nn.Module):
         if training:
             net._grad_sync = self._grad_sync  # render_autograd routes (latent, parameters) through the bucket all-reduce
         try:
-            local = self.wrapped(rays[:, lo:hi].contiguous(), want_weights=want_weights)
+            if hi == lo and rend is not None:   # fewer rays than ranks (inference): this rank contributes empty columns
+                local = self._empty_outputs(rays, rend, want_weights)
+            else:
+                local = self.wrapped(rays[:, lo:hi].contiguous(), want_weights=want_weights)
         finally:
             if training:
                 net._grad_sync = None
@@ -203,7 +241,12 @@ class ShardedRenderWrapper(torch.nn.Module):
             leaves = [(None, i, t) for i, t in enumerate(local)]
         else:
             leaves = [(k, kk, vv) for k, v in local.items() for kk, vv in v.items()]
-        cols = [t.reshape(t.shape[0], t.shape[1], -1) for _, _, t in leaves]
+        def _width(t):  # explicit: reshape(..., -1) is ambiguous for an empty shard
+            w = 1
+            for d in t.shape[2:]:
+                w *= int(d)
+            return w
+        cols = [t.reshape(t.shape[0], t.shape[1], _width(t)) for _, _, t in leaves]
         widths = [c.shape[-1] for c in cols]
         packed = torch.cat(cols, dim=-1)
         full = _gather_dim1(packed.detach(), sizes, self.group)

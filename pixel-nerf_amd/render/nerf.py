@@ -6,7 +6,8 @@ With a pixelnerf_amd PixelNeRFNet the whole forward (coarse sampling -> fused ne
 compositing -> inverse-CDF + depth resampling + sort -> fused network -> compositing) is one
 C call (pnr_render_forward).  Any other `model(xyz, coarse=, viewdirs=)` callable still works:
 sampling and compositing run as HIP kernels around the caller's model, chunked by
-eval_batch_size exactly like the reference.
+eval_batch_size exactly like the reference -- and differentiably (autograd.composite_autograd /
+sample_fine_autograd), so a renderer around an arbitrary nn.Module trains as it does in the reference.
 
 Random numbers.  `rng="philox"` (default in eval mode with a pixelnerf_amd net): the sampling kernels draw from a
 counter-based generator (Philox4x32-10) keyed by a 64-bit seed -- `torch.initial_seed()` of the ray device's generator
@@ -125,15 +126,16 @@ class NeRFRenderer(torch.nn.Module):
             for pnts in split_points:
                 val_all.append(model(pnts.contiguous(), coarse=coarse))
         out = torch.cat(val_all, dim=dim).reshape(B, K, -1)
-        if torch.is_grad_enabled() and out.requires_grad:
-            # the HIP compositing kernel below is not an autograd node: silently returning gradient-free outputs would
-            # "train" nothing.  The differentiable path is the fused one (pixelnerf_amd.PixelNeRFNet through forward()).
-            raise NotImplementedError(
-                "NeRFRenderer with a generic model callable is inference-only (no gradient flows through the HIP compositing "
-                "kernel): wrap the call in torch.no_grad(), or train a pixelnerf_amd PixelNeRFNet, whose renders are differentiable")
         if self.training and self.noise_std > 0.0:
             out = torch.cat([out[..., :3], out[..., 3:4] + torch.randn_like(out[..., 3:4]) * self.noise_std], -1)
-        return ops.composite(rays, z_samp, out[..., :4].contiguous(), self.white_bkgd, want_weights=True)
+        rgbs = out[..., :4].contiguous()
+        if torch.is_grad_enabled() and (rgbs.requires_grad or z_samp.requires_grad):
+            # training with an arbitrary model: the compositing kernels as an autograd node (pnr_composite /
+            # pnr_composite_backward); gradients reach the model through its outputs and, for the depth samples of the fine
+            # pass, through the sample positions (points above are torch ops on z_samp)
+            from ..autograd import composite_autograd
+            return composite_autograd(rays, z_samp, rgbs, self.white_bkgd)
+        return ops.composite(rays, z_samp, rgbs, self.white_bkgd, want_weights=True)
 
     # ---- forward ----
     def _draw_noise(self, R, dev):
@@ -209,8 +211,15 @@ class NeRFRenderer(torch.nn.Module):
         wc, rgbc, depthc = self.composite(model, rays, z_coarse, coarse=True, sb=SB)
         outputs = DotMap(coarse=self._format(dict(rgb=rgbc, depth=depthc, weights=wc), SB, want_weights))
         if Kf > 0:
-            z_all = ops.sample_fine(rays, wc.detach(), depthc, z_coarse, noise.get("u2"), noise.get("u3"),
-                                    noise.get("n4") if Kfd > 0 else None, self.depth_std, self.lindisp)
+            n4 = noise.get("n4") if Kfd > 0 else None
+            if n4 is not None and torch.is_grad_enabled() and depthc.requires_grad:
+                # nerf.py:292: the coarse depth is not detached -- the depth samples carry the fine loss back to it
+                from ..autograd import sample_fine_autograd
+                z_all = sample_fine_autograd(rays, wc.detach(), depthc, z_coarse, noise.get("u2"), noise.get("u3"), n4,
+                                             self.depth_std, self.lindisp)
+            else:
+                z_all = ops.sample_fine(rays, wc.detach(), depthc, z_coarse, noise.get("u2"), noise.get("u3"), n4,
+                                        self.depth_std, self.lindisp)
             wf, rgbf, depthf = self.composite(model, rays, z_all, coarse=False, sb=SB)
             outputs.fine = self._format(dict(rgb=rgbf, depth=depthf, weights=wf), SB, want_weights)
         return outputs

@@ -101,6 +101,17 @@ def _worker(rank, world, port, B):
         assert calls["broadcast"] == 0
         assert torch.equal(enc.latent, ref["latent"]) and torch.equal(net.poses, ref["poses"])
         assert torch.equal(net.focal, ref["focal"]) and (net.num_views_per_obj, net.num_objs) == (2, 2)
+        # channel-last transfer (layout="nhwc"): the receivers get the grid in the layout the fused kernels read, installed as
+        # the encoder's cached channel-last copy, and `encoder.latent` is its (N,C,H,W)-shaped view -- same values, no transpose
+        if rank != 0:
+            enc.latent, net.poses, net.num_views_per_obj = torch.zeros(1, 1, 1, 1), torch.zeros(1, 3, 4), 1
+        enc.latent_nhwc = lambda: enc.latent.permute(0, 2, 3, 1).contiguous()
+        broadcast_encoded(net, src=0, latent_shape=(4, 6, 5, 7), layout="nhwc")
+        assert tuple(enc.latent.shape) == (4, 6, 5, 7) and torch.equal(enc.latent, ref["latent"]) and torch.equal(net.poses, ref["poses"])
+        if rank != 0:
+            key, nhwc = enc._nhwc
+            assert nhwc.is_contiguous() and torch.equal(nhwc, ref["latent"].permute(0, 2, 3, 1))
+            assert key == (enc.latent.data_ptr(), enc.latent._version, (4, 6, 5, 7)) and nhwc.data_ptr() == enc.latent.data_ptr()
         # strong-scaling placement (bench.py --workload dtu): contiguous shards of ONE image, gathered with padding, give
         # back the image in ray order
         Rimg = 11
@@ -179,6 +190,12 @@ def _train_worker(rank, world, port, B):
         with torch.no_grad():  # inference through the same wrapper: no bucket, no graph
             o2 = par(rays)
         assert not o2["coarse"]["rgb"].requires_grad and par.comm_stats["all_reduce_calls"] == 1
+        # fewer rays than ranks: a rank without rays would never join the step's all_reduce -> refused up front on every rank
+        with pytest.raises(ValueError, match="at least one ray per rank"):
+            par(rays[:, :1])
+        with torch.no_grad():  # ... while inference just gathers an empty shard
+            o3 = par(rays[:, :1])
+        assert o3["coarse"]["rgb"].shape == (2, 1, 3)
     finally:
         dist.destroy_process_group()
 

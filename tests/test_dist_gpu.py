@@ -110,3 +110,106 @@ def test_bench_strong_dtu_two_ranks(repo_root, bcast):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["rays_per_image"] == 120000 and d["config"]["rays_rank0"] == 60000
     assert d["comm"]["grid_bytes"] == 3 * 512 * 150 * 200 * 4 and d["comm"]["bcast_ms_rank0"] > 0
+
+
+# ---------------------------------------------------------------- RCCL first contact (backend "nccl" on ROCm), world size 1
+# The GPU box has one device and RCCL refuses two ranks on one device, so the multi-rank tests above run on gloo.  These
+# run the SAME code paths on a real RCCL communicator of one rank: communicator creation with device_id binding,
+# broadcast (both algorithms, both layouts), the output all_gather, the training all_reduce bucket, dist.gather in bench.py.
+def _rccl1_worker(rank, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from helpers import golden_setup
+        from test_api_gpu import build_net
+        from test_hip_training_api import all_grads, make_train_net
+        from pixelnerf_amd.dist import ShardedRenderWrapper, broadcast_encoded
+        from pixelnerf_amd.render import NeRFRenderer
+        assert dist.get_backend() == "nccl"
+        t = torch.arange(1024, dtype=torch.float32, device=dev)
+        dist.all_reduce(t)  # an RCCL kernel really runs
+        assert torch.equal(t, torch.arange(1024, dtype=torch.float32, device=dev))
+
+        g, scene, meta, mc, mf, rays, noise = golden_setup("dtu_mini_64_128")
+        net = build_net(dev, scene, precision="f16x3")
+        lat0, poses0 = net.encoder.latent.clone(), net.poses.clone()
+        for algo in ("tree", "flat"):
+            for layout in ("nchw", "nhwc"):
+                broadcast_encoded(net, src=0, latent_shape=tuple(lat0.shape), algo=algo, layout=layout)
+                assert torch.equal(net.encoder.latent, lat0) and torch.equal(net.poses, poses0) and net.num_views_per_obj == 3
+        broadcast_encoded(net, src=0)  # shape-discovery form
+        rend = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=False).to(dev).eval()
+        r = rays.to(dev)
+        plain = rend.bind_parallel(net, None, simple_output=False).eval()
+        sharded = ShardedRenderWrapper(rend.bind_parallel(net, None, simple_output=False).eval())
+        with torch.no_grad():
+            torch.manual_seed(11)
+            a = plain(r, want_weights=True)
+            torch.manual_seed(11)
+            b = sharded(r, want_weights=True)
+        for p in ("coarse", "fine"):
+            for k in ("rgb", "depth", "weights"):
+                assert torch.equal(a[p][k], b[p][k]), (p, k)
+
+        # training through the RCCL all_reduce bucket: the gradients of the plain path, bit for bit (one rank: the sum is the value)
+        g, scene, meta, mc, mf, rays, noise = golden_setup("train_64_32")
+        gt = torch.rand(4, 32, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+        grads = []
+        for wrap in (False, True):
+            tnet, lat = make_train_net(dev, scene, "f16x3")
+            trend = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).to(dev).train()
+            par = trend.bind_parallel(tnet, None, simple_output=False).train()
+            if wrap:
+                par = ShardedRenderWrapper(par)
+            torch.manual_seed(5)
+            out = par(rays.to(dev))
+            loss = ((out["coarse"]["rgb"] - gt) ** 2).mean() + ((out["fine"]["rgb"] - gt) ** 2).mean()
+            loss.backward()
+            grads.append(all_grads(tnet, lat))
+            if wrap:
+                assert par.comm_stats["all_reduce_calls"] == 1 and par.comm_stats["all_reduce_bytes"] > 4 * 2 * 13 * 512 * 512
+        for k in grads[0]:  # (the grid gradient is summed with fp32 atomics across workgroups: equal up to the summation order)
+            same = torch.equal(grads[0][k], grads[1][k]) or (k == "latent" and torch.allclose(grads[0][k], grads[1][k], rtol=1e-5, atol=1e-9))
+            assert same, k
+        q.put("ok")
+    except Exception as e:
+        q.put(repr(e))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world1_broadcast_gather_allreduce_match_plain_path():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    mp.spawn(_rccl1_worker, args=(port, q), nprocs=1, join=True)
+    assert q.get() == "ok"
+
+
+def test_bench_force_dist_one_rank_rccl(repo_root):
+    """`bench.py --gpus 1 --force-dist --backend nccl`: the headline step through the distributed code path (RCCL communicator,
+    grid broadcast, gather) on the one device; the JSON carries the `comm` block at N = 1."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for extra in ([], ["--workload", "dtu", "--prec", "f16", "--bcast", "flat"]):
+        res = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl",
+                              "--steps", "2", "--warmup", "1", "--rays", "8192", "--no-extras", "--no-cpu-baseline", "--no-eager-baseline",
+                              "--no-f32-check", "--no-peer", "--no-latency"] + extra, capture_output=True, text=True, timeout=900, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, res.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["backend"] == "nccl"
+        assert d["comm"]["bcast_ms_rank0"] >= 0 and d["comm"]["gather_ms_rank0"] >= 0 and d["comm"]["grid_bytes"] > 0
