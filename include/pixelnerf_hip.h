@@ -73,7 +73,7 @@ int pnr_version(int *major, int *minor);
 /* ABI revision of THIS header: bumped whenever a struct layout or an entry point's argument list changes.  The
  * library returns the value it was compiled with; a binding must compare it with the header it was written against
  * before the first call (pixelnerf_amd/_lib.py does, and refuses a stale or foreign .so). */
-#define PNR_ABI_VERSION 5
+#define PNR_ABI_VERSION 6
 int pnr_abi_version(void);
 int pnr_device_info(int *num_cus, int *lds_bytes_per_block);
 
@@ -393,6 +393,22 @@ int pnr_render_views(const PnrScene *scene /*host*/, const void *packed_coarse, 
                      int lindisp, const float *u1, const float *u2, const float *u3, const float *n4,
                      unsigned long long seed, float *rgb_c, float *depth_c, float *weights_c, float *rgb_f,
                      float *depth_f, float *weights_f, void *workspace, void *stream);
+
+/* ---- SpatialEncoder.index as a stand-alone operator ------------------------------------------
+ * src/model/encoder.py:80-109 (SpatialEncoder.index): F.grid_sample(latent, uv[:, :, None], mode "bilinear",
+ * padding_mode "border", align_corners=True)[..., 0] on the encoded grid -- latent_nhwc (NV,Hl,Wl,C) is the
+ * channel-last copy (pnr_nchw_to_nhwc / pnr_pyramid_to_latent), uv (NV,N,2) the NORMALISED coordinates in
+ * [-1,1] (x, y) the reference forms at encoder.py:96-99 (`uv * latent_scaling / image_size - 1`),
+ * out (NV,C,N) as the reference returns it.  ATen's corner arithmetic in its operation order; a NaN
+ * coordinate reads texel 0 (what the fused kernels do, pinned by the adv_plane golden).  The fused
+ * network kernels do not call this: they gather the same rows themselves.
+ * _backward: d_latent_nhwc (NV,Hl,Wl,C) is ACCUMULATED into (zero it first; fp32 atomics), d_uv (NV,N,2) is
+ * written; either may be NULL.  Gradient through the border clip as ATen's clip_coordinates_set_grad
+ * (zero outside the open interval (0, size-1)). */
+int pnr_grid_index(const float *latent_nhwc, int NV, int Hl, int Wl, int C, const float *uv, long long N,
+                   float *out, void *stream);
+int pnr_grid_index_backward(const float *latent_nhwc, int NV, int Hl, int Wl, int C, const float *uv,
+                            long long N, const float *g_out, float *d_latent_nhwc, float *d_uv, void *stream);
 
 /* ---- PositionalEncoding as a stand-alone operator --------------------------------------------
  * src/model/code.py:30-42 (PositionalEncoding.forward): x (N, d_in) ->

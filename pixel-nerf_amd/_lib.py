@@ -11,11 +11,14 @@ import shutil
 import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelnerf_hip.so")  # override: A/B experiments
+# PIXELNERF_HIP_LIB selects another build of the library (A/B experiments, tools/build_variant.sh).  A build made with ANY
+# experiment switch is compiled with -DPNR_VARIANT and reports a NEGATIVE ABI revision: load() refuses it unless the
+# process says PIXELNERF_ALLOW_VARIANT=1 (the A/B tools do) -- a stray -D can no longer yield a library that passes for the product
+LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelnerf_hip.so")
 SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_split.hip", "pnr_bwd.hip", "pnr_f32.hip", "pnr_encode.hip"]
 HEADERS = ["pnr_common.h", "pnr_layout.h", "pnr_device.h", "pnr_raysrc.h", "pnr_internal.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
 
-ABI_VERSION = 5  # PNR_ABI_VERSION of the include/pixelnerf_hip.h this binding (struct layouts, argtypes below) was written against
+ABI_VERSION = 6  # PNR_ABI_VERSION of the include/pixelnerf_hip.h this binding (struct layouts, argtypes below) was written against
 PREC_F16, PREC_BF16, PREC_F32, PREC_F16X3 = 0, 1, 2, 3
 PRECISIONS = {"f16": PREC_F16, "fp16": PREC_F16, "bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -93,6 +96,8 @@ PROTOTYPES = {
                                        ctypes.c_ulonglong, ctypes.c_longlong, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pnr_pyramid_to_latent": (_I, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                    ctypes.POINTER(ctypes.c_int), _I, _I, _P, _P, _P]),
+    "pnr_grid_index": (_I, [_P, _I, _I, _I, _I, _P, ctypes.c_longlong, _P, _P]),
+    "pnr_grid_index_backward": (_I, [_P, _I, _I, _I, _I, _P, ctypes.c_longlong, _P, _P, _P, _P]),
     "pnr_positional_encoding": (_I, [_P, ctypes.c_longlong, _I, _I, _P, _P, _I, _P, _P]),
     "pnr_positional_encoding_backward": (_I, [_P, _P, ctypes.c_longlong, _I, _I, _P, _P, _I, _P, _P]),
     "pnr_sample_training_rays": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
@@ -155,7 +160,6 @@ PROTOTYPES = {
 }
 # test hook exported by the library but not part of the public header
 _EXTRA = {"pnr_debug_set_x_dump": (_I, [_P]),
-          "pnr_debug_set_split_tile": (_I, [_I]),
           "pnr_debug_phase_timing": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, _P]),
           "pnr_debug_phase_timing_split": (_I, [ctypes.POINTER(PnrScene), _P, _P, _P, _P, _I, _I, _I, _P, _P, _P])}
 
@@ -234,6 +238,8 @@ def load():
         abi = lib.pnr_abi_version()
     except AttributeError:
         abi = None
+    if abi is not None and abi < 0 and os.environ.get("PIXELNERF_ALLOW_VARIANT") == "1":
+        abi = -abi  # an experiment build, asked for explicitly
     if abi != ABI_VERSION:
         raise PixelNerfHipError(f"{LIB_PATH} implements ABI revision {abi}, this binding was written against {ABI_VERSION} "
                                 "(include/pixelnerf_hip.h PNR_ABI_VERSION): rebuild it (__graft_entry__.build())")

@@ -30,7 +30,16 @@ extern "C" int pnr_version(int *major, int *minor) {
     return PNR_OK;
 }
 
-extern "C" int pnr_abi_version(void) { return PNR_ABI_VERSION; }
+// A library built with experiment switches (tools/build_variant.sh passes -DPNR_VARIANT next to them; the kernel sources only
+// honour a switch under `#if defined(PNR_VARIANT) && defined(...)`) identifies itself with a NEGATIVE revision: the product
+// binding refuses it (pixelnerf_amd/_lib.py), the A/B tools opt in.
+extern "C" int pnr_abi_version(void) {
+#ifdef PNR_VARIANT
+    return -PNR_ABI_VERSION;
+#else
+    return PNR_ABI_VERSION;
+#endif
+}
 
 extern "C" int pnr_device_info(int *num_cus, int *lds_bytes_per_block) {
     int dev = 0;

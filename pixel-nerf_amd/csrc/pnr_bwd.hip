@@ -156,48 +156,26 @@ template <typename P>
 __device__ __forceinline__ void bwd_block(f32x16 (&G)[IT][JT], char *smem, int b, Ring<P> &R, int NS, const BwdParams &q,
                                           size_t off, const bool *valid, uint32_t a_rd0, uint32_t a_rd1, uint32_t a_wr,
                                           uint32_t mask_off, size_t mask_layer, long long rows_left, int wv, int lane) {
-#ifdef PNR_EXP_BWD_NODUMP  // experiment (timing only): no gradient dumps
-    constexpr bool DUMP = false;
-#else
     constexpr bool DUMP = true;
-#endif
     // gradient dumps (operands of the weight-gradient GEMMs): copied out of the image behind the barrier, whole rows
     const size_t off_tile = off - (size_t)(((lane & 31) * D_HID + (wv * IT) * 32 + (lane >> 5) * 16) * 2);
     __syncthreads();  // every wave is done reading the gradient image (previous GEMM)
     write_act<P, false, false>(G, smem, a_wr);
     __syncthreads();
-#ifndef PNR_DUMP_IN_GEMM
     if (DUMP) dump_image<MT>(smem, LDS_A, q.g_fc1[b] + off_tile, rows_left, wv, lane);
-#endif
     f32x16 t[IT][JT];
     // mask_off / mask_layer: this thread's word within a layer of q.d_mask / words per layer (layer 2b: x, 2b+1: net)
     const unsigned long long mk_n = (q.d_mask + (size_t)(2 * b + 1) * mask_layer)[mask_off];
     zero_acc(t);
-#ifdef PNR_DUMP_IN_GEMM
-    {
-        const DumpJob dj = {smem + LDS_A, q.g_fc1[b] + off_tile, rows_left, wv, lane};
-        gemm<P, AdvanceBwd, DUMP>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS, &dj);
-    }
-#else
     gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
-#endif
     apply_mask(t, mk_n);
     __syncthreads();
     write_act<P, false, false>(t, smem, a_wr);
     __syncthreads();
-#ifndef PNR_DUMP_IN_GEMM
     if (DUMP) dump_image<MT>(smem, LDS_A, q.g_fc0[b] + off_tile, rows_left, wv, lane);
-#endif
     const unsigned long long mk_a = (q.d_mask + (size_t)(2 * b) * mask_layer)[mask_off];
     zero_acc(t);
-#ifdef PNR_DUMP_IN_GEMM
-    {
-        const DumpJob dj = {smem + LDS_A, q.g_fc0[b] + off_tile, rows_left, wv, lane};
-        gemm<P, AdvanceBwd, DUMP>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS, &dj);
-    }
-#else
     gemm<P, AdvanceBwd>(t, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
-#endif
     masked_add(G, t, mk_a);
 }
 
@@ -288,12 +266,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
             for (int b = COMBINE_LAYER - 1; b >= 0; --b)
                 bwd_block<P>(G, smem, b, R, NS, q, off_view, valid, a_rd0, a_rd1, a_wr,
                              mask_pooled + (uint32_t)view * (uint32_t)q.ntiles * NTHREADS, mask_layer, rows_left, wv, lane);
-#ifdef PNR_EXP_BWD_NOZ  // experiment (TIMING ONLY, wrong results: the weight ring falls out of step with the stream)
-            {
-                dump_only<P>(G, q.g_x0 + off_view, valid);
-                continue;
-            }
-#endif
             // ---- d z_lat = sum_b dY_b W_z[b] and d(code) = dY_0 W_in (resnetfc.py:147,175-180 backward): four more
             // transposed-stream GEMMs on gradient images this tile has just produced.  dY_2, dY_1 (= g_fc1[1], g_fc1[0])
             // come back from their dumps (written by this workgroup a moment ago, L2-resident), dY_0 = G is in registers.

@@ -206,13 +206,7 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT_], const char *smem, u
             dump_v = *reinterpret_cast<const u32x4 *>(dj->src + row * ROW_ACT + dj->lane * 16);
         }
 
-#ifdef PNR_EXP_FAKE_W  // experiment: refill from a fixed 8 KiB window (no L2 streaming); results are wrong
-        const char *pf = R.wave_base + (size_t)(R.pf_rs & 0) * (IT * 1024);
-#elif defined(PNR_EXP_WRAP_W)  // experiment: the stream wraps inside its first PNR_EXP_WRAP_W ring steps (L2-resident); wrong results
-        const char *pf = R.wave_base + (size_t)(R.pf_rs % PNR_EXP_WRAP_W) * (IT * 1024);
-#else
         const char *pf = R.wave_base + (size_t)R.pf_rs * (IT * 1024);
-#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cur = j & 1;
@@ -223,15 +217,8 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT_], const char *smem, u
             // the compiler's schedule is the default.
 #pragma unroll
             for (int jt = 0; jt < JT_; ++jt) {
-#ifndef PNR_EXP_NO_BLOAD  // experiment: B fragments stay what the first read returned; results are wrong
                 b[cur ^ 1][jt] = lds8<P>(smem, baddr0 + jt * jstride + (j + 1) * 32);
-#else
-                b[cur ^ 1][jt] = b[cur][jt];
-#endif
             }
-#ifdef PNR_PIN_SCHEDULE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             typename P::T8 a[IT];
 #pragma unroll
             for (int it = 0; it < IT; ++it) a[it] = R.r[j][it];
@@ -239,46 +226,8 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[IT][JT_], const char *smem, u
             for (int it = 0; it < IT; ++it)
 #pragma unroll
                 for (int jt = 0; jt < JT_; ++jt) acc[it][jt] = P::mfma(a[it], b[cur][jt], acc[it][jt]);
-#ifdef PNR_PIN_SCHEDULE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifndef PNR_EXP_NO_WLOAD  // experiment: never refill the ring (no weight traffic at all); results are wrong
 #pragma unroll
             for (int it = 0; it < IT; ++it) R.r[j][it] = gload8<P>(pf + j * (IT * 1024) + it * 1024);
-#endif
-#ifdef PNR_PIN_SCHEDULE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef PNR_SGB
-            // issue pattern of one k-step: every LDS read of the next step's B fragments and every refill of this
-            // step's ring slot sits behind one MFMA (the MFMA pipe is busy 8 passes per instruction; the memory
-            // instructions issue in its shadow and the refill gets the full 3-step prefetch distance)
-#if PNR_SGB == 2  // LDS reads behind single MFMAs first, the refills last, two MFMAs apart where the step has enough of them
-#pragma unroll
-            for (int i = 0; i < JT_; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            if constexpr (IT * JT_ - JT_ - IT > 0) __builtin_amdgcn_sched_group_barrier(0x008, IT * JT_ - JT_ - IT, 0);
-#pragma unroll
-            for (int i = 0; i < IT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-#else
-#pragma unroll
-            for (int i = 0; i < JT_; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < IT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-            if constexpr (IT * JT_ - JT_ - IT > 0) __builtin_amdgcn_sched_group_barrier(0x008, IT * JT_ - JT_ - IT, 0);
-#endif
-#endif
         }
         baddr0 += 128;
         ADV::step4(R, NS);

@@ -330,7 +330,160 @@ __global__ void sample_training_rays_kernel(const float *__restrict__ poses, con
     g[0] = im[0] * 0.5f + 0.5f; g[1] = im[(size_t)H * W] * 0.5f + 0.5f; g[2] = im[(size_t)2 * H * W] * 0.5f + 0.5f;
 }
 
+// ---------------------------------------------------------------- SpatialEncoder.index as a stand-alone operator
+// src/model/encoder.py:80-109: F.grid_sample(latent, uv, bilinear, padding "border", align_corners=True) on a (NV,C,Hl,Wl)
+// grid at (NV,N) normalised coordinates -> (NV,C,N).  The grid is read in the channel-last copy the fused kernels use (one
+// corner = one contiguous row); a workgroup owns 64 points of one view: per 64-channel chunk every wave blends the four
+// corner rows of its 16 points with lanes along the channels (256-byte coalesced reads) into an LDS tile, which then leaves
+// with lanes along the points (256-byte runs of one channel's output row) -- the reference's (NV,C,N) layout without a
+// strided store.  Corner arithmetic in ATen's op order (no FMA contraction); a NaN coordinate reads texel 0 like
+// project_point (pnr_device.h) and the fused kernels do.
+struct IndexCorner {
+    int off[4];   // texel index (y * Wl + x) of nw, ne, sw, se
+    float w[4];
+    float ix, iy;
+    int x_on, y_on;  // coordinate strictly inside (0, size-1): grid_sample's border clip passes the gradient
+};
+#pragma clang fp contract(off)
+__device__ __forceinline__ IndexCorner index_corner(float gx, float gy, int Wl_, int Hl_) {
+    const float Wl = (float)Wl_, Hl = (float)Hl_;
+    float ix = ((gx + 1.f) / 2.f) * (Wl - 1.f), iy = ((gy + 1.f) / 2.f) * (Hl - 1.f);
+    IndexCorner c;
+    c.x_on = ix > 0.f && ix < Wl - 1.f;
+    c.y_on = iy > 0.f && iy < Hl - 1.f;
+    ix = fminf(Wl - 1.f, fmaxf(ix, 0.f));
+    iy = fminf(Hl - 1.f, fmaxf(iy, 0.f));
+    if (!(ix == ix)) { ix = 0.f; c.x_on = 0; }
+    if (!(iy == iy)) { iy = 0.f; c.y_on = 0; }
+    const float ix0 = floorf(ix), iy0 = floorf(iy);
+    const float ix1 = ix0 + 1.f, iy1 = iy0 + 1.f;
+    c.w[0] = (ix1 - ix) * (iy1 - iy); c.w[1] = (ix - ix0) * (iy1 - iy);
+    c.w[2] = (ix1 - ix) * (iy - iy0); c.w[3] = (ix - ix0) * (iy - iy0);
+    const int x0 = (int)ix0, y0 = (int)iy0;
+    const int x1 = min(x0 + 1, Wl_ - 1), y1 = min(y0 + 1, Hl_ - 1);  // an out-of-range corner carries weight 0
+    if (x0 + 1 > Wl_ - 1) { c.w[1] = 0.f; c.w[3] = 0.f; }
+    if (y0 + 1 > Hl_ - 1) { c.w[2] = 0.f; c.w[3] = 0.f; }
+    c.off[0] = y0 * Wl_ + x0; c.off[1] = y0 * Wl_ + x1; c.off[2] = y1 * Wl_ + x0; c.off[3] = y1 * Wl_ + x1;
+    c.ix = ix; c.iy = iy;
+    return c;
+}
+
+constexpr int GI_P = 64;   // points per workgroup
+constexpr int GI_C = 64;   // channels per LDS tile
+
+__global__ void __launch_bounds__(256)
+grid_index_kernel(const float *__restrict__ grid, int Hl, int Wl, int C, const float *__restrict__ uv, long long N,
+                  float *__restrict__ out) {
+    __shared__ float tile[GI_P][GI_C + 1];
+    __shared__ IndexCorner corner[GI_P];
+    const int v = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long n0 = (long long)blockIdx.x * GI_P;
+    if (threadIdx.x < GI_P) {
+        const long long n = n0 + threadIdx.x;
+        IndexCorner c = {};
+        if (n < N) c = index_corner(uv[((size_t)v * N + n) * 2], uv[((size_t)v * N + n) * 2 + 1], Wl, Hl);
+        corner[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const float *gv = grid + (size_t)v * Hl * Wl * C;
+    for (int c0 = 0; c0 < C; c0 += GI_C) {
+        const int ch = c0 + lane;
+#pragma unroll 4
+        for (int i = 0; i < GI_P / 4; ++i) {
+            const int p = wv * (GI_P / 4) + i;
+            const IndexCorner &k = corner[p];
+            float r = 0.f;
+            if (ch < C && n0 + p < N) {
+                // ATen's accumulation order: nw, ne, sw, se
+                r = gv[(size_t)k.off[0] * C + ch] * k.w[0];
+                r = r + gv[(size_t)k.off[1] * C + ch] * k.w[1];
+                r = r + gv[(size_t)k.off[2] * C + ch] * k.w[2];
+                r = r + gv[(size_t)k.off[3] * C + ch] * k.w[3];
+            }
+            tile[p][lane] = r;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < GI_C / 4; ++i) {
+            const int cc = wv * (GI_C / 4) + i;
+            if (c0 + cc < C && n0 + lane < N) out[((size_t)v * C + c0 + cc) * N + n0 + lane] = tile[lane][cc];
+        }
+        __syncthreads();
+    }
+}
+
+// backward: d grid (channel-last, accumulated with atomics: 256-byte runs per corner) and d uv (NV,N,2).
+//   d out / d ix = (ne - nw)(iy1 - iy) + (se - sw)(iy - iy0), times (Wl - 1) / 2 for the normalised coordinate; zero where the
+//   border clip is active (ATen clip_coordinates_set_grad) -- the rule position_bwd_kernel (pnr_bwd.hip) applies on the fused path.
+__global__ void __launch_bounds__(256)
+grid_index_bwd_kernel(const float *__restrict__ grid, int Hl, int Wl, int C, const float *__restrict__ uv, long long N,
+                      const float *__restrict__ g_out, float *__restrict__ d_grid, float *__restrict__ d_uv) {
+    __shared__ float tile[GI_P][GI_C + 1];
+    __shared__ IndexCorner corner[GI_P];
+    __shared__ float duv[GI_P][2];
+    const int v = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long n0 = (long long)blockIdx.x * GI_P;
+    if (threadIdx.x < GI_P) {
+        const long long n = n0 + threadIdx.x;
+        IndexCorner c = {};
+        if (n < N) c = index_corner(uv[((size_t)v * N + n) * 2], uv[((size_t)v * N + n) * 2 + 1], Wl, Hl);
+        corner[threadIdx.x] = c;
+        duv[threadIdx.x][0] = 0.f; duv[threadIdx.x][1] = 0.f;
+    }
+    __syncthreads();
+    const float *gv = grid + (size_t)v * Hl * Wl * C;
+    float *dg = d_grid ? d_grid + (size_t)v * Hl * Wl * C : nullptr;
+    float ax[GI_P / 4], ay[GI_P / 4];
+#pragma unroll
+    for (int i = 0; i < GI_P / 4; ++i) { ax[i] = 0.f; ay[i] = 0.f; }
+    for (int c0 = 0; c0 < C; c0 += GI_C) {
+#pragma unroll 4
+        for (int i = 0; i < GI_C / 4; ++i) {
+            const int cc = wv * (GI_C / 4) + i;
+            tile[lane][cc] = (c0 + cc < C && n0 + lane < N) ? g_out[((size_t)v * C + c0 + cc) * N + n0 + lane] : 0.f;
+        }
+        __syncthreads();
+        const int ch = c0 + lane;
+#pragma unroll
+        for (int i = 0; i < GI_P / 4; ++i) {
+            const int p = wv * (GI_P / 4) + i;
+            if (ch >= C || n0 + p >= N) continue;
+            const IndexCorner &k = corner[p];
+            const float g = tile[p][lane];
+            if (dg) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (k.w[q] != 0.f && g != 0.f) atomicAdd(dg + (size_t)k.off[q] * C + ch, k.w[q] * g);
+            }
+            if (d_uv) {
+                const float nw = gv[(size_t)k.off[0] * C + ch], ne = gv[(size_t)k.off[1] * C + ch];
+                const float sw = gv[(size_t)k.off[2] * C + ch], se = gv[(size_t)k.off[3] * C + ch];
+                const float fx = k.ix - floorf(k.ix), fy = k.iy - floorf(k.iy);
+                ax[i] += g * ((ne - nw) * (1.f - fy) + (se - sw) * fy);
+                ay[i] += g * ((sw - nw) * (1.f - fx) + (se - ne) * fx);
+            }
+        }
+        __syncthreads();
+    }
+    if (d_uv) {
+#pragma unroll
+        for (int i = 0; i < GI_P / 4; ++i) {
+            float sx = ax[i], sy = ay[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
+            const int p = wv * (GI_P / 4) + i;
+            if (lane == 0 && n0 + p < N) {
+                const IndexCorner &k = corner[p];
+                d_uv[((size_t)v * N + n0 + p) * 2] = k.x_on ? sx * (((float)Wl - 1.f) / 2.f) : 0.f;
+                d_uv[((size_t)v * N + n0 + p) * 2 + 1] = k.y_on ? sy * (((float)Hl - 1.f) / 2.f) : 0.f;
+            }
+        }
+    }
+}
+#pragma clang fp contract(fast)
+
 }  // namespace pnr
+
 
 extern "C" int pnr_sample_training_rays(const float *poses, const float *images, const float *focal, const float *c,
                                         const float *bboxes, const long long *ids, const float *ux, const float *uy, int SB,
@@ -425,10 +578,6 @@ extern "C" int pnr_pyramid_to_latent(const float *const *stages, const int *chan
         lds = layout(P);
         if (lds <= 48 * 1024 || P == 8) break;
     }
-#ifdef PNR_PYR_P
-    P = PNR_PYR_P;  // experiment: fixed run length
-    lds = layout(P);
-#endif
     if (lds > 160 * 1024) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: source windows do not fit the LDS (too many channels)");
     for (int s = 0; s < n_stages; ++s)
         if (p.nxw[s] > 256) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: a stage more than 32x wider than stage 0 is not supported");
@@ -441,4 +590,28 @@ extern "C" int pnr_pyramid_to_latent(const float *const *stages, const int *chan
     if (H0 > 65535 || NV > 65535) return pnr_fail(PNR_E_INVALID, "pnr_pyramid_to_latent: grid too large");
     hipLaunchKernelGGL(k, dim3(tiles_x, H0, NV), dim3(256), lds, (hipStream_t)stream, p, H0, W0, latent_nhwc, latent_nchw);
     return pnr_check_launch("pnr_pyramid_to_latent");
+}
+
+extern "C" int pnr_grid_index(const float *latent_nhwc, int NV, int Hl, int Wl, int C, const float *uv, long long N, float *out,
+                              void *stream) {
+    if (NV < 0 || Hl <= 0 || Wl <= 0 || C <= 0 || N < 0) return pnr_fail(PNR_E_INVALID, "pnr_grid_index: bad sizes");
+    if (NV == 0 || N == 0) return PNR_OK;
+    if (!latent_nhwc || !uv || !out) return pnr_fail(PNR_E_INVALID, "pnr_grid_index: null argument");
+    if ((long long)Hl * Wl * C >= (1LL << 31) || NV > 65535 || (N + pnr::GI_P - 1) / pnr::GI_P > 0x7fffffffLL)
+        return pnr_fail(PNR_E_INVALID, "pnr_grid_index: one view's grid must stay below 2^31 elements, NV <= 65535");
+    hipLaunchKernelGGL(pnr::grid_index_kernel, dim3((unsigned)((N + pnr::GI_P - 1) / pnr::GI_P), (unsigned)NV), dim3(256), 0,
+                       (hipStream_t)stream, latent_nhwc, Hl, Wl, C, uv, N, out);
+    return pnr_check_launch("pnr_grid_index");
+}
+
+extern "C" int pnr_grid_index_backward(const float *latent_nhwc, int NV, int Hl, int Wl, int C, const float *uv, long long N,
+                                       const float *g_out, float *d_latent_nhwc, float *d_uv, void *stream) {
+    if (NV < 0 || Hl <= 0 || Wl <= 0 || C <= 0 || N < 0) return pnr_fail(PNR_E_INVALID, "pnr_grid_index_backward: bad sizes");
+    if (NV == 0 || N == 0 || (!d_latent_nhwc && !d_uv)) return PNR_OK;
+    if (!latent_nhwc || !uv || !g_out) return pnr_fail(PNR_E_INVALID, "pnr_grid_index_backward: null argument");
+    if ((long long)Hl * Wl * C >= (1LL << 31) || NV > 65535 || (N + pnr::GI_P - 1) / pnr::GI_P > 0x7fffffffLL)
+        return pnr_fail(PNR_E_INVALID, "pnr_grid_index_backward: one view's grid must stay below 2^31 elements, NV <= 65535");
+    hipLaunchKernelGGL(pnr::grid_index_bwd_kernel, dim3((unsigned)((N + pnr::GI_P - 1) / pnr::GI_P), (unsigned)NV), dim3(256), 0,
+                       (hipStream_t)stream, latent_nhwc, Hl, Wl, C, uv, N, g_out, d_latent_nhwc, d_uv);
+    return pnr_check_launch("pnr_grid_index_backward");
 }

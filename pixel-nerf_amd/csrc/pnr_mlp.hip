@@ -103,24 +103,6 @@ __device__ __forceinline__ void gather_table(const EvalParams &q, char *smem, in
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
             const int p = wv * (MT / NW) + i + u;
-#ifdef PNR_F16_PK_LOOKUP  // experiment: packed f16 bilinear (v_pk_mul/fma_f16), overflow clamped by MODE.FP16_OVFL
-            if constexpr (P::kIsF16) {
-                u32x4 o;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f16x2 acc2;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const f16x2 wc = {(_Float16)w[u][c], (_Float16)w[u][c]};
-                        const f16x2 vc = {v[u][c][2 * k], v[u][c][2 * k + 1]};
-                        acc2 = c == 0 ? vc * wc : vc * wc + acc2;
-                    }
-                    o[k] = __builtin_bit_cast(uint32_t, acc2);
-                }
-                *reinterpret_cast<u32x4 *>(smem + LDS_Z + p * ROW_ACT + lane * 16) = o;
-                continue;
-            }
-#endif
             float r[8];
             if constexpr (P::kIsF16) {
                 // v_fma_mix_f32: fp32 FMA that converts its f16 operand on the fly (op_sel picks the half of the packed
@@ -208,19 +190,10 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
     PNR_T(PH_WRITE_X);
     __syncthreads();
     PNR_T(PH_BAR2);
-#ifndef PNR_DUMP_IN_GEMM
     if constexpr (TRAIN) dump_image<TL::MT>(smem, TL::LDS_A, q.d_a[b] + dump_tile, rows_left, wv, lane);
-#endif
     {
         f32x16 net[IT][JT];
         add_bias<true>(net, bias_lane, 1 + 2 * b);
-#ifdef PNR_DUMP_IN_GEMM
-        if constexpr (TRAIN) {
-            static_assert(TL::MT == 64, "the in-GEMM dump copies 8 rows per wave");
-            const DumpJob dj = {smem + TL::LDS_A, q.d_a[b] + dump_tile, rows_left, wv, lane};
-            gemm<P, ADV, true>(net, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS, &dj);
-        } else
-#endif
         gemm<P, ADV>(net, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
         PNR_T(PH_GEMM_FC0);
         __syncthreads();  // every wave is done reading relu(x)
@@ -230,9 +203,7 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
     }
     __syncthreads();
     PNR_T(PH_BAR4);
-#ifndef PNR_DUMP_IN_GEMM
     if constexpr (TRAIN) dump_image<TL::MT>(smem, TL::LDS_A, q.d_n[b] + dump_tile, rows_left, wv, lane);
-#endif
     add_bias<false>(x, bias_lane, 2 + 2 * b);
     // multi-view pooling: the running sum of the previous views comes back from its scratch UNDER this GEMM (`net` is dead,
     // its registers hold the loads in flight), so the view boundary costs no exposed memory round trip
@@ -243,12 +214,6 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
             for (int i = 0; i < IT * JT * 4; ++i) parked[i] = park[i * NTHREADS];  // [slot][thread]: 1 KiB per wave-instruction
         }
     }
-#ifdef PNR_DUMP_IN_GEMM
-    if constexpr (TRAIN) {
-        const DumpJob dj = {smem + TL::LDS_A, q.d_n[b] + dump_tile, rows_left, wv, lane};
-        gemm<P, ADV, true>(x, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS, &dj);
-    } else
-#endif
     gemm<P, ADV>(x, smem, a_rd0, a_rd1, KS_BIG / 4, R, NS);
     if constexpr (MV_PARK) {
         if (park) {
@@ -270,12 +235,10 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
     if (with_z) {
         if constexpr (FOLD) {  // lin_z[b+1](z) = bilinear lookup in table b+1 (LDS_Z is free: its last readers ran before fc_0)
             PNR_T(PH_GEMM_FC1_Z);
-#ifndef PNR_EXP_NO_LOOKUP12  // experiment: upper bound of hiding the block-1/2 lookups entirely (wrong results)
             if constexpr (TL::SINGLE_IMAGE) __syncthreads();  // the rows land in the image fc_1 has just been reading
             gather_table<P, TL::SINGLE_IMAGE ? PNR_GB12 : 2, TL>(q, smem, wv, lane, b + 1);  // the residual stream is live here: smaller batches
             __syncthreads();
             add_from_z<P>(x, smem, a_wr - TL::LDS_A + TL::LDS_Z);
-#endif
             PNR_T(PH_TABLE);
         } else {
             gemm<P, ADV>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);
@@ -315,9 +278,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
     }
 
     f16_ovfl_mode<P>();
-#ifdef PNR_PRIO  // experiment (pnr_split.hip ships this form): static priority for the second-dispatched half of the workgroup
-    if (wv >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     Ring<P> R;
     R.wave_base = q.wstream + (size_t)wv * ((FOLD ? RS_TOTAL_F : RS_TOTAL) * IT * 1024) + lane * 16;
     R.pf_rs = 0;
@@ -339,13 +299,11 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
         // training + multi-view: the running view sum is parked (simple read-modify-write at the view boundary, as in
         // pnr_split.hip) -- with the dump bookkeeping live as well, the in-register form spilled 76 registers
         [[maybe_unused]] constexpr bool PARK_SUM = MV && TRAIN;
-#ifndef PNR_MV_PARK
         // multi-view: running view sum in 64 live registers.  The instantiation then sits at the 256-register limit and spills
         // 20-40 registers to scratch OUTSIDE the GEMM loops; the spill-free alternatives (-DPNR_MV_PARK: sum parked in an
         // L2-resident scratch, simple or prefetched under the last fc_1) measured 2.7-4 % and 4-8 % SLOWER on the same box
         // (profiles/r02_mv_pooling_ab.txt), so the registers stay.
         [[maybe_unused]] f32x16 xsum[(MV && !PARK_SUM) ? IT : 1][(MV && !PARK_SUM) ? JT : 1];
-#endif
         const size_t dump_pooled = (((size_t)tile * MT + pl) * D_HID + (wv * IT) * 32 + h * 16) * 2;
         // relu bit masks (training): [layer][view][tile][thread] words; pooled layers use view slot 0
         const size_t mask_layer = (size_t)NS * (size_t)q.ntiles * NTHREADS;
@@ -357,9 +315,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             const uint32_t mask_view = mask_pooled + (uint32_t)view * (uint32_t)q.ntiles * NTHREADS;
             __syncthreads();  // previous users of LDS_IN / LDS_META / LDS_Z are done
             PNR_T(PH_SYNC_TOP);
-#ifdef PNR_EXP_NO_FEATURE  // experiment: feature phase only for the first tile (stale LDS afterwards; wrong results)
-            if (tile == (int)blockIdx.x) {
-#endif
             geometry<P, RAYS, TL>(q, smem, tile, view, tid);
             __syncthreads();
             PNR_T(PH_GEOMETRY);
@@ -372,9 +327,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             }
             if constexpr (FOLD) gather_table<P, TL::SINGLE_IMAGE ? PNR_GB0 : (MV ? 2 : 4), TL>(q, smem, wv, lane, 0);
             else gather<P, TRAIN, MV ? 2 : 4, TL>(q, smem, wv, lane, tile, view);  // multi-view also holds the view sum
-#ifdef PNR_EXP_NO_FEATURE
-            }
-#endif
             __syncthreads();
             PNR_T(PH_GATHER);
             add_bias<true>(x, bias_lane, B_IN_Z0);
@@ -382,7 +334,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
             if constexpr (FOLD) add_from_z<P>(x, smem, a_wr - LDS_A + LDS_Z);  // lin_z[0] via table 0
             else gemm<P, ADV>(x, smem, z_rd0, z_rd1, KS_BIG / 4, R, NS);  // lin_z[0]   resnetfc.py:175-180
             PNR_T(PH_GEMM_IN_Z0);
-#if !defined(PNR_MV_PARK)
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b)
                 res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
@@ -417,28 +368,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                         if (view + 1 == NS) x[it][jt] = xsum[it][jt] * inv;
                     }
             }
-#else
-            if constexpr (!MV) {
-#pragma unroll 1
-                for (int b = 0; b < COMBINE_LAYER; ++b)
-                    res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, b + 1 < COMBINE_LAYER, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer, rows_left);
-            } else {
-#pragma unroll 1
-            for (int b = 0; b + 1 < COMBINE_LAYER; ++b)
-                res_block<P, TIMING, TRAIN, FOLD, TL>(x, smem, b, true, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                  a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer, rows_left);
-            // last per-view block.  Multi-view: mean over source views (util.combine_interleaved, util.py:461-466) -- the
-            // running view sum is PARKED in a per-workgroup scratch (q.mv_ws, [slot][thread] layout, each lane re-reads
-            // only what it wrote itself: no synchronisation) instead of 64 live registers across three residual blocks;
-            // it is fetched back under the block's fc_1 GEMM and the sum / mean is formed right behind it.  Fixed
-            // summation order view 0 + view 1 + ...: deterministic.
-            f32x4 *ws = MV ? reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid : nullptr;
-            res_block<P, TIMING, TRAIN, FOLD, TL, MV>(x, smem, COMBINE_LAYER - 1, false, R, NS, bias_lane, a_rd0, a_rd1, z_rd0, z_rd1,
-                                                      a_wr, tid, tim, tlast, q, dump_view, valid, wv, lane, mask_view, mask_layer, rows_left, ws, view == 0,
-                                                      view + 1 == NS, 1.f / (float)NS);
-            }
-#endif
         }
 #pragma unroll 1
         for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b)
@@ -542,19 +471,10 @@ ProfileScope::~ProfileScope() {
 // is taken when it needs fewer rounds-times-cost (32 768 points on 256 CUs: 2 rounds either way -> 64; 49 152: 2 rounds
 // of 96 against 3 of 64 -> 96).  Both forms give the same bits per point.
 static inline bool use_tile96(const EvalParams &q, bool mv) {
-#ifdef PNR_FORCE_TILE64
-    return false;
-#else
-#ifdef PNR_MV_TILE96
-    (void)mv;
-    if (!(q.tables && !q.d_z)) return false;
-#else
     if (!(q.tables && !mv && !q.d_z)) return false;  // multi-view: the 64-point tile
-#endif
     const long long ncu = num_cus();
     const long long r96 = ((q.P + 95) / 96 + ncu - 1) / ncu, r64 = ((q.P + 63) / 64 + ncu - 1) / ncu;
     return r96 * 137 <= r64 * 100;
-#endif
 }
 
 // per (device, stream) scratch of the multi-view instantiations (the split-operand kernel, and -DPNR_MV_PARK builds of this one): the parked view sum, one tile
@@ -586,22 +506,14 @@ static int launch(EvalParams &q, bool mv, hipStream_t st) {
     int mt = 64, lds = Tile<64>::LDS_TOTAL;
     if (RAYS && q.d_z) k = mv ? eval_kernel<PREC, true, true, false, true> : eval_kernel<PREC, true, false, false, true>;
     else if (use_tile96(q, mv)) {
-#ifdef PNR_MV_TILE96
-        k = mv ? eval_kernel<PREC, RAYS, true, false, false, true, 96> : eval_kernel<PREC, RAYS, false, false, false, true, 96>;
-#else
         k = eval_kernel<PREC, RAYS, false, false, false, true, 96>;
-#endif
         mt = 96; lds = Tile<96>::LDS_TOTAL;
     }
     else if (q.tables) k = mv ? eval_kernel<PREC, RAYS, true, false, false, true> : eval_kernel<PREC, RAYS, false, false, false, true>;
     const long long nt = (q.P + mt - 1) / mt;
     q.ntiles = (int)nt;
     const int grid = (int)(nt < num_cus() ? nt : num_cus());
-#ifndef PNR_MV_PARK
     if (mv && RAYS && q.d_z)  // the training instantiation parks its view sum
-#else
-    if (mv)
-#endif
     {
         q.mv_ws = mv_scratch(st, (size_t)num_cus() * 96 * D_HID * sizeof(float));
         if (!q.mv_ws) return pnr_fail(PNR_E_HIP, "pnr_eval: cannot allocate the multi-view pooling scratch (48 MiB)");

@@ -25,7 +25,6 @@
 //                                                (transposed head / tail streams, gradient of the stream in the accumulators,
 //                                                gradient images copied out the same way, d z_lat / d code as fp32 rows).
 //   pack_weights_bwd_split_kernel                its weight streams, from the raw parameters.
-//   eval_split96_kernel                          96-point K-half-staged experiment (measured slower; test hook only).
 // The weight gradients over those images are dw_split_kernel (pnr_bwd.hip); host side: pnr_f32.hip (pnr_*_split_train).
 #include <hip/hip_runtime.h>
 
@@ -122,13 +121,7 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
             dv_hi = *reinterpret_cast<const u32x4 *>(dj->src_hi + body * ROW_ACT);
             dv_lo = *reinterpret_cast<const u32x4 *>(dj->src_lo + body * ROW_ACT);
         }
-#ifdef PNR_EXP_FAKE_W  // experiment: every refill reads the same 16 KiB window (L1-resident: the instruction stream without the L2 -> CU traffic); wrong results
-        const size_t pf = (size_t)(R.pf_rs & 0) * (IT * 1024);
-#elif defined(PNR_EXP_WRAP_W)  // experiment: the stream wraps inside its first PNR_EXP_WRAP_W ring steps (L2-resident); wrong results
-        const size_t pf = (size_t)(R.pf_rs % PNR_EXP_WRAP_W) * (IT * 1024);
-#else
         const size_t pf = (size_t)R.pf_rs * (IT * 1024);
-#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cur = j & 1;
@@ -141,20 +134,6 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
 #pragma unroll
             for (int it = 0; it < IT; ++it) { ah[it] = R.h[j][it]; al[it] = R.l[j][it]; }
             // the three products of one accumulator are spread over the step so that consecutive MFMAs are independent
-#ifdef PNR_SPLIT_ORDER_JT_OUTER  // experiment: point tile outer, feature tile inner (consecutive MFMAs share the B fragment instead of the A fragment)
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int it = 0; it < IT; ++it) acc[it][jt] = mf(ah[it], bh[cur][jt], acc[it][jt]);
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int it = 0; it < IT; ++it) acc[it][jt] = mf(ah[it], bl[cur][jt], acc[it][jt]);
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int it = 0; it < IT; ++it) acc[it][jt] = mf(al[it], bh[cur][jt], acc[it][jt]);
-#else
 #pragma unroll
             for (int it = 0; it < IT; ++it)
 #pragma unroll
@@ -167,15 +146,11 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
             for (int it = 0; it < IT; ++it)
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(al[it], bh[cur][jt], acc[it][jt]);
-#endif
-#ifndef PNR_EXP_NO_WLOAD  // experiment: never refill the ring (no weight traffic at all); results are wrong
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
                 R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
             }
-#endif
-#ifndef PNR_SPLIT_NO_SGB
             // Issue order of one k-step, pinned (round 3): hipcc batches the 16 refills of a loop body behind its last MFMA and
             // clusters the LDS reads; here every LDS read of the next step's B fragments follows ONE MFMA and every weight
             // refill follows TWO -- (M L) x 2JT, (M M G) x 2IT.  Same-box A/B on sn64 / srn_car / DTU: +2.7 ... +6 % in four
@@ -192,7 +167,6 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
             }
             if constexpr (3 * IT * JT - 2 * JT - 4 * IT > 0) __builtin_amdgcn_sched_group_barrier(0x008, 3 * IT * JT - 2 * JT - 4 * IT, 0);
-#endif
         }
         bhi0 += 128;
         ADV::step(R, NS);
@@ -216,28 +190,18 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo) {
     for (int k = 0; k < 4; ++k) {
         f32x2 p = {v[2 * k], v[2 * k + 1]};
         if (RELU) {
-#ifdef PNR_SPLIT_RELU_FMAX  // A/B: fmaxf lowers to TWO v_max_f32 per value under IEEE mode (canonicalise the input, then max with 0)
-            p[0] = fmaxf(p[0], 0.f); p[1] = fmaxf(p[1], 0.f);
-#else
             // one v_med3_f32 per value: median(v, 0, FLT_MAX) = max(v, 0) for every finite v (the head saturates at 65504 anyway;
             // with +inf as the upper bound LLVM folds the median back into the two-instruction maxnum).  NOT an inline-asm
             // v_max_f32: the accumulators come straight out of the MFMA pipe and hipcc does not place the MFMA -> VALU wait
             // states in front of inline asm -- that form read stale registers in the multi-view instantiations.
             p[0] = __builtin_amdgcn_fmed3f(p[0], 0.f, 3.402823466e38f); p[1] = __builtin_amdgcn_fmed3f(p[1], 0.f, 3.402823466e38f);
-#endif
         }
         const f16x2 h = __builtin_convertvector(p, f16x2);
         uh[k] = __builtin_bit_cast(uint32_t, h);
-#ifdef PNR_SPLIT_NO_MIX
-        const f32x2 back = __builtin_convertvector(h, f32x2);
-        const f16x2 l = __builtin_convertvector(p - back, f16x2);
-        ul[k] = __builtin_bit_cast(uint32_t, l);
-#else
         uint32_t l;
         asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(uh[k]), "v"(p[0]));
         asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(uh[k]), "v"(p[1]));
         ul[k] = l;
-#endif
     }
     hi = __builtin_bit_cast(h8, uh);
     lo = __builtin_bit_cast(h8, ul);
@@ -327,11 +291,7 @@ __device__ __forceinline__ void add_from_table(f32x16 (&x)[IT][JT], const char *
 // of weights the same view streams.  (Round 2 ran multi-view scenes on 32-point tiles with the sum in registers: twice the
 // weight stream per point, 105-147 k rays/s; -DPNR_SPLIT_MV32 rebuilds that form.)  Fixed summation order
 // (view 0 + view 1) + ...: bit-identical to the in-register form.
-#ifdef PNR_SPLIT_MV32
-constexpr int SPLIT_MV_TILE = 32;
-#else
 constexpr int SPLIT_MV_TILE = 64;
-#endif
 template <bool RAYS, bool MV, bool TIMING = false, bool TRAIN = false>
 __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const EvalParams q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -349,12 +309,10 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
     const float *bias_lane = q.bias + wv * BIAS_FLOATS_PER_WAVE + h * 16;
 
     f16_ovfl_mode<PH>();
-#ifndef PNR_SPLIT_NO_PRIO
     // static priority for the second-dispatched half of the workgroup (the arbitration loser of every segment when both waves of
     // a SIMD run at priority 0; MI355X_MICROARCH.md, "two waves per SIMD", item 4): one s_setprio before the main loop, no flips.
     // Same-box A/B: +0.9 % on sn64 / srn_car / DTU (profiles/r03_split_kernel_ab.txt).  Does not touch results.
     if (wv >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     SplitRing R;
     R.base_h = q.wstream + (size_t)wv * (RS_TOTAL_F * IT * 1024) + lane * 16;
     R.base_l = R.base_h + PACKED_BYTES;  // the tail blob follows the head blob (pnr_pack_mlp_split)
@@ -394,9 +352,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
     [[maybe_unused]] size_t tr_mask_view = 0, tr_mask_pooled = 0;
     [[maybe_unused]] const size_t tr_mask_layer = (size_t)NS * (size_t)q.ntiles * NTHREADS;
     [[maybe_unused]] auto put_mask = [&](const f32x16 (&a)[IT][JT], int layer, size_t word) {
-#ifdef PNR_EXP_TRAIN_NOMASK  // experiment (TIMING ONLY, wrong gradients): no relu masks
-        return;
-#endif
         unsigned long long m = 0ull;
 #pragma unroll
         for (int it = 0; it < IT; ++it)
@@ -409,11 +364,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             }
         (q.d_mask + (size_t)layer * tr_mask_layer)[word] = m;
     };
-#ifdef PNR_SPLIT_DUMP_IN_GEMM
-    constexpr bool DUMP_IN_GEMM = TRAIN;
-#else
     constexpr bool DUMP_IN_GEMM = false;
-#endif
     [[maybe_unused]] auto dump_job = [&](char *head, int b) {
         const long long rows = b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled;
         const size_t total = (size_t)(b < COMBINE_LAYER ? (long long)NS * q.P : q.P) * (D_HID * 2);
@@ -428,9 +379,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
     };
     // TRAIN: the operand images just published (head, tail) -> their 16-bit row sets, whole 1 KiB rows per wave instruction
     [[maybe_unused]] auto dump_pair = [&](char *head, int b) {
-#ifdef PNR_EXP_TRAIN_NODUMP  // experiment (TIMING ONLY, wrong gradients): no operand image copies
-        return;
-#endif
         const long long rows = b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled;
         const size_t total = (size_t)(b < COMBINE_LAYER ? (long long)NS * q.P : q.P) * (D_HID * 2);
         dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), tr_rows_left, wv, lane);
@@ -472,12 +420,10 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         gemm_split(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);        // fc_1
         PNR_T(PH_GEMM_FC1_Z);
         if (lookup) {
-#ifndef PNR_EXP_NO_LOOKUP12  // experiment: upper bound of hiding the block-1/2 lookups entirely (wrong results)
             __syncthreads();
             gather_table_f32<2, ST>(q, smem, wv, lane, b + 1);
             __syncthreads();
             add_from_table<ST>(x, smem, pl, h, wv);
-#endif
             PNR_T(PH_TABLE);
         }
     };
@@ -596,328 +542,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const f32x4 *>(smem + ST::LDS_OUT + (w * MT + tid) * 16);
             // models.py:260-265: rgb = sigmoid(out[:3]), sigma = relu(out[3])
-            f32x4 res = {1.f / (1.f + expf(-s[0])), 1.f / (1.f + expf(-s[1])), 1.f / (1.f + expf(-s[2])), fmaxf(s[3], 0.f)};
-            if (g < q.P) *reinterpret_cast<f32x4 *>(q.out + g * 4) = res;
-        }
-        PNR_T(PH_FINAL);
-    }
-}
-
-// ---------------------------------------------------------------- 96-point tile (single view), round 3 -- EXPERIMENT, not selected
-// RESULT: correct (bit-identical to the 64-point form) and 15 % SLOWER.  x + net + the ring are 224 of 256 registers, the split
-// epilogue's temporaries push hipcc over the edge (151 spilled registers, all outside the GEMM loops but inside every staging
-// phase: fc_1 takes 90 k cycles per 96-point GEMM against 36.9 k of MFMA issue), and even spill-free the two half-workgroup
-// write phases + two extra barriers per GEMM leave ~7 %.  Kept as the measured negative result behind DESIGN.md 4.4's claim
-// that the next step needs assembly-level register control; forced only by pnr_debug_set_split_tile(96).
-// The weight stream is what this kernel pays for (+34 % rays/s without it, profiles/r03_split_kernel_ab.txt), and bytes per
-// MFMA only fall with more points per weight fragment.  64 points was the LDS limit of the two full operand images (head +
-// tail, 2 x 66.5 KB); here the images hold ONE K-HALF at a time (256 of the 512 operand features: 2 x 49.5 KB for 96 points):
-//     waves 0-3 own features 0..255  -> they split their accumulators into the images, barrier, every wave multiplies k-steps
-//     0..15; barrier; waves 4-7 (features 256..511) write theirs over the same space, barrier, k-steps 16..31.
-// Two extra barriers per GEMM; the split epilogue is VALU-bound per SIMD, so writing in two half-workgroup phases costs what
-// the one full-workgroup phase did.  Registers as the f16 kernel's 96-point tile: x + net = 192 accumulators, a 2-step
-// head/tail ring (32), single-buffered B fragments (24).  The fp32 table rows (2 KiB per point) go through the image space in two
-// passes of 48 points.  A weight fragment feeds 3 point tiles x 3 products = 9 MFMAs (6 at 64 points): a third less L2 -> CU
-// stream per point.  Same k order and product order per accumulator as the 64-point kernel: bit-identical results.
-struct Split96 {
-    static constexpr int MT = 96, JT = 3;
-    static constexpr int ROW_H = (D_HID / 2) * 2 + 16;      // 528 B: one K-half of a point's heads (or tails), 33 16-byte slots
-    static constexpr int A_HI = 0;
-    static constexpr int A_LO = MT * ROW_H;                 // 50,688
-    static constexpr int IMG_END = 2 * MT * ROW_H;          // 101,376
-    static constexpr int LDS_IN = IMG_END;                  // lin_in operand, head image
-    static constexpr int IN_LO_DELTA = MT * ROW_IN;         // 13,824
-    static constexpr int LDS_META = LDS_IN + 2 * MT * ROW_IN;
-    static constexpr int LDS_OUT = LDS_META + MT * 32;
-    static constexpr int LDS_TOTAL = LDS_OUT + NW * MT * 16;  // 144,384 B
-    static constexpr int ROW_TAB = D_HID * 4 + 16;          // fp32 table row
-    static constexpr int TAB_PTS = 48;                      // points per lookup pass
-    static constexpr int LDS_Z = 0;
-    static_assert(TAB_PTS * ROW_TAB <= IMG_END, "a lookup pass must fit in the image space");
-    static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
-};
-
-struct SplitRing2 {
-    h8 h[2][IT], l[2][IT];
-    const char *base_h, *base_l;
-    int pf_rs;  // ring step the next refill fetches (single view: the stream is walked once per tile, wrapping at RS_TOTAL_F)
-};
-
-// one K-half (16 k-steps) of acc += W X on the staged images; B fragments single-buffered (the partner wave covers the LDS latency)
-__device__ __forceinline__ void gemm_half96(f32x16 (&acc)[IT][3], const char *smem, uint32_t b0, SplitRing2 &R) {
-#pragma unroll 1
-    for (int body = 0; body < 8; ++body) {
-        const size_t pf = (size_t)R.pf_rs * (IT * 1024);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            h8 bh[3], bl[3];
-#pragma unroll
-            for (int jt = 0; jt < 3; ++jt) {
-                bh[jt] = lds8<PH>(smem, b0 + jt * (32 * Split96::ROW_H) + j * 32);
-                bl[jt] = lds8<PH>(smem, b0 + jt * (32 * Split96::ROW_H) + Split96::A_LO + j * 32);
-            }
-            h8 ah[IT], al[IT];
-#pragma unroll
-            for (int it = 0; it < IT; ++it) { ah[it] = R.h[j][it]; al[it] = R.l[j][it]; }
-#pragma unroll
-            for (int it = 0; it < IT; ++it)
-#pragma unroll
-                for (int jt = 0; jt < 3; ++jt) acc[it][jt] = mf(ah[it], bh[jt], acc[it][jt]);
-#pragma unroll
-            for (int it = 0; it < IT; ++it)
-#pragma unroll
-                for (int jt = 0; jt < 3; ++jt) acc[it][jt] = mf(ah[it], bl[jt], acc[it][jt]);
-#pragma unroll
-            for (int it = 0; it < IT; ++it)
-#pragma unroll
-                for (int jt = 0; jt < 3; ++jt) acc[it][jt] = mf(al[it], bh[jt], acc[it][jt]);
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
-                R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
-            }
-        }
-        b0 += 64;
-        R.pf_rs = R.pf_rs + 2 == RS_TOTAL_F ? 0 : R.pf_rs + 2;
-    }
-}
-
-// relu(acc) of THIS wave's 64 features -> its K-half images (storage order inside the half)
-__device__ __forceinline__ void write_half96(const f32x16 (&acc)[IT][3], char *smem, uint32_t waddr) {
-#pragma unroll
-    for (int it = 0; it < IT; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 3; ++jt) {
-            const f32x16 &a = acc[it][jt];
-            const uint32_t ad = waddr + jt * 32 * Split96::ROW_H + it * 64;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = a[8 * half + e];
-                h8 hi, lo;
-                split8<true>(v, hi, lo);
-                *reinterpret_cast<h8 *>(smem + Split96::A_HI + ad + 16 * half) = hi;
-                *reinterpret_cast<h8 *>(smem + Split96::A_LO + ad + 16 * half) = lo;
-            }
-        }
-}
-
-// acc (+)= W relu(src) over the full K = 512, the operand staged one K-half at a time (see the header comment)
-__device__ __forceinline__ void gemm_staged96(f32x16 (&acc)[IT][3], const f32x16 (&src)[IT][3], char *smem, int wv, uint32_t a_rd0,
-                                              uint32_t a_wr, SplitRing2 &R) {
-    __syncthreads();  // the image space is free (previous GEMM's reads / table rows consumed)
-    if (wv < NW / 2) write_half96(src, smem, a_wr);
-    __syncthreads();
-    gemm_half96(acc, smem, a_rd0, R);
-    __syncthreads();  // every wave is done reading K-half 0
-    if (wv >= NW / 2) write_half96(src, smem, a_wr);
-    __syncthreads();
-    gemm_half96(acc, smem, a_rd0, R);
-}
-
-// table b in two passes of 48 points: rows through the image space, every lane adds its own slots of its points
-template <int GB>
-__device__ __forceinline__ void lookup96(f32x16 (&x)[IT][3], const EvalParams &q, char *smem, int wv, int lane, int pl, int h, int b) {
-    const float *tab = reinterpret_cast<const float *>(q.tables) + (size_t)b * q.table_stride + lane * 4;
-    constexpr int PPW = Split96::TAB_PTS / NW;  // 6 points per wave and pass
-    static_assert(PPW % GB == 0, "lookup batch");
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        __syncthreads();  // the image space is free (GEMM reads / the previous pass's adds are done)
-#pragma unroll 1
-        for (int i = 0; i < PPW; i += GB) {
-            f32x4 v[GB][4][2];
-            f32x4 w[GB];
-#pragma unroll
-            for (int u = 0; u < GB; ++u) {
-                const int p = pass * Split96::TAB_PTS + wv * PPW + i + u;
-                const u32x4 off = *reinterpret_cast<const u32x4 *>(smem + Split96::LDS_META + p * 32);
-                w[u] = *reinterpret_cast<const f32x4 *>(smem + Split96::LDS_META + p * 32 + 16);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    v[u][c][0] = *reinterpret_cast<const f32x4 *>(tab + off[c]);
-                    v[u][c][1] = *reinterpret_cast<const f32x4 *>(tab + off[c] + D_HID / 2);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < GB; ++u) {
-                const int pr = wv * PPW + i + u;  // row inside the pass
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    f32x4 r = v[u][0][hh] * w[u][0];
-                    r += v[u][1][hh] * w[u][1];
-                    r += v[u][2][hh] * w[u][2];
-                    r += v[u][3][hh] * w[u][3];
-                    *reinterpret_cast<f32x4 *>(smem + pr * Split96::ROW_TAB + hh * (D_HID * 2) + lane * 16) = r;
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int jt = 0; jt < 3; ++jt) {
-            const int pr = jt * 32 + pl - pass * Split96::TAB_PTS;
-            if (pr >= 0 && pr < Split96::TAB_PTS) {
-#pragma unroll
-                for (int it = 0; it < IT; ++it) {
-                    const char *row = smem + pr * Split96::ROW_TAB + ((wv * IT + it) * 32 + h * 16) * 4;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const f32x4 t = *reinterpret_cast<const f32x4 *>(row + 16 * k);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) x[it][jt][4 * k + e] += t[e];
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <bool RAYS, bool TIMING = false>
-__global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split96_kernel(const EvalParams q) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef Split96 ST;
-    constexpr int JT = ST::JT, MT = ST::MT;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pl = lane & 31, h = lane >> 5;
-    const uint32_t a_rd0 = ST::A_HI + pl * ST::ROW_H + h * 16;
-    const uint32_t in_rd0 = ST::LDS_IN + pl * ROW_IN + h * 16;
-    const uint32_t a_wr = pl * ST::ROW_H + ((wv & 3) * IT) * 64 + h * 32;
-    const float *bias_lane = q.bias + wv * BIAS_FLOATS_PER_WAVE + h * 16;
-
-    f16_ovfl_mode<PH>();
-#ifndef PNR_SPLIT_NO_PRIO
-    if (wv >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
-    SplitRing2 R;
-    R.base_h = q.wstream + (size_t)wv * (RS_TOTAL_F * IT * 1024) + lane * 16;
-    R.base_l = R.base_h + PACKED_BYTES;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            R.h[j][it] = gload8<PH>(R.base_h + j * (IT * 1024) + it * 1024);
-            R.l[j][it] = gload8<PH>(R.base_l + j * (IT * 1024) + it * 1024);
-        }
-    R.pf_rs = 2;
-    [[maybe_unused]] unsigned long long *tim = q.tim;
-    [[maybe_unused]] unsigned long long tlast = TIMING ? __builtin_readcyclecounter() : 0ull;
-
-    for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
-        f32x16 x[IT][JT];
-        __syncthreads();  // previous tile: every reader of the images / IN / META / OUT is done
-        PNR_T(PH_SYNC_TOP);
-#pragma unroll 1
-        for (int wi = tid; wi < MT * 8; wi += NTHREADS) geometry_item<PH, RAYS, ST>(q, smem, tile, 0, wi % MT, (wi / MT + 1) & 7);
-        __syncthreads();
-        PNR_T(PH_GEOMETRY);
-        // lin_in (resnetfc.py:147): K = 64 from the IN images, 4 ring steps
-        add_bias<true>(x, bias_lane, B_IN_Z0);
-#pragma unroll 1
-        for (int body = 0; body < 2; ++body) {
-            const size_t pf = (size_t)R.pf_rs * (IT * 1024);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                h8 bh[JT], bl[JT];
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-                    bh[jt] = lds8<PH>(smem, in_rd0 + jt * (32 * ROW_IN) + (body * 2 + j) * 32);
-                    bl[jt] = lds8<PH>(smem, in_rd0 + jt * (32 * ROW_IN) + ST::IN_LO_DELTA + (body * 2 + j) * 32);
-                }
-#pragma unroll
-                for (int it = 0; it < IT; ++it)
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt) x[it][jt] = mf(R.h[j][it], bh[jt], x[it][jt]);
-#pragma unroll
-                for (int it = 0; it < IT; ++it)
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt) x[it][jt] = mf(R.h[j][it], bl[jt], x[it][jt]);
-#pragma unroll
-                for (int it = 0; it < IT; ++it)
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt) x[it][jt] = mf(R.l[j][it], bh[jt], x[it][jt]);
-#pragma unroll
-                for (int it = 0; it < IT; ++it) {
-                    R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
-                    R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
-                }
-            }
-            R.pf_rs = R.pf_rs + 2 == RS_TOTAL_F ? 0 : R.pf_rs + 2;
-        }
-        PNR_T(PH_GEMM_IN_Z0);
-        lookup96<2>(x, q, smem, wv, lane, pl, h, 0);  // lin_z[0] via table 0
-        PNR_T(PH_GATHER);
-#pragma unroll 1
-        for (int b = 0; b < N_BLOCKS; ++b) {
-            {
-                f32x16 net[IT][JT];
-                add_bias<true>(net, bias_lane, 1 + 2 * b);
-                gemm_staged96(net, x, smem, wv, a_rd0, a_wr, R);   // fc_0(relu(x))   resnetfc.py:55-57
-                PNR_T(PH_GEMM_FC0);
-                add_bias<false>(x, bias_lane, 2 + 2 * b);
-                gemm_staged96(x, net, smem, wv, a_rd0, a_wr, R);   // x += fc_1(relu(net))   :58-62
-            }
-            PNR_T(PH_GEMM_FC1_Z);
-            if (b + 1 < COMBINE_LAYER) {
-#ifndef PNR_EXP_NO_LOOKUP12
-                lookup96<2>(x, q, smem, wv, lane, pl, h, b + 1);   // lin_z[b+1] via table b+1
-#endif
-                PNR_T(PH_TABLE);
-            }
-        }
-        // lin_out(relu(x)): each wave contracts its own 64 features (its accumulators are the B operand); 2 real ring steps
-        // + 2 zero steps of the packed stream, which are skipped
-        {
-            f32x16 o[JT];
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[jt][r] = 0.f;
-#pragma unroll
-            for (int qk = 0; qk < 2 * IT; ++qk) {
-                const int xit = qk >> 1, rr = qk & 1;
-                const h8 ah = R.h[qk / IT][qk % IT], al = R.l[qk / IT][qk % IT];
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = x[xit][jt][8 * rr + e];
-                    h8 bh, bl;
-                    split8<true>(v, bh, bl);
-                    o[jt] = mf(ah, bh, o[jt]);
-                    o[jt] = mf(ah, bl, o[jt]);
-                    o[jt] = mf(al, bh, o[jt]);
-                }
-            }
-            // the ring held lin_out's steps s, s+1 (pf_rs = s+2); s+2, s+3 are padding: next come the stream's first steps
-            int nxt = R.pf_rs + 2 == RS_TOTAL_F ? 0 : R.pf_rs + 2;
-            const size_t pf = (size_t)nxt * (IT * 1024);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int it = 0; it < IT; ++it) {
-                    R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
-                    R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
-                }
-            R.pf_rs = nxt + 2 == RS_TOTAL_F ? 0 : nxt + 2;
-            if (h == 0) {
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-                    f32x4 t = {o[jt][0], o[jt][1], o[jt][2], o[jt][3]};
-                    *reinterpret_cast<f32x4 *>(smem + ST::LDS_OUT + (wv * MT + jt * 32 + pl) * 16) = t;
-                }
-            }
-        }
-        PNR_T(PH_LIN_OUT);
-        __syncthreads();
-        PNR_T(PH_BAR_OUT);
-        if (tid < MT) {
-            const long long g = (long long)tile * MT + tid;
-            f32x4 s = *reinterpret_cast<const f32x4 *>(q.bout);
-#pragma unroll
-            for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const f32x4 *>(smem + ST::LDS_OUT + (w * MT + tid) * 16);
             f32x4 res = {1.f / (1.f + expf(-s[0])), 1.f / (1.f + expf(-s[1])), 1.f / (1.f + expf(-s[2])), fmaxf(s[3], 0.f)};
             if (g < q.P) *reinterpret_cast<f32x4 *>(q.out + g * 4) = res;
         }
@@ -1057,18 +681,11 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
     long long rows_left = 0;
     // the gradient image just published (head, tail) -> its 16-bit row sets (operands of the weight-gradient GEMM), whole rows
     auto dump_pair = [&](char *head, long long rows, bool per_view) {
-#ifdef PNR_EXP_BWD_NODUMP  // experiment (TIMING ONLY, wrong gradients): no gradient image copies
-        return;
-#endif
         const size_t total = (size_t)(per_view ? (long long)NS * q.P : q.P) * (D_HID * 2);
         dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), rows_left, wv, lane);
         dump_image<MT>(smem, ST::A_LO, head + total + (size_t)rows * (D_HID * 2), rows_left, wv, lane);
     };
-#ifdef PNR_SPLIT_DUMP_IN_GEMM
-    constexpr bool DUMP_IN_GEMM = true;
-#else
     constexpr bool DUMP_IN_GEMM = false;
-#endif
     [[maybe_unused]] auto dump_job = [&](char *head, long long rows, bool per_view) {
         const size_t total = (size_t)(per_view ? (long long)NS * q.P : q.P) * (D_HID * 2);
         SplitDump dj;
@@ -1259,8 +876,6 @@ static int bwd_split_cus() {
     return n;
 }
 
-static int g_force_split_tile = 0;  // test hook (pnr_debug_set_split_tile): 0 = automatic, 64 / 96 = forced
-
 
 static int split_launch(const PnrScene *s, const void *packed, const void *tables, EvalParams &q, bool rays, hipStream_t st) {
     if (!s || !packed || !tables || !q.out) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: null argument");
@@ -1285,12 +900,10 @@ static int split_launch(const PnrScene *s, const void *packed, const void *table
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         ncu = prop.multiProcessorCount;
-    // tile: 64 points.  The 96-point K-half-staged form (eval_split96_kernel) is correct -- bit-identical, tested -- but
-    // MEASURED SLOWER (253 vs 298 k rays/s on one box, profiles/r03_split_kernel_ab.txt): it only runs when a test or an
-    // experiment forces it (pnr_debug_set_split_tile(96)).
-    const bool t96 = !mv && g_force_split_tile == 96 && !q.f_x5;
-    const int MT = t96 ? Split96::MT : (mv ? SplitTileT<SPLIT_MV_TILE>::MT : SplitTileT<64>::MT);
-    const int lds = t96 ? Split96::LDS_TOTAL : (mv ? SplitTileT<SPLIT_MV_TILE>::LDS_TOTAL : SplitTileT<64>::LDS_TOTAL);
+    // tile: 64 points (the two full operand images fill the LDS; the 96-point K-half-staged form of round 3 measured 15 % slower,
+    // profiles/r03_split_kernel_ab.txt, and was removed with the other experiment code in round 4)
+    const int MT = mv ? SplitTileT<SPLIT_MV_TILE>::MT : SplitTileT<64>::MT;
+    const int lds = mv ? SplitTileT<SPLIT_MV_TILE>::LDS_TOTAL : SplitTileT<64>::LDS_TOTAL;
     const long long nt = (q.P + MT - 1) / MT;
     q.ntiles = (int)nt;
     const int grid = (int)(nt < ncu ? nt : ncu);
@@ -1300,14 +913,13 @@ static int split_launch(const PnrScene *s, const void *packed, const void *table
     }
     auto k = mv ? (rays ? eval_split_kernel<true, true> : eval_split_kernel<false, true>)
                 : (rays ? eval_split_kernel<true, false> : eval_split_kernel<false, false>);
-    if (t96) k = rays ? eval_split96_kernel<true> : eval_split96_kernel<false>;
     if (q.f_x5) {  // training forward: the same kernel + fp32 rows of what the backward keeps
-        if (!rays || t96) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: the training instantiation takes ray samples on 64-point tiles");
+        if (!rays) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: the training instantiation takes ray samples on 64-point tiles");
         k = mv ? eval_split_kernel<true, true, false, true> : eval_split_kernel<true, false, false, true>;
     }
     if (q.tim) {  // diagnostic instantiation (pnr_debug_phase_timing_split): single view, rays
         if (mv || !rays) return pnr_fail(PNR_E_INVALID, "phase timing: single-view ray launches only");
-        k = t96 ? eval_split96_kernel<true, true> : eval_split_kernel<true, false, true>;
+        k = eval_split_kernel<true, false, true>;
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_split_kernel)");
@@ -1359,13 +971,6 @@ int mlp_backward_split_chain(const void *packed_bwd_split, const unsigned long l
 }
 
 }  // namespace pnr
-
-// test hook (not in the public header): force the single-view tile of the split-operand kernel (0 = automatic, 64, 96)
-extern "C" int pnr_debug_set_split_tile(int mt) {
-    if (mt != 0 && mt != 64 && mt != 96) return pnr_fail(PNR_E_INVALID, "pnr_debug_set_split_tile: 0, 64 or 96");
-    pnr::g_force_split_tile = mt;
-    return PNR_OK;
-}
 
 extern "C" size_t pnr_packed_mlp_split_bytes(void) { return 2 * pnr::PACKED_BYTES; }
 

@@ -3,10 +3,11 @@ torchvision is not available here, so the trunk is written out in plain torch wi
 torchvision's parameter names (`model.conv1`, `model.bn1`, `model.layerN.i.convK` ...), which
 keeps reference checkpoints loadable (src/model/encoder.py:13-178).
 
-forward() builds the (SB*NS, 512, Hl, Wl) feature pyramid exactly as the reference does
-(encoder.py:111-164); the per-sample bilinear lookup `index()` (encoder.py:80-109) is NOT
-called by the product path -- it is fused into the HIP network kernel, which reads the
-channel-last copy of `latent` made by `latent_nhwc()`."""
+forward() yields the (SB*NS, 512, Hl, Wl) feature grid of the reference (encoder.py:111-164): the trunk's stage outputs,
+each resampled to the first stage's resolution, concatenated along the channels.  The per-sample bilinear lookup `index()`
+(encoder.py:80-109) is NOT called by the product path -- it is fused into the HIP network kernel, which reads the
+channel-last copy of `latent` made by `latent_nhwc()`; called on its own it is a HIP operator too (`pnr_grid_index` +
+backward, csrc/pnr_encode.hip), like `PositionalEncoding`."""
 import warnings
 
 import torch
@@ -58,6 +59,25 @@ class _ResNet(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
 
+class _GridIndex(torch.autograd.Function):
+    """`latent` (NV,C,Hl,Wl) sampled at normalised `uv` (NV,N,2): pnr_grid_index on the channel-last copy of the grid, with
+    pnr_grid_index_backward behind it (gradients to the grid and to the coordinates, like F.grid_sample's)."""
+
+    @staticmethod
+    def forward(ctx, latent, uv, enc):
+        nhwc = enc.latent_nhwc() if latent is enc.latent else ops.nchw_to_nhwc(latent.detach().float())
+        uv = uv.contiguous()
+        ctx.save_for_backward(nhwc, uv)
+        return ops.grid_index(nhwc, uv)
+
+    @staticmethod
+    def backward(ctx, g):
+        nhwc, uv = ctx.saved_tensors
+        d_lat, d_uv = ops.grid_index_backward(nhwc, uv, g.contiguous().float(), want_latent=ctx.needs_input_grad[0],
+                                              want_uv=ctx.needs_input_grad[1])
+        return (None if d_lat is None else d_lat.permute(0, 3, 1, 2)), d_uv, None
+
+
 class SpatialEncoder(nn.Module):
     def __init__(self, backbone="resnet34", pretrained=True, num_layers=4, index_interp="bilinear",
                  index_padding="border", upsample_interp="bilinear", feature_scale=1.0, use_first_pool=True,
@@ -98,8 +118,26 @@ class SpatialEncoder(nn.Module):
     # (torch.cuda.CUDAGraph; the pixelnerf_amd kernels launch on the capturing stream like any other).  The graph's output
     # buffers are cloned, so every call still returns fresh tensors like the reference.  Any failure while capturing turns
     # the feature off for the module (plain eager launches).  SpatialEncoder.use_graph = False disables it.
+    # A captured graph holds raw pointers to the trunk's parameters and buffers: the cache is keyed by their addresses as well
+    # (a replaced storage -> a new capture), dropped by every `_apply` (.to() / .half() / .cpu()), and never copied or pickled
+    # (`__getstate__`, which copy.deepcopy and pickle both go through: a CUDAGraph is a process-local handle).
     use_graph = True
     MAX_GRAPHS = 4
+    _TRANSIENT = ("_graphs", "latents", "_nhwc")  # per-process caches: rebuilt on demand, never part of a copy / checkpoint
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._TRANSIENT:
+            state.pop(k, None)
+        state["_nhwc"] = None
+        return state
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_graphs", None)  # the captured launches point at the storages `fn` is about to replace
+        return super()._apply(fn, *args, **kwargs)
+
+    def _storage_fingerprint(self):
+        return tuple(t.data_ptr() for t in list(self.model.parameters()) + list(self.model.buffers()))
 
     def _graphable(self, x):
         return (self.use_graph and not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
@@ -108,11 +146,15 @@ class SpatialEncoder(nn.Module):
     def _forward_graph(self, x):
         if not hasattr(self, "_graphs"):
             self._graphs = {}
-        key = (tuple(x.shape), x.device.index)
+        key = (tuple(x.shape), x.device.index, self._storage_fingerprint())
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= self.MAX_GRAPHS:
-                return None
+                stale = [k for k in self._graphs if k[2] != key[2]]  # captures of storages that no longer exist
+                for k in stale:
+                    del self._graphs[k]
+                if len(self._graphs) >= self.MAX_GRAPHS:
+                    return None
             try:
                 static_in = x.clone()
                 side = torch.cuda.Stream(device=x.device)
@@ -142,58 +184,56 @@ class SpatialEncoder(nn.Module):
         return self.latent
 
     def forward(self, x):
-        """encoder.py:111-164."""
+        """images (NV,3,H,W) -> `latent` (NV, latent_size, Hl, Wl), also kept on the module (encoder.py:111-164)."""
         if self._graphable(x):
             out = self._forward_graph(x)
             if out is not None:
                 return out
         return self._forward_eager(x)
 
+    def _resize_input(self, x):
+        """optional input rescaling in front of the trunk (encoder.py:118-126): enlarging interpolates, shrinking averages"""
+        if self.feature_scale == 1.0:
+            return x
+        grow = self.feature_scale > 1.0
+        return F.interpolate(x, scale_factor=self.feature_scale, mode="bilinear" if grow else "area",
+                             align_corners=True if grow else None, recompute_scale_factor=True)
+
+    def _stages(self, x):
+        """the stem and the first num_layers - 1 residual stages of the trunk; every stage's output is one pyramid level"""
+        trunk = self.model
+        levels = [trunk.relu(trunk.bn1(trunk.conv1(x)))]
+        for depth, stage in enumerate((trunk.layer1, trunk.layer2, trunk.layer3, trunk.layer4)[: self.num_layers - 1]):
+            feed = trunk.maxpool(levels[-1]) if (depth == 0 and self.use_first_pool) else levels[-1]
+            levels.append(stage(feed))
+        return levels
+
     def _forward_eager(self, x, scaling=True):
-        if self.feature_scale != 1.0:
-            x = F.interpolate(x, scale_factor=self.feature_scale,
-                              mode="bilinear" if self.feature_scale > 1.0 else "area",
-                              align_corners=True if self.feature_scale > 1.0 else None,
-                              recompute_scale_factor=True)
-        x = x.to(device=self.latent.device)
-        x = self.model.relu(self.model.bn1(self.model.conv1(x)))
-        latents = [x]
-        if self.num_layers > 1:
-            if self.use_first_pool:
-                x = self.model.maxpool(x)
-            x = self.model.layer1(x)
-            latents.append(x)
-        if self.num_layers > 2:
-            x = self.model.layer2(x)
-            latents.append(x)
-        if self.num_layers > 3:
-            x = self.model.layer3(x)
-            latents.append(x)
-        if self.num_layers > 4:
-            x = self.model.layer4(x)
-            latents.append(x)
-        self.latents = latents
-        if (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and self.upsample_interp == "bilinear"
-                and all(t.shape[1] % 64 == 0 for t in latents)):
+        levels = self._stages(self._resize_input(x).to(device=self.latent.device))
+        self.latents = levels
+        fused_ok = (not torch.is_grad_enabled() and x.is_cuda and levels[0].dtype == torch.float32
+                    and self.upsample_interp == "bilinear" and all(t.shape[1] % 64 == 0 for t in levels))
+        if fused_ok:
             # inference: one HIP pass writes the NHWC grid the fused kernel reads AND the reference's NCHW tensor
-            nhwc, self.latent = ops.pyramid_to_latent(latents, want_nchw=True)
+            nhwc, self.latent = ops.pyramid_to_latent(levels, want_nchw=True)
             self._nhwc = ((self.latent.data_ptr(), self.latent._version, tuple(self.latent.shape)), nhwc)
-            if scaling:
-                self._set_scaling()
-            return self.latent
-        align_corners = None if self.index_interp == "nearest " else True
-        latent_sz = latents[0].shape[-2:]
-        for i in range(len(latents)):
-            latents[i] = F.interpolate(latents[i], latent_sz, mode=self.upsample_interp, align_corners=align_corners)
-        self.latent = torch.cat(latents, dim=1)
-        self._set_scaling()
+        else:
+            # training (autograd must see the resampling) or a non-default interpolation: torch's own resampling of every
+            # level to the first level's size.  The reference asks for align_corners=True whatever the mode (its test for
+            # "nearest" can never match, encoder.py:152), which only the interpolating modes accept -- same here.
+            size = levels[0].shape[-2:]
+            interpolating = self.upsample_interp in ("linear", "bilinear", "bicubic", "trilinear")
+            self.latent = torch.cat([F.interpolate(t, size, mode=self.upsample_interp, align_corners=True if interpolating else None)
+                                     for t in levels], dim=1)
+        if scaling or not fused_ok:
+            self._set_scaling()
         return self.latent
 
     def _set_scaling(self):
-        """encoder.py:161-163."""
-        self.latent_scaling[0] = self.latent.shape[-1]
-        self.latent_scaling[1] = self.latent.shape[-2]
-        self.latent_scaling = self.latent_scaling / (self.latent_scaling - 1) * 2.0
+        """pixel -> normalised-coordinate factors of the grid, (W, H) / (W - 1, H - 1) * 2 (encoder.py:161-163)"""
+        wh = torch.tensor([float(self.latent.shape[-1]), float(self.latent.shape[-2])], dtype=torch.float32,
+                          device=self.latent_scaling.device)
+        self.latent_scaling = wh / (wh - 1.0) * 2.0
 
     def latent_nhwc(self):
         """Channel-last copy of `latent` for the fused kernel (one bilinear corner = one
@@ -205,23 +245,27 @@ class SpatialEncoder(nn.Module):
         return self._nhwc[1]
 
     def index(self, uv, cam_z=None, image_size=(), z_bounds=None):
-        """encoder.py:80-109, for callers that use the encoder on its own (the renderer does
-        not: the lookup is fused into the network kernel)."""
-        with torch.profiler.record_function("encoder_index"):  # encoder.py:90
-            return self._index(uv, image_size)
-
-    def _index(self, uv, image_size):
-        if uv.shape[0] == 1 and self.latent.shape[0] > 1:
-            uv = uv.expand(self.latent.shape[0], -1, -1)
-        if len(image_size) > 0:
-            if len(image_size) == 1:
-                image_size = (image_size, image_size)
-            scale = self.latent_scaling / image_size
-            uv = uv * scale - 1.0
-        uv = uv.unsqueeze(2)
-        samples = F.grid_sample(self.latent, uv, align_corners=True, mode=self.index_interp,
-                                padding_mode=self.index_padding)
-        return samples[:, :, :, 0]
+        """Pixel-aligned features at image points (encoder.py:80-109), for callers that use the encoder on its own (the
+        renderer does not: the lookup is fused into the network kernel).
+        :param uv (NV|1, N, 2) image points (x, y); pixel units when `image_size` is given, else already in [-1, 1]
+        :param image_size () | (s,) | (w, h): the image extent the pixel coordinates refer to
+        :return (NV, latent_size, N)"""
+        with torch.profiler.record_function("encoder_index"):  # the reference's scope name (encoder.py:90)
+            lat = self.latent
+            if uv.shape[0] == 1 and lat.shape[0] > 1:
+                uv = uv.expand(lat.shape[0], -1, -1)
+            if len(image_size) > 0:
+                if torch.is_tensor(image_size):
+                    extent = image_size.to(device=uv.device, dtype=torch.float32).reshape(-1)
+                else:
+                    extent = torch.tensor([float(v) for v in image_size], dtype=torch.float32, device=uv.device)
+                if extent.numel() == 1:
+                    extent = extent.expand(2)
+                uv = uv * (self.latent_scaling / extent) - 1.0
+            if self.index_interp != "bilinear" or self.index_padding != "border":
+                raise NotImplementedError("SpatialEncoder.index: the HIP lookup implements what every shipped config uses "
+                                          "(index_interp='bilinear', index_padding='border')")
+            return _GridIndex.apply(lat, uv.float(), self)
 
     @classmethod
     def from_conf(cls, conf):

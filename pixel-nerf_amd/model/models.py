@@ -77,6 +77,14 @@ class PixelNeRFNet(torch.nn.Module):
         self._tables = {}
         self._grad_sync = None  # set for the duration of a call by dist.ShardedRenderWrapper (gradient all-reduce across ranks)
 
+    def __getstate__(self):
+        # copies / pickles (copy.deepcopy for EMA or replica nets, torch.save(net)) carry parameters, buffers and encode() state;
+        # the device-side scene descriptor (ctypes struct of raw pointers), the folded tables and a sharding wrapper's hook are
+        # per-process caches of THIS object and are rebuilt on demand
+        d = dict(self.__dict__)
+        d["_scene"], d["_tables"], d["_grad_sync"] = None, {}, None
+        return d
+
     # ------------------------------------------------------------------ encode (PyTorch-ROCm)
     @staticmethod
     def _per_view_pair(v, what):

@@ -600,6 +600,36 @@ def positional_encoding_backward(x, g_out, freqs2, phases2, include_input=True):
     return gx
 
 
+def grid_index(latent_nhwc, uv):
+    """SpatialEncoder.index's lookup (src/model/encoder.py:100-109) through pnr_grid_index: latent_nhwc (NV,Hl,Wl,C) channel-last
+    grid, uv (NV,N,2) NORMALISED coordinates in [-1,1] -> (NV,C,N) as F.grid_sample(bilinear, border, align_corners=True)."""
+    lib = _lib.load()
+    latent_nhwc = _f32(latent_nhwc, "latent_nhwc", (None, None, None, None))
+    NV, Hl, Wl, C = latent_nhwc.shape
+    uv = _f32(uv, "uv", (NV, None, 2))
+    N = uv.shape[1]
+    out = torch.empty((NV, C, N), dtype=torch.float32, device=uv.device)
+    with torch.cuda.device(uv.device):
+        _lib.check(lib.pnr_grid_index(_p(latent_nhwc), NV, Hl, Wl, C, _p(uv), N, _p(out), _stream()), "pnr_grid_index")
+    return out
+
+
+def grid_index_backward(latent_nhwc, uv, g_out, want_latent=True, want_uv=True):
+    """-> (d_latent_nhwc (NV,Hl,Wl,C) | None, d_uv (NV,N,2) | None) of grid_index (pnr_grid_index_backward)."""
+    lib = _lib.load()
+    latent_nhwc = _f32(latent_nhwc, "latent_nhwc", (None, None, None, None))
+    NV, Hl, Wl, C = latent_nhwc.shape
+    uv = _f32(uv, "uv", (NV, None, 2))
+    N = uv.shape[1]
+    g_out = _f32(g_out, "g_out", (NV, C, N))
+    d_lat = torch.zeros_like(latent_nhwc) if want_latent else None
+    d_uv = torch.empty_like(uv) if want_uv else None
+    with torch.cuda.device(uv.device):
+        _lib.check(lib.pnr_grid_index_backward(_p(latent_nhwc), NV, Hl, Wl, C, _p(uv), N, _p(g_out), _p(d_lat), _p(d_uv), _stream()),
+                   "pnr_grid_index_backward")
+    return d_lat, d_uv
+
+
 def pyramid_to_latent(stages, want_nchw=True):
     """Encoder output formatting (src/model/encoder.py:150-163): stages = list of (NV,C_s,H_s,W_s) float32
     HIP tensors (ResNet stage outputs).  -> (latent_nhwc (NV,H0,W0,sum C), latent_nchw (NV,sum C,H0,W0) | None):

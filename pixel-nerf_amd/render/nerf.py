@@ -315,26 +315,16 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
         fp = self._weights_key()
         hit = self._replicas.get(i)
         if hit is None:
-            # not parameters: do not drag the grid, the device-side scene descriptor (ctypes) or the packed streams through
-            # deepcopy -- the replica rebuilds its own lazily
+            # the copy carries parameters and buffers only: PixelNeRFNet / ResnetFC / SpatialEncoder drop their per-process caches
+            # (scene descriptor, folded tables, packed streams, encoder HIP graphs) in __getstate__; the feature grid is not
+            # dragged through the copy either -- the replica gets this call's grid below
             src = self.net
-            keep = (src.encoder.latent, src._scene, src._tables, getattr(src.encoder, "_nhwc", None), src._grad_sync)
-            packs = [(m, m._packed, {k: m.__dict__.pop(k) for k in m._CACHE_KEYS if k in m.__dict__})
-                     for m in (src.mlp_coarse, src.mlp_fine) if m is not None]
-            src.encoder.latent, src._scene, src._tables, src._grad_sync = torch.empty(0), None, {}, None
-            if hasattr(src.encoder, "_nhwc"):
-                src.encoder._nhwc = None
-            for m, _, _ in packs:
-                m._packed = {}
+            grid, nhwc = src.encoder.latent, getattr(src.encoder, "_nhwc", None)
+            src.encoder.latent = torch.empty(0)
             try:
                 rep = copy.deepcopy(src).to(self.devices[i])
             finally:
-                src.encoder.latent, src._scene, src._tables, src._grad_sync = keep[0], keep[1], keep[2], keep[4]
-                if hasattr(src.encoder, "_nhwc"):
-                    src.encoder._nhwc = keep[3]
-                for m, pk, caches in packs:
-                    m._packed = pk
-                    m.__dict__.update(caches)
+                src.encoder.latent, src.encoder._nhwc = grid, nhwc
             for p in rep.parameters():
                 p.requires_grad_(False)  # gradients go to the SOURCE parameters (see forward)
             hit = [fp, rep, copy.deepcopy(self.renderer).to(self.devices[i])]

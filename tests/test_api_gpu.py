@@ -173,6 +173,59 @@ def test_encode_then_render_and_cache_invalidation(dev):
         assert rgb.shape == (1, 128, 3) and depth.shape == (1, 128)
 
 
+def test_encoder_graph_cache_survives_copies_and_storage_changes(dev):
+    """The reference eval flow -- render_par.eval(), net.encode() under no_grad, render_par(rays) with --gpu_id "0 1" -- captures
+    the encoder's HIP graph BEFORE the first replica is built: the module must still deep-copy / pickle (the graph cache is a
+    per-process cache, not state), and a capture must never be replayed against parameter storages that were replaced."""
+    import copy
+    import io
+    from testdata import synthetic
+    from pixelnerf_amd.model import make_model
+    from pixelnerf_amd.model.encoder import SpatialEncoder
+    from pixelnerf_amd.render import NeRFRenderer
+    from pixelnerf_amd.util.conf import Conf, default_model_conf
+    torch.manual_seed(0)
+    conf = default_model_conf()
+    conf["encoder"] = Conf(backbone="resnet34", pretrained=False, num_layers=4, use_first_pool=False)
+    net = make_model(conf).to(dev).eval()
+    for m in (net.mlp_coarse, net.mlp_fine):
+        m.load_state_dict(mlp_params(11))
+    scene, meta = scene_for("sn64")
+    rays = synthetic.target_rays(meta, n_rays=64).to(dev)
+    src = meta["src_c2w"].to(dev)
+    img = (torch.rand(1, 3, 64, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 2 - 1)
+    assert SpatialEncoder.use_graph
+    with torch.no_grad():
+        net.encode(img, src, torch.tensor(119.4256, device=dev))
+        assert len(getattr(net.encoder, "_graphs", {})) == 1, "the encoder graph was not captured"
+        clone = copy.deepcopy(net)  # EMA copies, user deepcopy
+        assert not hasattr(clone.encoder, "_graphs")
+        torch.save(net, io.BytesIO())
+        rend = NeRFRenderer(n_coarse=16, n_fine=8, n_fine_depth=4, white_bkgd=True).to(dev).eval()
+        par = rend.bind_parallel(net, [0, 0], simple_output=True).eval()  # builds replicas by deepcopy
+        torch.manual_seed(5)
+        rgb, _ = par(rays)
+        torch.manual_seed(5)
+        ref, _ = rend.bind_parallel(net, None, simple_output=True).eval()(rays)
+        assert torch.equal(rgb, ref)
+        again = copy.deepcopy(net)  # after a render: scene descriptor (ctypes), folded tables and packed streams exist by now
+        assert again._scene is None and again._tables == {} and again.mlp_coarse._packed == {}
+        torch.save(net, io.BytesIO())
+        # replaced parameter storage: the old capture points at freed memory -- a fresh capture (or eager) must be used
+        lat1 = net.encoder(img).clone()
+        w = net.encoder.model.conv1.weight
+        w.data = w.data * 1.5  # new storage, new values
+        lat2 = net.encoder(img).clone()
+        SpatialEncoder.use_graph = False
+        try:
+            lat3 = net.encoder(img).clone()
+        finally:
+            SpatialEncoder.use_graph = True
+        assert not torch.allclose(lat1, lat2) and torch.allclose(lat2, lat3, rtol=1e-4, atol=1e-5)
+        net.half().float()  # every _apply drops the captures
+        assert not hasattr(net.encoder, "_graphs") or len(net.encoder._graphs) == 0
+
+
 @pytest.mark.parametrize("name", ["dtu_mini_64_128", "mv_mini_lindisp", "sn64_coarse_only_mlp"])
 def test_renderer_api_exact_fp32_mode(dev, name):
     """make_model(conf, precision="f32"): the unfused exact path behind the same API; agrees with the

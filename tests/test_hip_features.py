@@ -131,3 +131,58 @@ def test_spatial_encoder_index_matches_reference(ops, dev, name):
         got = zlat[0, 0].cpu().t()  # (512, 64)
         # reconstructing uv from (x, y) costs ~1e-5 px; the grid is O(1) per texel step
         assert (got - ref[v]).abs().max() <= 1e-4, float((got - ref[v]).abs().max())
+
+
+def _encoder_with_grid(dev, s):
+    import warnings
+    from pixelnerf_amd.model.encoder import SpatialEncoder
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc = SpatialEncoder("resnet34", pretrained=False, use_first_pool=False).to(dev).eval()
+    lat = s["latent"].to(dev)
+    enc.latent = lat
+    wh = torch.tensor([float(lat.shape[-1]), float(lat.shape[-2])], device=dev)
+    enc.latent_scaling = wh / (wh - 1) * 2.0
+    return enc
+
+
+@pytest.mark.parametrize("name", ["sn64", "dtu_mini", "mv_mini"])
+def test_spatial_encoder_index_operator_matches_reference(dev, name):
+    """SpatialEncoder.index called on its own (src/model/encoder.py:80-109) is the HIP operator pnr_grid_index: against the
+    outputs of the reference's own `index` on the same grid and pixel coordinates (goldens), incl. points outside the image."""
+    g = load_golden("stages")
+    s, meta = scene_for(name)
+    enc = _encoder_with_grid(dev, s)
+    uv = torch.from_numpy(g[name + "_uv"]).to(dev)
+    ref = torch.from_numpy(g[name + "_index"])
+    with torch.no_grad():
+        got = enc.index(uv, None, s["image_shape"].to(dev))
+    assert got.shape == ref.shape
+    assert (got.cpu() - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max())), float((got.cpu() - ref).abs().max())
+    # one uv set for all views (encoder.py:91-92) and already-normalised coordinates (no image_size)
+    with torch.no_grad():
+        one = enc.index(uv[:1], None, s["image_shape"].to(dev))
+        nrm = enc.index(uv * (enc.latent_scaling / s["image_shape"].to(dev)) - 1.0)
+    assert torch.equal(one[0], got[0]) and torch.equal(nrm, got)
+
+
+def test_spatial_encoder_index_operator_gradients(dev):
+    """gradients of the stand-alone lookup to the grid and to the coordinates against torch autograd through F.grid_sample
+    (what the reference's index() differentiates through), interior and clamped points"""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(2)
+    lat = torch.randn(2, 128, 9, 13, generator=gen)
+    uv = torch.rand(2, 200, 2, generator=gen) * 2.6 - 1.3  # a fifth of the points beyond the border
+    gw = torch.randn(2, 128, 200, generator=gen)
+    a, b = lat.clone().requires_grad_(True), uv.clone().requires_grad_(True)
+    ref = F.grid_sample(a, b.unsqueeze(2), align_corners=True, mode="bilinear", padding_mode="border")[..., 0]
+    (ref * gw).sum().backward()
+    s = {"latent": lat}
+    enc = _encoder_with_grid(dev, s)
+    la, ub = lat.to(dev).requires_grad_(True), uv.to(dev).requires_grad_(True)
+    enc.latent = la
+    got = enc.index(ub)
+    (got * gw.to(dev)).sum().backward()
+    assert (got.detach().cpu() - ref.detach()).abs().max() <= 2e-6 * float(ref.abs().max())
+    assert (la.grad.cpu() - a.grad).abs().max() <= 1e-5 * max(1.0, float(a.grad.abs().max()))
+    assert (ub.grad.cpu() - b.grad).abs().max() <= 2e-5 * max(1.0, float(b.grad.abs().max()))

@@ -162,26 +162,3 @@ def test_split_operands_saturate_instead_of_overflowing(ops, dev):
     vd = torch.from_numpy(g["sn64_viewdirs"]).to(dev)
     out = ops.eval_points(sc, ops.pack_mlp(state, "f16x3"), xyz, vd, tables=ops.fold_latent(sc, state, "f16x3"))
     assert torch.isfinite(out).all()
-
-
-@pytest.mark.parametrize("R,K", [(1024, 192), (301, 64), (96, 7)])
-def test_split_tile96_is_bit_identical_to_tile64(ops, dev, R, K):
-    """the 96-point K-half-staged form of the fp32-class kernel (single view) walks the same k order with the same three
-    products per accumulator as the 64-point form: identical bits per point, whatever the tile (incl. ragged last tiles)"""
-    from pixelnerf_amd import _lib
-    lib = _lib.load()
-    s, meta = scene_for("sn64")
-    sc = dscene(ops, dev, "sn64")
-    pk, tab = split_net(ops, dev, sc, 11)
-    from testdata import synthetic
-    rays = synthetic.target_rays(meta).reshape(-1, 8)[:R].contiguous().to(dev)
-    z = torch.sort(ops.sample_coarse(rays, torch.rand(R, K, device=dev)), dim=-1)[0]
-    outs = {}
-    try:
-        for mt in (64, 96):
-            assert lib.pnr_debug_set_split_tile(mt) == 0
-            outs[mt] = ops.eval_ray_samples(sc, pk, rays, z, tables=tab).clone()
-    finally:
-        lib.pnr_debug_set_split_tile(0)
-    assert torch.isfinite(outs[96]).all()
-    assert torch.equal(outs[64], outs[96])

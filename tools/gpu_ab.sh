@@ -3,6 +3,7 @@
 # kernel-level quick bench (f16 folded, sn64) and the per-phase timing; results -> gpurun_out/ab_<name>.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
+export PIXELNERF_ALLOW_VARIANT=1  # the variants report a negative ABI revision (tools/build_variant.sh)
 shopt -s nullglob
 for lib in default build/libpnr_*.so; do
     name=$(basename "$lib" .so); name=${name#libpnr_}

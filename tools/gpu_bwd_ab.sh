@@ -2,6 +2,7 @@
 # A/B of library variants on the training-backward kernels (tools/gpu_bwd_kernels_bench.py) -> gpurun_out/bwd_ab.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
+export PIXELNERF_ALLOW_VARIANT=1  # the variants report a negative ABI revision (tools/build_variant.sh)
 : > gpurun_out/bwd_ab.txt
 shopt -s nullglob
 for lib in default build/libpnr_*.so; do

@@ -2,6 +2,7 @@
 # Generic A/B: run "$@" once with the default library and once per build/libpnr_*.so -> gpurun_out/lib_ab.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
+export PIXELNERF_ALLOW_VARIANT=1  # the variants report a negative ABI revision (tools/build_variant.sh)
 : > gpurun_out/lib_ab.txt
 shopt -s nullglob
 for lib in default build/libpnr_*.so; do

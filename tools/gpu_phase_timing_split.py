@@ -7,9 +7,7 @@ from pixelnerf_amd import ops
 from testdata import synthetic
 
 dev = torch.device("cuda:0")
-MT = int(os.environ.get("PNR_SPLIT_TILE", "64"))
-from pixelnerf_amd import _lib
-_lib.load().pnr_debug_set_split_tile(MT)
+MT = 64
 scene, meta = synthetic.make_scene("sn64")
 sc = ops.make_scene(scene["latent"].to(dev), scene["poses"].to(dev), scene["focal"].to(dev), scene["c"].to(dev), scene["image_shape"], 1)
 R, K = 16384, 192

@@ -3,6 +3,7 @@
 # the f16x3 quick bench (sn64 + multi-view shapes) and, unless the name ends in "nt", the per-phase timing.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
+export PIXELNERF_ALLOW_VARIANT=1  # the variants report a negative ABI revision (tools/build_variant.sh)
 shopt -s nullglob
 for lib in default build/libpnr_s_*.so; do
     name=$(basename "$lib" .so); name=${name#libpnr_}

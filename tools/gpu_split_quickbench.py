@@ -7,9 +7,6 @@ from pixelnerf_amd import ops  # noqa: E402
 from testdata import synthetic  # noqa: E402
 
 dev = torch.device("cuda:0")
-if os.environ.get("PNR_SPLIT_TILE"):
-    from pixelnerf_amd import _lib
-    _lib.load().pnr_debug_set_split_tile(int(os.environ["PNR_SPLIT_TILE"]))
 cases = [("sn64", 16384, 192), ("srn_car", 8192, 192), ("dtu", 8192, 192)]
 if "--mv" in sys.argv:
     cases = cases[1:]

@@ -2,6 +2,7 @@
 # A/B of library variants on the config-5 training step (tools/gpu_train_bench.py --quick) -> gpurun_out/train_ab.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
+export PIXELNERF_ALLOW_VARIANT=1  # the variants report a negative ABI revision (tools/build_variant.sh)
 : > gpurun_out/train_ab.txt
 shopt -s nullglob
 for lib in default build/libpnr_*.so default; do
