@@ -45,14 +45,26 @@ FUSED_SPLIT_TRAINING = True
 
 def _sigma_noise(rgbs, cfg):
     """nerf.py:225-226 (training only, noise_std > 0): sigmas = sigmas + randn_like(sigmas) * noise_std, drawn from torch's
-    generator after each network pass like the reference.  -> (rgb | noisy sigma, mask of points whose own sigma was positive
-    -- the relu' the compositing backward can no longer read off the noisy value) or (rgbs, None)"""
+    generator after each network pass like the reference.  Under a sharding wrapper (cfg["ray_id_stride"] = rays per object of
+    the WHOLE batch, cfg["ray_id_offset"] = this shard's first ray) the draw is made for the whole batch and this shard's rows
+    are cut out of it: ranks / devices that share a seed then add to every ray exactly the noise a single process would have
+    added (identical draws for different rays on different ranks would correlate the shards).
+    -> (rgb | noisy sigma, mask of points whose own sigma was positive -- the relu' the compositing backward can no longer
+    read off the noisy value) or (rgbs, None)"""
     std = cfg.get("noise_std", 0.0)
     if not std > 0.0:
         return rgbs, None
     live = (rgbs[..., 3] > 0).float()
     noisy = rgbs.clone()
-    noisy[..., 3] += torch.randn(rgbs.shape[:-1], dtype=rgbs.dtype, device=rgbs.device) * std  # one (R,K) draw per pass, reference order
+    R, K = rgbs.shape[:2]
+    stride, lo = int(cfg.get("ray_id_stride", 0) or 0), int(cfg.get("ray_id_offset", 0) or 0)
+    SB = max(int(cfg.get("num_objs", 1) or 1), 1)
+    if stride > 0 and R % SB == 0 and lo + R // SB <= stride and R // SB != stride:
+        b = R // SB
+        n = torch.randn((SB, stride, K), dtype=rgbs.dtype, device=rgbs.device)[:, lo:lo + b].reshape(R, K)
+    else:
+        n = torch.randn((R, K), dtype=rgbs.dtype, device=rgbs.device)  # one (R,K) draw per pass, reference order
+    noisy[..., 3] += n * std
     return noisy, live
 
 
@@ -343,7 +355,9 @@ def render_autograd(renderer, net, rays, noise, want_weights):
     cfg = dict(net=net, noise=noise, n_coarse=renderer.n_coarse, n_fine=Kf,
                n_fine_depth=min(renderer.n_fine_depth, Kf), depth_std=renderer.depth_std,
                noise_std=float(renderer.noise_std) if renderer.training else 0.0,
-               white_bkgd=bool(renderer.white_bkgd), lindisp=bool(renderer.lindisp))
+               white_bkgd=bool(renderer.white_bkgd), lindisp=bool(renderer.lindisp),
+               ray_id_offset=int(getattr(renderer, "ray_id_offset", 0)), ray_id_stride=int(getattr(renderer, "ray_id_stride", 0)),
+               num_objs=int(net.num_objs))
     latent = net.encoder.latent
     if net.stop_encoder_grad:
         latent = latent.detach()

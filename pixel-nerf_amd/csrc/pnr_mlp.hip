@@ -15,6 +15,7 @@
 // averaged before block 3 (util.combine_interleaved, util.py:461-471).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <vector>
 
 #include "pnr_common.h"
@@ -482,17 +483,25 @@ static inline bool use_tile96(const EvalParams &q, bool mv) {
 float *mv_scratch(hipStream_t st, size_t bytes) {
     struct Slot { int dev; hipStream_t st; float *p; size_t bytes; };
     static std::vector<Slot> slots;
+    static std::mutex mu;  // single-process multi-GPU training runs one autograd thread per device: the table is shared
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
+    // growing the table allocates: illegal inside a HIP-graph capture -- the first multi-view launch on a stream (or the first
+    // one that needs more) must happen outside of one (a warm-up call does it); inside a capture only an existing slot is handed out
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     for (auto &sl : slots)
         if (sl.dev == dev && sl.st == st) {
             if (sl.bytes >= bytes) return sl.p;
+            if (capturing) return nullptr;
             (void)hipFree(sl.p);
             sl.p = nullptr; sl.bytes = 0;
             if (hipMalloc(&sl.p, bytes) != hipSuccess) return nullptr;
             sl.bytes = bytes;
             return sl.p;
         }
+    if (capturing) return nullptr;
     Slot sl = {dev, st, nullptr, bytes};
     if (hipMalloc(&sl.p, bytes) != hipSuccess) return nullptr;
     slots.push_back(sl);
