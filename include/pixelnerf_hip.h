@@ -394,6 +394,25 @@ int pnr_render_views(const PnrScene *scene /*host*/, const void *packed_coarse, 
                      unsigned long long seed, float *rgb_c, float *depth_c, float *weights_c, float *rgb_f,
                      float *depth_f, float *weights_f, void *workspace, void *stream);
 
+/* ---- fp16-range guard of the fp32-class ("f16x3") kernels ---------------------------------------
+ * The split-operand kernels carry every operand as an fp16 (head, tail) pair: values up to 65504 are
+ * represented to ~2^-22, beyond that the head SATURATES (MODE.FP16_OVFL) and the result silently leaves
+ * the reference's arithmetic class (src/model/resnetfc.py:132-184 computes in fp32, whatever the
+ * magnitude).  Random-init networks stay four orders of magnitude below the limit; a checkpoint need not.
+ * pnr_saturation_guard(flags) arms the guard for the CALLING HOST THREAD: until it is called again with
+ * NULL, every launch of a split-operand network kernel on that thread runs the instantiation that
+ * follows the largest value entering each operand image (one v_max3_f32 per pair in the split epilogue,
+ * ~1 % of the kernel) and ORs into flags[0] (coarse-network launches and the direct pnr_eval_*_split
+ * entries) / flags[1] (fine-network launches of pnr_render_*):
+ *   bit 2b    a value >= 65504 in relu(x) entering blocks[b].fc_0        (b = 0..4)
+ *   bit 2b+1  a value >= 65504 in relu(net) entering blocks[b].fc_1
+ *   bit 10    a value >= 65504 in the stream in front of lin_out
+ *   bit 11    a non-finite network output
+ * flags: DEVICE array of two 32-bit words, zeroed by the caller, read back by the caller (asynchronously:
+ * pixelnerf_amd copies it to pinned memory and looks at it on the next call, like the parameter check).
+ * The guard never changes a result. */
+int pnr_saturation_guard(unsigned int *flags_dev);
+
 /* ---- SpatialEncoder.index as a stand-alone operator ------------------------------------------
  * src/model/encoder.py:80-109 (SpatialEncoder.index): F.grid_sample(latent, uv[:, :, None], mode "bilinear",
  * padding_mode "border", align_corners=True)[..., 0] on the encoded grid -- latent_nhwc (NV,Hl,Wl,C) is the

@@ -96,6 +96,7 @@ PROTOTYPES = {
                                        ctypes.c_ulonglong, ctypes.c_longlong, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pnr_pyramid_to_latent": (_I, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                    ctypes.POINTER(ctypes.c_int), _I, _I, _P, _P, _P]),
+    "pnr_saturation_guard": (_I, [_P]),
     "pnr_grid_index": (_I, [_P, _I, _I, _I, _I, _P, ctypes.c_longlong, _P, _P]),
     "pnr_grid_index_backward": (_I, [_P, _I, _I, _I, _I, _P, ctypes.c_longlong, _P, _P, _P, _P]),
     "pnr_positional_encoding": (_I, [_P, ctypes.c_longlong, _I, _I, _P, _P, _I, _P, _P]),

@@ -78,6 +78,7 @@ def _train_eval(net, scene, coarse, rays, z):
     """network forward of one training pass -> (rgbsigma (R,K,4), saved operands).  precision 'f32': the exact, unfused fp32
     chain (validation grade); 'f16x3': the same chain with split-operand (fp32-class) GEMMs on the f16 matrix cores;
     'f16' / 'bf16': the fused kernel's training instantiation (16-bit operand dumps)."""
+    ops.saturation_guard_slot(rays.device, 0 if coarse else 1)  # (when the fp16-range guard is armed for this call)
     if net.precision == "f16x3" and FUSED_SPLIT_TRAINING:
         pk = net.packed(coarse)  # the folded split stream of inference (before tables(): packed() runs the content check)
         return ops.eval_ray_samples_split_train(scene, pk, net.tables(coarse), rays, z)

@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "pnr_common.h"
+#include "pnr_internal.h"
 #include "pnr_layout.h"
 
 static thread_local char g_err[512] = "";
@@ -50,5 +51,18 @@ extern "C" int pnr_device_info(int *num_cus, int *lds_bytes_per_block) {
     if (e != hipSuccess) return pnr_check_hip(e, "hipGetDeviceProperties");
     if (num_cus) *num_cus = prop.multiProcessorCount;
     if (lds_bytes_per_block) *lds_bytes_per_block = pnr::LDS_TOTAL;
+    return PNR_OK;
+}
+
+// ---- fp16-range guard of the fp32-class ("f16x3") kernels
+static thread_local unsigned int *g_sat_flags = nullptr;
+static thread_local int g_sat_slot = 0;
+
+unsigned int *pnr::saturation_guard_word() { return g_sat_flags ? g_sat_flags + g_sat_slot : nullptr; }
+void pnr::saturation_guard_slot(int slot) { g_sat_slot = slot == 1 ? 1 : 0; }
+
+extern "C" int pnr_saturation_guard(unsigned int *flags_dev) {
+    g_sat_flags = flags_dev;
+    g_sat_slot = 0;
     return PNR_OK;
 }

@@ -77,6 +77,8 @@ struct EvalParams {
     // fp32 rows in natural feature order (f_x5), and the relu masks in d_mask
     char *s_a[5], *s_n[5];
     float *f_x5;
+    // GUARD instantiation of the split-operand kernel: one word that collects "layer l saw a value beyond the fp16 range" bits
+    unsigned int *sat_flag;
 };
 
 // phase ids of the TIMING instantiation (wave 0 of workgroup 0, s_memtime ticks)

@@ -34,6 +34,12 @@ int mlp_backward_split_chain(const void *packed_bwd_split, const unsigned long l
                              long long P, int NS, void *const *g_fc1, void *const *g_fc0, void *g_x0, float *d_zlat /* (NS*P,512) */,
                              float *d_in /* (NS*P,42), nullable */, hipStream_t st);
 
+// fp16-range guard of the fp32-class kernels (pnr_saturation_guard, pnr_api.hip): the flag word the next split-operand launch
+// of THIS host thread reports into (NULL = guard off), and which of the caller's two words that is (render entries set the
+// slot: 0 = coarse-network launch, 1 = fine-network launch).
+unsigned int *saturation_guard_word();
+void saturation_guard_slot(int slot);
+
 // per (device, stream) scratch for the parked view sum of multi-view launches (one tile of fp32 accumulators per workgroup),
 // allocated at the first multi-view launch on a stream and kept; NULL on allocation failure.  Defined in pnr_mlp.hip.
 float *mv_scratch(hipStream_t st, size_t bytes);

@@ -37,7 +37,11 @@ __device__ inline GemmSrc gemm_source(const PnrMlpWeights &p, int g) {
 // FOLD: the stream without the three lin_z GEMMs (they are folded into per-texel tables, pnr_fold_latent)
 // LO: the f16 TAIL of the weight, f16(w - f16(w)), for the split-operand kernel (pnr_split.hip)
 // One thread = one lane's 8-element fragment slice (a 16-byte store; the index arithmetic is paid once per 8 elements).
-template <typename T, bool FOLD, bool LO = false>
+// OWNK: the K order of the split-operand kernel's 512-wide linears (pnr_split.hip, stage_own / gemm_split_rot): ring steps
+//       0-3 of a layer = this wave's OWN K block (features 64 wv .. 64 wv + 63) in REGISTER order -- k-step j, lane half h,
+//       element e <-> feat_of(wv IT + (j >> 1), h, 8 (j & 1) + e): what the wave's accumulators hold -- then the blocks of waves
+//       wv+1 .. wv+7 (mod 8) in the storage order of the operand image.
+template <typename T, bool FOLD, bool LO = false, bool OWNK = false>
 __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
     constexpr int TOTAL = FOLD ? RS_TOTAL_F : RS_TOTAL;
     const size_t idx8 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,7 +76,15 @@ __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
         } else if (src.kind == 2) {
             // B operand comes from the LDS activation buffer: k-step s reads storage elements
             // 16s..16s+15 = what half (s&1) of feature tile (s>>1) wrote as registers 8h+e.
-            const int k = feat_of(s >> 1, s & 1, 8 * h + e);
+            int k;
+            if (OWNK) {
+                const int body = s >> 2, j = s & 3;
+                if (body == 0) k = feat_of(wv * IT + (j >> 1), h, 8 * (j & 1) + e);
+                else {
+                    const int ss = ((wv + body) & (NW - 1)) * 4 + j;  // k-step of the image order this ring step stands for
+                    k = feat_of(ss >> 1, ss & 1, 8 * h + e);
+                }
+            } else k = feat_of(s >> 1, s & 1, 8 * h + e);
             v = src.w[f_out * D_HID + k];
         } else {
             // lin_out: B operand = the wave's own accumulators; k-step q = IT*s + it covers
@@ -331,8 +343,13 @@ extern "C" int pnr_pack_mlp_split(const PnrMlpWeights *w, void *packed, void *st
     const size_t n = (size_t)RS_TOTAL_F * IT * (FRAG_ELEMS / 8) * NW;  // one thread per 8 elements
     const int threads = 256;
     const unsigned blocks = (unsigned)((n + threads - 1) / threads);
-    hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, false>), dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed);
-    hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, true>), dim3(blocks), dim3(threads), 0, st, *w,
+#if defined(PNR_VARIANT) && defined(PNR_X_OLD_BLOCK)  // A/B twin of pnr_split.hip's block(): the image order for every K block
+    constexpr bool OWNK = false;
+#else
+    constexpr bool OWNK = true;
+#endif
+    hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, false, OWNK>), dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed);
+    hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, true, OWNK>), dim3(blocks), dim3(threads), 0, st, *w,
                        (_Float16 *)((char *)packed + PACKED_BYTES));
     const int nb = NBIAS * NW * BIAS_FLOATS_PER_WAVE;
     hipLaunchKernelGGL(pack_bias_kernel<true>, dim3((nb + threads - 1) / threads), dim3(threads), 0, st, *w,

@@ -388,13 +388,17 @@ static int render_impl(const PnrScene *scene, const void *packed_coarse, const v
     if (weights_c) w_c = weights_c;  // write straight into the caller's buffer
     int rc;
     if ((rc = sample_coarse_src(rs, ns, R, Kc, lindisp, z_c, stream))) return rc;
+    saturation_guard_slot(0);  // (fp16-range guard, when armed: the coarse network reports into word 0, a fine network into word 1)
     if ((rc = eval_samples_src(scene, packed_coarse, tables_coarse, precision, rs, z_c, R, rays_per_obj, Kc, rgbs_c, st))) return rc;
     if ((rc = composite_src(rs, z_c, rgbs_c, R, Kc, white_bkgd, w_c, rgb_c, depth_c, stream))) return rc;
     if (Kf > 0) {
         if (packed_fine) {
             if ((rc = sample_fine_src(rs, w_c, depth_c, z_c, ns, R, Kc, Kf - Kfd, Kfd, depth_std, lindisp, z_f, nullptr, nullptr,
                                       nullptr, stream))) return rc;
-            if ((rc = eval_samples_src(scene, packed_fine, tables_fine, precision, rs, z_f, R, rays_per_obj, Kc + Kf, rgbs_f, st))) return rc;
+            saturation_guard_slot(1);
+            rc = eval_samples_src(scene, packed_fine, tables_fine, precision, rs, z_f, R, rays_per_obj, Kc + Kf, rgbs_f, st);
+            saturation_guard_slot(0);
+            if (rc) return rc;
         } else {
             // mlp_fine is None (models.py:242, eval/eval.py:140): the fine pass runs the coarse network on the merged
             // samples, Kc of which it has just evaluated -- evaluate the Kf new ones only and merge in sorted order

@@ -94,20 +94,9 @@ struct SplitAdvBwd {
 __device__ __forceinline__ f32x16 mf(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // acc[it][jt] += (Wh + Wl)(Xh + Xl) without the tail-tail term; B rows at bhi0 + jt*jstride (+ lo_delta for the tails)
-// Training: the copy of the operand / gradient image a GEMM multiplies from -- (head, tail) rows of 1 KiB, the wave's MT / NW = 8
-// rows of a 64-point tile -- can ride INSIDE that GEMM's loop (-DPNR_SPLIT_DUMP_IN_GEMM): body b reads row b of both images
-// from LDS in front of its first MFMA and stores them behind its last, in the shadow of the body's 48 MFMAs, instead of 16 LDS
-// reads + 16 stores per wave in front of the GEMM.
-struct SplitDump {
-    const char *src_hi, *src_lo;  // LDS images + this wave's first row + lane * 16
-    char *dst_hi, *dst_lo;        // the same position in the two row sets
-    long long rows_left;          // rows of the tile that exist
-    int row0;                     // this wave's first row of the tile
-};
-
-template <int JT, typename ADV = SplitAdvFwd, bool DUMP = false>
+template <int JT, typename ADV = SplitAdvFwd>
 __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *smem, uint32_t bhi0, uint32_t jstride,
-                                           uint32_t lo_delta, int nbody, SplitRing &R, int NS, [[maybe_unused]] const SplitDump *dj = nullptr) {
+                                           uint32_t lo_delta, int nbody, SplitRing &R, int NS) {
     h8 bh[2][JT], bl[2][JT];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
@@ -116,11 +105,6 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
     }
 #pragma unroll 1
     for (int body = 0; body < nbody; ++body) {
-        [[maybe_unused]] u32x4 dv_hi, dv_lo;
-        if constexpr (DUMP) {
-            dv_hi = *reinterpret_cast<const u32x4 *>(dj->src_hi + body * ROW_ACT);
-            dv_lo = *reinterpret_cast<const u32x4 *>(dj->src_lo + body * ROW_ACT);
-        }
         const size_t pf = (size_t)R.pf_rs * (IT * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -170,12 +154,6 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
         }
         bhi0 += 128;
         ADV::step(R, NS);
-        if constexpr (DUMP) {
-            if (dj->row0 + body < dj->rows_left) {
-                *reinterpret_cast<u32x4 *>(dj->dst_hi + (size_t)body * (D_HID * 2)) = dv_hi;
-                *reinterpret_cast<u32x4 *>(dj->dst_lo + (size_t)body * (D_HID * 2)) = dv_lo;
-            }
-        }
     }
 }
 
@@ -183,8 +161,9 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
 // tail = f16(v - head): one v_fma_mix{lo,hi}_f16 per value (fp32 FMA of the f16 head taken straight out of its packed
 // register, times -1, plus v; result rounded once to f16) -- the same bits as convert-back + subtract + convert
 // (v - head is exact in fp32), 5 VALU operations per pair instead of 8.
-template <bool RELU>
-__device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo) {
+// GUARD: `amax` follows the largest value split (one v_max3_f32 per pair): the fp16-range guard of pnr_saturation_guard().
+template <bool RELU, bool GUARD = false>
+__device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo, [[maybe_unused]] float *amax = nullptr) {
     u32x4 uh, ul;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -196,6 +175,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo) {
             // states in front of inline asm -- that form read stale registers in the multi-view instantiations.
             p[0] = __builtin_amdgcn_fmed3f(p[0], 0.f, 3.402823466e38f); p[1] = __builtin_amdgcn_fmed3f(p[1], 0.f, 3.402823466e38f);
         }
+        if constexpr (GUARD) *amax = fmaxf(*amax, RELU ? fmaxf(p[0], p[1]) : fmaxf(fabsf(p[0]), fabsf(p[1])));
         const f16x2 h = __builtin_convertvector(p, f16x2);
         uh[k] = __builtin_bit_cast(uint32_t, h);
         uint32_t l;
@@ -227,6 +207,143 @@ __device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][JT], char *s
                 *reinterpret_cast<h8 *>(smem + ST::A_LO + ad + 16 * half) = lo;
             }
         }
+}
+
+// ---- "own K block first" form of the 512 x 512 linears (round 4) -----------------------------------------------------------
+// A wave's accumulators ARE B fragments of the next linear: lane (point pl, half h) holds, in registers 8 rr .. 8 rr + 7 of
+// feature tile `it`, exactly the 8 K-elements an MFMA B operand wants from that lane for the 16 features
+// feat_of(wv IT + it, {0,1}, 8 rr + {0..7}) (the property lin_out has always used).  So the next GEMM's products against THIS
+// wave's 64 features need no LDS round trip and no barrier: relu + (head, tail) split of 16 accumulator values yields the B
+// fragments of one k-step, which are multiplied right away (12 MFMAs) AND stored into the operand images for the other seven
+// waves.  The split epilogue (VALU-bound: ~170 operations per wave and GEMM, 8 % of a tile with the matrix pipe idle) thereby
+// runs in the shadow of 48 MFMAs per wave that had to be issued anyway, and the barrier that publishes the images is crossed
+// with an eighth of the GEMM already done.  The packed stream carries each wave's own K block first, in register order, then
+// the blocks of waves wv+1 .. wv+7 (mod 8) in the image's storage order (pnr_pack.hip, OWNK).  Per output element the 512
+// products are summed in a wave-dependent block order -- fixed per (feature, wave), identical for every point and tile size:
+// chunked = whole and sharded = unsharded stay bit for bit.
+template <typename ST, int JT, bool GUARD>
+__device__ __forceinline__ void stage_own(f32x16 (&acc)[IT][JT], const f32x16 (&src)[IT][JT], char *smem, uint32_t waddr,
+                                          SplitRing &R, int NS, [[maybe_unused]] float *amax) {
+    static_assert(IT == 2, "k-step j of the own block = (feature tile j >> 1, register half j & 1)");
+    h8 bh[2][JT], bl[2][JT];
+    auto make = [&](int j, int buf) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = src[j >> 1][jt][8 * (j & 1) + e];
+            split8<true, GUARD>(v, bh[buf][jt], bl[buf][jt], amax);
+        }
+    };
+    make(0, 0);
+    const size_t pf = (size_t)R.pf_rs * (IT * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cur = j & 1;
+        if (j + 1 < 4) make(j + 1, cur ^ 1);
+        h8 ah[IT], al[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) { ah[it] = R.h[j][it]; al[it] = R.l[j][it]; }
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(ah[it], bh[cur][jt], acc[it][jt]);
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(ah[it], bl[cur][jt], acc[it][jt]);
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(al[it], bh[cur][jt], acc[it][jt]);
+        // the same fragments, for the other waves: storage position of (feature tile j >> 1, register half j & 1), as write_split
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const uint32_t ad = waddr + jt * 32 * ROW_ACT + (j >> 1) * 64 + 16 * (j & 1);
+            *reinterpret_cast<h8 *>(smem + ST::A_HI + ad) = bh[cur][jt];
+            *reinterpret_cast<h8 *>(smem + ST::A_LO + ad) = bl[cur][jt];
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
+            R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
+        }
+        // issue order of one k-step, pinned: the split of the NEXT k-step's 16 values (~40 VALU) is spread over this step's
+        // 12 MFMAs, the image stores and the ring refills of THIS step sit behind its later MFMAs -- left to itself hipcc puts
+        // all 16 refills behind the stage's last MFMA and runs the last 30 MFMAs back to back with the VALU work in front of them
+#if !(defined(PNR_VARIANT) && defined(PNR_X_STAGE_NOPIN))
+#pragma unroll
+        for (int i = 0; i < 3 * IT * JT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                          // up to 4 VALU
+            if (i >= 4 && i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS write  (i = 4, 6, 8, 10)
+            if (i >= 5 && i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read  (i = 5, 7, 9, 11)
+        }
+#endif
+    }
+    ring_advance(R, NS);
+}
+
+// the other seven K blocks of the same linear, from the operand images: blocks (wv + 1) .. (wv + 7) mod 8, the order the stream
+// carries them in.  Loop body and pinned issue order of gemm_split.
+template <int JT>
+__device__ __forceinline__ void gemm_split_rot(f32x16 (&acc)[IT][JT], const char *smem, uint32_t a_rd0, uint32_t jstride,
+                                               uint32_t lo_delta, int wv, SplitRing &R, int NS) {
+    h8 bh[2][JT], bl[2][JT];
+    uint32_t bhi0 = a_rd0 + (uint32_t)((wv + 1) & (NW - 1)) * 128;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        bh[0][jt] = lds8<PH>(smem, bhi0 + jt * jstride);
+        bl[0][jt] = lds8<PH>(smem, bhi0 + jt * jstride + lo_delta);
+    }
+#pragma unroll 1
+    for (int m = 2; m <= NW; ++m) {
+        const uint32_t nxt = a_rd0 + (uint32_t)((wv + m) & (NW - 1)) * 128;  // (after the last block: this wave's own, read and dropped)
+        const size_t pf = (size_t)R.pf_rs * (IT * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cur = j & 1;
+            const uint32_t rd = j < 3 ? bhi0 + (j + 1) * 32 : nxt;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                bh[cur ^ 1][jt] = lds8<PH>(smem, rd + jt * jstride);
+                bl[cur ^ 1][jt] = lds8<PH>(smem, rd + jt * jstride + lo_delta);
+            }
+            h8 ah[IT], al[IT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) { ah[it] = R.h[j][it]; al[it] = R.l[j][it]; }
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(ah[it], bh[cur][jt], acc[it][jt]);
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(ah[it], bl[cur][jt], acc[it][jt]);
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(al[it], bh[cur][jt], acc[it][jt]);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
+                R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * JT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * IT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+            }
+            if constexpr (3 * IT * JT - 2 * JT - 4 * IT > 0) __builtin_amdgcn_sched_group_barrier(0x008, 3 * IT * JT - 2 * JT - 4 * IT, 0);
+        }
+        bhi0 = nxt;
+        ring_advance(R, NS);
+    }
 }
 
 // fp32 bilinear lookup of table b: wave handles points wave*8..+7; lane handles storage slots 4*lane..+3 and 256 + 4*lane..+3
@@ -292,7 +409,7 @@ __device__ __forceinline__ void add_from_table(f32x16 (&x)[IT][JT], const char *
 // weight stream per point, 105-147 k rays/s; -DPNR_SPLIT_MV32 rebuilds that form.)  Fixed summation order
 // (view 0 + view 1) + ...: bit-identical to the in-register form.
 constexpr int SPLIT_MV_TILE = 64;
-template <bool RAYS, bool MV, bool TIMING = false, bool TRAIN = false>
+template <bool RAYS, bool MV, bool TIMING = false, bool TRAIN = false, bool GUARD = false>
 __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const EvalParams q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef SplitTileT<MV ? SPLIT_MV_TILE : 64> ST;
@@ -364,19 +481,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             }
         (q.d_mask + (size_t)layer * tr_mask_layer)[word] = m;
     };
-    constexpr bool DUMP_IN_GEMM = false;
-    [[maybe_unused]] auto dump_job = [&](char *head, int b) {
-        const long long rows = b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled;
-        const size_t total = (size_t)(b < COMBINE_LAYER ? (long long)NS * q.P : q.P) * (D_HID * 2);
-        SplitDump dj;
-        dj.row0 = wv * (MT / NW);
-        dj.src_hi = smem + ST::A_HI + dj.row0 * ROW_ACT + lane * 16;
-        dj.src_lo = dj.src_hi + (ST::A_LO - ST::A_HI);
-        dj.dst_hi = head + ((size_t)rows + dj.row0) * (D_HID * 2) + lane * 16;
-        dj.dst_lo = dj.dst_hi + total;
-        dj.rows_left = tr_rows_left;
-        return dj;
-    };
     // TRAIN: the operand images just published (head, tail) -> their 16-bit row sets, whole 1 KiB rows per wave instruction
     [[maybe_unused]] auto dump_pair = [&](char *head, int b) {
         const long long rows = b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled;
@@ -384,24 +488,33 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), tr_rows_left, wv, lane);
         dump_image<MT>(smem, ST::A_LO, head + total + (size_t)rows * (D_HID * 2), tr_rows_left, wv, lane);
     };
-    // one residual block on x (resnetfc.py:66-88); lookup: lin_z[b+1] via table b+1 behind it
+    // fp16-range guard (GUARD instantiation, pnr_saturation_guard): bit l of sat_bits = "a value >= 65504 (the largest fp16: heads
+    // saturate there) went into the operand image of layer l" (2b: relu(x) entering blocks[b].fc_0, 2b+1: relu(net) entering
+    // fc_1, 10: the stream in front of lin_out), bit 11 = a non-finite network output
+    [[maybe_unused]] uint32_t sat_bits = 0;
+    [[maybe_unused]] float amax = 0.f;
+    [[maybe_unused]] auto sat_note = [&](int layer) {
+        if constexpr (GUARD) {
+            if (amax >= 65504.f) sat_bits |= 1u << layer;
+            amax = 0.f;
+        }
+    };
+    // one residual block on x (resnetfc.py:66-88); lookup: lin_z[b+1] via table b+1 behind it.
+    // Every 512-wide linear = stage_own (split epilogue + this wave's own K block, from registers) | barrier | gemm_split_rot
     auto block = [&](f32x16 (&x)[IT][JT], int b, bool lookup) {
         if constexpr (TRAIN) put_mask(x, 2 * b, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
         __syncthreads();  // table rows / previous operand images are no longer read
         PNR_T(PH_BAR1);
+#if defined(PNR_VARIANT) && defined(PNR_X_OLD_BLOCK)  // A/B twin: round 3's form (whole split epilogue, barrier, all 8 K blocks from the images)
         write_split<ST>(x, smem, a_wr);
         PNR_T(PH_WRITE_X);
         __syncthreads();
         PNR_T(PH_BAR2);
-        if constexpr (TRAIN && !DUMP_IN_GEMM) dump_pair(q.s_a[b], b);
+        if constexpr (TRAIN) dump_pair(q.s_a[b], b);
         {
             f32x16 net[IT][JT];
             add_bias<true>(net, bias_lane, 1 + 2 * b);
-            if constexpr (DUMP_IN_GEMM) {
-                const SplitDump dj = dump_job(q.s_a[b], b);
-                gemm_split<JT, SplitAdvFwd, true>(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS, &dj);
-            } else
-            gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);  // fc_0
+            gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
             PNR_T(PH_GEMM_FC0);
             if constexpr (TRAIN) put_mask(net, 2 * b + 1, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
             __syncthreads();
@@ -411,13 +524,34 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         }
         __syncthreads();
         PNR_T(PH_BAR4);
-        if constexpr (TRAIN && !DUMP_IN_GEMM) dump_pair(q.s_n[b], b);
+        if constexpr (TRAIN) dump_pair(q.s_n[b], b);
         add_bias<false>(x, bias_lane, 2 + 2 * b);
-        if constexpr (DUMP_IN_GEMM) {
-            const SplitDump dj = dump_job(q.s_n[b], b);
-            gemm_split<JT, SplitAdvFwd, true>(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS, &dj);
-        } else
-        gemm_split(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);        // fc_1
+        gemm_split(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
+#else
+        {
+            f32x16 net[IT][JT];
+            add_bias<true>(net, bias_lane, 1 + 2 * b);
+            stage_own<ST, JT, GUARD>(net, x, smem, a_wr, R, NS, &amax);                            // fc_0, own block
+            sat_note(2 * b);
+            PNR_T(PH_WRITE_X);
+            __syncthreads();
+            PNR_T(PH_BAR2);
+            if constexpr (TRAIN) dump_pair(q.s_a[b], b);
+            gemm_split_rot<JT>(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, wv, R, NS);   // fc_0, blocks of the other waves
+            PNR_T(PH_GEMM_FC0);
+            if constexpr (TRAIN) put_mask(net, 2 * b + 1, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
+            __syncthreads();
+            PNR_T(PH_BAR3);
+            add_bias<false>(x, bias_lane, 2 + 2 * b);
+            stage_own<ST, JT, GUARD>(x, net, smem, a_wr, R, NS, &amax);                            // fc_1, own block
+            sat_note(2 * b + 1);
+            PNR_T(PH_WRITE_NET);
+        }
+        __syncthreads();
+        PNR_T(PH_BAR4);
+        if constexpr (TRAIN) dump_pair(q.s_n[b], b);
+        gemm_split_rot<JT>(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, wv, R, NS);         // fc_1
+#endif
         PNR_T(PH_GEMM_FC1_Z);
         if (lookup) {
             __syncthreads();
@@ -511,7 +645,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = x[xit][jt][8 * rr + e];
                     h8 bh, bl;
-                    split8<true>(v, bh, bl);
+                    split8<true, GUARD>(v, bh, bl, &amax);
                     o[jt] = mf(ah, bh, o[jt]);
                     o[jt] = mf(ah, bl, o[jt]);
                     o[jt] = mf(al, bh, o[jt]);
@@ -525,6 +659,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
                     R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
                 }
             ring_advance(R, NS);
+            sat_note(10);
             if (h == 0) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
@@ -543,9 +678,18 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const f32x4 *>(smem + ST::LDS_OUT + (w * MT + tid) * 16);
             // models.py:260-265: rgb = sigmoid(out[:3]), sigma = relu(out[3])
             f32x4 res = {1.f / (1.f + expf(-s[0])), 1.f / (1.f + expf(-s[1])), 1.f / (1.f + expf(-s[2])), fmaxf(s[3], 0.f)};
-            if (g < q.P) *reinterpret_cast<f32x4 *>(q.out + g * 4) = res;
+            if (g < q.P) {
+                *reinterpret_cast<f32x4 *>(q.out + g * 4) = res;
+                if constexpr (GUARD) {
+                    const float t = res[0] + res[1] + res[2] + res[3];
+                    if (!(fabsf(t) <= 3.0e38f)) sat_bits |= 1u << 11;  // NaN / inf output
+                }
+            }
         }
         PNR_T(PH_FINAL);
+    }
+    if constexpr (GUARD) {
+        if (sat_bits && q.sat_flag) atomicOr(q.sat_flag, sat_bits);
     }
 }
 
@@ -685,27 +829,10 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
         dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), rows_left, wv, lane);
         dump_image<MT>(smem, ST::A_LO, head + total + (size_t)rows * (D_HID * 2), rows_left, wv, lane);
     };
-    constexpr bool DUMP_IN_GEMM = false;
-    [[maybe_unused]] auto dump_job = [&](char *head, long long rows, bool per_view) {
-        const size_t total = (size_t)(per_view ? (long long)NS * q.P : q.P) * (D_HID * 2);
-        SplitDump dj;
-        dj.row0 = wv * (MT / NW);
-        dj.src_hi = smem + ST::A_HI + dj.row0 * ROW_ACT + lane * 16;
-        dj.src_lo = dj.src_hi + (ST::A_LO - ST::A_HI);
-        dj.dst_hi = head + ((size_t)rows + dj.row0) * (D_HID * 2) + lane * 16;
-        dj.dst_lo = dj.dst_hi + total;
-        dj.rows_left = rows_left;
-        return dj;
-    };
-    // the GEMM on the image just published, with the image's copy-out in front of it or inside its loop
+    // the GEMM on the image just published, with the image's copy-out in front of it
     auto gemm_dump = [&](f32x16 (&a)[IT][JT], char *head, long long rows, bool per_view) {
-        if constexpr (DUMP_IN_GEMM) {
-            const SplitDump dj = dump_job(head, rows, per_view);
-            gemm_split<JT, SplitAdvBwd, true>(a, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS, &dj);
-        } else {
-            dump_pair(head, rows, per_view);
-            gemm_split<JT, SplitAdvBwd>(a, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
-        }
+        dump_pair(head, rows, per_view);
+        gemm_split<JT, SplitAdvBwd>(a, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
     };
     // reverse of one residual block (resnetfc.py:55-62):  given G = dL/d(x + fc_1(relu(fc_0(relu(x))))),
     //   dY(fc_1) = G ;  d net = (fc_1^T G) . [net > 0] = dY(fc_0) ;  G += (fc_0^T d net) . [x > 0]
@@ -913,9 +1040,17 @@ static int split_launch(const PnrScene *s, const void *packed, const void *table
     }
     auto k = mv ? (rays ? eval_split_kernel<true, true> : eval_split_kernel<false, true>)
                 : (rays ? eval_split_kernel<true, false> : eval_split_kernel<false, false>);
+    // fp16-range guard armed on this host thread (pnr_saturation_guard): the instantiations that follow the largest value
+    // entering every operand image; word `slot` of the caller's flag array (0: a coarse-network launch, 1: a fine-network one)
+    unsigned int *guard = saturation_guard_word();
+    q.sat_flag = guard;
+    if (guard)
+        k = mv ? (rays ? eval_split_kernel<true, true, false, false, true> : eval_split_kernel<false, true, false, false, true>)
+               : (rays ? eval_split_kernel<true, false, false, false, true> : eval_split_kernel<false, false, false, false, true>);
     if (q.f_x5) {  // training forward: the same kernel + fp32 rows of what the backward keeps
         if (!rays) return pnr_fail(PNR_E_INVALID, "pnr_eval_split: the training instantiation takes ray samples on 64-point tiles");
-        k = mv ? eval_split_kernel<true, true, false, true> : eval_split_kernel<true, false, false, true>;
+        k = mv ? (guard ? eval_split_kernel<true, true, false, true, true> : eval_split_kernel<true, true, false, true>)
+               : (guard ? eval_split_kernel<true, false, false, true, true> : eval_split_kernel<true, false, false, true>);
     }
     if (q.tim) {  // diagnostic instantiation (pnr_debug_phase_timing_split): single view, rays
         if (mv || !rays) return pnr_fail(PNR_E_INVALID, "phase timing: single-view ray launches only");

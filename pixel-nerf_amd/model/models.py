@@ -183,6 +183,49 @@ class PixelNeRFNet(torch.nn.Module):
             self._tables[slot] = (key, ops.fold_latent(sc, dict(mlp.state_dict()), self._effective_precision()), sc)
         return self._tables[slot][1]
 
+    # ---- fp16-range guard of the fp32-class precision (ops.saturation_guard_*; include/pixelnerf_hip.h).  "f16x3" represents
+    # every operand as an fp16 (head, tail) pair: exact to ~2^-22 up to 65504, SATURATING beyond -- silently outside the
+    # reference's fp32 arithmetic for a network whose hidden activations grow that large.  The guarded instantiation of the
+    # kernel (about 1 % slower) therefore runs on the FIRST call after the weights or the encoded scene changed (and on every
+    # 16th training call); its verdict arrives asynchronously and is reported as a RuntimeWarning by a later call.
+    # PIXELNERF_SATURATION_GUARD=always / off overrides the policy.
+    def _guard_begin(self, training=False):
+        """-> True when this call runs guarded (the caller must call _guard_end)"""
+        import os
+        self._guard_report()
+        if self._effective_precision() != "f16x3":
+            return False
+        mode = os.environ.get("PIXELNERF_SATURATION_GUARD", "auto")
+        if mode == "off" or torch.cuda.is_current_stream_capturing():
+            return False
+        mlps = [m for m in (self.mlp_coarse, self.mlp_fine) if m is not None]
+        lat = self.encoder.latent
+        key = (tuple(m._fingerprint() for m in mlps), lat.data_ptr(), lat._version, tuple(lat.shape))
+        n = self.__dict__.get("_guard_calls", 0)
+        self.__dict__["_guard_calls"] = n + 1
+        due = mode == "always" or key != self.__dict__.get("_guard_key") or (training and n % 16 == 0)
+        if not due:
+            return False
+        self.__dict__["_guard_key"] = key
+        ops.saturation_guard_arm(lat.device)
+        return True
+
+    def _guard_end(self):
+        ops.saturation_guard_disarm(self.encoder.latent.device)
+
+    def _guard_report(self, wait=False):
+        lat = self.encoder.latent
+        if not (torch.is_tensor(lat) and lat.is_cuda):
+            return None
+        got = ops.saturation_guard_poll(lat.device, wait=wait)
+        if got is not None and (got[0] or got[1]):
+            parts = [f"{name} network: {ops.describe_saturation(b)}" for name, b in (("coarse", got[0]), ("fine", got[1])) if b]
+            warnings.warn("pixelnerf_amd (precision 'f16x3'): hidden activations reached the fp16 range limit of 65504 -- "
+                          + "; ".join(parts) + ".  Operand heads saturate there, so these renders are NOT within the fp32-class "
+                          "tolerance of the reference; use make_model(conf, precision='f32') (exact, slower) for this checkpoint.",
+                          RuntimeWarning, stacklevel=3)
+        return got
+
     def _wants_grad(self):
         lat = getattr(self.encoder, "latent", None)
         return torch.is_grad_enabled() and (self.mlp_coarse.any_requires_grad()
@@ -209,8 +252,16 @@ class PixelNeRFNet(torch.nn.Module):
                                           "GEMMs) or 'f32' (exact fp32 validation path)")
             from .. import autograd
             return autograd.points_autograd(self, xyz, viewdirs.reshape(SB, B, 3), coarse)
-        return ops.eval_points(sc, self.packed(coarse), xyz.float(), viewdirs.reshape(SB, B, 3).float(),
-                               tables=self.tables(coarse))
+        pk = self.packed(coarse)
+        tab = self.tables(coarse)
+        guarded = self._guard_begin()
+        try:
+            if guarded:
+                ops.saturation_guard_slot(xyz.device, 0 if (coarse or self.mlp_fine is None) else 1)
+            return ops.eval_points(sc, pk, xyz.float(), viewdirs.reshape(SB, B, 3).float(), tables=tab)
+        finally:
+            if guarded:
+                self._guard_end()
 
     # ------------------------------------------------------------------ checkpoints
     # file layout of the reference's trainer (src/model/models.py:268-316): <checkpoints_path>/<name>/pixel_nerf_{latest,init}

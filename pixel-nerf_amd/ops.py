@@ -630,6 +630,75 @@ def grid_index_backward(latent_nhwc, uv, g_out, want_latent=True, want_uv=True):
     return d_lat, d_uv
 
 
+# ---------------------------------------------------------------- fp16-range guard of the fp32-class kernels
+# include/pixelnerf_hip.h, pnr_saturation_guard: while armed, the split-operand network kernels note every layer whose operand
+# image received a value >= 65504 (fp16 heads saturate there: the result leaves the reference's fp32 arithmetic class) or whose
+# output is not finite.  The flag words travel to pinned host memory with an asynchronous copy and are looked at on a later
+# call -- no host synchronisation, like the parameter content check of ResnetFC.
+_SAT = {}
+SAT_LAYER_NAMES = ([f"relu(x) entering blocks.{b}.fc_0" if i == 0 else f"relu(net) entering blocks.{b}.fc_1" for b in range(5) for i in (0, 1)]
+                   + ["the stream in front of lin_out", "a non-finite network output"])
+
+
+def _sat_state(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SAT.get(idx)
+    if st is None:
+        st = dict(flags=torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", idx)),
+                  host=torch.zeros(2, dtype=torch.int32).pin_memory(), event=None, armed=False)
+        _SAT[idx] = st
+    return st
+
+
+def saturation_guard_arm(device):
+    """arm the guard for the launches this host thread makes next on `device` (until saturation_guard_disarm)"""
+    st = _sat_state(device)
+    _lib.check(_lib.load().pnr_saturation_guard(_p(st["flags"])), "pnr_saturation_guard")
+    st["armed"] = True
+
+
+def saturation_guard_slot(device, slot):
+    """while armed: direct network launches (pnr_eval_*_split*) report into word `slot` (0 = coarse network, 1 = fine network);
+    the render entries pick the word themselves"""
+    st = _sat_state(device)
+    if st["armed"]:
+        _lib.check(_lib.load().pnr_saturation_guard(ctypes.c_void_p(st["flags"].data_ptr() + 4 * (1 if slot else 0))), "pnr_saturation_guard")
+
+
+def saturation_guard_disarm(device):
+    """disarm, and send the flag words on their way to the host (asynchronous; saturation_guard_poll reads them)"""
+    st = _sat_state(device)
+    _lib.check(_lib.load().pnr_saturation_guard(None), "pnr_saturation_guard")
+    if st["armed"]:
+        st["armed"] = False
+        with torch.cuda.device(st["flags"].device):
+            st["host"].copy_(st["flags"], non_blocking=True)
+            st["flags"].zero_()
+            st["event"] = torch.cuda.Event()
+            st["event"].record()
+
+
+def saturation_guard_poll(device, wait=False):
+    """-> (bits of the coarse-network launches, bits of the fine-network launches) of the guarded calls whose flag copy has
+    arrived since the last poll, or None when nothing is pending / the copy is still in flight (wait=True blocks for it)"""
+    st = _sat_state(device)
+    ev = st["event"]
+    if ev is None:
+        return None
+    if wait:
+        ev.synchronize()
+    elif not ev.query():
+        return None
+    st["event"] = None
+    bits = [int(v) & 0xFFFFFFFF for v in st["host"].tolist()]
+    st["host"].zero_()
+    return bits[0], bits[1]
+
+
+def describe_saturation(bits):
+    return ", ".join(SAT_LAYER_NAMES[i] for i in range(len(SAT_LAYER_NAMES)) if bits >> i & 1)
+
+
 def pyramid_to_latent(stages, want_nchw=True):
     """Encoder output formatting (src/model/encoder.py:150-163): stages = list of (NV,C_s,H_s,W_s) float32
     HIP tensors (ResNet stage outputs).  -> (latent_nhwc (NV,H0,W0,sum C), latent_nchw (NV,sum C,H0,W0) | None):

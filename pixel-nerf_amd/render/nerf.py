@@ -188,19 +188,30 @@ class NeRFRenderer(torch.nn.Module):
                 from ..autograd import render_autograd
                 if noise is None:
                     noise = self._draw_noise(R, rays.device)
-                res = render_autograd(self, model, rays, noise, want_weights)
+                guarded = model._guard_begin(training=True)
+                try:
+                    res = render_autograd(self, model, rays, noise, want_weights)
+                finally:
+                    if guarded:
+                        model._guard_end()
             else:
                 # mlp_fine is None (eval/eval.py:140): pass no fine network, so the fine pass re-uses the coarse pass's
                 # outputs at the shared sample positions instead of evaluating them again
                 own_fine = Kf > 0 and getattr(model, "mlp_fine", None) is not None
                 pk_c, pk_f = model.packed(True), (model.packed(False) if own_fine else None)  # before tables(): see PixelNeRFNet.tables
                 tc = model.tables(True)
-                res = ops.render_forward(model.scene(), pk_c, pk_f,
-                                         rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
-                                         white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights,
-                                         tables=None if tc is None else (tc, model.tables(False) if own_fine else None),
-                                         seed=self._next_seed(rays.device) if seeded else 0,
-                                         ray_id_offset=self.ray_id_offset, ray_id_stride=self.ray_id_stride)
+                tf = model.tables(False) if (own_fine and tc is not None) else None
+                guarded = model._guard_begin()  # fp16-range guard of the fp32-class kernels: first call on new weights / scene
+                try:
+                    res = ops.render_forward(model.scene(), pk_c, pk_f,
+                                             rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
+                                             white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights,
+                                             tables=None if tc is None else (tc, tf),
+                                             seed=self._next_seed(rays.device) if seeded else 0,
+                                             ray_id_offset=self.ray_id_offset, ray_id_stride=self.ray_id_stride)
+                finally:
+                    if guarded:
+                        model._guard_end()
             outputs = DotMap(coarse=self._format(res["coarse"], SB, want_weights))
             if Kf > 0:
                 outputs.fine = self._format(res["fine"], SB, want_weights)

@@ -162,3 +162,73 @@ def test_split_operands_saturate_instead_of_overflowing(ops, dev):
     vd = torch.from_numpy(g["sn64_viewdirs"]).to(dev)
     out = ops.eval_points(sc, ops.pack_mlp(state, "f16x3"), xyz, vd, tables=ops.fold_latent(sc, state, "f16x3"))
     assert torch.isfinite(out).all()
+
+
+# ---------------------------------------------------------------- fp16-range guard (pnr_saturation_guard)
+def _guarded_eval(ops, dev, state, name="sn64", coarse_slot=0):
+    s, _ = scene_for(name)
+    sc = dscene(ops, dev, name)
+    g = load_golden("stages")
+    xyz = torch.from_numpy(g[name + "_xyz"]).to(dev)
+    vd = torch.from_numpy(g[name + "_viewdirs"]).to(dev)
+    pk, tab = ops.pack_mlp(state, "f16x3"), ops.fold_latent(sc, state, "f16x3")
+    plain = ops.eval_points(sc, pk, xyz, vd, tables=tab).clone()
+    ops.saturation_guard_arm(dev)
+    try:
+        ops.saturation_guard_slot(dev, coarse_slot)
+        guarded = ops.eval_points(sc, pk, xyz, vd, tables=tab).clone()
+    finally:
+        ops.saturation_guard_disarm(dev)
+    bits = ops.saturation_guard_poll(dev, wait=True)
+    assert ops.saturation_guard_poll(dev) is None  # consumed
+    return plain, guarded, bits
+
+
+@pytest.mark.parametrize("name", ["sn64", "mv_mini"])
+def test_saturation_guard_is_silent_on_in_range_networks_and_changes_no_bit(ops, dev, name):
+    state = {k: v.to(dev) for k, v in mlp_params(11).items()}
+    plain, guarded, bits = _guarded_eval(ops, dev, state, name)
+    assert bits == (0, 0)
+    assert torch.equal(plain, guarded)  # the guarded instantiation computes the same bits
+
+
+def test_saturation_guard_names_the_layer_that_left_the_fp16_range(ops, dev):
+    """lin_z[0] scaled by 1e6: the stream entering block 0 is far beyond 65504 -> bit 0 (relu(x) entering blocks.0.fc_0) and
+    everything downstream; a hot lin_out input only -> bit 10 alone; the fine-network slot reports into the second word"""
+    p = {k: v.clone() for k, v in mlp_params(11).items()}
+    p["lin_z.0.weight"] *= 1e6
+    _, out, bits = _guarded_eval(ops, dev, {k: v.to(dev) for k, v in p.items()})
+    assert torch.isfinite(out).all()
+    assert bits[0] & 1 and bits[1] == 0, bits
+    assert "blocks.0.fc_0" in ops.describe_saturation(bits[0])
+    # only the last residual update is large: fc_1 of block 4 scaled up -> the stream in front of lin_out saturates, nothing before it
+    p = {k: v.clone() for k, v in mlp_params(11).items()}
+    p["blocks.4.fc_1.weight"] *= 3e5
+    _, out, bits = _guarded_eval(ops, dev, {k: v.to(dev) for k, v in p.items()}, coarse_slot=1)
+    assert bits[0] == 0 and bits[1] == 1 << 10, bits
+    assert ops.describe_saturation(bits[1]) == "the stream in front of lin_out"
+
+
+def test_renderer_warns_once_when_a_checkpoint_leaves_the_fp16_range(dev):
+    """API level: the first render on new weights runs guarded; its verdict is reported by the NEXT call as a RuntimeWarning that
+    names network and layer.  In-range weights: no warning, and the guard does not run again on unchanged weights / scene."""
+    import warnings
+    from pixelnerf_amd.render import NeRFRenderer
+    from test_api_gpu import build_net
+    g, scene, meta, mc, mf, rays, noise = golden_setup("sn64_64_128")
+    net = build_net(dev, scene, precision="f16x3")
+    rend = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=True).to(dev).eval()
+    nz = {k: v.to(dev) for k, v in noise.items()}
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)  # a guard report would fail the in-range part
+        a = rend(net, rays.to(dev), _noise=nz)
+        torch.cuda.synchronize()
+        b = rend(net, rays.to(dev), _noise=nz)
+        assert torch.equal(a.fine.rgb, b.fine.rgb)  # guarded (first) and plain (second) call: same bits
+        assert net.__dict__["_guard_calls"] == 2
+    with torch.no_grad():
+        net.mlp_fine.lin_z[1].weight.mul_(1e6)  # only the FINE network leaves the range, at block 1
+        rend(net, rays.to(dev), _noise=nz)      # guarded: new weights
+        torch.cuda.synchronize()
+        with pytest.warns(RuntimeWarning, match=r"fine network: .*blocks\.1\.fc_0"):
+            rend(net, rays.to(dev), _noise=nz)
