@@ -362,8 +362,8 @@ def extra_train_step(dev, prec, scene_name="train", steps=40, warmup=8, with_gra
         # (tools/gpu_train_graph.py): a failure inside graph capture must never take this benchmark line down.
         import subprocess
         try:
-            child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_train_graph.py"), "step"], capture_output=True,
-                                   text=True, timeout=300)
+            child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_train_graph.py"), "step", "--prec", prec],
+                                   capture_output=True, text=True, timeout=300)
             line = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
             if child.returncode == 0 and line:
                 r = json.loads(line[-1])["step"]
@@ -817,7 +817,7 @@ def main():
             # BASELINE configs[2..4] on this one GPU, outside the timed region
             for key, fn in (("train_step", lambda: extra_train_step(dev, "f16")),
                             ("train_step_multiview", lambda: extra_train_step(dev, "f16", "train_mv", steps=20, warmup=4, with_graph=False)),
-                            ("train_step_fp32_class", lambda: extra_train_step(dev, "f16x3", steps=16, warmup=4, with_graph=False)),
+                            ("train_step_fp32_class", lambda: extra_train_step(dev, "f16x3", steps=16, warmup=4, with_graph=True)),
                             ("train_step_fp32_class_multiview", lambda: extra_train_step(dev, "f16x3", "train_mv", steps=12, warmup=3, with_graph=False)),
                             ("train_step_fp32_class_gemm_per_layer", lambda: train_step_unfused_twin(dev)),
                             ("train_step_torch_eager_gpu_baseline", lambda: train_step_eager_torch(dev)),

@@ -408,6 +408,7 @@ int pnr_render_views(const PnrScene *scene /*host*/, const void *packed_coarse, 
  *   bit 2b+1  a value >= 65504 in relu(net) entering blocks[b].fc_1
  *   bit 10    a value >= 65504 in the stream in front of lin_out
  *   bit 11    a non-finite network output
+ *   bit 12    (pnr_fold_latent_f32, called while armed) a feature-grid value or lin_z weight beyond the fp16 range
  * flags: DEVICE array of two 32-bit words, zeroed by the caller, read back by the caller (asynchronously:
  * pixelnerf_amd copies it to pinned memory and looks at it on the next call, like the parameter check).
  * The guard never changes a result. */

@@ -637,6 +637,55 @@ static void linear_bwd(const Mm &c, const float *dY, int lddy, const float *W, i
 constexpr int WG_SPLIT = 32;  // row slices of the weight-gradient reduction
 
 // dW (N,Kd), db (N) from dY (M,N) and X (M,Kd); part / bpart: WG_SPLIT * (N*Kd + N) floats of workspace
+// lin_out's gradient (resnetfc.py:183; 4 x 512: dW[o][k] = sum_r g[r][o] relu(x5[r][k]), db[o] = sum_r g[r][o]) is a
+// REDUCTION over the points, not a GEMM worth the matrix cores: 200 MFLOP over 100 MB of fp32 rows at config-5 size.  Round 3
+// ran it on the split-operand GEMM kernel (82 us per pass at 17.6 % MFMA busy: a 4-row A operand in a 128-row tile); here
+// every thread owns two features and walks a row slice with plain fp32 FMAs (exact products, one rounding per add), row
+// slices -> partials -> fixed-order reduce, like lin_out_grad_kernel of the 16-bit path: HBM-bound, ~25-30 us.
+constexpr int LOF_BLOCKS = 256;
+__global__ void __launch_bounds__(256)
+lin_out_grad_f32_kernel(const float *__restrict__ g, const float *__restrict__ x5, long long P, float *__restrict__ part) {
+    const int t = threadIdx.x;
+    const long long per = (P + LOF_BLOCKS - 1) / LOF_BLOCKS;
+    const long long r0 = (long long)blockIdx.x * per, r1 = r0 + per < P ? r0 + per : P;
+    float acc[4][2] = {}, bs[4] = {};
+#pragma unroll 8  // 8 rows of loads in flight
+    for (long long r = r0; r < r1; ++r) {
+        const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + r * 4);
+        const f32x2 xv = *reinterpret_cast<const f32x2 *>(x5 + r * D_HID + 2 * t);
+        const float xa = fmaxf(xv[0], 0.f), xb = fmaxf(xv[1], 0.f);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            acc[o][0] = __builtin_fmaf(gv[o], xa, acc[o][0]);
+            acc[o][1] = __builtin_fmaf(gv[o], xb, acc[o][1]);
+            bs[o] += gv[o];
+        }
+    }
+    float *pz = part + (size_t)blockIdx.x * (4 * D_HID + 4);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        pz[o * D_HID + 2 * t] = acc[o][0];
+        pz[o * D_HID + 2 * t + 1] = acc[o][1];
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) pz[4 * D_HID + o] = bs[o];
+    }
+}
+__global__ void lin_out_reduce_f32_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * D_HID + 4) return;
+    float s = 0.f;
+    for (int z = 0; z < LOF_BLOCKS; ++z) s += part[(size_t)z * (4 * D_HID + 4) + idx];
+    if (idx < 4 * D_HID) dW[idx] = s;
+    else if (db) db[idx - 4 * D_HID] = s;
+}
+// g (P,4) unscaled fp32, x5 (P,512) fp32 rows in natural feature order; part: >= LOF_BLOCKS * 2052 floats
+static void lin_out_grad_f32(hipStream_t st, const float *g, const float *x5, long long P, float *dW, float *db, float *part) {
+    hipLaunchKernelGGL(lin_out_grad_f32_kernel, dim3(LOF_BLOCKS), dim3(256), 0, st, g, x5, P, part);
+    hipLaunchKernelGGL(lin_out_reduce_f32_kernel, dim3((4 * D_HID + 4 + 255) / 256), dim3(256), 0, st, part, dW, db);
+}
+
 static void wgrad(const Mm &c, const float *dY, int lddy, const float *X, int ldx, bool relu_x, long long M, int N, int Kd,
                   float *dW, float *db, float *part, bool in_unscaled = false) {
     float *bpart = part + (size_t)WG_SPLIT * N * Kd;
@@ -866,8 +915,8 @@ extern "C" int pnr_mlp_backward_split(const PnrMlpWeights *w, const PnrSplitSave
     jobs[nj++] = PnrWeightGradJob{g_x0, sv->in_op, rows, 1, 0, (float *)grads->lin_in_w, (float *)grads->lin_in_b, D_IN_PAD, D_IN};
     rc = pnr_weight_grad_batched(jobs, nj, PNR_PREC_F16X3, 1.f, grad_scale + 1, dw_ws, stream);
     if (rc != PNR_OK) return rc;
-    const Mm st = {hs, true, grad_scale, grad_scale + 1};
-    wgrad(st, g_out, D_OUT, sv->x5, D_HID, true, P, D_OUT, D_HID, (float *)grads->lin_out_w, (float *)grads->lin_out_b, part, true);
+    static_assert((size_t)WG_SPLIT * (D_HID * D_HID + D_HID) >= (size_t)LOF_BLOCKS * (4 * D_HID + 4), "lin_out partials fit the slice workspace");
+    lin_out_grad_f32(hs, g_out, sv->x5, P, (float *)grads->lin_out_w, (float *)grads->lin_out_b, part);
     return pnr_check_launch("pnr_mlp_backward_split");
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pnr_common.h"
+#include "pnr_internal.h"
 #include "pnr_layout.h"
 
 namespace pnr {
@@ -193,6 +194,106 @@ fold_kernel(const float *__restrict__ grid, const FoldJobs jobs, T *__restrict__
     }
 }
 
+
+// The same fold at fp32-CLASS precision on the f16 matrix cores (round 4): both operands are split into fp16 (head, tail) pairs
+// on their way into LDS and every product is the three MFMAs of pnr_split.hip (x w ~= xh wh + xh wl + xl wh, fp32 accumulate;
+// the dropped tail-tail term is 2^-22 of the product) -- the arithmetic class of the kernel that consumes the tables, at ~5x the
+// rate of the fp32-MFMA fold above (157 TFLOP/s peak against 3 MFMAs on a 2.5 PFLOP/s pipe).  The fold is per scene at
+// inference (2.5 ms per network for the DTU grid, on EVERY rank of a sharded render) and per STEP in training (the grid is a
+// trained tensor: 0.27 ms of the 6.3 ms fp32-class step).  128 texels x 128 features per 256-thread workgroup (4 waves of
+// 64 x 64 = 2 x 2 MFMA tiles), K chunks of 32; [row][k] f16 images with 80-byte rows (conflict-free 16-byte fragment reads).
+// sat: when non-null, bit 12 is raised if a grid value or a lin_z weight is beyond the fp16 range (pnr_saturation_guard).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int FS_TM = 128, FS_TN = 128, FS_K = 32, FS_ROW = FS_K + 8;  // halves per LDS row (32 used)
+__global__ void __launch_bounds__(256)
+fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__restrict__ tables, long long M, unsigned int *sat) {
+    __shared__ __attribute__((aligned(16))) _Float16 sXh[FS_TM][FS_ROW], sXl[FS_TM][FS_ROW], sWh[FS_TN][FS_ROW], sWl[FS_TN][FS_ROW];
+    const float *__restrict__ W = jobs.W[blockIdx.z];
+    const float *__restrict__ bias = jobs.bias[blockIdx.z];
+    float *__restrict__ table = tables + (size_t)blockIdx.z * (size_t)M * D_HID;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const long long m0 = (long long)blockIdx.x * FS_TM;
+    const int n0 = blockIdx.y * FS_TN;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    const int i = lane & 31, kh = lane >> 5;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float amax = 0.f;
+    auto split4 = [&](const f32x4_t v, _Float16 *hi, _Float16 *lo) {
+        f16x4_t h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (_Float16)v[e];
+            l[e] = (_Float16)(v[e] - (float)h[e]);
+            amax = fmaxf(amax, fabsf(v[e]));
+        }
+        *reinterpret_cast<f16x4_t *>(hi) = h;
+        *reinterpret_cast<f16x4_t *>(lo) = l;
+    };
+    for (int k0 = 0; k0 < C_LAT; k0 += FS_K) {
+        f32x4_t xv[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // 128 rows x 8 float4 per operand: thread -> (row, 4 columns)
+            const int e = t + u * 256, row = e >> 3, c4 = (e & 7) * 4;
+            xv[u] = (m0 + row < M) ? *reinterpret_cast<const f32x4_t *>(grid + (m0 + row) * C_LAT + k0 + c4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            wv[u] = *reinterpret_cast<const f32x4_t *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
+        }
+        __syncthreads();  // the previous chunk's fragments have been read
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = t + u * 256, row = e >> 3, c4 = (e & 7) * 4;
+            split4(xv[u], &sXh[row][c4], &sXl[row][c4]);
+            split4(wv[u], &sWh[row][c4], &sWl[row][c4]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < FS_K / 16; ++kk) {
+            f16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ah[a] = *reinterpret_cast<const f16x8_t *>(&sXh[wm + a * 32 + i][kk * 16 + kh * 8]);
+                al[a] = *reinterpret_cast<const f16x8_t *>(&sXl[wm + a * 32 + i][kk * 16 + kh * 8]);
+                bh[a] = *reinterpret_cast<const f16x8_t *>(&sWh[wn + a * 32 + i][kk * 16 + kh * 8]);
+                bl[a] = *reinterpret_cast<const f16x8_t *>(&sWl[wn + a * 32 + i][kk * 16 + kh * 8]);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // D layout: column = lane & 31 -> feature, row (r & 3) + 8 (r >> 2) + 4 kh -> texel
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + wn + b * 32 + i;
+        const float bn = bias[n];
+        const int slot = slot_of(n);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < M) table[m * D_HID + slot] = acc[a][b][r] + bn;
+            }
+    }
+    if (sat && amax >= 65504.f) atomicOr(sat, 1u << 12);
+}
+
 }  // namespace pnr
 
 namespace pnr {
@@ -331,7 +432,13 @@ extern "C" int pnr_fold_latent_f32(const PnrScene *s, const PnrMlpWeights *w, fl
         if (!w->lin_z_w[b] || !w->lin_z_b[b]) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: null lin_z parameters");
         jobs.W[b] = w->lin_z_w[b]; jobs.bias[b] = w->lin_z_b[b];
     }
+#if defined(PNR_VARIANT) && defined(PNR_X_FOLD_F32MFMA)  // A/B twin: round 3's exact-fp32-MFMA fold
     hipLaunchKernelGGL(fold_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, jobs, tables, M, 3.4028234664e38f);
+#else
+    (void)grid;
+    dim3 sgrid((unsigned)((M + FS_TM - 1) / FS_TM), D_HID / FS_TN, COMBINE_LAYER);
+    hipLaunchKernelGGL(fold_split_kernel, sgrid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, jobs, tables, M, saturation_guard_word());
+#endif
     return pnr_check_launch("pnr_fold_latent_f32");
 }
 

@@ -637,7 +637,7 @@ def grid_index_backward(latent_nhwc, uv, g_out, want_latent=True, want_uv=True):
 # call -- no host synchronisation, like the parameter content check of ResnetFC.
 _SAT = {}
 SAT_LAYER_NAMES = ([f"relu(x) entering blocks.{b}.fc_0" if i == 0 else f"relu(net) entering blocks.{b}.fc_1" for b in range(5) for i in (0, 1)]
-                   + ["the stream in front of lin_out", "a non-finite network output"])
+                   + ["the stream in front of lin_out", "a non-finite network output", "the feature grid / lin_z weights of the per-texel fold"])
 
 
 def _sat_state(device):

@@ -199,10 +199,10 @@ class NeRFRenderer(torch.nn.Module):
                 # outputs at the shared sample positions instead of evaluating them again
                 own_fine = Kf > 0 and getattr(model, "mlp_fine", None) is not None
                 pk_c, pk_f = model.packed(True), (model.packed(False) if own_fine else None)  # before tables(): see PixelNeRFNet.tables
-                tc = model.tables(True)
-                tf = model.tables(False) if (own_fine and tc is not None) else None
                 guarded = model._guard_begin()  # fp16-range guard of the fp32-class kernels: first call on new weights / scene
                 try:
+                    tc = model.tables(True)   # (a fold that happens now is guarded too: grid values / lin_z weights)
+                    tf = model.tables(False) if (own_fine and tc is not None) else None
                     res = ops.render_forward(model.scene(), pk_c, pk_f,
                                              rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
                                              white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights,

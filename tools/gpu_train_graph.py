@@ -22,8 +22,13 @@ from testdata import synthetic  # noqa: E402
 
 
 def main():
-    stages = [a for a in sys.argv[1:] if not a.startswith("-")] or ["fwd", "fwdbwd", "step"]
+    argv = list(sys.argv[1:])
     prec = "f16"
+    if "--prec" in argv:  # "f16" (default) or "f16x3": the fused fp32-class step
+        i = argv.index("--prec")
+        prec = argv[i + 1]
+        del argv[i:i + 2]
+    stages = [a for a in argv if not a.startswith("-")] or ["fwd", "fwdbwd", "step"]
     dev = torch.device("cuda:0")
     scene, meta = synthetic.make_scene("train")
     rays = synthetic.target_rays(meta, n_rays=128).to(dev)
