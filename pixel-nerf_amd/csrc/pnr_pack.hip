@@ -230,8 +230,10 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
         f16x4_t h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            h[e] = (_Float16)v[e];
-            l[e] = (_Float16)(v[e] - (float)h[e]);
+            // heads and tails SATURATE at the fp16 limit like the operands of the kernel that reads the tables (MODE.FP16_OVFL
+            // there): an out-of-range grid value or weight gives a large finite table entry (and raises the guard bit), never inf - inf
+            h[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+            l[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e] - (float)h[e], -65504.f, 65504.f);
             amax = fmaxf(amax, fabsf(v[e]));
         }
         *reinterpret_cast<f16x4_t *>(hi) = h;

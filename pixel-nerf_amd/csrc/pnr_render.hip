@@ -11,8 +11,10 @@
 namespace pnr {
 
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr int MAX_KC = 256;    // coarse samples per ray supported by sample_fine
-constexpr int MAX_KTOT = 512;  // coarse + fine samples per ray supported by sample_fine
+// sample_fine keeps a ray's cdf (Kc + 1 floats) and its merged sample set (Kc + Kf floats) in LDS, one wavefront per ray:
+// dynamic shared memory, so the only limit is the 160 KiB of a CU (about 10 000 samples per ray at 4 rays per workgroup) --
+// the reference has none (nerf.py:120-161), and no shipped config comes near it (64 + 128)
+constexpr int SAMPLE_FINE_LDS_MAX = 160 * 1024;
 
 #pragma clang fp contract(off)  // keep the reference's separately-rounded mul/add sequences
 
@@ -73,16 +75,15 @@ sample_fine_kernel(const RaySrc rs, const float *__restrict__ wc, const float *_
                    const float *__restrict__ zc, const NoiseSrc ns, int R, int Kc, int Kimp, int Kfd, float depth_std, int lindisp,
                    float *__restrict__ zout, int *__restrict__ depth_ranks, float *__restrict__ z_new,
                    int *__restrict__ ranks_all) {
-    __shared__ float s_cdf[WAVES_PER_BLOCK][MAX_KC + 1];
-    __shared__ float s_z[WAVES_PER_BLOCK][MAX_KTOT];
+    extern __shared__ float s_fine[];  // per wavefront: cdf[Kc + 1] | z[Kc + Kimp + Kfd]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r0 = blockIdx.x * WAVES_PER_BLOCK + wv;
     const bool active = r0 < R;  // inactive wavefronts still take part in the block barriers
     const int r = active ? r0 : R - 1;
-    float *cdf = s_cdf[wv], *zs = s_z[wv];
+    const int Ktot = Kc + Kimp + Kfd;
+    float *cdf = s_fine + (size_t)wv * (Kc + 1 + Ktot), *zs = cdf + Kc + 1;
     float near, far;
     load_bounds(rs, r, near, far);
-    const int Ktot = Kc + Kimp + Kfd;
 
     if (Kimp > 0) {
         // weights + 1e-5, pdf, cdf with leading 0 (nerf.py:130-133).  The running sum is kept in
@@ -280,13 +281,18 @@ static int sample_fine_src(const RaySrc &rs, const float *weights_c, const float
                            const NoiseSrc &ns, int R, int Kc, int Kimp, int Kfd, float depth_std, int lindisp, float *z_sorted,
                            int32_t *depth_ranks, float *z_new, int32_t *ranks_all, void *stream) {
     if (R < 0 || Kc <= 0 || Kimp < 0 || Kfd < 0) return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: bad sizes");
-    if (Kc > MAX_KC || Kc + Kimp + Kfd > MAX_KTOT)
-        return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: supports n_coarse <= 256 and n_coarse + n_fine <= 512");
+    const size_t lds = (size_t)WAVES_PER_BLOCK * (2 * (size_t)Kc + 1 + Kimp + Kfd) * sizeof(float);
+    if (lds > (size_t)SAMPLE_FINE_LDS_MAX)
+        return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: 2 n_coarse + n_fine + 1 must stay below 10240 samples per ray (the ray's cdf and sample set live in LDS)");
     if (R == 0) return PNR_OK;
     if (!z_coarse || !z_sorted || (Kimp > 0 && !weights_c) || (Kfd > 0 && !depth_c))
         return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: null argument");
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sample_fine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(sample_fine_kernel)");
+    }
     hipLaunchKernelGGL(sample_fine_kernel, dim3((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(WAVES_PER_BLOCK * 64),
-                       0, (hipStream_t)stream, rs, weights_c, depth_c, z_coarse, ns, R, Kc, Kimp, Kfd, depth_std, lindisp,
+                       lds, (hipStream_t)stream, rs, weights_c, depth_c, z_coarse, ns, R, Kc, Kimp, Kfd, depth_std, lindisp,
                        z_sorted, depth_ranks, z_new, ranks_all);
     return pnr_check_launch("pnr_sample_fine");
 }
@@ -295,8 +301,8 @@ extern "C" int pnr_sample_fine(const float *rays, const float *weights_c, const 
                                const float *u2, const float *u3, const float *n4, int R, int Kc, int Kimp, int Kfd,
                                float depth_std, int lindisp, float *z_sorted, int32_t *depth_ranks, void *stream) {
     if (R < 0 || Kc <= 0 || Kimp < 0 || Kfd < 0) return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: bad sizes");
-    if (Kc > MAX_KC || Kc + Kimp + Kfd > MAX_KTOT)
-        return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: supports n_coarse <= 256 and n_coarse + n_fine <= 512");
+    if ((size_t)WAVES_PER_BLOCK * (2 * (size_t)Kc + 1 + Kimp + Kfd) * sizeof(float) > (size_t)SAMPLE_FINE_LDS_MAX)
+        return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: 2 n_coarse + n_fine + 1 must stay below 10240 samples per ray (the ray's cdf and sample set live in LDS)");
     if (R > 0 && (!rays || (Kimp > 0 && (!u2 || !u3)) || (Kfd > 0 && !n4)))
         return pnr_fail(PNR_E_INVALID, "pnr_sample_fine: null argument");
     return sample_fine_src(explicit_rays(rays), weights_c, depth_c, z_coarse, explicit_noise(nullptr, u2, u3, n4), R, Kc, Kimp,

@@ -165,6 +165,10 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
 template <bool RELU, bool GUARD = false>
 __device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo, [[maybe_unused]] float *amax = nullptr) {
     u32x4 uh, ul;
+    if constexpr (GUARD) {  // on the INPUT values (v_max3_f32 per pair; negative values cannot raise it, relu or not the magnitude matters)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *amax = RELU ? fmaxf(*amax, fmaxf(v[2 * k], v[2 * k + 1])) : fmaxf(*amax, fmaxf(fabsf(v[2 * k]), fabsf(v[2 * k + 1])));
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         f32x2 p = {v[2 * k], v[2 * k + 1]};
@@ -175,7 +179,6 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo, [[ma
             // states in front of inline asm -- that form read stale registers in the multi-view instantiations.
             p[0] = __builtin_amdgcn_fmed3f(p[0], 0.f, 3.402823466e38f); p[1] = __builtin_amdgcn_fmed3f(p[1], 0.f, 3.402823466e38f);
         }
-        if constexpr (GUARD) *amax = fmaxf(*amax, RELU ? fmaxf(p[0], p[1]) : fmaxf(fabsf(p[0]), fabsf(p[1])));
         const f16x2 h = __builtin_convertvector(p, f16x2);
         uh[k] = __builtin_bit_cast(uint32_t, h);
         uint32_t l;

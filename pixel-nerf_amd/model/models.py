@@ -203,7 +203,8 @@ class PixelNeRFNet(torch.nn.Module):
         key = (tuple(m._fingerprint() for m in mlps), lat.data_ptr(), lat._version, tuple(lat.shape))
         n = self.__dict__.get("_guard_calls", 0)
         self.__dict__["_guard_calls"] = n + 1
-        due = mode == "always" or key != self.__dict__.get("_guard_key") or (training and n % 16 == 0)
+        # (training: the weights change every step -- the key would fire every time; every 16th call instead)
+        due = mode == "always" or (training and n % 16 == 0) or (not training and key != self.__dict__.get("_guard_key"))
         if not due:
             return False
         self.__dict__["_guard_key"] = key

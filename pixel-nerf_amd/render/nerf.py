@@ -202,7 +202,11 @@ class NeRFRenderer(torch.nn.Module):
                 guarded = model._guard_begin()  # fp16-range guard of the fp32-class kernels: first call on new weights / scene
                 try:
                     tc = model.tables(True)   # (a fold that happens now is guarded too: grid values / lin_z weights)
+                    if guarded:
+                        ops.saturation_guard_slot(rays.device, 1)
                     tf = model.tables(False) if (own_fine and tc is not None) else None
+                    if guarded:
+                        ops.saturation_guard_slot(rays.device, 0)
                     res = ops.render_forward(model.scene(), pk_c, pk_f,
                                              rays, self.n_coarse, Kf, Kfd, noise, depth_std=self.depth_std,
                                              white_bkgd=self.white_bkgd, lindisp=self.lindisp, want_weights=want_weights,

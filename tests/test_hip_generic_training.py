@@ -25,7 +25,7 @@ def dev():
 
 class TinyField(torch.nn.Module):
     """An arbitrary radiance field with the reference's model call contract: (SB,B,3) points [+ viewdirs] -> (SB,B,4).
-    Raw (possibly negative) sigma on purpose: the relu is the renderer's (nerf.py:228)."""
+    Raw (sometimes negative) sigma on purpose: the relu is the renderer's (nerf.py:228)."""
     use_viewdirs = True
 
     def __init__(self, seed):
@@ -43,7 +43,7 @@ class TinyField(torch.nn.Module):
 
     def forward(self, xyz, coarse=True, viewdirs=None):
         h = (self.coarse_net if coarse else self.fine_net)(torch.cat([xyz, viewdirs], dim=-1))
-        return torch.cat([torch.sigmoid(h[..., :3]), h[..., 3:4] * 4.0], dim=-1)
+        return torch.cat([torch.sigmoid(h[..., :3]), 2.0 * torch.sin(h[..., 3:4]) + 1.0], dim=-1)  # in [-1, 3]: mostly positive, some negative
 
 
 def make_rays(SB, B, seed):
@@ -119,6 +119,9 @@ def test_generic_model_training_matches_torch_autograd(dev, white, lindisp, Kfd)
     out = renderer(model_gpu, rays.to(dev), want_weights=True, _noise={k: v.to(dev) for k, v in noise.items()})
     got = {p: dict(rgb=out[p].rgb, depth=out[p].depth, weights=out[p].weights) for p in ("coarse", "fine")}
     assert got["fine"]["rgb"].requires_grad and got["coarse"]["depth"].requires_grad
+    if Kfd > 0:  # the test is only meaningful for the position gradient when the depth samples are not clamped away
+        d = got["coarse"]["depth"].detach().reshape(-1)
+        assert float(((d > rays.reshape(-1, 8)[:, 6].to(dev) + 0.2) & (d < rays.reshape(-1, 8)[:, 7].to(dev) - 0.2)).float().mean()) > 0.5
     loss = loss_of(got, {"rgb": tgt["rgb"].to(dev), "depth": tgt["depth"].to(dev), "w": [t.to(dev) for t in tgt["w"]]})
     loss.backward()
 

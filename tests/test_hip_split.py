@@ -165,7 +165,7 @@ def test_split_operands_saturate_instead_of_overflowing(ops, dev):
 
 
 # ---------------------------------------------------------------- fp16-range guard (pnr_saturation_guard)
-def _guarded_eval(ops, dev, state, name="sn64", coarse_slot=0):
+def _guarded_eval(ops, dev, state, name="sn64", coarse_slot=0, fold_under_guard=False):
     s, _ = scene_for(name)
     sc = dscene(ops, dev, name)
     g = load_golden("stages")
@@ -176,6 +176,8 @@ def _guarded_eval(ops, dev, state, name="sn64", coarse_slot=0):
     ops.saturation_guard_arm(dev)
     try:
         ops.saturation_guard_slot(dev, coarse_slot)
+        if fold_under_guard:
+            tab = ops.fold_latent(sc, state, "f16x3")
         guarded = ops.eval_points(sc, pk, xyz, vd, tables=tab).clone()
     finally:
         ops.saturation_guard_disarm(dev)
@@ -189,6 +191,7 @@ def test_saturation_guard_is_silent_on_in_range_networks_and_changes_no_bit(ops,
     state = {k: v.to(dev) for k, v in mlp_params(11).items()}
     plain, guarded, bits = _guarded_eval(ops, dev, state, name)
     assert bits == (0, 0)
+    print(f"guarded vs plain instantiation [{name}]: max abs diff {float((plain - guarded).abs().max()):.3e}")
     assert torch.equal(plain, guarded)  # the guarded instantiation computes the same bits
 
 
@@ -196,11 +199,16 @@ def test_saturation_guard_names_the_layer_that_left_the_fp16_range(ops, dev):
     """lin_z[0] scaled by 1e6: the stream entering block 0 is far beyond 65504 -> bit 0 (relu(x) entering blocks.0.fc_0) and
     everything downstream; a hot lin_out input only -> bit 10 alone; the fine-network slot reports into the second word"""
     p = {k: v.clone() for k, v in mlp_params(11).items()}
-    p["lin_z.0.weight"] *= 1e6
+    p["lin_z.0.weight"] *= 1e5  # weights ~6e3 (inside the fp16 range: the fold is clean), table entries ~1e5 (beyond it)
     _, out, bits = _guarded_eval(ops, dev, {k: v.to(dev) for k, v in p.items()})
     assert torch.isfinite(out).all()
-    assert bits[0] & 1 and bits[1] == 0, bits
+    assert bits[0] & 1 and bits[1] == 0 and not bits[0] >> 12 & 1, bits
     assert "blocks.0.fc_0" in ops.describe_saturation(bits[0])
+    # a lin_z weight itself beyond the range: the per-texel fold (run while the guard is armed) reports it (bit 12)
+    p = {k: v.clone() for k, v in mlp_params(11).items()}
+    p["lin_z.2.weight"] *= 1e7
+    _, out, bits = _guarded_eval(ops, dev, {k: v.to(dev) for k, v in p.items()}, fold_under_guard=True)
+    assert torch.isfinite(out).all() and bits[0] >> 12 & 1, bits
     # only the last residual update is large: fc_1 of block 4 scaled up -> the stream in front of lin_out saturates, nothing before it
     p = {k: v.clone() for k, v in mlp_params(11).items()}
     p["blocks.4.fc_1.weight"] *= 3e5
@@ -227,7 +235,7 @@ def test_renderer_warns_once_when_a_checkpoint_leaves_the_fp16_range(dev):
         assert torch.equal(a.fine.rgb, b.fine.rgb)  # guarded (first) and plain (second) call: same bits
         assert net.__dict__["_guard_calls"] == 2
     with torch.no_grad():
-        net.mlp_fine.lin_z[1].weight.mul_(1e6)  # only the FINE network leaves the range, at block 1
+        net.mlp_fine.lin_z[1].weight.mul_(1e5)  # only the FINE network leaves the range, at block 1 (the weights themselves stay inside)
         rend(net, rays.to(dev), _noise=nz)      # guarded: new weights
         torch.cuda.synchronize()
         with pytest.warns(RuntimeWarning, match=r"fine network: .*blocks\.1\.fc_0"):

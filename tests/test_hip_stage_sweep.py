@@ -46,7 +46,9 @@ CASES = [  # (R, Kc, Kimp, Kfd, lindisp, white, near, far)
     (33, 17, 0, 9, True, True, 0.8, 1.8),
     (64, 64, 112, 16, False, True, 1.2, 4.0),
     (129, 31, 64, 0, True, False, 0.5, 50.0),
-    (5, 256, 240, 16, False, True, 1.2, 4.0),   # sampler limits: n_coarse 256, total 512
+    (5, 256, 240, 16, False, True, 1.2, 4.0),   # round 1-3's sampler limits: n_coarse 256, total 512
+    (3, 400, 600, 24, False, True, 1.2, 4.0),   # beyond them: 1024 samples per ray (dynamic LDS)
+    (2, 1024, 2000, 48, True, False, 0.5, 6.0),  # 3072 samples per ray, 64 KiB of LDS per workgroup
     (300, 8, 1, 1, False, False, 2.0, 2.0),     # near == far: every z identical, zero-length intervals
 ]
 

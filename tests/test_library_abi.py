@@ -102,8 +102,8 @@ def test_argument_validation_without_gpu(lib):
     # invalid arguments are rejected on the host before any HIP call
     assert lib.pnr_sample_coarse(None, None, 4, 0, 0, None, None) == -1
     assert b"bad sizes" in lib.pnr_last_error()
-    assert lib.pnr_sample_fine(None, None, None, None, None, None, None, 4, 300, 0, 0, 0.01, 0, None, None, None) == -1
-    assert b"n_coarse <= 256" in lib.pnr_last_error()
+    assert lib.pnr_sample_fine(None, None, None, None, None, None, None, 4, 6000, 0, 0, 0.01, 0, None, None, None) == -1
+    assert b"samples per ray" in lib.pnr_last_error()  # the ray's cdf + sample set must fit the LDS (no such limit below ~10 000)
     assert lib.pnr_composite(None, None, None, 3, 8, 0, None, None, None, None) == -1
     assert lib.pnr_pack_mlp(None, 0, None, None) == -1
     assert lib.pnr_pack_mlp_bwd(None, 0, None, None) == -1
