@@ -221,7 +221,11 @@ def test_encoder_graph_cache_survives_copies_and_storage_changes(dev):
             lat3 = net.encoder(img).clone()
         finally:
             SpatialEncoder.use_graph = True
-        assert not torch.allclose(lat1, lat2) and torch.allclose(lat2, lat3, rtol=1e-4, atol=1e-5)
+        # (the new capture and the eager run may pick different convolution algorithms: equal to a few 1e-4, while the stale
+        # capture would be off by the factor 1.5 -- the trunk is positively homogeneous in conv1's weight)
+        scale = float(lat3.abs().max())
+        assert float((lat2 - lat3).abs().max()) <= 2e-3 * scale and float((lat1 * 1.5 - lat3).abs().max()) <= 2e-3 * scale
+        assert float((lat1 - lat3).abs().max()) > 0.1 * scale
         net.half().float()  # every _apply drops the captures
         assert not hasattr(net.encoder, "_graphs") or len(net.encoder._graphs) == 0
 

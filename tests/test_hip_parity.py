@@ -298,9 +298,9 @@ def test_errors_are_loud(ops, dev):
         ops.eval_ray_samples(sc, pc, torch.zeros(4, 7, device=dev), torch.zeros(4, 8, device=dev))
     with pytest.raises(KeyError):
         ops.pack_mlp({"lin_in.weight": torch.zeros(512, 42, device=dev)})
-    with pytest.raises(_lib.PixelNerfHipError):  # n_coarse beyond the sampler's static limit
-        ops.sample_fine(torch.zeros(2, 8, device=dev), torch.zeros(2, 300, device=dev), torch.zeros(2, device=dev),
-                        torch.zeros(2, 300, device=dev), torch.zeros(2, 4, device=dev), torch.zeros(2, 4, device=dev), None)
+    with pytest.raises(_lib.PixelNerfHipError):  # a ray's cdf + sample set beyond what the LDS holds (2 n_coarse + n_fine >= 10240)
+        ops.sample_fine(torch.zeros(2, 8, device=dev), torch.zeros(2, 6000, device=dev), torch.zeros(2, device=dev),
+                        torch.zeros(2, 6000, device=dev), torch.zeros(2, 4, device=dev), torch.zeros(2, 4, device=dev), None)
 
 
 def test_f16_activations_saturate_instead_of_overflowing(ops, dev):
