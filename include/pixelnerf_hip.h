@@ -57,13 +57,15 @@ typedef struct PnrScene {
 
 /* One ResnetFC (src/model/resnetfc.py:66-130) at the only shape the reference ships:
  * d_in=42, d_latent=512, d_hidden=512, n_blocks=5, combine_layer=3, d_out=4, ReLU, average
- * pooling.  nn.Linear layout: weight (out, in) row-major, bias (out). */
+ * (or max) pooling.  nn.Linear layout: weight (out, in) row-major, bias (out). */
 typedef struct PnrMlpWeights {
     const float *lin_in_w, *lin_in_b;       /* (512,42), (512)  */
     const float *lin_z_w[3], *lin_z_b[3];   /* (512,512), (512) */
     const float *fc0_w[5], *fc0_b[5];       /* blocks[b].fc_0   */
     const float *fc1_w[5], *fc1_b[5];       /* blocks[b].fc_1   */
     const float *lin_out_w, *lin_out_b;     /* (4,512), (4)     */
+    int32_t combine_max;                    /* pooling over the source views (util.combine_interleaved, util.py:461-471):
+                                               0 = "average" (every shipped config), 1 = "max" (inference entries only) */
 } PnrMlpWeights;
 
 const char *pnr_last_error(void);

@@ -257,6 +257,24 @@ def stage_goldens():
     return rec
 
 
+def combine_max_goldens():
+    """PixelNeRFNet.forward of the UNMODIFIED reference with `combine_type = "max"` on both ResnetFCs (util.combine_interleaved's
+    other branch, src/util/util.py:467-468; resnetfc.py:168-172) on the multi-view scenes' stage points (tests/golden/stages.npz
+    holds the points): the pin of the oracle's and the kernels' view maximum."""
+    st = np.load(os.path.join(ROOT, "tests", "golden", "stages.npz"))
+    rec = {}
+    for scene_name in ("dtu_mini", "mv_mini"):
+        scene, meta = synthetic.make_scene(scene_name, seed=SCENE_SEED)
+        net = build_reference_net(True)
+        net.mlp_coarse.combine_type = net.mlp_fine.combine_type = "max"
+        set_encode_state(net, scene)
+        xyz, vd = torch.from_numpy(st[f"{scene_name}_xyz"]), torch.from_numpy(st[f"{scene_name}_viewdirs"])
+        with torch.no_grad():
+            rec[f"{scene_name}_out_coarse"] = net(xyz, coarse=True, viewdirs=vd).numpy()
+            rec[f"{scene_name}_out_fine"] = net(xyz, coarse=False, viewdirs=vd).numpy()
+    return rec
+
+
 def plane_goldens():
     """Points ON and BEHIND a source camera's image plane (SURVEY App. A "known sharp edges": no frustum culling,
     `xc.z == 0` divides by zero, `xc.z > 0` mirrors; models.py:206-212,237-239) through the reference's
@@ -408,7 +426,7 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "adv_plane", "neighbours", "gradients", "manifest"])
+    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "adv_plane", "neighbours", "gradients", "combine_max", "manifest"])
     for name in names:
         if name == "manifest":
             path = os.path.join(outdir, "state_dict_manifest.txt")
@@ -416,7 +434,7 @@ def main():
             print("wrote", path)
             continue
         rec = (stage_goldens() if name == "stages" else neighbour_goldens() if name == "neighbours" else plane_goldens() if name == "adv_plane"
-               else gradient_goldens() if name == "gradients" else run_scenario(name))
+               else gradient_goldens() if name == "gradients" else combine_max_goldens() if name == "combine_max" else run_scenario(name))
         path = os.path.join(outdir, name + ".npz")
         np.savez_compressed(path, **rec)
         print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))

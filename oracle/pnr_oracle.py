@@ -113,9 +113,9 @@ def index_latent(latent, uv, image_shape):
 
 
 def resnetfc_forward(p, zx, combine_inner_dims, d_latent=512, n_blocks=5, combine_layer=3,
-                     return_hidden=False):
-    """src/model/resnetfc.py:132-184 (ReLU activations, combine_type='average',
-    use_spade=False) with ResnetBlockFC.forward (resnetfc.py:53-62) inlined.
+                     return_hidden=False, combine_type="average"):
+    """src/model/resnetfc.py:132-184 (ReLU activations, use_spade=False) with ResnetBlockFC.forward
+    (resnetfc.py:53-62) inlined; combine_type = util.combine_interleaved's agg_type (util.py:461-471).
 
     p: dict of tensors with the reference state_dict names (lin_in.weight, ...).
     zx: (rows, d_latent + d_in).  combine_inner_dims = (NS, B).
@@ -127,7 +127,8 @@ def resnetfc_forward(p, zx, combine_inner_dims, d_latent=512, n_blocks=5, combin
         if b == combine_layer:
             # util.combine_interleaved, src/util/util.py:461-471
             if not (len(combine_inner_dims) == 1 and combine_inner_dims[0] == 1):
-                x = x.reshape(-1, *combine_inner_dims, *x.shape[1:]).mean(dim=1)
+                x = x.reshape(-1, *combine_inner_dims, *x.shape[1:])
+                x = x.mean(dim=1) if combine_type == "average" else torch.max(x, dim=1)[0]  # util.py:465-468
         if d_latent > 0 and b < combine_layer:
             tz = torch.nn.functional.linear(z, p[f"lin_z.{b}.weight"], p[f"lin_z.{b}.bias"])
             x = x + tz  # resnetfc.py:175-180
@@ -151,7 +152,7 @@ def repeat_interleave(t, repeats):
     return out.reshape(-1, *t.shape[1:])
 
 
-def pixelnerf_forward(scene, mlp, xyz, viewdirs, return_hidden=False):
+def pixelnerf_forward(scene, mlp, xyz, viewdirs, return_hidden=False, combine_type="average"):
     """src/model/models.py:146-266 for the shipped configuration (use_encoder, use_xyz,
     normalize_z, use_code{6, 1.5, include_input}, use_viewdirs, not use_code_viewdirs,
     no global encoder).
@@ -180,7 +181,7 @@ def pixelnerf_forward(scene, mlp, xyz, viewdirs, return_hidden=False):
     latent = index_latent(scene["latent"], uv, scene["image_shape"])  # :213-215
     latent = latent.transpose(1, 2).reshape(-1, latent.shape[1])  # :219-221
     mlp_input = torch.cat((latent, z_feature), dim=-1)  # :227
-    out = resnetfc_forward(mlp, mlp_input, (NS, B), return_hidden=return_hidden)  # :242-255
+    out = resnetfc_forward(mlp, mlp_input, (NS, B), return_hidden=return_hidden, combine_type=combine_type)  # :242-255
     hidden = None
     if return_hidden:
         out, hidden = out

@@ -42,6 +42,7 @@ class PnrMlpWeights(ctypes.Structure):
         ("fc0_w", ctypes.c_void_p * 5), ("fc0_b", ctypes.c_void_p * 5),
         ("fc1_w", ctypes.c_void_p * 5), ("fc1_b", ctypes.c_void_p * 5),
         ("lin_out_w", ctypes.c_void_p), ("lin_out_b", ctypes.c_void_p),
+        ("combine_max", ctypes.c_int32),
     ]
 
 

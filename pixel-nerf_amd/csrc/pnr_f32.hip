@@ -557,21 +557,31 @@ __global__ void unpool_f32_kernel(const float *__restrict__ gp, float *__restric
 }
 
 // xp[p][f] = mean_v x[v*np + p][f]
-__global__ void pool_f32_kernel(const float *__restrict__ x, float *__restrict__ xp, int np, int NS) {
+__global__ void pool_f32_kernel(const float *__restrict__ x, float *__restrict__ xp, int np, int NS, int cmax) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)np * D_HID) return;
-    float s = 0.f;
-    for (int v = 0; v < NS; ++v) s += x[(size_t)v * np * D_HID + idx];
+    float s = x[idx];
+    if (cmax) {  // util.py:467-468
+        for (int v = 1; v < NS; ++v) s = fmaxf(s, x[(size_t)v * np * D_HID + idx]);
+        xp[idx] = s;
+        return;
+    }
+    for (int v = 1; v < NS; ++v) s += x[(size_t)v * np * D_HID + idx];
     xp[idx] = s / (float)NS;
 }
 
 // xp[(o*B + p)][f] = mean_v x[((o*NS + v)*B + p)][f] : util.combine_interleaved with inner dims (NS, B) (util.py:461-471)
-__global__ void pool_interleaved_f32_kernel(const float *__restrict__ x, float *__restrict__ xp, long long groups, int NS, int B) {
+__global__ void pool_interleaved_f32_kernel(const float *__restrict__ x, float *__restrict__ xp, long long groups, int NS, int B, int cmax) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= groups * B * D_HID) return;
     const long long o = idx / ((long long)B * D_HID), rem = idx - o * (long long)B * D_HID;
-    float s = 0.f;
-    for (int v = 0; v < NS; ++v) s += x[((size_t)o * NS + v) * (size_t)B * D_HID + rem];
+    float s = x[((size_t)o * NS) * (size_t)B * D_HID + rem];
+    if (cmax) {
+        for (int v = 1; v < NS; ++v) s = fmaxf(s, x[((size_t)o * NS + v) * (size_t)B * D_HID + rem]);
+        xp[idx] = s;
+        return;
+    }
+    for (int v = 1; v < NS; ++v) s += x[((size_t)o * NS + v) * (size_t)B * D_HID + rem];
     xp[idx] = s / (float)NS;
 }
 
@@ -744,7 +754,7 @@ static int eval_f32(const PnrScene *s, const PnrMlpWeights *w, EvalParams q, boo
         const float *xs = x;
         if (NS > 1) {  // util.combine_interleaved
             const long long n = (long long)np * D_HID;
-            hipLaunchKernelGGL(pool_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xp, np, NS);
+            hipLaunchKernelGGL(pool_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xp, np, NS, w->combine_max ? 1 : 0);
             xs = xp;
         }
         float *xw = (NS > 1) ? xp : x;
@@ -772,6 +782,7 @@ static int check_saved(const PnrF32Saved *sv, int NS) {
 static int eval_f32_train(const PnrScene *s, const PnrMlpWeights *w, EvalParams q, const PnrF32Saved *sv, hipStream_t stream, bool fast) {
     const Mm st = {stream, fast, nullptr, nullptr};
     if (!s || !w || !q.out) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: null argument");
+    if (w->combine_max && s->NS > 1) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: combine_type \"max\" is an inference form (no backward)");
     if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: bad scene shape");
     if (!check_saved(sv, s->NS)) return pnr_fail(PNR_E_INVALID, "pnr_eval_ray_samples_f32_train: null activation buffer in PnrF32Saved");
     if (q.P == 0) return PNR_OK;
@@ -792,7 +803,7 @@ static int eval_f32_train(const PnrScene *s, const PnrMlpWeights *w, EvalParams 
     }
     if (NS > 1) {  // util.combine_interleaved
         const long long n = (long long)np * D_HID;
-        hipLaunchKernelGGL(pool_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sv->pool_in, sv->xin[COMBINE_LAYER], np, NS);
+        hipLaunchKernelGGL(pool_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sv->pool_in, sv->xin[COMBINE_LAYER], np, NS, 0);
     }
     for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b) {
         linear(st, sv->xin[b], D_HID, w->fc0_w[b], w->fc0_b[b], sv->net[b], D_HID, np, D_HID, D_HID, true, false);
@@ -881,6 +892,7 @@ extern "C" int pnr_mlp_backward_split(const PnrMlpWeights *w, const PnrSplitSave
     using namespace pnr;
     if (!w || !g_out || !grads || !d_zlat || !workspace || !grad_scale || P <= 0 || NS <= 0)
         return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: bad argument");
+    if (w->combine_max && NS > 1) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: combine_type \"max\" is an inference form (no backward)");
     if (!check_split_saved(sv)) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: null buffer in PnrSplitSaved");
     if (workspace_bytes < pnr_mlp_backward_split_workspace_bytes(P, NS)) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: workspace too small");
     if (P * NS > 0x7fffffc0LL) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_split: too many points");
@@ -933,6 +945,7 @@ extern "C" int pnr_mlp_backward_f32(const PnrMlpWeights *w, const PnrF32Saved *s
     using namespace pnr;
     if (!w || !g_out || !grads || !d_zlat || !workspace || P <= 0 || NS <= 0)
         return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: bad argument");
+    if (w->combine_max && NS > 1) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: combine_type \"max\" is an inference form (no backward)");
     if (split_gemm && !grad_scale)
         return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: the split-operand form needs grad_scale = device [s, 1/s] (pnr_grad_scale)");
     if (!check_saved(sv, NS)) return pnr_fail(PNR_E_INVALID, "pnr_mlp_backward_f32: null activation buffer in PnrF32Saved");
@@ -999,7 +1012,7 @@ extern "C" int pnr_resnetfc_forward_f32(const PnrMlpWeights *w, const float *zx,
     float *xs = x, *ns = net;
     if (NS > 1) {  // util.combine_interleaved(x, (NS, B), "average")   resnetfc.py:168-170
         const long long n = np * D_HID;
-        hipLaunchKernelGGL(pool_interleaved_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xp, np / B, NS, B);
+        hipLaunchKernelGGL(pool_interleaved_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xp, np / B, NS, B, w->combine_max ? 1 : 0);
         xs = xp; ns = netp;
     }
     for (int b = COMBINE_LAYER; b < N_BLOCKS; ++b) {

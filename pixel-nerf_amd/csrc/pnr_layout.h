@@ -86,7 +86,8 @@ constexpr int BIAS_FLOATS_PER_WAVE = IT * 2 * 16;  // [it][h][r]
 constexpr size_t BIAS_OFFSET_BYTES = WSTREAM_BYTES;
 constexpr size_t BIAS_BYTES = (size_t)NBIAS * NW * BIAS_FLOATS_PER_WAVE * 4;
 constexpr size_t BOUT_OFFSET_BYTES = BIAS_OFFSET_BYTES + BIAS_BYTES;
-constexpr size_t PACKED_BYTES = BOUT_OFFSET_BYTES + 16;
+constexpr size_t PACKED_BYTES = BOUT_OFFSET_BYTES + 32;  // lin_out bias (4 floats) | network flags word (+ pad)
+constexpr int BOUT_FLAGS_INDEX = 4;  // 32-bit word behind lin_out's bias: bit 0 = combine_type "max" (util.py:467-468)
 
 // hidden feature held by D-register r of half h in feature tile T (global tile index 0..15)
 __host__ __device__ constexpr int feat_of(int T, int h, int r) {

@@ -177,7 +177,7 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
                                           uint32_t z_rd0, uint32_t z_rd1, uint32_t a_wr, int tid,
                                           unsigned long long *tim, unsigned long long &tlast,
                                           const EvalParams &q, size_t dump_off, const bool *valid, int wv, int lane,
-                                          uint32_t mask_off = 0, size_t mask_layer = 0, long long rows_left = 0, f32x4 *park = nullptr, bool park_first = true, bool park_last = true, float park_inv = 1.f) {
+                                          uint32_t mask_off = 0, size_t mask_layer = 0, long long rows_left = 0, f32x4 *park = nullptr, bool park_first = true, bool park_last = true, float park_inv = 1.f, bool park_max = false) {
     typedef Advance<0, FOLD ? RS_VIEW_END_F : RS_VIEW_END, FOLD ? RS_TOTAL_F : RS_TOTAL> ADV;
     constexpr int JT = TL::JT;
     // dump_off: byte offset of this lane's 32-byte slot in a (rows,512) 16-bit dump array
@@ -226,9 +226,12 @@ __device__ __forceinline__ void res_block(f32x16 (&x)[IT][TL::JT], char *smem, i
                     for (int k = 0; k < 4; ++k) {
                         const int i = (it * JT + jt) * 4 + k;
                         f32x4 v = {x[it][jt][4 * k], x[it][jt][4 * k + 1], x[it][jt][4 * k + 2], x[it][jt][4 * k + 3]};
-                        if (!park_first) v += parked[i];
+                        if (!park_first) {
+                            if (park_max) { v[0] = fmaxf(parked[i][0], v[0]); v[1] = fmaxf(parked[i][1], v[1]); v[2] = fmaxf(parked[i][2], v[2]); v[3] = fmaxf(parked[i][3], v[3]); }
+                            else v += parked[i];
+                        }
                         if (!park_last) park[i * NTHREADS] = v;
-                        else v *= park_inv;
+                        else if (!park_max) v *= park_inv;
                         x[it][jt][4 * k] = v[0]; x[it][jt][4 * k + 1] = v[1]; x[it][jt][4 * k + 2] = v[2]; x[it][jt][4 * k + 3] = v[3];
                     }
         }
@@ -300,6 +303,8 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
         // training + multi-view: the running view sum is parked (simple read-modify-write at the view boundary, as in
         // pnr_split.hip) -- with the dump bookkeeping live as well, the in-register form spilled 76 registers
         [[maybe_unused]] constexpr bool PARK_SUM = MV && TRAIN;
+        // pooling over the source views: util.combine_interleaved's mean, or (network flag word, pnr_layout.h) its "max"
+        [[maybe_unused]] const bool cmax = MV && (reinterpret_cast<const int *>(q.bout)[BOUT_FLAGS_INDEX] & 1) != 0;
         // multi-view: running view sum in 64 live registers.  The instantiation then sits at the 256-register limit and spills
         // 20-40 registers to scratch OUTSIDE the GEMM loops; the spill-free alternatives (-DPNR_MV_PARK: sum parked in an
         // L2-resident scratch, simple or prefetched under the last fc_1) measured 2.7-4 % and 4-8 % SLOWER on the same box
@@ -352,20 +357,27 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
                         for (int k = 0; k < 4; ++k) {
                             const int i = (it * JT + jt) * 4 + k;
                             f32x4 v = {x[it][jt][4 * k], x[it][jt][4 * k + 1], x[it][jt][4 * k + 2], x[it][jt][4 * k + 3]};
-                            if (!first) v = ws[i * NTHREADS] + v;  // same association as the in-register form: (v0 + v1) + ...
+                            if (!first) {  // same association as the in-register form: (v0 + v1) + ...
+                                const f32x4 prev = ws[i * NTHREADS];
+                                if (cmax) { v[0] = fmaxf(prev[0], v[0]); v[1] = fmaxf(prev[1], v[1]); v[2] = fmaxf(prev[2], v[2]); v[3] = fmaxf(prev[3], v[3]); }
+                                else v = prev + v;
+                            }
                             if (!last) ws[i * NTHREADS] = v;
-                            else v *= inv;
+                            else if (!cmax) v *= inv;
                             x[it][jt][4 * k] = v[0]; x[it][jt][4 * k + 1] = v[1]; x[it][jt][4 * k + 2] = v[2]; x[it][jt][4 * k + 3] = v[3];
                         }
                     }
             } else if constexpr (MV) {  // mean over source views (util.combine_interleaved, util.py:461-466)
-                const float inv = 1.f / (float)NS;
+                const float inv = cmax ? 1.f : 1.f / (float)NS;
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
 #pragma unroll
                     for (int jt = 0; jt < JT; ++jt) {
                         if (view == 0) xsum[it][jt] = x[it][jt];
-                        else xsum[it][jt] += x[it][jt];
+                        else if (cmax) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) xsum[it][jt][r] = fmaxf(xsum[it][jt][r], x[it][jt][r]);
+                        } else xsum[it][jt] += x[it][jt];
                         if (view + 1 == NS) x[it][jt] = xsum[it][jt] * inv;
                     }
             }

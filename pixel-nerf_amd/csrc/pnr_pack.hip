@@ -105,6 +105,7 @@ template <bool FOLD>
 __global__ void pack_bias_kernel(PnrMlpWeights p, float *__restrict__ bias, float *__restrict__ bout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < D_OUT) bout[idx] = p.lin_out_b[idx];
+    if (idx == 0) reinterpret_cast<int *>(bout)[BOUT_FLAGS_INDEX] = p.combine_max ? 1 : 0;
     if (idx >= NBIAS * NW * BIAS_FLOATS_PER_WAVE) return;
     const int r = idx & 15, h = (idx >> 4) & 1, it = (idx >> 5) % IT;
     const int wv = (idx / BIAS_FLOATS_PER_WAVE) % NW;

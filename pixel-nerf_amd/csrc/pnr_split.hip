@@ -567,8 +567,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
 
     for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
         f32x16 x[IT][JT];
-        constexpr bool MV_REGS = MV && SPLIT_MV_TILE == 32;
-        [[maybe_unused]] f32x16 xsum[MV_REGS ? IT : 1][MV_REGS ? JT : 1];
 #pragma unroll 1
         for (int view = 0; view < NS; ++view) {
             __syncthreads();  // previous tile / view: every reader of the images / IN / META is done
@@ -592,20 +590,12 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             }
 #pragma unroll 1
             for (int b = 0; b < COMBINE_LAYER; ++b) block(x, b, b + 1 < COMBINE_LAYER);
-            if constexpr (MV_REGS) {  // fixed summation order view 0 + view 1 + ...: deterministic
-                const float inv = 1.f / (float)NS;
-#pragma unroll
-                for (int it = 0; it < IT; ++it)
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt) {
-                        if (view == 0) xsum[it][jt] = x[it][jt];
-                        else xsum[it][jt] += x[it][jt];
-                        if (view + 1 == NS) x[it][jt] = xsum[it][jt] * inv;
-                    }
-            } else if constexpr (MV) {
+            if constexpr (MV) {
                 f32x4 *ws = reinterpret_cast<f32x4 *>(q.mv_ws) + (size_t)blockIdx.x * (IT * JT * 4 * NTHREADS) + tid;
                 const float inv = 1.f / (float)NS;
                 const bool first = view == 0, last = view + 1 == NS;
+                // util.combine_interleaved (util.py:461-471): mean, or -- network flag -- the maximum over the source views
+                const bool cmax = (reinterpret_cast<const int *>(q.bout)[BOUT_FLAGS_INDEX] & 1) != 0;
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
 #pragma unroll
@@ -615,9 +605,13 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
                         for (int k = 0; k < 4; ++k) {
                             const int i = (it * JT + jt) * 4 + k;
                             f32x4 v = {x[it][jt][4 * k], x[it][jt][4 * k + 1], x[it][jt][4 * k + 2], x[it][jt][4 * k + 3]};
-                            if (!first) v = ws[i * NTHREADS] + v;  // 1 KiB per wave-instruction
+                            if (!first) {  // 1 KiB per wave-instruction
+                                const f32x4 prev = ws[i * NTHREADS];
+                                if (cmax) { v[0] = fmaxf(prev[0], v[0]); v[1] = fmaxf(prev[1], v[1]); v[2] = fmaxf(prev[2], v[2]); v[3] = fmaxf(prev[3], v[3]); }
+                                else v = prev + v;
+                            }
                             if (!last) ws[i * NTHREADS] = v;
-                            else v *= inv;
+                            else if (!cmax) v *= inv;
                             x[it][jt][4 * k] = v[0]; x[it][jt][4 * k + 1] = v[1]; x[it][jt][4 * k + 2] = v[2]; x[it][jt][4 * k + 3] = v[3];
                         }
                     }

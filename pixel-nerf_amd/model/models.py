@@ -133,6 +133,12 @@ class PixelNeRFNet(torch.nn.Module):
                 "uses (conf/default.conf + default_mv.conf: use_encoder, use_xyz, normalize_z, "
                 "code{6,1.5,include_input}, use_viewdirs, use_code_viewdirs=False, latent 512)")
 
+    def _check_trainable(self):
+        """the differentiable paths pool the source views with the mean (every shipped config); "max" has inference kernels only"""
+        if int(self.num_views_per_obj) > 1 and any(m is not None and m.combine_type != "average" for m in (self.mlp_coarse, self.mlp_fine)):
+            raise NotImplementedError("training with combine_type='max' on a multi-view scene is not implemented (the view maximum "
+                                      "has inference kernels only; every shipped config pools with 'average')")
+
     def scene(self):
         """ops.Scene for the current encode() state (rebuilt only when that state changed)."""
         lat = self.encoder.latent
@@ -248,6 +254,7 @@ class PixelNeRFNet(torch.nn.Module):
         if SB != sc.SB:
             raise ValueError(f"xyz has {SB} objects but encode() saw {sc.SB}")
         if self._wants_grad():  # differentiable twin: training kernels + HIP backward (parameters and latent grid)
+            self._check_trainable()
             if self._effective_precision() not in ("f16", "bf16", "f32", "f16x3"):
                 raise NotImplementedError("training precisions: 'f16' / 'bf16' (fused 16-bit kernels), 'f16x3' (fp32-class split-operand "
                                           "GEMMs) or 'f32' (exact fp32 validation path)")

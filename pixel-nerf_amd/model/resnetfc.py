@@ -86,8 +86,13 @@ class ResnetFC(nn.Module):
     def supported(self):
         """The one shape the fused kernel implements = the one shape the reference ships."""
         return (self.d_in == 42 and self.d_out == 4 and self.n_blocks == 5 and self.d_latent == 512
-                and self.d_hidden == 512 and self.combine_layer == 3 and self.combine_type == "average"
+                and self.d_hidden == 512 and self.combine_layer == 3 and self.combine_type in ("average", "max")
                 and not self.use_spade)
+
+    def _combine_max(self):
+        """util.combine_interleaved's agg_type (src/util/util.py:461-471): "average" in every shipped config; "max" is carried as
+        a flag word of the packed network and applied where the kernels pool the source views (inference entries)"""
+        return self.combine_type == "max"
 
     _CACHE_KEYS = ("_named_cache", "_ordered_cache", "_wstruct_cache", "_content")
 
@@ -145,15 +150,15 @@ class ResnetFC(nn.Module):
 
     def _fingerprint(self):
         named = self._named()
-        return (self.__dict__.get("_opt_steps", 0), self.__dict__.get("_epoch", 0)) + tuple((p.data_ptr(), p._version) for _, p in named)
+        return (self.__dict__.get("_opt_steps", 0), self.__dict__.get("_epoch", 0), self.combine_type) + tuple((p.data_ptr(), p._version) for _, p in named)
 
     def _wstruct(self):
         """(PnrMlpWeights, tensors) of the current parameter storage: the struct holds pointers only, so it survives
         in-place updates and is rebuilt only when a parameter moved."""
-        key = tuple(p.data_ptr() for _, p in self._named())
+        key = tuple(p.data_ptr() for _, p in self._named()) + (self._combine_max(),)
         c = self.__dict__.get("_wstruct_cache")
         if c is None or c[0] != key:
-            c = (key, ops._weights_struct({k: p for k, p in self._named()}))
+            c = (key, ops._weights_struct({k: p for k, p in self._named()}, self._combine_max()))
             self.__dict__["_wstruct_cache"] = c
         return c[1]
 
@@ -223,7 +228,7 @@ class ResnetFC(nn.Module):
         if not self.supported():
             raise NotImplementedError(
                 "fused HIP network supports d_in=42, d_latent=512, d_hidden=512, n_blocks=5, "
-                "combine_layer=3, combine_type=average (conf/default_mv.conf); got a different ResnetFC")
+                "combine_layer=3, combine_type average | max (conf/default_mv.conf); got a different ResnetFC")
         return self._cached((precision, bool(folded)), precision,
                             lambda out: ops.pack_mlp(None, precision, folded=folded, weights=self._wstruct(), out=out))
 
@@ -259,7 +264,7 @@ class ResnetFC(nn.Module):
         assert zx.size(-1) == self.d_latent + self.d_in
         dims = tuple(int(d) for d in combine_inner_dims)
         flat = zx.reshape(-1, zx.shape[-1])
-        out = ops.resnetfc_forward(dict(self.state_dict()), flat, dims)
+        out = ops.resnetfc_forward(dict(self.state_dict()), flat, dims, combine_max=self._combine_max())
         if dims == (1,):
             return out.reshape(*zx.shape[:-1], self.d_out)
         # util.combine_interleaved: (-1, NS, B, ...) mean over dim 1 -> (-1, B, ...)   util.py:461-471

@@ -70,7 +70,9 @@ def _f32_workspace(lib, scene, P):
     return torch.empty(nbytes, dtype=torch.uint8, device=scene.device), nbytes
 
 
-def _weights_struct(state):
+def _weights_struct(state, combine_max=False):
+    """-> (PnrMlpWeights of the tensors' device pointers, the tensors).  combine_max: the network pools its source views with
+    util.combine_interleaved's "max" instead of the mean (src/util/util.py:461-471; ResnetFC.combine_type)."""
     keep = {}
     for k in _MLP_KEYS:
         if k not in state:
@@ -89,10 +91,11 @@ def _weights_struct(state):
         w.fc0_b[b] = keep[f"blocks.{b}.fc_0.bias"].data_ptr()
         w.fc1_w[b] = keep[f"blocks.{b}.fc_1.weight"].data_ptr()
         w.fc1_b[b] = keep[f"blocks.{b}.fc_1.bias"].data_ptr()
+    w.combine_max = 1 if combine_max else 0
     return w, keep
 
 
-def pack_mlp(state, precision="f16", backward=False, folded=False, weights=None, out=None):
+def pack_mlp(state, precision="f16", backward=False, folded=False, weights=None, out=None, combine_max=False):
     """state: {reference ResnetFC state_dict key: float32 HIP tensor}
     (src/model/resnetfc.py:66-130: lin_in, lin_out, blocks.N.fc_0/fc_1, lin_z.N).
     backward=True packs the transposed streams of the data-gradient chain instead;
@@ -101,7 +104,7 @@ def pack_mlp(state, precision="f16", backward=False, folded=False, weights=None,
     are updated in place); out: a PackedMLP of the same form whose buffer is overwritten (same stream: ordered)."""
     lib = _lib.load()
     prec = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
-    w, keep = weights if weights is not None else _weights_struct(state)
+    w, keep = weights if weights is not None else _weights_struct(state, combine_max)
     if prec == _lib.PREC_F32:
         if backward:
             raise _lib.PixelNerfHipError("precision='f32' has no backward path")
@@ -288,7 +291,7 @@ def eval_ray_samples(scene, packed, rays, z, tables=None):
 RESNETFC_CHUNK_ROWS = 1 << 17  # rows per launch set of resnetfc_forward (workspace 0.5 GB)
 
 
-def resnetfc_forward(state, zx, combine_inner_dims=(1,)):
+def resnetfc_forward(state, zx, combine_inner_dims=(1,), combine_max=False):
     """ResnetFC.forward on explicit rows (src/model/resnetfc.py:132-184): zx (rows, 554) fp32 = [latent | code+viewdir],
     combine_inner_dims = (1,) or (NS, B) with rows ordered [group][view][point]; returns lin_out's raw output
     (rows / NS, 4).  Unfused fp32 linears (the exact-fp32 path's kernels); whole (NS, B) groups per launch set."""
@@ -306,7 +309,7 @@ def resnetfc_forward(state, zx, combine_inner_dims=(1,)):
         raise ValueError("resnetfc_forward: combine_inner_dims must be (1,) or (NS, B)")
     if rows % (NS * B) != 0:
         raise ValueError("resnetfc_forward: rows must be a multiple of NS * B")
-    w, keep = _weights_struct(state)
+    w, keep = _weights_struct(state, combine_max)
     out = torch.empty((rows // NS, 4), dtype=torch.float32, device=zx.device)
     group = NS * B
     step = max(group, RESNETFC_CHUNK_ROWS // group * group)

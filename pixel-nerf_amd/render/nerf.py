@@ -186,6 +186,7 @@ class NeRFRenderer(torch.nn.Module):
                                           "the reference adds the noise only while training (nerf.py:225-226)")
             if needs_grad:  # training: differentiable path (HIP forward with operand dumps + HIP backward)
                 from ..autograd import render_autograd
+                model._check_trainable()
                 if noise is None:
                     noise = self._draw_noise(R, rays.device)
                 guarded = model._guard_begin(training=True)

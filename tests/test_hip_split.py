@@ -240,3 +240,55 @@ def test_renderer_warns_once_when_a_checkpoint_leaves_the_fp16_range(dev):
         torch.cuda.synchronize()
         with pytest.warns(RuntimeWarning, match=r"fine network: .*blocks\.1\.fc_0"):
             rend(net, rays.to(dev), _noise=nz)
+
+
+# ---------------------------------------------------------------- combine_type = "max" (util.py:467-468)
+@pytest.mark.parametrize("scene_name", ["dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("precision,bar_rgb,bar_sigma", [("f16x3", 2e-5, 1e-4), ("f32", 2e-5, 1e-4), ("f16", 6e-3, 2e-2)])
+def test_view_maximum_matches_reference(ops, dev, scene_name, precision, bar_rgb, bar_sigma):
+    """the reference with both ResnetFCs at combine_type "max" (tests/golden/combine_max.npz, frozen from the unmodified reference):
+    the flag word of the packed network switches the pooled tile of every inference kernel from the view mean to the view maximum"""
+    g, gm = load_golden("stages"), load_golden("combine_max")
+    sc = dscene(ops, dev, scene_name)
+    xyz = torch.from_numpy(g[f"{scene_name}_xyz"]).to(dev)
+    vd = torch.from_numpy(g[f"{scene_name}_viewdirs"]).to(dev)
+    for which, seed in (("coarse", 11), ("fine", 12)):
+        state = {k: v.to(dev) for k, v in mlp_params(seed).items()}
+        if precision == "f32":
+            out = ops.eval_points(sc, ops.pack_mlp(state, "f32", combine_max=True), xyz, vd)
+        else:
+            out = ops.eval_points(sc, ops.pack_mlp(state, precision, folded=True, combine_max=True), xyz, vd,
+                                  tables=ops.fold_latent(sc, state, precision))
+        out = out.cpu().numpy()
+        ref = gm[f"{scene_name}_out_{which}"]
+        e_rgb = np.abs(out[..., :3] - ref[..., :3]).max()
+        e_s = (np.abs(out[..., 3] - ref[..., 3]) / np.maximum(1.0, ref[..., 3])).max()
+        print(f"view maximum {scene_name} {which} {precision}: rgb max err {e_rgb:.3e}, sigma rel err {e_s:.3e}")
+        assert e_rgb <= bar_rgb and e_s <= bar_sigma
+        assert np.abs(out - g[f"{scene_name}_out_{which}"]).max() > 0.5  # not the view mean
+
+
+def test_view_maximum_through_the_model_api_and_training_guard(dev):
+    """make_model(conf) with mlp.combine_type = "max": renders through NeRFRenderer equal the oracle's; training raises"""
+    from pixelnerf_amd.render import NeRFRenderer
+    from test_api_gpu import build_net
+    g, scene, meta, mc, mf, rays, noise = golden_setup("srn_mini_64_128")
+    net = build_net(dev, scene, precision="f16x3")
+    net.mlp_coarse.combine_type = net.mlp_fine.combine_type = "max"
+    rend = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=True).to(dev).eval()
+    nz = {k: v.to(dev) for k, v in noise.items()}
+    with torch.no_grad():
+        out = rend(net, rays.to(dev), _noise=nz)
+    R = rays.shape[0] * rays.shape[1]
+    z_c = O.sample_coarse(rays.reshape(-1, 8), noise["u1"], 64)
+    pts = (rays.reshape(-1, 8)[:, None, :3] + z_c.unsqueeze(2) * rays.reshape(-1, 8)[:, None, 3:6]).reshape(scene["SB"], -1, 3)
+    vdr = rays.reshape(-1, 8)[:, None, 3:6].expand(-1, 64, -1).reshape(scene["SB"], -1, 3)
+    with torch.no_grad():
+        o = O.pixelnerf_forward(scene, mc, pts, vdr, combine_type="max").reshape(R, 64, 4)
+    _, rgb_ref, _ = O.composite_from_rgbsigma(rays.reshape(-1, 8), z_c, o, True)
+    assert (out.coarse.rgb.cpu().reshape(-1, 3) - rgb_ref).abs().max() <= 2e-5
+    assert (out.coarse.rgb.cpu().reshape(-1, 3) - torch.from_numpy(g["coarse_rgb"]).reshape(-1, 3)).abs().max() > 1e-2  # not the mean
+    net.train()
+    net.mlp_coarse.lin_in.weight.requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="combine_type='max'"):
+        rend.train()(net, rays.to(dev), _noise=nz)

@@ -30,10 +30,10 @@ def test_library_exports_every_declared_symbol(lib, repo_root):
 
 
 def test_struct_layouts_match_header():
-    # PnrScene: 4 pointers, 6 int32, 2 floats; PnrMlpWeights: 30 pointers; dumps: 13 / 13 pointers (11 dY dumps + d_zlat + d_in)
+    # PnrScene: 4 pointers, 6 int32, 2 floats; PnrMlpWeights: 30 pointers + the combine_max flag (padded to 8); dumps: 13 / 13 pointers (11 dY dumps + d_zlat + d_in)
     assert ctypes.sizeof(_lib.PnrTrainDumps) == 14 * 8 and ctypes.sizeof(_lib.PnrBackwardDumps) == 13 * 8
     assert ctypes.sizeof(_lib.PnrScene) == 4 * 8 + 6 * 4 + 2 * 4
-    assert ctypes.sizeof(_lib.PnrMlpWeights) == 30 * 8
+    assert ctypes.sizeof(_lib.PnrMlpWeights) == 30 * 8 + 8
 
 
 def test_struct_layouts_against_the_header_compiled_by_gcc(repo_root, tmp_path):

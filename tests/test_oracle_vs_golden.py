@@ -45,6 +45,22 @@ def test_pixelnerf_forward_matches_reference(scene_name):
         np.testing.assert_allclose(out[..., 3].numpy(), ref[..., 3], rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("scene_name", ["dtu_mini", "mv_mini"])
+def test_pixelnerf_forward_with_max_pooling_matches_reference(scene_name):
+    """combine_type = "max" (src/util/util.py:467-468): the reference's own outputs with both ResnetFCs switched to the view
+    maximum (tests/golden/combine_max.npz) -- and they differ from the view mean by O(1), so the branch is really exercised"""
+    g, gm = load_golden("stages"), load_golden("combine_max")
+    scene, _ = scene_for(scene_name)
+    xyz = torch.from_numpy(g[f"{scene_name}_xyz"])
+    vd = torch.from_numpy(g[f"{scene_name}_viewdirs"])
+    for which, seed in (("coarse", 11), ("fine", 12)):
+        out = O.pixelnerf_forward(scene, mlp_params(seed), xyz, vd, combine_type="max")
+        ref = gm[f"{scene_name}_out_{which}"]
+        np.testing.assert_allclose(out.numpy()[..., :3], ref[..., :3], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out.numpy()[..., 3], ref[..., 3], rtol=1e-5, atol=2e-5)
+        assert np.abs(ref - g[f"{scene_name}_out_{which}"]).max() > 0.5
+
+
 def test_points_on_and_behind_a_camera_plane_match_reference():
     """models.py:206-212 has no frustum culling: camera-space z == 0 gives u = x/0 = +-inf (border clamp) or 0/0 = NaN,
     which ATen's grid_sample maps to coordinate 0; z > 0 mirrors.  The reference's outputs on such points are finite and
