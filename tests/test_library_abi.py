@@ -82,8 +82,8 @@ def test_host_only_entry_points(lib):
     major, minor = ctypes.c_int(-1), ctypes.c_int(-1)
     assert lib.pnr_version(ctypes.byref(major), ctypes.byref(minor)) == 0
     assert (major.value, minor.value) == (0, 1)
-    # packed stream: 8 waves x 424 ring steps x 2 fragments x 1 KiB + biases + b_out
-    assert lib.pnr_packed_mlp_bytes() == 8 * 424 * 2 * 1024 + 11 * 8 * 64 * 4 + 16
+    # packed stream: 8 waves x 424 ring steps x 2 fragments x 1 KiB + biases + (b_out, network flags word, pad)
+    assert lib.pnr_packed_mlp_bytes() == 8 * 424 * 2 * 1024 + 11 * 8 * 64 * 4 + 32
     assert lib.pnr_render_workspace_bytes(0, 64, 128) == 0
     # backward stream: head 132 + per view (6 block GEMMs + 3 lin_z^T) x 32 + lin_in^T 4 = 424 ring steps
     assert lib.pnr_packed_mlp_bwd_bytes() == 8 * 424 * 2 * 1024

@@ -9,6 +9,7 @@ case "$PREC" in f16x3) KERNEL=eval_split_kernel ;; *) KERNEL=eval_kernel ;; esac
 OUT="$REPO/gpurun_out/pmc_$PREC"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export PIXELNERF_SATURATION_GUARD=off  # every launch of the profiled process is the plain instantiation (the guard runs once per new weights otherwise)
 CMD="python $REPO/bench.py --prec $PREC --steps 2 --warmup 1 --no-peer --no-latency --no-cpu-baseline --no-eager-baseline --no-f32-check --no-extras $*"
 run() {  # name, counters...
     local name=$1; shift

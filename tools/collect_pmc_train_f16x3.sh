@@ -7,6 +7,7 @@ REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$REPO/gpurun_out/pmc_train_f16x3"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export PIXELNERF_SATURATION_GUARD=off
 CMD="python $REPO/tools/gpu_train_f16x3_quick.py"
 run() { local name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -o "pmc_$name" -- $CMD > "$OUT/$name.log" 2>&1; }
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
@@ -21,7 +22,7 @@ for path in sorted(glob.glob(os.path.join(out, "**", "*counter_collection.csv"),
     per = {}
     for row in csv.DictReader(open(path)):
         k = row["Kernel_Name"]
-        if not any(s in k for s in ("dw_split_kernel", "bwd_split_kernel", "eval_split_kernel", "latent_scatter", "fold_kernel", "gemm3")):
+        if not any(s in k for s in ("dw_split_kernel", "bwd_split_kernel", "eval_split_kernel", "latent_scatter", "fold_kernel", "fold_split_kernel", "gemm3", "lin_out_grad_f32")):
             continue
         name = k.split("(")[0].replace("void pnr::", "")[:60]
         per.setdefault((name, row["Counter_Name"]), {}).setdefault(row["Dispatch_Id"], 0.0)
