@@ -279,11 +279,15 @@ def composite(scene, mlp, rays, z_samp, sb, white_bkgd, sigma_noise=None, eval_b
 
 
 def render(scene, mlp_coarse, mlp_fine, rays, noise, n_coarse, n_fine, n_fine_depth,
-           depth_std=0.01, white_bkgd=False, lindisp=False, detach_depth=False, sigma_noise=None, eval_batch_size=None):
+           depth_std=0.01, white_bkgd=False, lindisp=False, detach_depth=False, sigma_noise=None, eval_batch_size=None,
+           sampling_weights=None):
     """src/render/nerf.py:251-303.  rays (SB, B, 8); noise = dict(u1,u2,u3,n4) (missing keys
     allowed when the corresponding stage is skipped).  Returns a nested dict
     {coarse:{rgb,depth,weights,z,rgbsigma}, fine:{...}}; `fine` absent when n_fine == 0.
-    mlp_fine=None falls back to mlp_coarse (models.py:242)."""
+    mlp_fine=None falls back to mlp_coarse (models.py:242).
+    sampling_weights (R,Kc): coarse weights to draw the importance samples from instead of this run's own (which are detached
+    there anyway, nerf.py:288) -- a comparison with another implementation hands over ITS coarse weights so that both sides land
+    in the same cdf bins (the bin index is a discontinuous function of the weights: a 1-ulp difference can move a sample)."""
     assert rays.dim() == 3  # :269
     SB = rays.shape[0]
     rays = rays.reshape(-1, 8)
@@ -304,7 +308,7 @@ def render(scene, mlp_coarse, mlp_fine, rays, noise, n_coarse, n_fine, n_fine_de
         all_samps = [z_coarse]
         if n_fine - n_fine_depth > 0:
             all_samps.append(
-                sample_fine(rays, wc.detach(), noise["u2"], noise["u3"], n_coarse, lindisp)
+                sample_fine(rays, wc.detach() if sampling_weights is None else sampling_weights, noise["u2"], noise["u3"], n_coarse, lindisp)
             )  # :286-289
         if n_fine_depth > 0:
             # the reference passes the NON-detached coarse depth here (:292); detach_depth=True
