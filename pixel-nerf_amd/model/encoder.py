@@ -123,7 +123,7 @@ class SpatialEncoder(nn.Module):
     # (`__getstate__`, which copy.deepcopy and pickle both go through: a CUDAGraph is a process-local handle).
     use_graph = True
     MAX_GRAPHS = 4
-    _TRANSIENT = ("_graphs", "latents", "_nhwc")  # per-process caches: rebuilt on demand, never part of a copy / checkpoint
+    _TRANSIENT = ("_graphs", "latents", "_nhwc", "_scaling_cache")  # per-process caches: rebuilt on demand, never part of a copy / checkpoint
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -133,6 +133,7 @@ class SpatialEncoder(nn.Module):
         return state
 
     def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_scaling_cache", None)
         self.__dict__.pop("_graphs", None)  # the captured launches point at the storages `fn` is about to replace
         return super()._apply(fn, *args, **kwargs)
 
@@ -231,9 +232,14 @@ class SpatialEncoder(nn.Module):
 
     def _set_scaling(self):
         """pixel -> normalised-coordinate factors of the grid, (W, H) / (W - 1, H - 1) * 2 (encoder.py:161-163)"""
-        wh = torch.tensor([float(self.latent.shape[-1]), float(self.latent.shape[-2])], dtype=torch.float32,
-                          device=self.latent_scaling.device)
-        self.latent_scaling = wh / (wh - 1.0) * 2.0
+        # a pure function of the grid size: built once per (size, device) -- a host -> device copy per encode would put a
+        # synchronising transfer into an otherwise launch-only (HIP-graph replayed) inference encode
+        key = (int(self.latent.shape[-1]), int(self.latent.shape[-2]), str(self.latent_scaling.device))
+        cache = self.__dict__.setdefault("_scaling_cache", {})
+        if key not in cache:
+            wh = torch.tensor([float(key[0]), float(key[1])], dtype=torch.float32, device=self.latent_scaling.device)
+            cache[key] = wh / (wh - 1.0) * 2.0
+        self.latent_scaling = cache[key].clone()
 
     def latent_nhwc(self):
         """Channel-last copy of `latent` for the fused kernel (one bilinear corner = one
