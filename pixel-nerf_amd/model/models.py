@@ -214,17 +214,17 @@ class PixelNeRFNet(torch.nn.Module):
         if not due:
             return False
         self.__dict__["_guard_key"] = key
-        ops.saturation_guard_arm(lat.device)
+        ops.saturation_guard_arm(lat.device, owner=id(self))
         return True
 
     def _guard_end(self):
-        ops.saturation_guard_disarm(self.encoder.latent.device)
+        ops.saturation_guard_disarm(self.encoder.latent.device, owner=id(self))
 
     def _guard_report(self, wait=False):
         lat = self.encoder.latent
         if not (torch.is_tensor(lat) and lat.is_cuda):
             return None
-        got = ops.saturation_guard_poll(lat.device, wait=wait)
+        got = ops.saturation_guard_poll(lat.device, wait=wait, owner=id(self))
         if got is not None and (got[0] or got[1]):
             parts = [f"{name} network: {ops.describe_saturation(b)}" for name, b in (("coarse", got[0]), ("fine", got[1])) if b]
             warnings.warn("pixelnerf_amd (precision 'f16x3'): hidden activations reached the fp16 range limit of 65504 -- "
@@ -232,6 +232,12 @@ class PixelNeRFNet(torch.nn.Module):
                           "tolerance of the reference; use make_model(conf, precision='f32') (exact, slower) for this checkpoint.",
                           RuntimeWarning, stacklevel=3)
         return got
+
+    def __del__(self):
+        try:
+            ops.saturation_guard_release(id(self))
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def _wants_grad(self):
         lat = getattr(self.encoder, "latent", None)

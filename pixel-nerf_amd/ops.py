@@ -643,34 +643,43 @@ SAT_LAYER_NAMES = ([f"relu(x) entering blocks.{b}.fc_0" if i == 0 else f"relu(ne
                    + ["the stream in front of lin_out", "a non-finite network output", "the feature grid / lin_z weights of the per-texel fold"])
 
 
-def _sat_state(device):
+def _sat_state(device, owner=None):
+    """flag words + their pinned host copy, per (device, owner): two networks on one device do not read each other's verdicts"""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    st = _SAT.get(idx)
+    key = (idx, owner)
+    st = _SAT.get(key)
     if st is None:
         st = dict(flags=torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", idx)),
                   host=torch.zeros(2, dtype=torch.int32).pin_memory(), event=None, armed=False)
-        _SAT[idx] = st
+        _SAT[key] = st
     return st
 
 
-def saturation_guard_arm(device):
+def saturation_guard_release(owner):
+    """drop the guard state of an owner that goes away (PixelNeRFNet.__del__)"""
+    for key in [k for k in _SAT if k[1] == owner]:
+        _SAT.pop(key, None)
+
+
+def saturation_guard_arm(device, owner=None):
     """arm the guard for the launches this host thread makes next on `device` (until saturation_guard_disarm)"""
-    st = _sat_state(device)
+    st = _sat_state(device, owner)
     _lib.check(_lib.load().pnr_saturation_guard(_p(st["flags"])), "pnr_saturation_guard")
     st["armed"] = True
 
 
-def saturation_guard_slot(device, slot):
+def saturation_guard_slot(device, slot, owner=None):
     """while armed: direct network launches (pnr_eval_*_split*) report into word `slot` (0 = coarse network, 1 = fine network);
     the render entries pick the word themselves"""
-    st = _sat_state(device)
-    if st["armed"]:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = next((v for (d, o), v in _SAT.items() if d == idx and v["armed"]), None) if owner is None else _sat_state(device, owner)
+    if st is not None and st["armed"]:
         _lib.check(_lib.load().pnr_saturation_guard(ctypes.c_void_p(st["flags"].data_ptr() + 4 * (1 if slot else 0))), "pnr_saturation_guard")
 
 
-def saturation_guard_disarm(device):
+def saturation_guard_disarm(device, owner=None):
     """disarm, and send the flag words on their way to the host (asynchronous; saturation_guard_poll reads them)"""
-    st = _sat_state(device)
+    st = _sat_state(device, owner)
     _lib.check(_lib.load().pnr_saturation_guard(None), "pnr_saturation_guard")
     if st["armed"]:
         st["armed"] = False
@@ -681,10 +690,10 @@ def saturation_guard_disarm(device):
             st["event"].record()
 
 
-def saturation_guard_poll(device, wait=False):
+def saturation_guard_poll(device, wait=False, owner=None):
     """-> (bits of the coarse-network launches, bits of the fine-network launches) of the guarded calls whose flag copy has
     arrived since the last poll, or None when nothing is pending / the copy is still in flight (wait=True blocks for it)"""
-    st = _sat_state(device)
+    st = _sat_state(device, owner)
     ev = st["event"]
     if ev is None:
         return None
