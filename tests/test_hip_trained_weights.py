@@ -205,7 +205,8 @@ def test_gradient_parity_at_trained_weights(dev, trained):
     out = rend(net, rays.to(dev), want_weights=True, _noise={k: v.to(dev) for k, v in noise.items()})
     # the importance samples are a discontinuous function of the (detached) coarse weights, and trained densities are sharp: the
     # CPU side draws them from the HIP path's coarse weights, so a 1-ulp difference cannot put a sample -- and its share of the
-    # grid gradient -- into the neighbouring bin (a run without this measured 5.7e-3 on the latent gradient, 1e-4 elsewhere)
+    # grid gradient -- into the neighbouring bin on one side only (one run without this measured 5.7e-3 on the latent gradient of
+    # the two-view scene, 1e-4 elsewhere; the diagnostic below counts the samples the oracle's own weights would move)
     ref = O.render(sc, pc, pf, rays, noise, 64, 32, 16, white_bkgd=True,
                    sampling_weights=out.coarse.weights.detach().cpu().reshape(SB * B, 64))
     ref_loss = ((ref["coarse"]["rgb"] - gt) ** 2).mean() + ((ref["fine"]["rgb"] - gt) ** 2).mean()
