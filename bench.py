@@ -29,6 +29,9 @@ The JSON line also carries
   roofline     : the fused network kernel (>= 99 % of the work) against the dense f16 MFMA peak: algorithmic FLOP of the
                  launches in the timed region / their HIP-event time on the launch stream; executed_mfma_tflops counts the
                  MFMAs really issued (3 per product for f16x3, lin_z folded away); traffic from the committed PMC passes;
+  torch_eager_gpu_baseline : the same algorithm in eager PyTorch-ROCm fp32 on this GPU (oracle restatement), in the reference's
+                 execution shape -- 50 000-ray batches, 50 000-point model calls (eval/eval.py:137,264; nerf.py:190-216) -- and,
+                 under ..._unchunked_16384, as one model call per pass; speedup_vs_torch_eager_gpu refers to the former;
   cpu_baseline : the CPU restatement of the reference (oracle, kind "port", F.grid_sample like the reference) timed on this
                  host's cores on a bounded sample of the same workload, rank 0 / N=1 only; cpu_baseline_config1 =
                  BASELINE configs[0] verbatim (32 coarse, no fine pass, one 4096-ray call, CPU);

@@ -15,8 +15,13 @@
 // Folded form; 64-point tiles (several source views: the view sum parked in a per-workgroup scratch).  The unfused fp32-MFMA
 // path (pnr_f32.hip) remains the implementation-independent yardstick.
 //
+// Round 4: every 512-wide linear starts with the products against the wave's OWN 64 features, taken from its accumulators (they
+// are B fragments as they are), while the same fragments go to the operand images for the other waves: stage_own / gemm_split_rot.
+//
 // Kernels of this file:
-//   eval_split_kernel<RAYS, MV, TIMING, TRAIN>   the fused network.  TRAIN = the fp32-class TRAINING forward: the same launch also
+//   eval_split_kernel<RAYS, MV, TIMING, TRAIN, GUARD>   the fused network.  GUARD = the fp16-range guard (pnr_saturation_guard): the
+//                                                same bits, plus one flag bit per layer whose operand image received a value >= 65504.
+//                                                TRAIN = the fp32-class TRAINING forward: the same launch also
 //                                                copies every wide linear's (head, tail) operand image out of LDS (relu(x) /
 //                                                relu(net): the operands of the weight gradients), writes 1-bit relu masks and
 //                                                the stream in front of lin_out; the inference instantiations compile to the

@@ -166,14 +166,15 @@ def test_spatial_encoder_index_operator_matches_reference(dev, name):
     assert torch.equal(one[0], got[0]) and torch.equal(nrm, got)
 
 
-def test_spatial_encoder_index_operator_gradients(dev):
+@pytest.mark.parametrize("NV,C,H,W,N", [(2, 128, 9, 13, 200), (3, 70, 5, 7, 130), (1, 512, 2, 2, 1)])  # ragged channel / point counts too
+def test_spatial_encoder_index_operator_gradients(dev, NV, C, H, W, N):
     """gradients of the stand-alone lookup to the grid and to the coordinates against torch autograd through F.grid_sample
     (what the reference's index() differentiates through), interior and clamped points"""
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(2)
-    lat = torch.randn(2, 128, 9, 13, generator=gen)
-    uv = torch.rand(2, 200, 2, generator=gen) * 2.6 - 1.3  # a fifth of the points beyond the border
-    gw = torch.randn(2, 128, 200, generator=gen)
+    lat = torch.randn(NV, C, H, W, generator=gen)
+    uv = torch.rand(NV, N, 2, generator=gen) * 2.6 - 1.3  # a fifth of the points beyond the border
+    gw = torch.randn(NV, C, N, generator=gen)
     a, b = lat.clone().requires_grad_(True), uv.clone().requires_grad_(True)
     ref = F.grid_sample(a, b.unsqueeze(2), align_corners=True, mode="bilinear", padding_mode="border")[..., 0]
     (ref * gw).sum().backward()
@@ -183,6 +184,6 @@ def test_spatial_encoder_index_operator_gradients(dev):
     enc.latent = la
     got = enc.index(ub)
     (got * gw.to(dev)).sum().backward()
-    assert (got.detach().cpu() - ref.detach()).abs().max() <= 2e-6 * float(ref.abs().max())
+    assert (got.detach().cpu() - ref.detach()).abs().max() <= 2e-6 * float(ref.detach().abs().max())
     assert (la.grad.cpu() - a.grad).abs().max() <= 1e-5 * max(1.0, float(a.grad.abs().max()))
     assert (ub.grad.cpu() - b.grad).abs().max() <= 2e-5 * max(1.0, float(b.grad.abs().max()))
