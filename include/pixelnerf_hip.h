@@ -185,6 +185,29 @@ size_t pnr_resnetfc_forward_f32_workspace_bytes(long long rows, int NS);
 int pnr_resnetfc_forward_f32(const PnrMlpWeights *w /*host*/, const float *zx, long long rows, int NS, int B, float *out,
                              void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- nn.Linear as a stand-alone operator pair ----------------------------------------------------
+ * One `nn.Linear` of ResnetFC / ResnetBlockFC (src/model/resnetfc.py:53-62: fc_0, fc_1, shortcut; :147,175-183: lin_in, lin_z,
+ * scale_z, lin_out) with the ReLU in front of it and the residual behind it folded in, for ANY rows / d_in / d_out: the
+ * operator the host side composes ResnetFCs of NON-shipped shapes from (the shipped 42+512 -> 512 x 5 -> 4 shape runs in the
+ * fused kernels above).
+ *   Y (rows, d_out) = [Yin +] [relu](X (rows, d_in)) W^T + b      W (d_out, d_in) as nn.Linear stores it; b, Yin nullable;
+ *                                                                 Yin may alias Y
+ * precision PNR_PREC_F32: exact fp32 products (v_mfma_f32_32x32x2_f32); PNR_PREC_F16X3: fp32-class split operands on the f16
+ * matrix cores (~6x faster, the arithmetic of the fused fp32-class kernels). */
+int pnr_linear(const float *X, const float *W, const float *b /*nullable*/, const float *Yin /*nullable*/, float *Y, long long rows,
+               int d_in, int d_out, int relu_in, int precision, void *stream);
+/* its backward (what torch autograd derives for the lines above):
+ *   dX (rows, d_in)  = (dY W) . [X > 0 if relu_in]      (nullable)
+ *   dW (d_out, d_in) = dY^T [relu](X),  db (d_out) = sum_rows dY      (nullable; db only together with dW)
+ * The reduction over the rows is split into fixed slices summed in a fixed order (bit-reproducible, no atomics):
+ * workspace = pnr_linear_backward_workspace_bytes(d_in, d_out), needed when dW is requested.
+ * PNR_PREC_F16X3 carries dY as fp16 (head, tail) pairs at a power-of-two scale: grad_scale = device [s, 1/s] from
+ * pnr_grad_scale(dY) (required for that precision, ignored for PNR_PREC_F32). */
+size_t pnr_linear_backward_workspace_bytes(int d_in, int d_out);
+int pnr_linear_backward(const float *dY, const float *X, const float *W, long long rows, int d_in, int d_out, int relu_in,
+                        float *dX /*nullable*/, float *dW /*nullable*/, float *db /*nullable*/, const float *grad_scale /*device [s,1/s]*/,
+                        void *workspace, size_t workspace_bytes, int precision, void *stream);
+
 /* ---- exact-fp32 evaluation (validation grade) --------------------------------------------------
  * Same contract as pnr_eval_ray_samples / pnr_eval_points (PixelNeRFNet.forward, models.py:161-265)
  * with every operand in fp32: unfused, one GEMM launch per nn.Linear on the fp32 MFMA, activations

@@ -275,6 +275,31 @@ def combine_max_goldens():
     return rec
 
 
+def variants_goldens():
+    """PixelNeRFNet.forward of the UNMODIFIED reference under model confs OUTSIDE the shipped one (testdata.synthetic.VARIANTS:
+    use_code_viewdirs=True -- the reference's default --, normalize_z=False, use_xyz=False, Softplus + SPADE + max pooling, a global
+    encoder, no encoder at all, other ResnetFC shapes): the pin of the oracle's general forward and of the composed HIP path.
+    Inputs and weights are seeded functions (synthetic.variant_inputs / fill_state) -- the fixture holds the outputs only."""
+    import model as ref_model
+    rec = {}
+    for name in synthetic.VARIANTS:
+        scene, meta, xyz, vd, glob = synthetic.variant_inputs(name)
+        net = ref_model.make_model(Conf(synthetic.variant_model_conf(name))).eval()
+        for i, mlp in enumerate((net.mlp_coarse, net.mlp_fine)):
+            shapes = [(k, tuple(v.shape)) for k, v in mlp.state_dict().items()]
+            assert shapes == synthetic.resnetfc_shapes(net.d_in, net.d_latent, **synthetic.VARIANTS[name][2]), name
+            mlp.load_state_dict(synthetic.fill_state(shapes, synthetic.VARIANT_SEED + i))
+        set_encode_state(net, scene)
+        if glob is not None:
+            net.global_encoder.latent = glob  # what ImageEncoder.forward leaves behind (encoder.py:220)
+        with torch.no_grad():
+            rec[f"{name}_out_coarse"] = net(xyz, coarse=True, viewdirs=vd).numpy()
+            rec[f"{name}_out_fine"] = net(xyz, coarse=False, viewdirs=vd).numpy()
+        rec[f"{name}_d_in"] = np.int64(net.d_in)
+        rec[f"{name}_d_latent"] = np.int64(net.d_latent)
+    return rec
+
+
 def plane_goldens():
     """Points ON and BEHIND a source camera's image plane (SURVEY App. A "known sharp edges": no frustum culling,
     `xc.z == 0` divides by zero, `xc.z > 0` mirrors; models.py:206-212,237-239) through the reference's
@@ -426,7 +451,7 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "adv_plane", "neighbours", "gradients", "combine_max", "manifest"])
+    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "adv_plane", "neighbours", "gradients", "combine_max", "variants", "manifest"])
     for name in names:
         if name == "manifest":
             path = os.path.join(outdir, "state_dict_manifest.txt")
@@ -434,7 +459,8 @@ def main():
             print("wrote", path)
             continue
         rec = (stage_goldens() if name == "stages" else neighbour_goldens() if name == "neighbours" else plane_goldens() if name == "adv_plane"
-               else gradient_goldens() if name == "gradients" else combine_max_goldens() if name == "combine_max" else run_scenario(name))
+               else gradient_goldens() if name == "gradients" else combine_max_goldens() if name == "combine_max"
+               else variants_goldens() if name == "variants" else run_scenario(name))
         path = os.path.join(outdir, name + ".npz")
         np.savez_compressed(path, **rec)
         print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))

@@ -194,6 +194,86 @@ def pixelnerf_forward(scene, mlp, xyz, viewdirs, return_hidden=False, combine_ty
     return res
 
 
+def resnetfc_forward_general(p, zx, combine_inner_dims, d_in, d_latent, d_hidden, n_blocks, combine_layer=1000,
+                             combine_type="average", beta=0.0, use_spade=False):
+    """src/model/resnetfc.py:132-184 for ANY constructor arguments (resnetfc.py:66-130): Softplus(beta) instead of ReLU when
+    beta > 0 (:126-129, :43-46), SPADE modulation (:176-179), d_in == 0 (:149), d_latent == 0 (:144-145), a combine layer that is
+    never reached.  ResnetBlockFC.forward (:53-62) inlined (ResnetFC only builds equal-width blocks: no shortcut)."""
+    F = torch.nn.functional
+    act = (lambda t: F.softplus(t, beta=beta)) if beta > 0 else torch.relu
+    if d_latent > 0:
+        z, x = zx[..., :d_latent], zx[..., d_latent:]  # :142-143
+    else:
+        x = zx
+    if d_in > 0:
+        x = F.linear(x, p["lin_in.weight"], p["lin_in.bias"])  # :147
+    else:
+        x = torch.zeros(d_hidden, device=zx.device)  # :149
+    for b in range(n_blocks):
+        if b == combine_layer:  # :153-172 -> util.combine_interleaved, util.py:461-471
+            if not (len(combine_inner_dims) == 1 and combine_inner_dims[0] == 1):
+                x = x.reshape(-1, *combine_inner_dims, *x.shape[1:])
+                x = x.mean(dim=1) if combine_type == "average" else torch.max(x, dim=1)[0]
+        if d_latent > 0 and b < combine_layer:
+            tz = F.linear(z, p[f"lin_z.{b}.weight"], p[f"lin_z.{b}.bias"])  # :175
+            if use_spade:
+                sz = F.linear(z, p[f"scale_z.{b}.weight"], p[f"scale_z.{b}.bias"])  # :177
+                x = sz * x + tz  # :178
+            else:
+                x = x + tz  # :180
+        net = F.linear(act(x), p[f"blocks.{b}.fc_0.weight"], p[f"blocks.{b}.fc_0.bias"])  # :55
+        x = x + F.linear(act(net), p[f"blocks.{b}.fc_1.weight"], p[f"blocks.{b}.fc_1.bias"])  # :56-62
+    return F.linear(act(x), p["lin_out.weight"], p["lin_out.bias"])  # :183
+
+
+def pixelnerf_forward_general(scene, mlp, xyz, viewdirs, conf, global_latent=None):
+    """src/model/models.py:146-266 for ANY model conf (models.py:22-65): `conf` is the reference's model conf as a nested dict
+    (testdata.synthetic.variant_model_conf), `mlp` the state dict of the network to run (mlp_coarse / mlp_fine) whose shape is
+    conf["mlp_coarse"].  global_latent (SB*NS, G): what ImageEncoder.forward leaves in `global_encoder.latent` (encoder.py:220)."""
+    g = lambda k, d: conf.get(k, d)
+    use_encoder, use_xyz, normalize_z = g("use_encoder", True), g("use_xyz", False), g("normalize_z", True)
+    use_code, use_code_viewdirs, use_viewdirs = g("use_code", False), g("use_code_viewdirs", True), g("use_viewdirs", False)
+    code = conf.get("code", {})
+    enc = lambda t: positional_encoding(t, code.get("num_freqs", 6), code.get("freq_factor", math.pi), code.get("include_input", True))
+    SB, B, _ = xyz.shape
+    NS = scene["NS"]
+    poses = scene["poses"]
+    xyz = repeat_interleave(xyz, NS)  # :161
+    xyz_rot = torch.matmul(poses[:, None, :3, :3], xyz.unsqueeze(-1))[..., 0]  # :162-164
+    xyz_cam = xyz_rot + poses[:, None, :3, 3]  # :165
+    src = xyz_rot if normalize_z else xyz_cam  # :169-179
+    z_feature = src.reshape(-1, 3) if use_xyz else -src[..., 2].reshape(-1, 1)
+    if use_code and not use_code_viewdirs:
+        z_feature = enc(z_feature)  # :180-182
+    if use_viewdirs:
+        vd = repeat_interleave(viewdirs.reshape(SB, B, 3, 1), NS)  # :188-189
+        vd = torch.matmul(poses[:, None, :3, :3], vd).reshape(-1, 3)  # :190-193
+        z_feature = torch.cat((z_feature, vd), dim=1)  # :194-196
+    if use_code and use_code_viewdirs:
+        z_feature = enc(z_feature)  # :198-200
+    mlp_input = z_feature  # :202
+    d_latent = 0
+    if use_encoder:
+        uv = -xyz_cam[:, :, :2] / xyz_cam[:, :, 2:]  # :206
+        focal, c = scene["focal"], scene["c"]
+        uv = uv * repeat_interleave(focal.unsqueeze(1), NS if focal.shape[0] > 1 else 1)  # :207-209
+        uv = uv + repeat_interleave(c.unsqueeze(1), NS if c.shape[0] > 1 else 1)  # :210-212
+        latent = index_latent(scene["latent"], uv, scene["image_shape"])  # :213-215
+        d_latent = latent.shape[1]
+        latent = latent.transpose(1, 2).reshape(-1, d_latent)  # :219-221
+        mlp_input = torch.cat((latent, z_feature), dim=-1)  # :227
+    if g("use_global_encoder", False):
+        reps = mlp_input.shape[0] // global_latent.shape[0]  # :231-233
+        mlp_input = torch.cat((repeat_interleave(global_latent, reps), mlp_input), dim=-1)  # :234-235
+        d_latent += global_latent.shape[1]
+    m = conf["mlp_coarse"]
+    out = resnetfc_forward_general(mlp, mlp_input, (NS, B), mlp_input.shape[1] - d_latent, d_latent, m.get("d_hidden", 128),
+                                   m.get("n_blocks", 5), m.get("combine_layer", 1000), m.get("combine_type", "average"),
+                                   m.get("beta", 0.0), m.get("use_spade", False))  # :242-255
+    out = out.reshape(-1, B, 4)  # :258
+    return torch.cat([torch.sigmoid(out[..., :3]), torch.relu(out[..., 3:4])], dim=-1).reshape(SB, B, -1)  # :260-265
+
+
 # --------------------------------------------------------------------------------------
 # renderer side
 # --------------------------------------------------------------------------------------

@@ -141,6 +141,9 @@ PROTOTYPES = {
     "pnr_weight_grad_batched_workspace_bytes": (_SZ, [_I, ctypes.c_longlong]),
     "pnr_weight_grad_batched": (_I, [ctypes.POINTER(PnrWeightGradJob), _I, _I, _F, _P, _P, _P]),
     "pnr_grad_scale": (_I, [_P, ctypes.c_longlong, _P, _P]),
+    "pnr_linear": (_I, [_P, _P, _P, _P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P]),
+    "pnr_linear_backward_workspace_bytes": (_SZ, [_I, _I]),
+    "pnr_linear_backward": (_I, [_P, _P, _P, ctypes.c_longlong, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _I, _P]),
     "pnr_latent_scatter": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _P]),
     "pnr_composite": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "pnr_render_workspace_bytes": (_SZ, [_I, _I, _I]),

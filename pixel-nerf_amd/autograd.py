@@ -334,6 +334,39 @@ def sample_fine_autograd(rays, weights_c, depth_c, z_coarse, u2, u3, n4, depth_s
     return _SampleFineFunction.apply(rays, weights_c, depth_c, z_coarse, u2, u3, n4, float(depth_std), bool(lindisp))[0]
 
 
+class _LinearFunction(torch.autograd.Function):
+    """y = [residual +] [relu](x) W^T + b as ONE autograd node around pnr_linear / pnr_linear_backward: the building block of
+    ResnetFCs of non-shipped shapes (model/resnetfc.py `_forward_composed`; src/model/resnetfc.py:53-62,147,175-183).  Saves x
+    (the pre-ReLU input: relu' = [x > 0] is applied inside the data-gradient kernel) -- nothing else."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, relu_in, precision):
+        ctx.save_for_backward(x, weight)
+        ctx.relu_in, ctx.precision, ctx.has_bias = bool(relu_in), precision, bias is not None
+        return ops.linear(x, weight, bias, relu_in=relu_in, residual=residual, precision=precision)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        need_dx, need_dw, need_db, need_res = ctx.needs_input_grad[:4]
+        dy = dy.contiguous().float()
+        dx = dw = db = None
+        if need_dx or need_dw or (need_db and ctx.has_bias):
+            dx, dw, db = ops.linear_backward(dy, x, weight, relu_in=ctx.relu_in, need_dx=need_dx, need_dw=need_dw,
+                                             need_db=need_db and ctx.has_bias, precision=ctx.precision)
+        return dx, (dw if need_dw else None), db, (dy if need_res else None), None, None
+
+
+def linear_autograd(x, weight, bias=None, relu_in=False, residual=None, precision="f16x3"):
+    """Differentiable `ops.linear` (plain kernel call when nothing requires grad)."""
+    x = x.float()
+    if not x.is_contiguous():
+        x = x.contiguous()
+    if residual is not None:
+        residual = residual.float().contiguous()
+    return _LinearFunction.apply(x, weight, bias, residual, bool(relu_in), precision)
+
+
 def points_autograd(net, xyz, viewdirs, coarse):
     """net(xyz, viewdirs) with autograd: (SB,B,3) x 2 -> (SB,B,4)."""
     if xyz.requires_grad or viewdirs.requires_grad:

@@ -1023,6 +1023,48 @@ extern "C" int pnr_resnetfc_forward_f32(const PnrMlpWeights *w, const float *zx,
     return pnr_check_launch("pnr_resnetfc_forward_f32");
 }
 
+// ---- nn.Linear as a stand-alone operator pair (any rows / d_in / d_out): what ResnetFC / ResnetBlockFC of a NON-shipped shape
+// are composed of on the host side (model/resnetfc.py: d_hidden != 512, other block counts, shortcut / Softplus blocks, SPADE).
+static bool linear_precision_ok(int precision) { return precision == PNR_PREC_F32 || precision == PNR_PREC_F16X3; }
+
+extern "C" int pnr_linear(const float *X, const float *W, const float *b, const float *Yin, float *Y, long long rows, int d_in,
+                          int d_out, int relu_in, int precision, void *stream) {
+    using namespace pnr;
+    if (rows < 0 || d_in <= 0 || d_out <= 0 || !linear_precision_ok(precision))
+        return pnr_fail(PNR_E_INVALID, "pnr_linear: rows >= 0, d_in > 0, d_out > 0, precision PNR_PREC_F32 or PNR_PREC_F16X3");
+    if (rows == 0) return PNR_OK;
+    if (!X || !W || !Y) return pnr_fail(PNR_E_INVALID, "pnr_linear: null X / W / Y");
+    const Mm c = {(hipStream_t)stream, precision == PNR_PREC_F16X3, nullptr, nullptr};
+    linear(c, X, d_in, W, b, Y, d_out, rows, d_out, d_in, relu_in != 0, Yin != nullptr, Yin);
+    return pnr_check_launch("pnr_linear");
+}
+
+extern "C" size_t pnr_linear_backward_workspace_bytes(int d_in, int d_out) {
+    if (d_in <= 0 || d_out <= 0) return 0;
+    return (size_t)pnr::WG_SPLIT * ((size_t)d_in * d_out + d_out) * sizeof(float);
+}
+
+extern "C" int pnr_linear_backward(const float *dY, const float *X, const float *W, long long rows, int d_in, int d_out, int relu_in,
+                                   float *dX, float *dW, float *db, const float *grad_scale, void *workspace, size_t workspace_bytes,
+                                   int precision, void *stream) {
+    using namespace pnr;
+    if (rows <= 0 || d_in <= 0 || d_out <= 0 || !linear_precision_ok(precision))
+        return pnr_fail(PNR_E_INVALID, "pnr_linear_backward: rows > 0, d_in > 0, d_out > 0, precision PNR_PREC_F32 or PNR_PREC_F16X3");
+    if (!dY || !X || !W) return pnr_fail(PNR_E_INVALID, "pnr_linear_backward: null dY / X / W");
+    if (db && !dW) return pnr_fail(PNR_E_INVALID, "pnr_linear_backward: db comes out of the dW pass -- pass dW as well");
+    const bool fast = precision == PNR_PREC_F16X3;
+    if (fast && !grad_scale)
+        return pnr_fail(PNR_E_INVALID, "pnr_linear_backward: PNR_PREC_F16X3 needs grad_scale = device [s, 1/s] (pnr_grad_scale(dY))");
+    const Mm c = {(hipStream_t)stream, fast, fast ? grad_scale : nullptr, fast ? grad_scale + 1 : nullptr};
+    if (dW) {
+        if (!workspace || workspace_bytes < pnr_linear_backward_workspace_bytes(d_in, d_out))
+            return pnr_fail(PNR_E_INVALID, "pnr_linear_backward: workspace too small (pnr_linear_backward_workspace_bytes)");
+        wgrad(c, dY, d_out, X, d_in, relu_in != 0, rows, d_out, d_in, dW, db, (float *)workspace, true);
+    }
+    if (dX) linear_bwd(c, dY, d_out, W, d_in, d_out, dX, d_in, rows, relu_in ? X : nullptr, false, true, true);
+    return pnr_check_launch("pnr_linear_backward");
+}
+
 extern "C" size_t pnr_eval_f32_workspace_bytes(int NS, long long chunk_points) {
     if (NS <= 0 || chunk_points <= 0) return 0;
     return pnr::floats_per_point(NS) * (size_t)chunk_points * sizeof(float);

@@ -281,3 +281,44 @@ class SpatialEncoder(nn.Module):
                    upsample_interp=conf.get_string("upsample_interp", "bilinear"),
                    feature_scale=conf.get_float("feature_scale", 1.0),
                    use_first_pool=conf.get_bool("use_first_pool", True))
+
+
+class ImageEncoder(nn.Module):
+    """Global image encoder (src/model/encoder.py:166-233; `use_global_encoder` of PixelNeRFNet, unused by the shipped configs):
+    the same plain-torch ResNet trunk through its global average pool, one latent vector per image, optionally projected to
+    `latent_size`.  State-dict keys as the reference's (`model.*`, `fc.*`).  Stays in PyTorch-ROCm like the spatial trunk."""
+
+    def __init__(self, backbone="resnet34", pretrained=True, latent_size=128):
+        super().__init__()
+        if backbone not in ("resnet34", "resnet18"):
+            raise NotImplementedError("ImageEncoder: resnet18 / resnet34 trunks (BasicBlock) only")
+        if pretrained:
+            warnings.warn("ImageEncoder: no ImageNet weights are available offline; the trunk is randomly initialised "
+                          "(load a checkpoint)", stacklevel=2)
+        self.model = _ResNet((3, 4, 6, 3) if backbone == "resnet34" else (2, 2, 2, 2))
+        self.model.avgpool = nn.AdaptiveAvgPool2d((1, 1))  # torchvision's, kept by the reference (encoder.py:181-182 drop only fc)
+        self.register_buffer("latent", torch.empty(1, 1), persistent=False)
+        self.latent_size = latent_size
+        if latent_size != 512:
+            self.fc = nn.Linear(512, latent_size)
+
+    def index(self, uv, cam_z=None, image_size=(), z_bounds=()):
+        """(B, L) -> (B, L, N): the same vector at every query point (encoder.py:189-195)."""
+        return self.latent.unsqueeze(-1).expand(-1, -1, uv.shape[1])
+
+    def forward(self, x):
+        """x (B, 3, H, W) -> latent (B, latent_size), also kept in `self.latent` (encoder.py:197-222)."""
+        m = self.model
+        x = x.to(device=self.latent.device)
+        x = m.maxpool(m.relu(m.bn1(m.conv1(x))))
+        x = m.layer4(m.layer3(m.layer2(m.layer1(x))))
+        x = torch.flatten(m.avgpool(x), 1)
+        if self.latent_size != 512:
+            x = self.fc(x)
+        self.latent = x
+        return self.latent
+
+    @classmethod
+    def from_conf(cls, conf):
+        return cls(conf.get_string("backbone"), pretrained=conf.get_bool("pretrained", True),
+                   latent_size=conf.get_int("latent_size", 128))

@@ -17,4 +17,7 @@ def make_encoder(conf, **kwargs):
     enc_type = conf.get_string("type", "spatial")
     if enc_type == "spatial":
         return SpatialEncoder.from_conf(conf, **kwargs)
-    raise NotImplementedError("Unsupported encoder type (global encoder is unused by the shipped configs)")
+    if enc_type == "global":
+        from .encoder import ImageEncoder
+        return ImageEncoder.from_conf(conf, **kwargs)
+    raise NotImplementedError("Unsupported encoder type")

@@ -59,7 +59,10 @@ class PixelNeRFNet(torch.nn.Module):
         if self.use_viewdirs and not self.use_code_viewdirs:
             d_in += 3
         if self.use_global_encoder:
-            raise NotImplementedError("use_global_encoder=True is not used by any shipped config")
+            from .encoder import ImageEncoder
+            self.global_encoder = ImageEncoder.from_conf(conf["global_encoder"])
+            self.global_latent_size = self.global_encoder.latent_size
+            d_latent += self.global_latent_size
         d_out = 4
         self.latent_size = self.encoder.latent_size
         self.mlp_coarse = make_mlp(conf["mlp_coarse"], d_in, d_latent, d_out=d_out)
@@ -72,6 +75,9 @@ class PixelNeRFNet(torch.nn.Module):
         self.num_objs = 0
         self.num_views_per_obj = 1
         self.precision = precision
+        for m in (self.mlp_coarse, self.mlp_fine):
+            if m is not None:  # per-Linear operators of a non-shipped shape: exact fp32 only when the net is 'f32', else fp32-class
+                m.composed_precision = "f32" if precision == "f32" else "f16x3"
         self.fold = bool(fold)
         self._scene = None
         self._tables = {}
@@ -120,18 +126,28 @@ class PixelNeRFNet(torch.nn.Module):
         fl[..., 1].neg_()  # image y runs down, camera y up (models.py:129-130)
         self.focal = fl
         self.c = (self.image_shape * 0.5).unsqueeze(0) if c is None else self._per_view_pair(c, "c")
+        if self.use_global_encoder:
+            self.global_encoder(images)  # models.py:143-144
 
     # ------------------------------------------------------------------ device scene
+    def fused_supported(self):
+        """True for THE model configuration every shipped experiment resolves to (conf/default.conf + default_mv.conf:
+        use_encoder, use_xyz, normalize_z, code{6, 1.5, include_input}, use_viewdirs, use_code_viewdirs=False, latent 512,
+        ResnetFC 512 x 5, combine_layer 3): the fused HIP kernels implement exactly that.  Every other configuration the
+        reference's constructor accepts runs the composed forward (`_forward_composed`)."""
+        return (self.use_encoder and self.use_xyz and self.normalize_z and self.use_code
+                and self.use_viewdirs and not self.use_code_viewdirs and not self.use_global_encoder
+                and self.code.num_freqs == 6 and abs(self.code.freq_factor - 1.5) < 1e-12
+                and self.code.include_input and self.d_in == 42 and self.d_latent == 512
+                and self.mlp_coarse.supported() and (self.mlp_fine is None or self.mlp_fine.supported()))
+
     def _check_supported(self):
-        ok = (self.use_encoder and self.use_xyz and self.normalize_z and self.use_code
-              and self.use_viewdirs and not self.use_code_viewdirs and not self.use_global_encoder
-              and self.code.num_freqs == 6 and abs(self.code.freq_factor - 1.5) < 1e-12
-              and self.code.include_input and self.d_in == 42 and self.d_latent == 512)
-        if not ok:
+        if not self.fused_supported():
             raise NotImplementedError(
-                "the fused HIP network implements the model configuration every shipped experiment "
+                "this entry point is the fused HIP network's: it implements the model configuration every shipped experiment "
                 "uses (conf/default.conf + default_mv.conf: use_encoder, use_xyz, normalize_z, "
-                "code{6,1.5,include_input}, use_viewdirs, use_code_viewdirs=False, latent 512)")
+                "code{6,1.5,include_input}, use_viewdirs, use_code_viewdirs=False, latent 512, ResnetFC 512x5/3); "
+                "other configurations run through net(xyz, coarse=, viewdirs=) / NeRFRenderer (composed forward)")
 
     def _check_trainable(self):
         """the differentiable paths pool the source views with the mean (every shipped config); "max" has inference kernels only"""
@@ -252,8 +268,53 @@ class PixelNeRFNet(torch.nn.Module):
         with torch.profiler.record_function("model_inference"):  # the reference's scope name (models.py:156)
             return self._forward_points(xyz, coarse, viewdirs)
 
+    def _forward_composed(self, xyz, coarse, viewdirs):
+        """src/model/models.py:157-265 for the configurations the fused kernels do not cover (normalize_z=False,
+        use_code_viewdirs=True -- the reference's DEFAULT --, use_xyz=False, a global encoder, use_encoder=False, other ResnetFC
+        shapes): HIP operators for everything with arithmetic weight -- `SpatialEncoder.index` (pnr_grid_index), the positional
+        code (pnr_positional_encoding), every nn.Linear (pnr_linear), each with its HIP backward -- and torch ops on HIP tensors
+        for the 3x4 camera transforms, the projection and the concatenations in between.  Differentiable end to end."""
+        if not xyz.is_cuda:
+            raise ops._lib.PixelNerfHipError("PixelNeRFNet must live on a HIP device (no CPU path): net.to('cuda')")
+        SB, B, _ = xyz.shape
+        NS = int(self.num_views_per_obj)
+        rot, trans = self.poses[:, None, :3, :3], self.poses[:, None, :3, 3]       # world -> source camera, (SB*NS, 1, ...)
+        p_world = repeat_interleave(xyz.float(), NS)                                # (SB*NS, B, 3)
+        p_rot = (rot @ p_world.unsqueeze(-1)).squeeze(-1)
+        p_cam = p_rot + trans
+        rows = None
+        if self.d_in > 0:
+            src = p_rot if self.normalize_z else p_cam                              # models.py:169-179
+            feat = src.reshape(-1, 3) if self.use_xyz else -src[..., 2].reshape(-1, 1)
+            if self.use_code and not self.use_code_viewdirs:
+                feat = self.code(feat.contiguous())
+            if self.use_viewdirs:
+                assert viewdirs is not None  # models.py:186
+                d_cam = rot @ repeat_interleave(viewdirs.float().reshape(SB, B, 3, 1), NS)
+                feat = torch.cat((feat, d_cam.reshape(-1, 3)), dim=1)
+            if self.use_code and self.use_code_viewdirs:
+                feat = self.code(feat.contiguous())
+            rows = feat
+        if self.use_encoder:
+            fl, pp = self.focal.unsqueeze(1), self.c.unsqueeze(1)                   # (n|1, 1, 2) each
+            uv = -p_cam[..., :2] / p_cam[..., 2:3]                                  # models.py:206-212
+            uv = uv * repeat_interleave(fl, NS if fl.shape[0] > 1 else 1) + repeat_interleave(pp, NS if pp.shape[0] > 1 else 1)
+            lat = self.encoder.index(uv, None, self.image_shape)                    # (SB*NS, L, B)
+            if self.stop_encoder_grad:
+                lat = lat.detach()
+            lat = lat.transpose(1, 2).reshape(-1, self.latent_size)
+            rows = lat if self.d_in == 0 else torch.cat((lat, rows), dim=-1)
+        if self.use_global_encoder:
+            g = self.global_encoder.latent
+            assert rows.shape[0] % g.shape[0] == 0
+            rows = torch.cat((repeat_interleave(g, rows.shape[0] // g.shape[0]), rows), dim=-1)
+        mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
+        out = mlp(rows, combine_inner_dims=(NS, B)).reshape(-1, B, self.d_out)
+        return torch.cat((torch.sigmoid(out[..., :3]), torch.relu(out[..., 3:4])), dim=-1).reshape(SB, B, -1)
+
     def _forward_points(self, xyz, coarse, viewdirs):
-        self._check_supported()
+        if not self.fused_supported():
+            return self._forward_composed(xyz, coarse, viewdirs)
         assert viewdirs is not None  # models.py:186
         SB, B, _ = xyz.shape
         sc = self.scene()

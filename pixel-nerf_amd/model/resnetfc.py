@@ -2,9 +2,12 @@
 initialisation (src/model/resnetfc.py:10-130), so that reference checkpoints load unchanged
 (`mlp_coarse.lin_in.weight`, `mlp_coarse.blocks.N.fc_0.weight`, `mlp_coarse.lin_z.N.weight`...).
 
-The arithmetic of ResnetFC.forward (resnetfc.py:132-184) runs inside the fused HIP kernel
-(csrc/pnr_mlp.hip); `packed(precision)` hands the kernel its fragment stream and re-packs
-whenever a parameter changed."""
+The arithmetic of ResnetFC.forward (resnetfc.py:132-184) of THE shape every shipped config resolves to (42 + 512 -> 512 x 5
+blocks -> 4, combine_layer 3) runs inside the fused HIP kernels (csrc/pnr_mlp.hip, pnr_split.hip); `packed(precision)` hands them
+their fragment stream and re-packs whenever a parameter changed.  Every OTHER shape the reference's constructor accepts (other
+widths / block counts / combine layers, Softplus blocks, SPADE, d_in = 0, d_latent = 0) is composed on the host from one HIP
+operator per nn.Linear (`autograd.linear_autograd`: pnr_linear / pnr_linear_backward, ReLU and residual folded in) -- slower
+than the fused chain, differentiable, same results (`_forward_composed`)."""
 import weakref
 
 import torch
@@ -44,50 +47,77 @@ register_optimizer_step_post_hook(_count_optimizer_step)
 
 
 class ResnetBlockFC(nn.Module):
+    """fc_0 / fc_1 (+ shortcut when the widths differ) with the reference's names and initialisation (resnetfc.py:19-50).
+    The reference's own size_in != size_out branch cannot be constructed (it initialises the bias of a bias-free Linear,
+    resnetfc.py:48-49); here the shortcut is simply the bias-free kaiming Linear that branch asks for."""
+
     def __init__(self, size_in, size_out=None, size_h=None, beta=0.0):
         super().__init__()
         size_out = size_in if size_out is None else size_out
         size_h = min(size_in, size_out) if size_h is None else size_h
-        if size_in != size_out or beta > 0:
-            raise NotImplementedError("fused kernel: 512->512 ReLU blocks only (all shipped configs)")
         self.size_in, self.size_h, self.size_out = size_in, size_h, size_out
+        self.beta = float(beta)
         self.fc_0 = nn.Linear(size_in, size_h)
         self.fc_1 = nn.Linear(size_h, size_out)
         nn.init.constant_(self.fc_0.bias, 0.0)
         nn.init.kaiming_normal_(self.fc_0.weight, a=0, mode="fan_in")
         nn.init.constant_(self.fc_1.bias, 0.0)
         nn.init.zeros_(self.fc_1.weight)
-        self.activation = nn.ReLU()
-        self.shortcut = None
+        self.activation = nn.Softplus(beta=beta) if beta > 0 else nn.ReLU()
+        if size_in == size_out:
+            self.shortcut = None
+        else:
+            self.shortcut = nn.Linear(size_in, size_out, bias=False)
+            nn.init.kaiming_normal_(self.shortcut.weight, a=0, mode="fan_in")
+
+    def forward(self, x, precision="f16x3"):
+        """resnetfc.py:53-62 as three HIP linears: ReLU folded into the operator that consumes it, the residual into fc_1's
+        (a Softplus block applies its activation as a torch op in front)."""
+        from ..autograd import linear_autograd as lin
+        with torch.profiler.record_function("resblock"):  # the reference's scope name (resnetfc.py:54)
+            relu = self.beta <= 0
+            net = lin(x if relu else self.activation(x), self.fc_0.weight, self.fc_0.bias, relu_in=relu, precision=precision)
+            x_s = x if self.shortcut is None else lin(x, self.shortcut.weight, None, precision=precision)
+            return lin(net if relu else self.activation(net), self.fc_1.weight, self.fc_1.bias, relu_in=relu, residual=x_s,
+                       precision=precision)
 
 
 class ResnetFC(nn.Module):
     def __init__(self, d_in, d_out=4, n_blocks=5, d_latent=0, d_hidden=128, beta=0.0, combine_layer=1000,
                  combine_type="average", use_spade=False):
         super().__init__()
-        self.lin_in = nn.Linear(d_in, d_hidden)
-        nn.init.constant_(self.lin_in.bias, 0.0)
-        nn.init.kaiming_normal_(self.lin_in.weight, a=0, mode="fan_in")
+        if d_in > 0:
+            self.lin_in = nn.Linear(d_in, d_hidden)
+            nn.init.constant_(self.lin_in.bias, 0.0)
+            nn.init.kaiming_normal_(self.lin_in.weight, a=0, mode="fan_in")
         self.lin_out = nn.Linear(d_hidden, d_out)
         nn.init.constant_(self.lin_out.bias, 0.0)
         nn.init.kaiming_normal_(self.lin_out.weight, a=0, mode="fan_in")
         self.n_blocks, self.d_latent, self.d_in, self.d_out, self.d_hidden = n_blocks, d_latent, d_in, d_out, d_hidden
         self.combine_layer, self.combine_type, self.use_spade = combine_layer, combine_type, use_spade
+        self.beta = float(beta)
         self.blocks = nn.ModuleList([ResnetBlockFC(d_hidden, beta=beta) for _ in range(n_blocks)])
         if d_latent != 0:
             n_lin_z = min(combine_layer, n_blocks)
-            self.lin_z = nn.ModuleList([nn.Linear(d_latent, d_hidden) for _ in range(n_lin_z)])
-            for i in range(n_lin_z):
-                nn.init.constant_(self.lin_z[i].bias, 0.0)
-                nn.init.kaiming_normal_(self.lin_z[i].weight, a=0, mode="fan_in")
-        self.activation = nn.ReLU()
+
+            def per_block():
+                mods = nn.ModuleList([nn.Linear(d_latent, d_hidden) for _ in range(n_lin_z)])
+                for m in mods:
+                    nn.init.constant_(m.bias, 0.0)
+                    nn.init.kaiming_normal_(m.weight, a=0, mode="fan_in")
+                return mods
+            self.lin_z = per_block()
+            if use_spade:
+                self.scale_z = per_block()
+        self.activation = nn.Softplus(beta=beta) if beta > 0 else nn.ReLU()
+        self.composed_precision = "f16x3"  # arithmetic of the per-Linear operators of a non-shipped shape ('f16x3' | 'f32')
         self._packed = {}
 
     def supported(self):
         """The one shape the fused kernel implements = the one shape the reference ships."""
         return (self.d_in == 42 and self.d_out == 4 and self.n_blocks == 5 and self.d_latent == 512
                 and self.d_hidden == 512 and self.combine_layer == 3 and self.combine_type in ("average", "max")
-                and not self.use_spade)
+                and not self.use_spade and self.beta <= 0)
 
     def _combine_max(self):
         """util.combine_interleaved's agg_type (src/util/util.py:461-471): "average" in every shipped config; "max" is carried as
@@ -250,25 +280,57 @@ class ResnetFC(nn.Module):
                             lambda out: ops.pack_mlp(None, precision, backward=True, weights=self._wstruct(), out=out))
 
     def forward(self, zx, combine_inner_dims=(1,), combine_index=None, dim_size=None):
-        """src/model/resnetfc.py:132-184 on explicit rows zx (..., d_latent + d_in): the exact-fp32 HIP linears
-        (pnr_resnetfc_forward_f32), inference only.  The renderer never comes here -- PixelNeRFNet.forward runs the
-        fused kernel, which also does the feature lookup; this entry serves callers that hold their own (z, x) rows."""
-        if not self.supported():
-            raise NotImplementedError("HIP ResnetFC supports the shipped shape only (conf/default_mv.conf)")
+        """src/model/resnetfc.py:132-184 on explicit rows zx (..., d_latent + d_in).  The renderer never comes here for the
+        shipped model (PixelNeRFNet.forward runs the fused kernel, which also does the feature lookup); this entry serves callers
+        that hold their own (z, x) rows, and PixelNeRFNet's composed forward for non-shipped model variants.
+        Shipped shape under no_grad: the exact-fp32 HIP chain (pnr_resnetfc_forward_f32).  Anything else -- another shape, or
+        autograd through the call -- is composed from one HIP operator per nn.Linear (differentiable)."""
         if combine_index is not None:
             raise NotImplementedError("combine_index (frustum culling) is commented out in the reference as well")
-        if torch.is_grad_enabled() and (zx.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError(
-                "autograd through a direct ResnetFC.forward call is not implemented: training goes through "
-                "NeRFRenderer (train/train.py:199-215); wrap direct calls in torch.no_grad()")
         assert zx.size(-1) == self.d_latent + self.d_in
         dims = tuple(int(d) for d in combine_inner_dims)
-        flat = zx.reshape(-1, zx.shape[-1])
-        out = ops.resnetfc_forward(dict(self.state_dict()), flat, dims, combine_max=self._combine_max())
-        if dims == (1,):
-            return out.reshape(*zx.shape[:-1], self.d_out)
-        # util.combine_interleaved: (-1, NS, B, ...) mean over dim 1 -> (-1, B, ...)   util.py:461-471
-        return out.reshape(-1, dims[1], *zx.shape[1:-1], self.d_out)
+        with torch.profiler.record_function("resnetfc_infer"):  # the reference's scope name (resnetfc.py:141)
+            wants_grad = torch.is_grad_enabled() and (zx.requires_grad or self.any_requires_grad())
+            if self.supported() and not wants_grad and (dims == (1,) or len(dims) == 2):
+                flat = zx.reshape(-1, zx.shape[-1])
+                out = ops.resnetfc_forward(dict(self.state_dict()), flat, dims, combine_max=self._combine_max())
+                if dims == (1,):
+                    return out.reshape(*zx.shape[:-1], self.d_out)
+                # util.combine_interleaved: (-1, NS, B, ...) pooled over dim 1 -> (-1, B, ...)   util.py:461-471
+                return out.reshape(-1, dims[1], *zx.shape[1:-1], self.d_out)
+            return self._forward_composed(zx, dims)
+
+    def _forward_composed(self, zx, dims):
+        """resnetfc.py:141-184 for any constructor arguments: every nn.Linear is one `linear_autograd` node (pnr_linear /
+        pnr_linear_backward; `x + lin_z(z)` rides as that operator's residual, ReLUs as its input activation); the view pooling,
+        SPADE's product and a Softplus are torch ops on HIP tensors in between."""
+        from .. import util
+        from ..autograd import linear_autograd as lin
+        prec = self.composed_precision
+        relu = self.beta <= 0
+        if not zx.is_cuda:
+            raise ops._lib.PixelNerfHipError("ResnetFC.forward: tensors must live on a HIP device (no CPU path)")
+        zx = zx.float()
+        z = zx[..., : self.d_latent] if self.d_latent > 0 else None
+        x = zx[..., self.d_latent:] if self.d_latent > 0 else zx
+        if self.d_in > 0:
+            x = lin(x, self.lin_in.weight, self.lin_in.bias, precision=prec)
+        else:
+            x = torch.zeros(self.d_hidden, device=zx.device)          # resnetfc.py:149 (broadcast against the first lin_z)
+        for blkid in range(self.n_blocks):
+            if blkid == self.combine_layer:
+                x = util.combine_interleaved(x, dims, self.combine_type)
+            if self.d_latent > 0 and blkid < self.combine_layer:
+                lz = self.lin_z[blkid]
+                if self.use_spade:
+                    x = lin(z, self.scale_z[blkid].weight, self.scale_z[blkid].bias, precision=prec) * x \
+                        + lin(z, lz.weight, lz.bias, precision=prec)
+                elif x.shape[:-1] == z.shape[:-1]:
+                    x = lin(z, lz.weight, lz.bias, residual=x, precision=prec)
+                else:
+                    x = x + lin(z, lz.weight, lz.bias, precision=prec)
+            x = self.blocks[blkid](x, precision=prec)
+        return lin(x if relu else self.activation(x), self.lin_out.weight, self.lin_out.bias, relu_in=relu, precision=prec)
 
     @classmethod
     def from_conf(cls, conf, d_in, **kwargs):

@@ -1177,6 +1177,59 @@ def grad_scale(g):
     return out
 
 
+def _linear_prec(precision):
+    if precision in ("f32", _lib.PREC_F32):
+        return _lib.PREC_F32
+    if precision in ("f16x3", _lib.PREC_F16X3):
+        return _lib.PREC_F16X3
+    raise ValueError(f"linear: precision must be 'f16x3' (fp32-class, fast) or 'f32' (exact fp32 products), got {precision!r}")
+
+
+def linear(x, weight, bias=None, relu_in=False, residual=None, precision="f16x3"):
+    """One nn.Linear of ResnetFC / ResnetBlockFC with the ReLU in front and the residual behind folded in
+    (src/model/resnetfc.py:53-62,147,175-183):  y = [residual +] [relu](x) weight^T + bias.   x (..., d_in) -> (..., d_out)."""
+    lib = _lib.load()
+    d_out, d_in = weight.shape
+    x2 = _f32(x.reshape(-1, x.shape[-1]), "x", (None, d_in))
+    w = _f32(weight, "weight")
+    b = None if bias is None else _f32(bias, "bias", (d_out,))
+    rows = x2.shape[0]
+    r = None if residual is None else _f32(residual.reshape(-1, d_out), "residual", (rows, d_out))
+    y = torch.empty((rows, d_out), dtype=torch.float32, device=x2.device)
+    with torch.cuda.device(x2.device):
+        _lib.check(lib.pnr_linear(_p(x2), _p(w), _p(b), _p(r), _p(y), rows, d_in, d_out, int(bool(relu_in)), _linear_prec(precision),
+                                  _stream()), "pnr_linear")
+    return y.reshape(*x.shape[:-1], d_out)
+
+
+def linear_backward(dy, x, weight, relu_in=False, need_dx=True, need_dw=True, need_db=True, precision="f16x3"):
+    """-> (dx | None, dweight | None, dbias | None) of `linear` (the residual's gradient is dy itself)."""
+    lib = _lib.load()
+    d_out, d_in = weight.shape
+    x2 = _f32(x.reshape(-1, d_in), "x")
+    rows = x2.shape[0]
+    g = _f32(dy.reshape(-1, d_out), "dy", (rows, d_out))
+    w = _f32(weight, "weight")
+    dev = x2.device
+    need_dw = need_dw or need_db
+    dx = torch.empty((rows, d_in), dtype=torch.float32, device=dev) if need_dx else None
+    dw = torch.empty((d_out, d_in), dtype=torch.float32, device=dev) if need_dw else None
+    db = torch.empty((d_out,), dtype=torch.float32, device=dev) if need_db else None
+    if rows == 0:
+        for t in (dx, dw, db):
+            if t is not None:
+                t.zero_()
+        return (None if dx is None else dx.reshape(x.shape)), dw, db
+    prec = _linear_prec(precision)
+    with torch.cuda.device(dev):
+        sc = grad_scale(g) if prec == _lib.PREC_F16X3 else None
+        nbytes = lib.pnr_linear_backward_workspace_bytes(d_in, d_out) if need_dw else 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if need_dw else None
+        _lib.check(lib.pnr_linear_backward(_p(g), _p(x2), _p(w), rows, d_in, d_out, int(bool(relu_in)), _p(dx), _p(dw), _p(db), _p(sc),
+                                           _p(ws), nbytes, prec, _stream()), "pnr_linear_backward")
+    return (None if dx is None else dx.reshape(x.shape)), dw, db
+
+
 def mlp_backward(packed_bwd, fwd_dumps, g_out, grad_scale):
     """grad_scale: python float, or a 1-element device tensor (e.g. ops.grad_scale(g_out)[0:1])."""
     lib = _lib.load()

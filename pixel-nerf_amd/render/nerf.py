@@ -167,7 +167,9 @@ class NeRFRenderer(torch.nn.Module):
         SB = rays.shape[0]
         rays = rays.reshape(-1, 8).float().contiguous()
         R = rays.shape[0]
-        fused = hasattr(model, "scene") and hasattr(model, "packed")
+        # pixelnerf_amd.PixelNeRFNet in the shipped configuration: the fused kernels.  Any other model -- including a PixelNeRFNet
+        # configured outside what the fused kernels implement (composed forward) -- is a callable to the reference's control flow.
+        fused = hasattr(model, "scene") and hasattr(model, "packed") and (not hasattr(model, "fused_supported") or model.fused_supported())
         # (inside a HIP-graph capture the generator's offset cannot be read on the host: torch's own graph-safe draws are used)
         seeded = (_noise is None and fused and self.rng == "philox" and not (self.training and torch.is_grad_enabled())
                   and not (rays.is_cuda and torch.cuda.is_current_stream_capturing()))

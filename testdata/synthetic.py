@@ -274,3 +274,101 @@ def grad_sample_index(numel, key):
         return np.arange(numel)
     rs = np.random.RandomState(_name_hash(key))
     return np.sort(rs.choice(numel, GRAD_SAMPLES, replace=False))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# model configurations OUTSIDE the one every shipped experiment resolves to (src/model/models.py:22-65 accepts them all; the
+# reference's default for use_code_viewdirs is even True): the composed forward's fixtures (tests/golden/variants.npz, frozen from
+# the unmodified reference by oracle/make_goldens.py `variants`).  name -> (scene, model overrides, mlp conf)
+VARIANTS = {
+    # the reference's DEFAULT code arrangement: positions and view directions coded together (d_in = 6 x 13 = 78), shipped MLP shape
+    "code_viewdirs": ("mv_mini", dict(use_code_viewdirs=True),
+                      dict(n_blocks=5, d_hidden=512, combine_layer=3, combine_type="average")),
+    # camera-space (not rotation-only) positions; narrow network, views pooled after the first block
+    "no_normalize_z": ("dtu_mini", dict(normalize_z=False),
+                       dict(n_blocks=3, d_hidden=128, combine_layer=1, combine_type="average")),
+    # depth-only position feature (use_xyz=False: -z of the camera-space point, coded: 13 + 3 raw view direction)
+    "z_only": ("mv_mini", dict(use_xyz=False), dict(n_blocks=2, d_hidden=64, combine_layer=1, combine_type="average")),
+    # Softplus blocks + SPADE modulation + view maximum, a width that is no multiple of any tile size
+    "softplus_spade_max": ("mv_mini", dict(), dict(n_blocks=4, d_hidden=96, combine_layer=2, combine_type="max", beta=3.0,
+                                                   use_spade=True)),
+    # a global image latent in front of the pixel-aligned one
+    "global_encoder": ("srn_mini", dict(use_global_encoder=True, global_encoder=dict(backbone="resnet34", pretrained=False, latent_size=16)),
+                       dict(n_blocks=3, d_hidden=128, combine_layer=2, combine_type="average")),
+    # no image features at all (d_latent = 0: no lin_z), raw xyz without code or view directions (d_in = 3), never pooled
+    "no_encoder_raw_xyz": ("sn64", dict(use_encoder=False, use_code=False, use_viewdirs=False),
+                           dict(n_blocks=2, d_hidden=64, combine_type="average")),
+}
+VARIANT_POINTS = 40
+VARIANT_SEED = 31
+
+
+def variant_model_conf(name):
+    """the reference's model conf (conf/default.conf:3-48 keys) of one VARIANTS entry, as a plain nested dict"""
+    _, over, mlp = VARIANTS[name]
+    conf = dict(use_encoder=True, use_global_encoder=False, use_xyz=True, canon_xyz=False, normalize_z=True,
+                use_code=True, code=dict(num_freqs=6, freq_factor=1.5, include_input=True),
+                use_viewdirs=True, use_code_viewdirs=False,
+                mlp_coarse=dict(mlp, type="resnet"), mlp_fine=dict(mlp, type="resnet"),
+                encoder=dict(backbone="resnet34", pretrained=False, num_layers=4))
+    conf.update(over)
+    return conf
+
+
+def fill_state(shapes, seed):
+    """Seeded parameters for ANY ResnetFC: `shapes` = [(state_dict key, shape)] in state_dict order -> {key: float32 tensor}.
+    Weights kaiming fan-in scaled like the reference's init (resnetfc.py:36-39,89-117) except fc_1 (zero-initialised there)
+    ~ N(0, 0.03^2); biases ~ N(0, 0.01^2) -- every term of the network contributes, as in make_mlp_params."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for key, shape in shapes:
+        shape = tuple(int(v) for v in shape)
+        if len(shape) == 2:
+            std = 0.03 if key.endswith("fc_1.weight") else math.sqrt(2.0 / shape[1])
+            out[key] = torch.from_numpy((rs.randn(*shape) * std).astype(np.float32))
+        else:
+            out[key] = torch.from_numpy((rs.randn(*shape) * 0.01).astype(np.float32))
+    return out
+
+
+def variant_inputs(name):
+    """-> scene, meta, xyz (SB, P, 3), viewdirs (SB, P, 3), global latent (SB*NS, 16) | None: seeded query points around the object
+    (a few far outside, projecting off the source images)"""
+    scene_name, over, _ = VARIANTS[name]
+    scene, meta = make_scene(scene_name, seed=2)
+    rs = np.random.RandomState(_name_hash(name) % (2 ** 31))
+    SB, P = scene["SB"], VARIANT_POINTS
+    xyz = rs.uniform(-1.0, 1.0, (SB, P, 3)).astype(np.float32)
+    xyz[:, :4] *= 4.0
+    vd = rs.randn(SB, P, 3).astype(np.float32)
+    vd /= np.linalg.norm(vd, axis=-1, keepdims=True)
+    glob = None
+    if over.get("use_global_encoder"):
+        glob = torch.from_numpy((rs.randn(SB * scene["NS"], over["global_encoder"]["latent_size"]) * 0.5).astype(np.float32))
+    return scene, meta, torch.from_numpy(xyz), torch.from_numpy(vd), glob
+
+
+def resnetfc_shapes(d_in, d_latent, d_hidden=128, n_blocks=5, combine_layer=1000, use_spade=False, d_out=4, **_):
+    """[(state_dict key, shape)] of a ResnetFC in the reference's state_dict order (registration order of resnetfc.py:87-124;
+    oracle/make_goldens.py asserts it against the reference module when it freezes the variants fixture)."""
+    out = []
+
+    def lin(name, fan_out, fan_in):
+        out.extend([(name + ".weight", (fan_out, fan_in)), (name + ".bias", (fan_out,))])
+    if d_in > 0:
+        lin("lin_in", d_hidden, d_in)
+    lin("lin_out", d_out, d_hidden)
+    for b in range(n_blocks):
+        lin(f"blocks.{b}.fc_0", d_hidden, d_hidden)
+        lin(f"blocks.{b}.fc_1", d_hidden, d_hidden)
+    if d_latent != 0:
+        for name in ("lin_z",) + (("scale_z",) if use_spade else ()):
+            for b in range(min(combine_layer, n_blocks)):
+                lin(f"{name}.{b}", d_hidden, d_latent)
+    return out
+
+
+def variant_mlp_params(name, d_in, d_latent):
+    """-> (coarse, fine) state dicts of a VARIANTS entry (what the fixture's reference networks were loaded with)"""
+    shapes = resnetfc_shapes(d_in, d_latent, **VARIANTS[name][2])
+    return fill_state(shapes, VARIANT_SEED), fill_state(shapes, VARIANT_SEED + 1)

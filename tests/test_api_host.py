@@ -98,7 +98,7 @@ def test_forward_requires_hip_device(net):
         net(xyz, coarse=True, viewdirs=vd)
     with torch.no_grad(), pytest.raises(_lib.PixelNerfHipError):
         net(xyz, coarse=True, viewdirs=vd)
-    with pytest.raises(NotImplementedError):  # ResnetFC.forward on explicit rows is inference-only
+    with pytest.raises(_lib.PixelNerfHipError):  # ResnetFC.forward on explicit rows: HIP operators with or without autograd
         net.mlp_coarse(torch.zeros(2, 554))
     with torch.no_grad(), pytest.raises(_lib.PixelNerfHipError):
         net.mlp_coarse(torch.zeros(2, 554))
@@ -207,3 +207,26 @@ def test_checkpoint_helpers_follow_the_reference_layout(tmp_path):
     assert third.load_weights(fresh, opt_init=True) is None
     third.load_weights(fresh)
     assert torch.equal(third.mlp_coarse.lin_out.weight, w0 + 1.0)
+
+
+def test_model_variants_construct_with_the_reference_state_dict_layout():
+    """every model conf of testdata.synthetic.VARIANTS (outside the shipped one): d_in / d_latent as the reference derives them
+    (models.py:42-58, frozen in tests/golden/variants.npz) and the ResnetFC state_dict layout the generator asserted against the
+    reference module; the global encoder is the plain-torch trunk through its average pool"""
+    from pixelnerf_amd.model.encoder import ImageEncoder
+    from testdata import synthetic
+    g = load_golden("variants")
+    for name in synthetic.VARIANTS:
+        n = make_model(Conf(synthetic.variant_model_conf(name)))
+        assert (n.d_in, n.d_latent) == (int(g[f"{name}_d_in"]), int(g[f"{name}_d_latent"])), name
+        assert not n.fused_supported()
+        for mlp in (n.mlp_coarse, n.mlp_fine):
+            shapes = [(k, tuple(v.shape)) for k, v in mlp.state_dict().items()]
+            assert shapes == synthetic.resnetfc_shapes(n.d_in, n.d_latent, **synthetic.VARIANTS[name][2]), name
+    assert make_model(default_model_conf()).fused_supported()
+    enc = ImageEncoder("resnet18", pretrained=False, latent_size=16).eval()
+    with torch.no_grad():
+        lat = enc(torch.rand(3, 3, 32, 32))
+    assert lat.shape == (3, 16) and enc.latent is lat and enc.index(torch.zeros(3, 7, 2)).shape == (3, 16, 7)
+    assert "fc.weight" in enc.state_dict() and "model.layer4.1.conv2.weight" in enc.state_dict()
+    assert "fc.weight" not in ImageEncoder("resnet18", pretrained=False, latent_size=512).state_dict()

@@ -14,6 +14,7 @@ import torch
 from helpers import (ADVERSARIAL_SCENARIOS, RENDER_SCENARIOS, assert_close_frac, robust_render_stats, golden_setup, load_golden, mlp_params,
                      scene_for)
 from oracle import pnr_oracle as O
+from testdata import synthetic
 
 
 def test_positional_encoding_matches_reference():
@@ -59,6 +60,24 @@ def test_pixelnerf_forward_with_max_pooling_matches_reference(scene_name):
         np.testing.assert_allclose(out.numpy()[..., :3], ref[..., :3], rtol=0, atol=2e-5)
         np.testing.assert_allclose(out.numpy()[..., 3], ref[..., 3], rtol=1e-5, atol=2e-5)
         assert np.abs(ref - g[f"{scene_name}_out_{which}"]).max() > 0.5
+
+
+@pytest.mark.parametrize("name", sorted(synthetic.VARIANTS))
+def test_pixelnerf_forward_of_other_model_confs_matches_reference(name):
+    """model confs outside the shipped one (models.py:22-65: coded view directions -- the reference's default --, camera-space
+    positions, depth-only feature, Softplus / SPADE / max pooling, a global latent, no encoder; other ResnetFC shapes): the
+    reference's own outputs (tests/golden/variants.npz) against the oracle's general restatement"""
+    g = load_golden("variants")
+    scene, _, xyz, vd, glob = synthetic.variant_inputs(name)
+    conf = synthetic.variant_model_conf(name)
+    params = synthetic.variant_mlp_params(name, int(g[f"{name}_d_in"]), int(g[f"{name}_d_latent"]))
+    for which, p in zip(("coarse", "fine"), params):
+        out = O.pixelnerf_forward_general(scene, p, xyz, vd, conf, global_latent=glob).numpy()
+        ref = g[f"{name}_out_{which}"]
+        assert out.shape == ref.shape
+        np.testing.assert_allclose(out[..., :3], ref[..., :3], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out[..., 3], ref[..., 3], rtol=1e-4, atol=2e-4)
+    assert np.abs(g[f"{name}_out_coarse"] - g[f"{name}_out_fine"]).max() > 1e-3  # two different networks
 
 
 def test_points_on_and_behind_a_camera_plane_match_reference():
