@@ -8,6 +8,7 @@
 #include "pnr_layout.h"
 
 namespace pnr {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // which nn.Linear feeds GEMM g, and how its K index is ordered in the stream
 struct GemmSrc {
@@ -42,8 +43,10 @@ __device__ inline GemmSrc gemm_source(const PnrMlpWeights &p, int g) {
 //       0-3 of a layer = this wave's OWN K block (features 64 wv .. 64 wv + 63) in REGISTER order -- k-step j, lane half h,
 //       element e <-> feat_of(wv IT + (j >> 1), h, 8 (j & 1) + e): what the wave's accumulators hold -- then the blocks of waves
 //       wv+1 .. wv+7 (mod 8) in the storage order of the operand image.
+// out_lo (split-operand stream only): the tail stream is written by the same thread from the same loads (one pass over the
+// weights instead of two).
 template <typename T, bool FOLD, bool LO = false, bool OWNK = false>
-__global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
+__global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out, T *__restrict__ out_lo = nullptr) {
     constexpr int TOTAL = FOLD ? RS_TOTAL_F : RS_TOTAL;
     const size_t idx8 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx8 >= (size_t)TOTAL * IT * (FRAG_ELEMS / 8) * NW) return;
@@ -64,41 +67,56 @@ __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out) {
     const int i = lane & 31, h = lane >> 5;
     const int f_out = wv * SL + it * 32 + i;
     const GemmSrc src = gemm_source(p, g);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (src.kind == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = s * 16 + h * 8 + e;
+            if (k < D_IN) v[e] = src.w[f_out * D_IN + k];
+        }
+    } else if (src.kind == 1) {
+        const f32x4 *q = reinterpret_cast<const f32x4 *>(src.w + (size_t)f_out * C_LAT + s * 16 + h * 8);
+        const f32x4 a = q[0], b = q[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    } else if (src.kind == 2) {
+        // B operand comes from the LDS activation buffer: k-step s reads storage elements
+        // 16s..16s+15 = what half (s&1) of feature tile (s>>1) wrote as registers 8h+e.
+        // feat_of(T, hh, r) for r = r0 .. r0+7 (r0 a multiple of 8) = two runs of four consecutive features, 8 apart
+        int k;
+        if (OWNK) {
+            const int body = s >> 2, j = s & 3;
+            if (body == 0) k = feat_of(wv * IT + (j >> 1), h, 8 * (j & 1));
+            else {
+                const int ss = ((wv + body) & (NW - 1)) * 4 + j;  // k-step of the image order this ring step stands for
+                k = feat_of(ss >> 1, ss & 1, 8 * h);
+            }
+        } else k = feat_of(s >> 1, s & 1, 8 * h);
+        const float *row = src.w + (size_t)f_out * D_HID + k;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(row), b = *reinterpret_cast<const f32x4 *>(row + 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    } else {
+        // lin_out: B operand = the wave's own accumulators; k-step q = IT*s + it covers
+        // registers 8*(q&1)..+7 of the wave's feature tile (q>>1), for both lane halves.
+        if (s < 2 && i < D_OUT) {
+            const int q = IT * s + it;
+            const float *row = src.w + i * D_HID + feat_of(wv * IT + (q >> 1), h, 8 * (q & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = row[e]; v[4 + e] = row[8 + e]; }
+        }
+    }
     __attribute__((aligned(16))) T o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float v = 0.f;
-        if (src.kind == 0) {
-            const int k = s * 16 + h * 8 + e;
-            if (k < D_IN) v = src.w[f_out * D_IN + k];
-        } else if (src.kind == 1) {
-            const int k = s * 16 + h * 8 + e;
-            v = src.w[f_out * C_LAT + k];
-        } else if (src.kind == 2) {
-            // B operand comes from the LDS activation buffer: k-step s reads storage elements
-            // 16s..16s+15 = what half (s&1) of feature tile (s>>1) wrote as registers 8h+e.
-            int k;
-            if (OWNK) {
-                const int body = s >> 2, j = s & 3;
-                if (body == 0) k = feat_of(wv * IT + (j >> 1), h, 8 * (j & 1) + e);
-                else {
-                    const int ss = ((wv + body) & (NW - 1)) * 4 + j;  // k-step of the image order this ring step stands for
-                    k = feat_of(ss >> 1, ss & 1, 8 * h + e);
-                }
-            } else k = feat_of(s >> 1, s & 1, 8 * h + e);
-            v = src.w[f_out * D_HID + k];
-        } else {
-            // lin_out: B operand = the wave's own accumulators; k-step q = IT*s + it covers
-            // registers 8*(q&1)..+7 of the wave's feature tile (q>>1), for both lane halves.
-            if (s < 2) {
-                const int q = IT * s + it;
-                const int k = feat_of(wv * IT + (q >> 1), h, 8 * (q & 1) + e);
-                if (i < D_OUT) v = src.w[i * D_HID + k];
-            }
-        }
-        o[e] = LO ? (T)(v - (float)(T)v) : (T)v;
-    }
+    for (int e = 0; e < 8; ++e) o[e] = LO ? (T)(v[e] - (float)(T)v[e]) : (T)v[e];
     *reinterpret_cast<uint4 *>(out + idx8 * 8) = *reinterpret_cast<const uint4 *>(o);
+    if (out_lo) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (T)(v[e] - (float)(T)v[e]);
+        *reinterpret_cast<uint4 *>(out_lo + idx8 * 8) = *reinterpret_cast<const uint4 *>(o);
+    }
 }
 
 template <bool FOLD>
@@ -206,7 +224,6 @@ fold_kernel(const float *__restrict__ grid, const FoldJobs jobs, T *__restrict__
 // sat: when non-null, bit 12 is raised if a grid value or a lin_z weight is beyond the fp16 range (pnr_saturation_guard).
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int FS_TM = 128, FS_TN = 128, FS_K = 32, FS_ROW = FS_K + 8;  // halves per LDS row (32 used)
 __global__ void __launch_bounds__(256)
 fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__restrict__ tables, long long M, unsigned int *sat) {
@@ -227,7 +244,7 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float amax = 0.f;
-    auto split4 = [&](const f32x4_t v, _Float16 *hi, _Float16 *lo) {
+    auto split4 = [&](const f32x4 v, _Float16 *hi, _Float16 *lo) {
         f16x4_t h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -241,12 +258,12 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
         *reinterpret_cast<f16x4_t *>(lo) = l;
     };
     for (int k0 = 0; k0 < C_LAT; k0 += FS_K) {
-        f32x4_t xv[4], wv[4];
+        f32x4 xv[4], wv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // 128 rows x 8 float4 per operand: thread -> (row, 4 columns)
             const int e = t + u * 256, row = e >> 3, c4 = (e & 7) * 4;
-            xv[u] = (m0 + row < M) ? *reinterpret_cast<const f32x4_t *>(grid + (m0 + row) * C_LAT + k0 + c4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            wv[u] = *reinterpret_cast<const f32x4_t *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
+            xv[u] = (m0 + row < M) ? *reinterpret_cast<const f32x4 *>(grid + (m0 + row) * C_LAT + k0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            wv[u] = *reinterpret_cast<const f32x4 *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
         }
         __syncthreads();  // the previous chunk's fragments have been read
 #pragma unroll
@@ -458,9 +475,8 @@ extern "C" int pnr_pack_mlp_split(const PnrMlpWeights *w, void *packed, void *st
 #else
     constexpr bool OWNK = true;
 #endif
-    hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, false, OWNK>), dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed);
-    hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, true, OWNK>), dim3(blocks), dim3(threads), 0, st, *w,
-                       (_Float16 *)((char *)packed + PACKED_BYTES));
+    hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, false, OWNK>), dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed,
+                       (_Float16 *)((char *)packed + PACKED_BYTES));  // heads and tails from one pass over the weights
     const int nb = NBIAS * NW * BIAS_FLOATS_PER_WAVE;
     hipLaunchKernelGGL(pack_bias_kernel<true>, dim3((nb + threads - 1) / threads), dim3(threads), 0, st, *w,
                        (float *)((char *)packed + BIAS_OFFSET_BYTES), (float *)((char *)packed + BOUT_OFFSET_BYTES));
@@ -478,9 +494,9 @@ static int pack_mlp_impl(const PnrMlpWeights *w, int precision, void *packed, vo
     const int threads = 256;
     const unsigned blocks = (unsigned)((n + threads - 1) / threads);
     if (precision == PNR_PREC_F16)
-        hipLaunchKernelGGL((pack_weights_kernel<_Float16, FOLD>), dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed);
+        hipLaunchKernelGGL((pack_weights_kernel<_Float16, FOLD>), dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed, (_Float16 *)nullptr);
     else if (precision == PNR_PREC_BF16)
-        hipLaunchKernelGGL((pack_weights_kernel<__bf16, FOLD>), dim3(blocks), dim3(threads), 0, st, *w, (__bf16 *)packed);
+        hipLaunchKernelGGL((pack_weights_kernel<__bf16, FOLD>), dim3(blocks), dim3(threads), 0, st, *w, (__bf16 *)packed, (__bf16 *)nullptr);
     else
         return pnr_fail(PNR_E_INVALID, "pnr_pack_mlp: unknown precision");
     const int nb = NBIAS * NW * BIAS_FLOATS_PER_WAVE;

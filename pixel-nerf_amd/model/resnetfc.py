@@ -263,16 +263,30 @@ class ResnetFC(nn.Module):
                             lambda out: ops.pack_mlp(None, precision, folded=folded, weights=self._wstruct(), out=out))
 
     def _cached(self, key, precision, build):
+        """entry = [fingerprint, stream, content fingerprint recorded?, times served from the cache].
+        A training loop re-packs on every call (the optimizer-step count is part of the fingerprint) and never serves a stream
+        twice: there the device-side content fingerprint (pnr_params_checksum, ~25 us per network per step) protects nothing, so
+        a stream that replaces one that was never re-used is packed WITHOUT it.  The first call that would re-use such a stream
+        packs once more, this time with the fingerprint -- from then on every hit is verified as described above."""
         fp = self._fingerprint()
-        hit = self._packed.get(key)
-        if hit is not None and hit[0] == fp and precision != "f32" and self._content_verify(key):
-            fp, hit = self._fingerprint(), None
-        if hit is None or hit[0] != fp:
+        ent = self._packed.get(key)
+        checked = precision != "f32"
+        fresh = ent is not None and ent[0] == fp
+        if fresh and checked:
+            if not ent[2]:
+                fresh = False                      # packed in a re-pack-every-call phase: take the fingerprint now
+            elif self._content_verify(key):
+                fp, ent, fresh = self._fingerprint(), None, False
+        if not fresh:
             # the previous stream's buffer is overwritten in place (its users are earlier launches on the same stream)
-            self._packed[key] = (fp, build(None if hit is None else hit[1]))
-            if precision != "f32":
+            record = checked and (ent is None or ent[3] > 0 or ent[0] == fp)
+            ent = [fp, build(None if ent is None else ent[1]), record, 0]
+            self._packed[key] = ent
+            if record:
                 self._content_record(key)
-        return self._packed[key][1]
+        else:
+            ent[3] += 1
+        return ent[1]
 
     def packed_bwd(self, precision="f16"):
         """transposed weight streams for the backward data-gradient chain (training)."""
