@@ -98,34 +98,10 @@ struct SplitAdvBwd {
 
 __device__ __forceinline__ f32x16 mf(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-// Training copy-out riding inside a GEMM: the (head, tail) operand images just published go to their 16-bit row sets (operands
-// of the weight-gradient GEMM) one 1 KiB row pair per wave and loop body -- the LDS reads of a row in one body, its two global
-// stores in the next -- in the shadow of that body's 48 MFMAs instead of in front of the GEMM (dump_image: 16 LDS reads + 16
-// stores per wave before the first MFMA, with the matrix pipe idle: a third of the training forward's time in round 3).
-struct SplitDump {
-    const char *src;      // head image in LDS (row stride ROW_ACT); the tail image lo_delta behind it
-    uint32_t lo_delta;
-    char *dst_h, *dst_l;  // first row of this tile in the head / tail row sets (1 KiB rows)
-    long long rows_left;  // rows of the row sets from there on
-    int row0, lane;       // the wave's first row of the tile (8 rows per wave), its lane
-    u32x4 vh, vl;
-    __device__ __forceinline__ void read(int r) {
-        vh = *reinterpret_cast<const u32x4 *>(src + (row0 + r) * ROW_ACT + lane * 16);
-        vl = *reinterpret_cast<const u32x4 *>(src + lo_delta + (row0 + r) * ROW_ACT + lane * 16);
-    }
-    __device__ __forceinline__ void write(int r) const {
-        if (row0 + r < rows_left) {
-            *reinterpret_cast<u32x4 *>(dst_h + (size_t)(row0 + r) * (D_HID * 2) + lane * 16) = vh;
-            *reinterpret_cast<u32x4 *>(dst_l + (size_t)(row0 + r) * (D_HID * 2) + lane * 16) = vl;
-        }
-    }
-};
-
 // acc[it][jt] += (Wh + Wl)(Xh + Xl) without the tail-tail term; B rows at bhi0 + jt*jstride (+ lo_delta for the tails)
-// DUMP: nbody == 8 == rows per wave of a 64-point tile; row b is read in body b and stored in body b + 1 (the last after the loop)
-template <int JT, typename ADV = SplitAdvFwd, bool DUMP = false>
+template <int JT, typename ADV = SplitAdvFwd>
 __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *smem, uint32_t bhi0, uint32_t jstride,
-                                           uint32_t lo_delta, int nbody, SplitRing &R, int NS, [[maybe_unused]] SplitDump *dj = nullptr) {
+                                           uint32_t lo_delta, int nbody, SplitRing &R, int NS) {
     h8 bh[2][JT], bl[2][JT];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
@@ -134,10 +110,6 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
     }
 #pragma unroll 1
     for (int body = 0; body < nbody; ++body) {
-        if constexpr (DUMP) {
-            if (body > 0) dj->write(body - 1);
-            dj->read(body);
-        }
         const size_t pf = (size_t)R.pf_rs * (IT * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -188,7 +160,6 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
         bhi0 += 128;
         ADV::step(R, NS);
     }
-    if constexpr (DUMP) dj->write(nbody - 1);
 }
 
 // head / tail of 8 fp32 values (optionally through relu); MODE.FP16_OVFL is set: heads saturate at 65504.
@@ -323,11 +294,9 @@ __device__ __forceinline__ void stage_own(f32x16 (&acc)[IT][JT], const f32x16 (&
 
 // the other seven K blocks of the same linear, from the operand images: blocks (wv + 1) .. (wv + 7) mod 8, the order the stream
 // carries them in.  Loop body and pinned issue order of gemm_split.
-// DUMP (SplitDump): 7 bodies for the wave's 8 row pairs -- row 7 is read in front of the loop and stored in the first body, rows
-// 0..6 are read in bodies 0..6 and stored one body later (row 6 behind the loop).
-template <int JT, bool DUMP = false>
+template <int JT>
 __device__ __forceinline__ void gemm_split_rot(f32x16 (&acc)[IT][JT], const char *smem, uint32_t a_rd0, uint32_t jstride,
-                                               uint32_t lo_delta, int wv, SplitRing &R, int NS, [[maybe_unused]] SplitDump *dj = nullptr) {
+                                               uint32_t lo_delta, int wv, SplitRing &R, int NS) {
     h8 bh[2][JT], bl[2][JT];
     uint32_t bhi0 = a_rd0 + (uint32_t)((wv + 1) & (NW - 1)) * 128;
 #pragma unroll
@@ -335,13 +304,8 @@ __device__ __forceinline__ void gemm_split_rot(f32x16 (&acc)[IT][JT], const char
         bh[0][jt] = lds8<PH>(smem, bhi0 + jt * jstride);
         bl[0][jt] = lds8<PH>(smem, bhi0 + jt * jstride + lo_delta);
     }
-    if constexpr (DUMP) dj->read(NW - 1);
 #pragma unroll 1
     for (int m = 2; m <= NW; ++m) {
-        if constexpr (DUMP) {
-            dj->write(m == 2 ? NW - 1 : m - 3);
-            dj->read(m - 2);
-        }
         const uint32_t nxt = a_rd0 + (uint32_t)((wv + m) & (NW - 1)) * 128;  // (after the last block: this wave's own, read and dropped)
         const size_t pf = (size_t)R.pf_rs * (IT * 1024);
 #pragma unroll
@@ -388,7 +352,6 @@ __device__ __forceinline__ void gemm_split_rot(f32x16 (&acc)[IT][JT], const char
         bhi0 = nxt;
         ring_advance(R, NS);
     }
-    if constexpr (DUMP) dj->write(NW - 2);
 }
 
 // fp32 bilinear lookup of table b: wave handles points wave*8..+7; lane handles storage slots 4*lane..+3 and 256 + 4*lane..+3
@@ -533,28 +496,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), tr_rows_left, wv, lane);
         dump_image<MT>(smem, ST::A_LO, head + total + (size_t)rows * (D_HID * 2), tr_rows_left, wv, lane);
     };
-    // ... the same copy-out as a job for the GEMM that follows (SplitDump: one row pair per loop body, behind its MFMAs)
-    [[maybe_unused]] auto dump_job = [&](char *head, int b) {
-        const long long rows = b < COMBINE_LAYER ? tr_rows_view : tr_rows_pooled;
-        const size_t total = (size_t)(b < COMBINE_LAYER ? (long long)NS * q.P : q.P) * (D_HID * 2);
-        SplitDump dj;
-        dj.src = smem + ST::A_HI; dj.lo_delta = ST::A_LO - ST::A_HI;
-        dj.dst_h = head + (size_t)rows * (D_HID * 2); dj.dst_l = dj.dst_h + total;
-        dj.rows_left = tr_rows_left; dj.row0 = wv * (MT / NW); dj.lane = lane;
-        return dj;
-    };
-    // the seven foreign K blocks of a 512-wide linear; the training instantiation copies the operand images out on the way
-    auto rot = [&](f32x16 (&a)[IT][JT], [[maybe_unused]] char *head, [[maybe_unused]] int b) {
-        if constexpr (TRAIN) {
-#if defined(PNR_VARIANT) && defined(PNR_X_DUMP_FRONT)  // A/B twin: round 3's form, the whole copy-out in front of the GEMM
-            dump_pair(head, b);
-            gemm_split_rot<JT>(a, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, wv, R, NS);
-#else
-            SplitDump dj = dump_job(head, b);
-            gemm_split_rot<JT, true>(a, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, wv, R, NS, &dj);
-#endif
-        } else gemm_split_rot<JT>(a, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, wv, R, NS);
-    };
     // fp16-range guard (GUARD instantiation, pnr_saturation_guard): bit l of sat_bits = "a value >= 65504 (the largest fp16: heads
     // saturate there) went into the operand image of layer l" (2b: relu(x) entering blocks[b].fc_0, 2b+1: relu(net) entering
     // fc_1, 10: the stream in front of lin_out), bit 11 = a non-finite network output
@@ -603,7 +544,8 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             PNR_T(PH_WRITE_X);
             __syncthreads();
             PNR_T(PH_BAR2);
-            rot(net, q.s_a[b], b);   // fc_0, blocks of the other waves (TRAIN: the copy-out of relu(x)'s images rides inside)
+            if constexpr (TRAIN) dump_pair(q.s_a[b], b);
+            gemm_split_rot<JT>(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, wv, R, NS);   // fc_0, blocks of the other waves
             PNR_T(PH_GEMM_FC0);
             if constexpr (TRAIN) put_mask(net, 2 * b + 1, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
             __syncthreads();
@@ -615,7 +557,8 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         }
         __syncthreads();
         PNR_T(PH_BAR4);
-        rot(x, q.s_n[b], b);         // fc_1 (TRAIN: with the copy-out of relu(net)'s images)
+        if constexpr (TRAIN) dump_pair(q.s_n[b], b);
+        gemm_split_rot<JT>(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, wv, R, NS);         // fc_1
 #endif
         PNR_T(PH_GEMM_FC1_Z);
         if (lookup) {
@@ -890,18 +833,8 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
     };
     // the GEMM on the image just published, with the image's copy-out in front of it
     auto gemm_dump = [&](f32x16 (&a)[IT][JT], char *head, long long rows, bool per_view) {
-#if defined(PNR_VARIANT) && defined(PNR_X_DUMP_FRONT)  // A/B twin: round 3's form, the whole copy-out in front of the GEMM
         dump_pair(head, rows, per_view);
         gemm_split<JT, SplitAdvBwd>(a, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
-#else
-        static_assert(KS_BIG / 4 == MT / NW, "one row pair per loop body");
-        const size_t total = (size_t)(per_view ? (long long)NS * q.P : q.P) * (D_HID * 2);
-        SplitDump dj;
-        dj.src = smem + ST::A_HI; dj.lo_delta = ST::A_LO - ST::A_HI;
-        dj.dst_h = head + (size_t)rows * (D_HID * 2); dj.dst_l = dj.dst_h + total;
-        dj.rows_left = rows_left; dj.row0 = wv * (MT / NW); dj.lane = lane;
-        gemm_split<JT, SplitAdvBwd, true>(a, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS, &dj);
-#endif
     };
     // reverse of one residual block (resnetfc.py:55-62):  given G = dL/d(x + fc_1(relu(fc_0(relu(x))))),
     //   dY(fc_1) = G ;  d net = (fc_1^T G) . [net > 0] = dY(fc_0) ;  G += (fc_0^T d net) . [x > 0]

@@ -138,7 +138,7 @@ def test_resnetfc_of_any_shape_matches_oracle_with_gradients(dev, case, precisio
 
     zx_dev = zx.to(dev).requires_grad_(True)
     out = mlp(zx_dev, combine_inner_dims=dims)
-    assert out.shape == ref.shape and out.numel() == 4 * (G * B if pooled else G * NS * B)  # pooled: (groups, B, 4), util.py:464-466
+    assert out.shape == ref.shape and out.shape[0] == (G * B if pooled else G * NS * B)
     tol = 2e-6 if precision == "f32" else 2e-5
     assert maxrel(out, ref) <= tol, maxrel(out, ref)
     (out * w_out.to(dev)).sum().backward()
