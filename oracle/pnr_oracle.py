@@ -195,12 +195,20 @@ def pixelnerf_forward(scene, mlp, xyz, viewdirs, return_hidden=False, combine_ty
 
 
 def resnetfc_forward_general(p, zx, combine_inner_dims, d_in, d_latent, d_hidden, n_blocks, combine_layer=1000,
-                             combine_type="average", beta=0.0, use_spade=False):
+                             combine_type="average", beta=0.0, use_spade=False, kink_margin=None):
     """src/model/resnetfc.py:132-184 for ANY constructor arguments (resnetfc.py:66-130): Softplus(beta) instead of ReLU when
     beta > 0 (:126-129, :43-46), SPADE modulation (:176-179), d_in == 0 (:149), d_latent == 0 (:144-145), a combine layer that is
     never reached.  ResnetBlockFC.forward (:53-62) inlined (ResnetFC only builds equal-width blocks: no shortcut)."""
     F = torch.nn.functional
-    act = (lambda t: F.softplus(t, beta=beta)) if beta > 0 else torch.relu
+    if beta > 0:
+        act = lambda t: F.softplus(t, beta=beta)
+    else:
+        def act(t):
+            # test aid (not part of the reference): kink_margin (a list) collects min |t| / rms(t) over every ReLU input -- how
+            # close this input comes to a ReLU kink, where two arithmetic classes may legitimately pick different branches
+            if kink_margin is not None:
+                kink_margin.append(float(t.detach().abs().min() / (t.detach().pow(2).mean().sqrt() + 1e-30)))
+            return torch.relu(t)
     if d_latent > 0:
         z, x = zx[..., :d_latent], zx[..., d_latent:]  # :142-143
     else:

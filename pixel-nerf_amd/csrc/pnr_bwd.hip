@@ -577,11 +577,7 @@ dw_split_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__
     int cur = 0;
     for (long long r0 = r_begin; r0 < r_end; r0 += SR, cur ^= 1) {
         const bool more = r0 + SR < r_end;
-#if defined(PNR_VARIANT) && defined(PNR_X_DW_NOLOAD)  // TIMING ONLY (wrong results): the global loads of the first slab are re-used
-        if (more && r0 == r_begin) load_slab(r0 + SR);
-#else
         if (more) load_slab(r0 + SR);  // in flight under this slab's MFMAs
-#endif
         const char *sYh = dws + cur * (4 * SLAB), *sYl = sYh + SLAB, *sXh = sYh + 2 * SLAB, *sXl = sYh + 3 * SLAB;
 #pragma unroll
         for (int ks = 0; ks < SR / 16; ++ks) {
@@ -596,12 +592,6 @@ dw_split_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__
                 bh[b] = tr_frag<P::T8, LDB>(sXh + ks * 16 * LDB + (wk + b * 32) * 2 + frag_off);
                 bl[b] = tr_frag<P::T8, LDB>(sXl + ks * 16 * LDB + (wk + b * 32) * 2 + frag_off);
             }
-#if defined(PNR_VARIANT) && defined(PNR_X_DW_NOMFMA)  // TIMING ONLY (wrong results): the fragments are consumed by one VALU add each
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b][0] += (float)ah[a][0] + (float)bl[b][0] + (float)al[a][0] + (float)bh[b][0];
-#else
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -614,7 +604,6 @@ dw_split_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(al[a], bh[b], acc[a][b]);
-#endif
             if ((tile4 & 1) == 0 && (w & 1) == 0) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)

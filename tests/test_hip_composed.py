@@ -125,10 +125,27 @@ def test_resnetfc_of_any_shape_matches_oracle_with_gradients(dev, case, precisio
     mlp.load_state_dict(params)
     mlp = mlp.to(dev)
     mlp.composed_precision = precision
-    g = torch.Generator().manual_seed(1)
-    zx = torch.randn(G * NS * B, d_latent + d_in, generator=g) * 0.7
     dims = (NS, B)
     pooled = kw.get("combine_layer", 1000) < kw["n_blocks"]
+    # A ReLU input within rounding of zero may take the other branch in another arithmetic class (the fp32-class operators agree with
+    # fp32 to ~1e-6, not bit for bit), which moves every upstream gradient by O(1 / sqrt(elements)) -- measured here once: ONE unit of
+    # 20 480 flipped, 1.4e-3 on all gradients while every single operator was exact to 7e-7 on the same inputs
+    # (tools/gpu_debug_composed3.py).  The comparison is about the operators: of 19 seeded draws the input that stays FARTHEST from
+    # a kink (min |relu input| / rms of its layer, from the oracle) is used -- ~1.6e-5 for the 450 000 ReLU inputs of the largest case.
+    best = None
+    for seed in range(1, 20):
+        zx_try = torch.randn(G * NS * B, d_latent + d_in, generator=torch.Generator().manual_seed(seed)) * 0.7
+        margin = []
+        with torch.no_grad():
+            O.resnetfc_forward_general(params, zx_try, dims, d_in, d_latent, kw["d_hidden"], kw["n_blocks"], kw.get("combine_layer", 1000),
+                                       kw.get("combine_type", "average"), kw.get("beta", 0.0), kw.get("use_spade", False), kink_margin=margin)
+        m = min(margin) if margin else float("inf")
+        if best is None or m > best[0]:
+            best = (m, seed, zx_try)
+        if m > 1e-4:
+            break
+    g = torch.Generator().manual_seed(100 + best[1])
+    zx = best[2]
     cpu = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     zx_ref = zx.clone().requires_grad_(True)
     ref = O.resnetfc_forward_general(cpu, zx_ref, dims, d_in, d_latent, kw["d_hidden"], kw["n_blocks"], kw.get("combine_layer", 1000),
@@ -138,7 +155,7 @@ def test_resnetfc_of_any_shape_matches_oracle_with_gradients(dev, case, precisio
 
     zx_dev = zx.to(dev).requires_grad_(True)
     out = mlp(zx_dev, combine_inner_dims=dims)
-    assert out.shape == ref.shape and out.shape[0] == (G * B if pooled else G * NS * B)
+    assert out.shape == ref.shape and out.numel() == 4 * (G * B if pooled else G * NS * B)  # pooled: (groups, B, 4), util.py:464-466
     tol = 2e-6 if precision == "f32" else 2e-5
     assert maxrel(out, ref) <= tol, maxrel(out, ref)
     (out * w_out.to(dev)).sum().backward()

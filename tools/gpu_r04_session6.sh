@@ -3,12 +3,12 @@
 # then the fp32-class training step: ms/step + kernel stats of the default build and of two TIMING-ONLY twins of dw_split_kernel
 # (no global loads after the first slab / no MFMAs) that say which side of that kernel the time is on
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD
-OUT=gpurun_out/r04_s6; mkdir -p $OUT
+OUT=gpurun_out/r04_s6; mkdir -p $OUT gpurun_out/f
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -q -m gpu -s > $OUT/pytest_all.log 2>&1; echo "pytest(all) rc=$?" | tee -a $OUT/pytest_all.log
+timeout 1500 python -m pytest ${PYTEST_ARGS:-tests} -q -m gpu -s > $OUT/pytest_all.log 2>&1; echo "pytest(all) rc=$?" | tee -a $OUT/pytest_all.log
 grep -v amdgpu.ids $OUT/pytest_all.log | grep -i "passed\|failed\|error\|ResnetFC \|variant \|renderer around" | tail -40
 grep -v amdgpu.ids $OUT/pytest_all.log | grep -B5 -A40 "^___\|Error" | head -150
-echo "=== train step f16x3 (default build)"; timeout 300 python tools/gpu_train_f16x3_quick.py 2>&1 | grep -v amdgpu.ids | tee $OUT/train_default.log
+[ -n "$SKIP_QUICK" ] || timeout 300 python tools/gpu_train_f16x3_quick.py 2>&1 | grep -v amdgpu.ids | tee $OUT/train_default.log
 prof() {  # name, lib
     rm -rf $R/gpurun_out/f/st_$1
     ( cd /tmp; if [ -n "$2" ]; then export PIXELNERF_ALLOW_VARIANT=1 PIXELNERF_HIP_LIB=$2; fi
