@@ -211,6 +211,11 @@ class ShardedRenderWrapper(torch.nn.Module):
                          or (torch.is_tensor(getattr(getattr(net, "encoder", None), "latent", None)) and net.encoder.latent.requires_grad)))
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         B = rays.shape[1]
+        if training and hasattr(net, "fused_supported") and not net.fused_supported():
+            # the step's one gradient all-reduce is entered from the fused path's autograd Function; a network on the composed path
+            # (a model conf / ResnetFC shape outside the shipped one) would train every rank on its own shard without it
+            raise NotImplementedError("ShardedRenderWrapper: sharded TRAINING covers the fused network (the shipped model conf); a "
+                                      "composed-path network renders sharded, but its gradients are not all-reduced here")
         if training and B < world:
             # a rank without rays would never enter the renderer's autograd Function, i.e. never join the step's one
             # all_reduce, and its peers would block in it: refuse up front, identically on every rank
