@@ -120,6 +120,18 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pnr_grad_scale(None, 10, None, None) == -1
     assert lib.pnr_weight_grad(None, None, 10, 0, 1.0, 0, 0, None, None, None, None) == -1
     assert lib.pnr_position_backward(None, None, None, 1, 1, 1, None, None, None, None) == -1
+    # the stand-alone nn.Linear operator pair: sizes, precisions (exact fp32 / fp32-class only), operands, workspace, grad_scale
+    assert lib.pnr_linear(None, None, None, None, None, 4, 0, 8, 0, _lib.PREC_F32, None) == -1
+    assert lib.pnr_linear(64, 64, None, None, 64, 4, 8, 8, 0, _lib.PREC_F16, None) == -1
+    assert b"PNR_PREC_F32 or PNR_PREC_F16X3" in lib.pnr_last_error()
+    assert lib.pnr_linear(None, 64, None, None, 64, 4, 8, 8, 0, _lib.PREC_F32, None) == -1
+    assert lib.pnr_linear(None, None, None, None, None, 0, 8, 8, 0, _lib.PREC_F32, None) == 0   # no rows: a no-op
+    assert lib.pnr_linear_backward_workspace_bytes(42, 512) == 32 * (42 * 512 + 512) * 4 and lib.pnr_linear_backward_workspace_bytes(0, 4) == 0
+    assert lib.pnr_linear_backward(64, 64, 64, 4, 8, 8, 0, None, 64, None, None, None, 0, _lib.PREC_F32, None) == -1
+    assert b"workspace too small" in lib.pnr_last_error()
+    assert lib.pnr_linear_backward(64, 64, 64, 4, 8, 8, 0, 64, None, None, None, None, 0, _lib.PREC_F16X3, None) == -1
+    assert b"grad_scale" in lib.pnr_last_error()
+    assert lib.pnr_linear_backward(64, 64, 64, 4, 8, 8, 0, None, None, 64, None, None, 0, _lib.PREC_F32, None) == -1  # db without dW
     # empty batches are a successful no-op (reference: empty output, nerf.py:23-27)
     assert lib.pnr_sample_coarse(None, None, 0, 8, 0, None, None) == 0
     assert lib.pnr_composite(None, None, None, 0, 8, 0, None, None, None, None) == 0
