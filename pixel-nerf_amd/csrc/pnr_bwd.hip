@@ -1197,9 +1197,68 @@ extern "C" size_t pnr_train_masks_bytes(long long P, int NS) {
     return (size_t)11 * (size_t)NS * (size_t)((P + MT - 1) / MT) * NTHREADS * sizeof(unsigned long long);
 }
 
+// Large gradients (the stand-alone linear operators scale a whole (rows, d_out) tensor: 33 M values take 1.5 ms in one workgroup):
+// max |g| over many workgroups -- non-negative floats order like their bit patterns, a non-finite value enters as +inf -- into
+// scales[0] (zeroed first), then one thread turns the maximum into [scale, 1 / scale] exactly as grad_scale_kernel does.
+__global__ void __launch_bounds__(1024) grad_absmax_kernel(const float *__restrict__ g, long long n, unsigned int *__restrict__ out) {
+    __shared__ float red[1024];
+    float m = 0.f;
+    bool bad = false;
+    const long long n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? n / 4 : 0;
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
+    const long long stride = (long long)gridDim.x * 8 * 1024;
+    for (long long i0 = (long long)blockIdx.x * 8 * 1024 + threadIdx.x; i0 < n4; i0 += stride) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long i = i0 + (long long)u * 1024;
+            v[u] = i < n4 ? g4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = fabsf(v[u][e]);
+                bad |= !(a <= 3.0e38f);
+                m = fmaxf(m, a);
+            }
+    }
+    if (blockIdx.x == 0)
+        for (long long i = n4 * 4 + threadIdx.x; i < n; i += 1024) {
+            const float a = fabsf(g[i]);
+            bad |= !(a <= 3.0e38f);
+            m = fmaxf(m, a);
+        }
+    red[threadIdx.x] = bad ? __builtin_inff() : m;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(red[0]));
+}
+__global__ void grad_scale_from_max_kernel(float *__restrict__ scales) {
+    const float mx = __uint_as_float(reinterpret_cast<const unsigned int *>(scales)[0]);
+    float sc = 1.f;
+    if (!(mx <= 3.0e38f)) sc = __builtin_nanf("");
+    else if (mx > 0.f) sc = exp2f(fminf(fmaxf(6.f - ceilf(log2f(mx)), -100.f), 100.f));
+    scales[0] = sc;
+    scales[1] = 1.f / sc;
+}
+
 extern "C" int pnr_grad_scale(const float *g, long long n, float *scales, void *stream) {
     if (!g || !scales || n <= 0) return pnr_fail(PNR_E_INVALID, "pnr_grad_scale: bad argument");
-    hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, scales);
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= (1LL << 20)) {  // the renderer's (P, 4) output gradient: one workgroup, one launch
+        hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1024), 0, st, g, n, scales);
+        return pnr_check_launch("pnr_grad_scale");
+    }
+    const hipError_t e = hipMemsetAsync(scales, 0, 2 * sizeof(float), st);
+    if (e != hipSuccess) return pnr_check_hip(e, "hipMemsetAsync(pnr_grad_scale)");
+    const long long chunks = (n / 4 + 8 * 1024 - 1) / (8 * 1024);
+    const unsigned blocks = (unsigned)(chunks < 1024 ? (chunks < 1 ? 1 : chunks) : 1024);
+    hipLaunchKernelGGL(grad_absmax_kernel, dim3(blocks), dim3(1024), 0, st, g, n, reinterpret_cast<unsigned int *>(scales));
+    hipLaunchKernelGGL(grad_scale_from_max_kernel, dim3(1), dim3(1), 0, st, scales);
     return pnr_check_launch("pnr_grad_scale");
 }
 

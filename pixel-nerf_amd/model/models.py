@@ -279,10 +279,13 @@ class PixelNeRFNet(torch.nn.Module):
         SB, B, _ = xyz.shape
         NS = int(self.num_views_per_obj)
         rot, trans = self.poses[:, None, :3, :3], self.poses[:, None, :3, 3]       # world -> source camera, (SB*NS, 1, ...)
+
+        def rotate(v):  # (SB*NS, B, 3) -> R v per view, as three broadcast products (a batched 3x3 matmul of B tiny problems is a GEMM launch that costs more than the network's linears)
+            return rot[..., 0] * v[..., 0:1] + rot[..., 1] * v[..., 1:2] + rot[..., 2] * v[..., 2:3]
         p_world = repeat_interleave(xyz.float(), NS)                                # (SB*NS, B, 3)
-        p_rot = (rot @ p_world.unsqueeze(-1)).squeeze(-1)
+        p_rot = rotate(p_world)
         p_cam = p_rot + trans
-        rows = None
+        feat = lat = None
         if self.d_in > 0:
             src = p_rot if self.normalize_z else p_cam                              # models.py:169-179
             feat = src.reshape(-1, 3) if self.use_xyz else -src[..., 2].reshape(-1, 1)
@@ -290,11 +293,10 @@ class PixelNeRFNet(torch.nn.Module):
                 feat = self.code(feat.contiguous())
             if self.use_viewdirs:
                 assert viewdirs is not None  # models.py:186
-                d_cam = rot @ repeat_interleave(viewdirs.float().reshape(SB, B, 3, 1), NS)
+                d_cam = rotate(repeat_interleave(viewdirs.float().reshape(SB, B, 3), NS))
                 feat = torch.cat((feat, d_cam.reshape(-1, 3)), dim=1)
             if self.use_code and self.use_code_viewdirs:
                 feat = self.code(feat.contiguous())
-            rows = feat
         if self.use_encoder:
             fl, pp = self.focal.unsqueeze(1), self.c.unsqueeze(1)                   # (n|1, 1, 2) each
             uv = -p_cam[..., :2] / p_cam[..., 2:3]                                  # models.py:206-212
@@ -303,13 +305,18 @@ class PixelNeRFNet(torch.nn.Module):
             if self.stop_encoder_grad:
                 lat = lat.detach()
             lat = lat.transpose(1, 2).reshape(-1, self.latent_size)
-            rows = lat if self.d_in == 0 else torch.cat((lat, rows), dim=-1)
-        if self.use_global_encoder:
+        if self.use_global_encoder:                                                 # models.py:228-235: in FRONT of the other columns
             g = self.global_encoder.latent
-            assert rows.shape[0] % g.shape[0] == 0
-            rows = torch.cat((repeat_interleave(g, rows.shape[0] // g.shape[0]), rows), dim=-1)
+            n_rows = (lat if lat is not None else feat).shape[0]
+            assert n_rows % g.shape[0] == 0
+            g = repeat_interleave(g, n_rows // g.shape[0])
+            lat = g if lat is None else torch.cat((g, lat), dim=-1)
+        # mlp_input = (latent columns | code columns): handed over as its two parts (the ResnetFC splits it again at d_latent)
         mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
-        out = mlp(rows, combine_inner_dims=(NS, B)).reshape(-1, B, self.d_out)
+        if mlp.d_latent > 0 and (lat is None or lat.shape[-1] != mlp.d_latent):
+            raise ValueError("PixelNeRFNet: the network's d_latent does not match the latent columns of this model conf")
+        with torch.profiler.record_function("resnetfc_infer"):  # the reference's scope name (resnetfc.py:141)
+            out = mlp._forward_composed(None, (NS, B), parts=(lat, feat)).reshape(-1, B, self.d_out)
         return torch.cat((torch.sigmoid(out[..., :3]), torch.relu(out[..., 3:4])), dim=-1).reshape(SB, B, -1)
 
     def _forward_points(self, xyz, coarse, viewdirs):

@@ -314,19 +314,25 @@ class ResnetFC(nn.Module):
                 return out.reshape(-1, dims[1], *zx.shape[1:-1], self.d_out)
             return self._forward_composed(zx, dims)
 
-    def _forward_composed(self, zx, dims):
+    def _forward_composed(self, zx, dims, parts=None):
         """resnetfc.py:141-184 for any constructor arguments: every nn.Linear is one `linear_autograd` node (pnr_linear /
         pnr_linear_backward; `x + lin_z(z)` rides as that operator's residual, ReLUs as its input activation); the view pooling,
-        SPADE's product and a Softplus are torch ops on HIP tensors in between."""
+        SPADE's product and a Softplus are torch ops on HIP tensors in between.
+        parts = (z, x): the two column groups of zx handed over separately (PixelNeRFNet's composed forward: saves the
+        concatenation and the two slice copies of a (rows, d_latent + d_in) tensor)."""
         from .. import util
         from ..autograd import linear_autograd as lin
         prec = self.composed_precision
         relu = self.beta <= 0
+        if parts is not None:
+            z, x = parts
+            zx = x if x is not None else z
         if not zx.is_cuda:
             raise ops._lib.PixelNerfHipError("ResnetFC.forward: tensors must live on a HIP device (no CPU path)")
-        zx = zx.float()
-        z = zx[..., : self.d_latent] if self.d_latent > 0 else None
-        x = zx[..., self.d_latent:] if self.d_latent > 0 else zx
+        if parts is None:
+            zx = zx.float()
+            z = zx[..., : self.d_latent] if self.d_latent > 0 else None
+            x = zx[..., self.d_latent:] if self.d_latent > 0 else zx
         if self.d_in > 0:
             x = lin(x, self.lin_in.weight, self.lin_in.bias, precision=prec)
         else:
