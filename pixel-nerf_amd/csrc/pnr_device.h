@@ -382,7 +382,7 @@ __device__ __forceinline__ Proj project_point(const EvalParams &q, const float *
 // so that fp32 intermediates round like the PyTorch eager path.
 #pragma clang fp contract(off)
 template <typename P, bool RAYS, typename TL>
-__device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, int tile, int view, int p, int sub) {
+__device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, int tile, int view, int p, int sub, bool pad = true) {
     typedef typename P::T T;
     constexpr int MT = TL::MT, LDS_IN = TL::LDS_IN, LDS_META = TL::LDS_META;
     const int g = tile * MT + p;  // P < 2^31 (checked on the host)
@@ -421,13 +421,23 @@ __device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, i
         in_row[i] = hi;
         if constexpr (TL::IN_LO_DELTA != 0) reinterpret_cast<T *>(reinterpret_cast<char *>(in_row) + TL::IN_LO_DELTA)[i] = (T)(v - (float)hi);
     };
+    // two neighbouring elements (i even) as ONE 32-bit LDS store per image: the scalar 16-bit stores were what this phase waited on
+    auto put2 = [&](int i, float v0, float v1) {
+        struct alignas(4) Pair { T a, b; };
+        const Pair hi = {(T)v0, (T)v1};
+        *reinterpret_cast<Pair *>(in_row + i) = hi;
+        if constexpr (TL::IN_LO_DELTA != 0) {
+            const Pair lo = {(T)(v0 - (float)hi.a), (T)(v1 - (float)hi.b)};
+            *reinterpret_cast<Pair *>(reinterpret_cast<char *>(in_row + i) + TL::IN_LO_DELTA) = lo;
+        }
+    };
     if (sub == 0) {
         // identity part of the code, rotated view direction (models.py:188-196), zero pad
         const float dv0 = pose[0] * dx + pose[1] * dy + pose[2] * dz;
         const float dv1 = pose[4] * dx + pose[5] * dy + pose[6] * dz;
         const float dv2 = pose[8] * dx + pose[9] * dy + pose[10] * dz;
-        put(0, valid ? xr0 : 0.f); put(1, valid ? xr1 : 0.f); put(2, valid ? xr2 : 0.f);
-        put(39, dv0); put(40, dv1); put(41, dv2);
+        put2(0, valid ? xr0 : 0.f, valid ? xr1 : 0.f); put(2, valid ? xr2 : 0.f);
+        put(39, dv0); put2(40, dv1, dv2);
         // camera-space point, pinhole projection, bilinear corner setup
         const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, valid);
         uint32_t *mo = reinterpret_cast<uint32_t *>(smem + LDS_META + p * 32);
@@ -445,15 +455,17 @@ __device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, i
         // orders of magnitude and ~10x cheaper than libm's range-reduced sinf; the split-operand (fp32-class) kernel
         // keeps the precise one.
         auto sn = [](float a) { return TL::IN_LO_DELTA != 0 ? sinf(a) : __sinf(a); };
-        put(o + 0, valid ? sn(a0) : 0.f); put(o + 1, valid ? sn(a1) : 0.f); put(o + 2, valid ? sn(a2) : 0.f);
+        const float s0 = valid ? sn(a0) : 0.f, s1 = valid ? sn(a1) : 0.f, s2 = valid ? sn(a2) : 0.f;
         // the phase-shifted terms: ATen's addcmul(phases, x, freqs) (code.py:39) is ONE fused multiply-add per element -- x f
         // + pi/2 rounded once -- so the argument is formed with fmaf here as well (separately rounded it differs by up to an ulp
         // of the argument, 1.5e-5 at f = 48: found by tests/test_hip_features.py against the reference's own output)
-        put(o + 3, valid ? sn(__builtin_fmaf(xr0, f, HALF_PI)) : 0.f); put(o + 4, valid ? sn(__builtin_fmaf(xr1, f, HALF_PI)) : 0.f);
-        put(o + 5, valid ? sn(__builtin_fmaf(xr2, f, HALF_PI)) : 0.f);
-    } else {
-        // zero the K padding 42..63 (+ the 8-element row pad read by the last B prefetch)
-        for (int i = D_IN; i < D_IN_PAD + 8; ++i) put(i, 0.f);
+        const float c0 = valid ? sn(__builtin_fmaf(xr0, f, HALF_PI)) : 0.f, c1 = valid ? sn(__builtin_fmaf(xr1, f, HALF_PI)) : 0.f;
+        const float c2 = valid ? sn(__builtin_fmaf(xr2, f, HALF_PI)) : 0.f;
+        put(o, s0); put2(o + 1, s1, s2); put2(o + 3, c0, c1); put(o + 5, c2);  // o is odd: the even-indexed pairs are 4-byte aligned
+    } else if (pad) {
+        // zero the K padding 42..63 (+ the 8-element row pad read by the last B prefetch).  pad == false: the caller's rows keep
+        // their padding from an earlier tile (a dedicated LDS region that nothing else writes: the split-operand kernel)
+        for (int i = D_IN; i < D_IN_PAD + 8; i += 2) put2(i, 0.f, 0.f);
     }
 }
 #pragma clang fp contract(fast)

@@ -360,23 +360,54 @@ __device__ __forceinline__ void gemm_split_rot(f32x16 (&acc)[IT][JT], const char
 // rows land in the table image (ROW_TAB stride) at offset 0
 template <int GB, typename ST>
 __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem, int wv, int lane, int b) {
+    static_assert(GB == 2, "pairs of consecutive points");
     const float *tab = reinterpret_cast<const float *>(q.tables) + (size_t)b * q.table_stride + lane * 4;
-    static_assert((ST::MT / NW) % GB == 0, "gather batch");
+    // A wave's 8 points are consecutive samples of ONE ray (tiles never straddle rays: K is a multiple of the tile), and consecutive
+    // samples mostly fall into the same cell of the feature grid (sn64: 4-12 samples per texel): a point whose four corner offsets
+    // equal its predecessor's re-uses the predecessor's rows from registers instead of loading 8 KiB again.  The comparison is
+    // wave-uniform (every lane reads the same META words), the arithmetic per point is unchanged (same rows, same order).
+    f32x4 v[GB][4][2];
+    uint32_t last[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // offsets of the rows held in v[1]
 #pragma unroll 1
     for (int i = 0; i < ST::MT / NW; i += GB) {
-        f32x4 v[GB][4][2];
         f32x4 w[GB];
+        uint32_t off[GB][4];
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
             const int p = wv * (ST::MT / NW) + i + u;
-            const u32x4 off = *reinterpret_cast<const u32x4 *>(smem + ST::LDS_META + p * 32);
+            const u32x4 o = *reinterpret_cast<const u32x4 *>(smem + ST::LDS_META + p * 32);
             w[u] = *reinterpret_cast<const f32x4 *>(smem + ST::LDS_META + p * 32 + 16);
 #pragma unroll
+            for (int c = 0; c < 4; ++c) off[u][c] = __builtin_amdgcn_readfirstlane(o[c]);
+        }
+#if defined(PNR_VARIANT) && defined(PNR_X_GATHER_NOREUSE)  // A/B twin: every point loads its four corner rows (round 3's form)
+        const bool keep0 = false, keep1 = false;
+#else
+        const bool keep0 = off[0][0] == last[0] && off[0][1] == last[1] && off[0][2] == last[2] && off[0][3] == last[3];
+        const bool keep1 = off[1][0] == off[0][0] && off[1][1] == off[0][1] && off[1][2] == off[0][2] && off[1][3] == off[0][3];
+#endif
+        if (keep0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[0][c][0] = v[1][c][0]; v[0][c][1] = v[1][c][1]; }
+        } else {
+#pragma unroll
             for (int c = 0; c < 4; ++c) {
-                v[u][c][0] = *reinterpret_cast<const f32x4 *>(tab + off[c]);
-                v[u][c][1] = *reinterpret_cast<const f32x4 *>(tab + off[c] + D_HID / 2);
+                v[0][c][0] = *reinterpret_cast<const f32x4 *>(tab + off[0][c]);
+                v[0][c][1] = *reinterpret_cast<const f32x4 *>(tab + off[0][c] + D_HID / 2);
             }
         }
+        if (keep1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[1][c][0] = v[0][c][0]; v[1][c][1] = v[0][c][1]; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[1][c][0] = *reinterpret_cast<const f32x4 *>(tab + off[1][c]);
+                v[1][c][1] = *reinterpret_cast<const f32x4 *>(tab + off[1][c] + D_HID / 2);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) last[c] = off[1][c];
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
             const int p = wv * (ST::MT / NW) + i + u;
@@ -576,7 +607,13 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         for (int view = 0; view < NS; ++view) {
             __syncthreads();  // previous tile / view: every reader of the images / IN / META is done
             PNR_T(PH_SYNC_TOP);
-            if (MT == 64 || tid < MT * 8) geometry_item<PH, RAYS, ST>(q, smem, tile, view, tid % MT, tid / MT);
+            // (the K padding of the lin_in operand rows is written once: LDS_IN is this kernel's own region, only elements 0..41 change)
+            if (MT == 64 || tid < MT * 8)
+#if defined(PNR_VARIANT) && defined(PNR_X_GEOM_PAD_ALWAYS)  // A/B twin: the padding re-written for every tile
+                geometry_item<PH, RAYS, ST>(q, smem, tile, view, tid % MT, tid / MT, true);
+#else
+                geometry_item<PH, RAYS, ST>(q, smem, tile, view, tid % MT, tid / MT, tile == (int)blockIdx.x && view == 0);
+#endif
             __syncthreads();
             PNR_T(PH_GEOMETRY);
             gather_table_f32<2, ST>(q, smem, wv, lane, 0);
