@@ -382,7 +382,7 @@ __device__ __forceinline__ Proj project_point(const EvalParams &q, const float *
 // so that fp32 intermediates round like the PyTorch eager path.
 #pragma clang fp contract(off)
 template <typename P, bool RAYS, typename TL>
-__device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, int tile, int view, int p, int sub, bool pad = true) {
+__device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, int tile, int view, int p, int sub) {
     typedef typename P::T T;
     constexpr int MT = TL::MT, LDS_IN = TL::LDS_IN, LDS_META = TL::LDS_META;
     const int g = tile * MT + p;  // P < 2^31 (checked on the host)
@@ -421,7 +421,7 @@ __device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, i
         in_row[i] = hi;
         if constexpr (TL::IN_LO_DELTA != 0) reinterpret_cast<T *>(reinterpret_cast<char *>(in_row) + TL::IN_LO_DELTA)[i] = (T)(v - (float)hi);
     };
-    // two neighbouring elements (i even) as ONE 32-bit LDS store per image: the scalar 16-bit stores were what this phase waited on
+    // two neighbouring elements (i even) as ONE 32-bit LDS store per image
     auto put2 = [&](int i, float v0, float v1) {
         struct alignas(4) Pair { T a, b; };
         const Pair hi = {(T)v0, (T)v1};
@@ -462,9 +462,8 @@ __device__ __forceinline__ void geometry_item(const EvalParams &q, char *smem, i
         const float c0 = valid ? sn(__builtin_fmaf(xr0, f, HALF_PI)) : 0.f, c1 = valid ? sn(__builtin_fmaf(xr1, f, HALF_PI)) : 0.f;
         const float c2 = valid ? sn(__builtin_fmaf(xr2, f, HALF_PI)) : 0.f;
         put(o, s0); put2(o + 1, s1, s2); put2(o + 3, c0, c1); put(o + 5, c2);  // o is odd: the even-indexed pairs are 4-byte aligned
-    } else if (pad) {
-        // zero the K padding 42..63 (+ the 8-element row pad read by the last B prefetch).  pad == false: the caller's rows keep
-        // their padding from an earlier tile (a dedicated LDS region that nothing else writes: the split-operand kernel)
+    } else {
+        // zero the K padding 42..63 (+ the 8-element row pad read by the last B prefetch)
         for (int i = D_IN; i < D_IN_PAD + 8; i += 2) put2(i, 0.f, 0.f);
     }
 }

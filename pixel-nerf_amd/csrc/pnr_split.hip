@@ -366,6 +366,8 @@ __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem
     // samples mostly fall into the same cell of the feature grid (sn64: 4-12 samples per texel): a point whose four corner offsets
     // equal its predecessor's re-uses the predecessor's rows from registers instead of loading 8 KiB again.  The comparison is
     // wave-uniform (every lane reads the same META words), the arithmetic per point is unchanged (same rows, same order).
+    // Same-box A/B against loading every point's rows (profiles/r04_split_kernel_ab.txt, session 9): lookups 30.2 k -> 19.7 k
+    // cycles per tile; sn64 +1.1 %, srn_car +3.4 %, DTU +2.0 %.
     f32x4 v[GB][4][2];
     uint32_t last[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // offsets of the rows held in v[1]
 #pragma unroll 1
@@ -380,12 +382,8 @@ __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem
 #pragma unroll
             for (int c = 0; c < 4; ++c) off[u][c] = __builtin_amdgcn_readfirstlane(o[c]);
         }
-#if defined(PNR_VARIANT) && defined(PNR_X_GATHER_NOREUSE)  // A/B twin: every point loads its four corner rows (round 3's form)
-        const bool keep0 = false, keep1 = false;
-#else
         const bool keep0 = off[0][0] == last[0] && off[0][1] == last[1] && off[0][2] == last[2] && off[0][3] == last[3];
         const bool keep1 = off[1][0] == off[0][0] && off[1][1] == off[0][1] && off[1][2] == off[0][2] && off[1][3] == off[0][3];
-#endif
         if (keep0) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) { v[0][c][0] = v[1][c][0]; v[0][c][1] = v[1][c][1]; }
@@ -607,13 +605,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         for (int view = 0; view < NS; ++view) {
             __syncthreads();  // previous tile / view: every reader of the images / IN / META is done
             PNR_T(PH_SYNC_TOP);
-            // (the K padding of the lin_in operand rows is written once: LDS_IN is this kernel's own region, only elements 0..41 change)
-            if (MT == 64 || tid < MT * 8)
-#if defined(PNR_VARIANT) && defined(PNR_X_GEOM_PAD_ALWAYS)  // A/B twin: the padding re-written for every tile
-                geometry_item<PH, RAYS, ST>(q, smem, tile, view, tid % MT, tid / MT, true);
-#else
-                geometry_item<PH, RAYS, ST>(q, smem, tile, view, tid % MT, tid / MT, tile == (int)blockIdx.x && view == 0);
-#endif
+            if (MT == 64 || tid < MT * 8) geometry_item<PH, RAYS, ST>(q, smem, tile, view, tid % MT, tid / MT);
             __syncthreads();
             PNR_T(PH_GEOMETRY);
             gather_table_f32<2, ST>(q, smem, wv, lane, 0);
