@@ -28,7 +28,9 @@ timed step also contains the single feature-grid broadcast from rank 0 and the f
 The JSON line also carries
   roofline     : the fused network kernel (>= 99 % of the work) against the dense f16 MFMA peak: algorithmic FLOP of the
                  launches in the timed region / their HIP-event time on the launch stream; executed_mfma_tflops counts the
-                 MFMAs really issued (3 per product for f16x3, lin_z folded away); traffic from the committed PMC passes;
+                 MFMAs really issued (3 per product for f16x3, lin_z folded away); traffic = bytes per launch at the L2 <-> fabric
+                 interface, MEASURED IN THIS RUN by two rocprofv3 --pmc passes around a 2-step child of the same command (the
+                 committed PMC profile, stamped with the kernel-source hash, is the fallback and rides along for comparison);
   torch_eager_gpu_baseline : the same algorithm in eager PyTorch-ROCm fp32 on this GPU (oracle restatement), in the reference's
                  execution shape -- 50 000-ray batches, 50 000-point model calls (eval/eval.py:137,264; nerf.py:190-216) -- and,
                  under ..._unchunked_16384, as one model call per pass; speedup_vs_torch_eager_gpu refers to the former;
@@ -152,6 +154,49 @@ def pmc_traffic_per_launch(prec):
         return None, "%s was measured on kernel sources %s, this build is %s: refused as stale" % (
             rel, d.get("_kernel_source_sha16"), kernel_source_sha16(prec)), None
     return (2.0 * d["FETCH_SIZE"]["avg_per_launch"] + d["WRITE_SIZE"]["avg_per_launch"]) * 1024.0, None, d.get("_derived")
+
+
+def measure_traffic_live(prec, timeout_s=150):
+    """`roofline.traffic` measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- separate passes, no trace domain
+    besides --kernel-trace, as MI355X_MICROARCH.md prescribes) around a 2-step child of this very command; per launch of the fused
+    kernel, averaged over its coarse and fine launches like `achieved`; KiB units, FETCH_SIZE doubled (gfx950).
+    -> (bytes per launch, None) or (None, reason).  Never raises: the committed profile stays the fallback."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return None, "rocprofv3 not found"
+    kname = KERNEL_OF[prec].split("::")[-1]
+    env = dict(os.environ, PIXELNERF_SATURATION_GUARD="off", TMPDIR="/tmp")  # every launch = the plain instantiation
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    got = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as out:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                cmd = [tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc_" + counter, "--",
+                       sys.executable, os.path.abspath(__file__), "--prec", prec, "--steps", "2", "--warmup", "1", "--no-peer", "--no-latency",
+                       "--no-cpu-baseline", "--no-eager-baseline", "--no-f32-check", "--no-extras", "--no-live-pmc"]
+                p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    p.wait(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    os.killpg(p.pid, 9)
+                    return None, "rocprofv3 --pmc %s pass timed out after %d s" % (counter, timeout_s)
+                per = {}
+                for path in glob.glob(os.path.join(out, "**", "pmc_%s*counter_collection.csv" % counter), recursive=True):
+                    for row in csv.DictReader(open(path)):
+                        if row["Counter_Name"] == counter and (kname + "<" in row["Kernel_Name"] or kname + "I" in row["Kernel_Name"]):
+                            per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                if not per:
+                    return None, "the rocprofv3 --pmc %s pass (rc %s) recorded no %s launch" % (counter, p.returncode, kname)
+                got[counter] = (sum(per.values()) / len(per), len(per))
+    except Exception as e:  # a profiler that is absent / refuses counters must not take the bench line down
+        return None, "%s: %s" % (type(e).__name__, str(e)[:200])
+    return (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0, None
 
 
 def roofline_block(prec, rays_rank0, steps, kern_ms, n_launch, NS, fold, elapsed, default_shape):
@@ -548,6 +593,8 @@ def main():
     ap.add_argument("--bcast-layout", default="nhwc", choices=["nhwc", "nchw"],
                     help="layout the feature grid travels in: channel-last (what the kernels read; receivers skip the transpose) or NCHW")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed BASELINE configs 3/4/5 section (extra.configs)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure `roofline.traffic` "
+                    "in this run (profiling / A/B invocations; the committed profile is reported instead)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -700,6 +747,17 @@ def main():
                 "what": "the same workload, same steps / warm-up, timed in a second region right after the headline: " + DTYPE_NOTE[pp],
                 "value": R * args.steps / pe, "unit": "rays/s", "ms_per_step": pe / args.steps * 1e3, "dtype": pp,
                 "roofline": roofline_block(pp, R, args.steps, pk, pn, NS, True, pe, default_shape)}
+    if world == 1 and rank == 0 and default_shape and not args.no_live_pmc:
+        # roofline.traffic measured in THIS run (outside the timed region): two counter passes around a 2-step child
+        live, why = measure_traffic_live(args.prec)
+        rf = res["roofline"]
+        if live is not None:
+            rf["traffic_committed_profile"] = rf["traffic"]
+            rf["traffic"] = live
+            rf["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE; one pass each) around "
+                                    "a 2-step child of this command, average over its fused-kernel launches")
+        else:
+            rf["traffic_live_error"] = why
     if world == 1 and not args.no_cpu_baseline:
         # bounded CPU sample of the same workload; also yields the matched-PSNR figure.  torch's intra-op pool does not
         # scale to every core of a many-socket host on 512-wide GEMMs: pick the thread count that is FASTEST on a 64-ray

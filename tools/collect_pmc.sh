@@ -10,7 +10,7 @@ OUT="$REPO/gpurun_out/pmc_$PREC"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export PIXELNERF_SATURATION_GUARD=off  # every launch of the profiled process is the plain instantiation (the guard runs once per new weights otherwise)
-CMD="python $REPO/bench.py --prec $PREC --steps 2 --warmup 1 --no-peer --no-latency --no-cpu-baseline --no-eager-baseline --no-f32-check --no-extras $*"
+CMD="python $REPO/bench.py --prec $PREC --steps 2 --warmup 1 --no-peer --no-latency --no-cpu-baseline --no-eager-baseline --no-f32-check --no-extras --no-live-pmc $*"
 run() {  # name, counters...
     local name=$1; shift
     timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -o "pmc_$name" -- $CMD > "$OUT/$name.log" 2>&1

@@ -17,7 +17,7 @@ except Exception as e: print("bench parse failed", e); print(open("$OUT/bench.er
 PY
 export PIXELNERF_SATURATION_GUARD=off
 for prec in f16x3 f16; do
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/stats_$prec -o st -- python $OLDPWD/bench.py --prec $prec --steps 20 --warmup 5 --no-peer --no-latency --no-cpu-baseline --no-eager-baseline --no-f32-check --no-extras > $OLDPWD/$OUT/stats_$prec.log 2>&1)
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/stats_$prec -o st -- python $OLDPWD/bench.py --prec $prec --steps 20 --warmup 5 --no-peer --no-latency --no-cpu-baseline --no-eager-baseline --no-f32-check --no-extras --no-live-pmc > $OLDPWD/$OUT/stats_$prec.log 2>&1)
     f=$(find $OUT/stats_$prec -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/bench_${prec}_kernel_stats.csv && head -6 "$f" | cut -c1-200
     rm -rf $OUT/stats_$prec
 done

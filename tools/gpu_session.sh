@@ -24,7 +24,7 @@ case $what in
 ab) bash tools/gpu_split_ab.sh ;;
 stats)
     for prec in f16x3 f16; do
-        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/stats_$prec -o st -- python $OLDPWD/bench.py --prec $prec --steps 20 --warmup 5 --no-peer --no-latency --no-cpu-baseline --no-eager-baseline --no-f32-check --no-extras > $OLDPWD/$OUT/stats_$prec.log 2>&1)
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/stats_$prec -o st -- python $OLDPWD/bench.py --prec $prec --steps 20 --warmup 5 --no-peer --no-latency --no-cpu-baseline --no-eager-baseline --no-f32-check --no-extras --no-live-pmc > $OLDPWD/$OUT/stats_$prec.log 2>&1)
         f=$(find $OUT/stats_$prec -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
     done ;;
 pmc)
