@@ -157,10 +157,13 @@ def pmc_traffic_per_launch(prec):
 
 
 def measure_traffic_live(prec, timeout_s=150):
-    """`roofline.traffic` measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- separate passes, no trace domain
-    besides --kernel-trace, as MI355X_MICROARCH.md prescribes) around a 2-step child of this very command; per launch of the fused
-    kernel, averaged over its coarse and fine launches like `achieved`; KiB units, FETCH_SIZE doubled (gfx950).
-    -> (bytes per launch, None) or (None, reason).  Never raises: the committed profile stays the fallback."""
+    """`roofline.traffic` measured IN THIS RUN: rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; GRBM_GUI_ACTIVE + the MFMA-busy pair --
+    separate passes, no trace domain besides --kernel-trace, as MI355X_MICROARCH.md prescribes) around a 2-step child of this very
+    command; per launch of the fused kernel, averaged over its coarse and fine launches like `achieved`; KiB units, FETCH_SIZE
+    doubled (gfx950).  The third pass also yields the average shader clock DURING the kernel (GRBM_GUI_ACTIVE summed over the 8 XCDs
+    / 8 / the launch's duration in that pass's kernel trace) and the MFMA-busy share: the pool's boxes sustain different clocks
+    under this kernel's load, which is most of their 3-5 % spread in `value`.
+    -> (bytes per launch, None, extras) or (None, reason, {}).  Never raises: the committed profile stays the fallback."""
     import csv
     import glob
     import shutil
@@ -168,16 +171,18 @@ def measure_traffic_live(prec, timeout_s=150):
     import tempfile
     tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(tool):
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", {}
     kname = KERNEL_OF[prec].split("::")[-1]
+    is_kernel = lambda n: kname + "<" in n or kname + "I" in n  # noqa: E731
     env = dict(os.environ, PIXELNERF_SATURATION_GUARD="off", TMPDIR="/tmp")  # every launch = the plain instantiation
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    got = {}
+    got, extras = {}, {}
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as out:
-            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-                cmd = [tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc_" + counter, "--",
+            for name, counters, required in (("fetch", ["FETCH_SIZE"], True), ("write", ["WRITE_SIZE"], True),
+                                             ("clock", ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"], False)):
+                cmd = [tool, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", "pmc_" + name, "--",
                        sys.executable, os.path.abspath(__file__), "--prec", prec, "--steps", "2", "--warmup", "1", "--no-peer", "--no-latency",
                        "--no-cpu-baseline", "--no-eager-baseline", "--no-f32-check", "--no-extras", "--no-live-pmc"]
                 p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -185,18 +190,32 @@ def measure_traffic_live(prec, timeout_s=150):
                     p.wait(timeout=timeout_s)
                 except subprocess.TimeoutExpired:
                     os.killpg(p.pid, 9)
-                    return None, "rocprofv3 --pmc %s pass timed out after %d s" % (counter, timeout_s)
+                    if required:
+                        return None, "rocprofv3 --pmc %s pass timed out after %d s" % (name, timeout_s), {}
+                    continue
                 per = {}
-                for path in glob.glob(os.path.join(out, "**", "pmc_%s*counter_collection.csv" % counter), recursive=True):
+                for path in glob.glob(os.path.join(out, "**", "pmc_%s*counter_collection.csv" % name), recursive=True):
                     for row in csv.DictReader(open(path)):
-                        if row["Counter_Name"] == counter and (kname + "<" in row["Kernel_Name"] or kname + "I" in row["Kernel_Name"]):
-                            per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
-                if not per:
-                    return None, "the rocprofv3 --pmc %s pass (rc %s) recorded no %s launch" % (counter, p.returncode, kname)
-                got[counter] = (sum(per.values()) / len(per), len(per))
+                        if row["Counter_Name"] in counters and is_kernel(row["Kernel_Name"]):
+                            d = per.setdefault(row["Counter_Name"], {})
+                            d[row["Dispatch_Id"]] = d.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                if required and counters[0] not in per:
+                    return None, "the rocprofv3 --pmc %s pass (rc %s) recorded no %s launch" % (name, p.returncode, kname), {}
+                for c, d in per.items():
+                    got[c] = sum(d.values()) / len(d)
+                if name == "clock" and "GRBM_GUI_ACTIVE" in got:
+                    dur = []
+                    for path in glob.glob(os.path.join(out, "**", "pmc_clock*kernel_trace.csv"), recursive=True):
+                        for row in csv.DictReader(open(path)):
+                            if is_kernel(row["Kernel_Name"]):
+                                dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9)
+                    if dur:
+                        extras["shader_clock_ghz_during_kernel"] = got["GRBM_GUI_ACTIVE"] / 8.0 / (sum(dur) / len(dur)) / 1e9
+                    if got.get("SQ_BUSY_CU_CYCLES"):
+                        extras["mfma_busy_frac_measured_in_run"] = got["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * got["SQ_BUSY_CU_CYCLES"])
     except Exception as e:  # a profiler that is absent / refuses counters must not take the bench line down
-        return None, "%s: %s" % (type(e).__name__, str(e)[:200])
-    return (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0, None
+        return None, "%s: %s" % (type(e).__name__, str(e)[:200]), {}
+    return (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0, None, extras
 
 
 def roofline_block(prec, rays_rank0, steps, kern_ms, n_launch, NS, fold, elapsed, default_shape):
@@ -749,13 +768,14 @@ def main():
                 "roofline": roofline_block(pp, R, args.steps, pk, pn, NS, True, pe, default_shape)}
     if world == 1 and rank == 0 and default_shape and not args.no_live_pmc:
         # roofline.traffic measured in THIS run (outside the timed region): two counter passes around a 2-step child
-        live, why = measure_traffic_live(args.prec)
+        live, why, live_extras = measure_traffic_live(args.prec)
         rf = res["roofline"]
         if live is not None:
             rf["traffic_committed_profile"] = rf["traffic"]
             rf["traffic"] = live
             rf["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE; one pass each) around "
                                     "a 2-step child of this command, average over its fused-kernel launches")
+            rf.update(live_extras)  # shader clock during the kernel / MFMA-busy share of this box (third pass)
         else:
             rf["traffic_live_error"] = why
     if world == 1 and not args.no_cpu_baseline:
