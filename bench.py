@@ -620,6 +620,15 @@ def main():
         # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, RCCL), exactly the
         # command the driver would have used; rank 0 of the child job prints the single JSON line
         return self_launch(args.gpus)
+    # stdout carries the ONE JSON line and nothing else: RCCL prints its version banner to the C-level stdout of every process
+    # that creates a communicator (seen with --force-dist: five lines behind the JSON).  File descriptor 1 is pointed at stderr
+    # for the rest of the run; the line goes out through a duplicate of the original descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -686,7 +695,7 @@ def main():
                    "roofline": roofline_block(args.prec, st["rays_this_rank"], args.steps, st["kern_ms"], st["n_launch"], st["NS"], True,
                                               elapsed, False)}
         if res is not None:
-            print(json.dumps(res), flush=True)
+            emit(res)
         if dist_on:
             dist.destroy_process_group()
         return 0
@@ -935,7 +944,7 @@ def main():
                 if rank == 0:
                     res["extra"] = {"strong_dtu": {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}}
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res)
     if dist_on:
         dist.destroy_process_group()
     return 0
