@@ -56,10 +56,12 @@ def positional_encoding(x, num_freqs=6, freq_factor=1.5, include_input=True):
 USE_GRID_SAMPLE = False  # baselines set this: call F.grid_sample exactly like the reference
 
 
-def index_latent(latent, uv, image_shape):
+def index_latent(latent, uv, image_shape, mode="bilinear", padding="border"):
     """src/model/encoder.py:80-109 + :161-163, with F.grid_sample(bilinear, border,
     align_corners=True) written out (or called directly when USE_GRID_SAMPLE, which is what
-    the timed baselines use so that they run the reference's own ATen op).
+    the timed baselines use so that they run the reference's own ATen op).  mode / padding:
+    encoder.py:27-28 `index_interp` / `index_padding`; anything but the shipped (bilinear, border)
+    is the reference's own F.grid_sample call (encoder.py:100-108).
 
     latent (NV, C, Hl, Wl); uv (NV, N, 2) in source-image pixels; image_shape (W, H).
     Returns (NV, C, N).
@@ -71,9 +73,9 @@ def index_latent(latent, uv, image_shape):
     ls = ls.to(uv.device)
     scale = ls / image_shape.to(device=uv.device, dtype=torch.float32)  # encoder.py:98
     g = uv * scale - 1.0  # encoder.py:99
-    if USE_GRID_SAMPLE:
+    if USE_GRID_SAMPLE or mode != "bilinear" or padding != "border":
         samples = torch.nn.functional.grid_sample(latent, g.unsqueeze(2), align_corners=True,
-                                                  mode="bilinear", padding_mode="border")
+                                                  mode=mode, padding_mode=padding)
         return samples[:, :, :, 0]
     # grid_sample, align_corners=True: pix = (g + 1) / 2 * (size - 1)
     ix = ((g[..., 0] + 1) / 2) * (Wl - 1)
@@ -266,7 +268,9 @@ def pixelnerf_forward_general(scene, mlp, xyz, viewdirs, conf, global_latent=Non
         focal, c = scene["focal"], scene["c"]
         uv = uv * repeat_interleave(focal.unsqueeze(1), NS if focal.shape[0] > 1 else 1)  # :207-209
         uv = uv + repeat_interleave(c.unsqueeze(1), NS if c.shape[0] > 1 else 1)  # :210-212
-        latent = index_latent(scene["latent"], uv, scene["image_shape"])  # :213-215
+        enc_conf = conf.get("encoder", {})
+        latent = index_latent(scene["latent"], uv, scene["image_shape"], enc_conf.get("index_interp", "bilinear"),
+                              enc_conf.get("index_padding", "border"))  # :213-215
         d_latent = latent.shape[1]
         latent = latent.transpose(1, 2).reshape(-1, d_latent)  # :219-221
         mlp_input = torch.cat((latent, z_feature), dim=-1)  # :227

@@ -269,8 +269,12 @@ class SpatialEncoder(nn.Module):
                     extent = extent.expand(2)
                 uv = uv * (self.latent_scaling / extent) - 1.0
             if self.index_interp != "bilinear" or self.index_padding != "border":
-                raise NotImplementedError("SpatialEncoder.index: the HIP lookup implements what every shipped config uses "
-                                          "(index_interp='bilinear', index_padding='border')")
+                # the HIP lookup implements what every shipped config uses (bilinear / border); any other mode the reference's
+                # constructor accepts (encoder.py:27-28) is ATen's grid_sample on the HIP tensors, exactly the reference's call
+                # (encoder.py:100-108) -- PixelNeRFNet.fused_supported() sends such a conf down the composed forward
+                samples = F.grid_sample(lat, uv.unsqueeze(2), align_corners=True, mode=self.index_interp,
+                                        padding_mode=self.index_padding)
+                return samples[:, :, :, 0]
             return _GridIndex.apply(lat, uv.float(), self)
 
     @classmethod

@@ -133,12 +133,14 @@ class PixelNeRFNet(torch.nn.Module):
     def fused_supported(self):
         """True for THE model configuration every shipped experiment resolves to (conf/default.conf + default_mv.conf:
         use_encoder, use_xyz, normalize_z, code{6, 1.5, include_input}, use_viewdirs, use_code_viewdirs=False, latent 512,
-        ResnetFC 512 x 5, combine_layer 3): the fused HIP kernels implement exactly that.  Every other configuration the
+        ResnetFC 512 x 5, combine_layer 3, encoder lookups bilinear / border): the fused HIP kernels implement exactly that.  Every other configuration the
         reference's constructor accepts runs the composed forward (`_forward_composed`)."""
         return (self.use_encoder and self.use_xyz and self.normalize_z and self.use_code
                 and self.use_viewdirs and not self.use_code_viewdirs and not self.use_global_encoder
                 and self.code.num_freqs == 6 and abs(self.code.freq_factor - 1.5) < 1e-12
                 and self.code.include_input and self.d_in == 42 and self.d_latent == 512
+                # the fused lookup hard-codes grid_sample(bilinear, border, align_corners=True) (encoder.py:100-108)
+                and self.encoder.index_interp == "bilinear" and self.encoder.index_padding == "border"
                 and self.mlp_coarse.supported() and (self.mlp_fine is None or self.mlp_fine.supported()))
 
     def _check_supported(self):

@@ -230,3 +230,20 @@ def test_model_variants_construct_with_the_reference_state_dict_layout():
     assert lat.shape == (3, 16) and enc.latent is lat and enc.index(torch.zeros(3, 7, 2)).shape == (3, 16, 7)
     assert "fc.weight" in enc.state_dict() and "model.layer4.1.conv2.weight" in enc.state_dict()
     assert "fc.weight" not in ImageEncoder("resnet18", pretrained=False, latent_size=512).state_dict()
+
+
+def test_encoder_lookup_modes_gate_the_fused_kernels():
+    """the fused lookup is grid_sample(bilinear, border) only: any other `index_interp` / `index_padding` the reference's encoder
+    accepts (encoder.py:27-28) must take the composed forward, whose `index` is then ATen's grid_sample"""
+    for over in (dict(index_padding="zeros"), dict(index_interp="nearest"), dict(index_padding="reflection")):
+        c = default_model_conf()
+        c["encoder"] = dict(c["encoder"], **over)
+        assert not make_model(Conf(c)).fused_supported(), over
+    c = default_model_conf()
+    c["encoder"] = dict(c["encoder"], index_padding="zeros")
+    enc = make_model(Conf(c)).encoder
+    enc.latent = torch.rand(2, 512, 4, 5)
+    uv = torch.tensor([[[-1.5, 0.0], [0.3, 0.2], [1.0, 1.0]]]).expand(2, -1, -1)
+    got = enc.index(uv)  # a CPU tensor is fine here: this branch is plain torch
+    want = torch.nn.functional.grid_sample(enc.latent, uv.unsqueeze(2), align_corners=True, mode="bilinear", padding_mode="zeros")[..., 0]
+    assert got.shape == (2, 512, 3) and torch.equal(got, want)

@@ -107,7 +107,7 @@ def test_composite_with_negative_last_delta_matches_reference(ops, dev, name):
     np.testing.assert_allclose(rgb.cpu().numpy(), g["fine_rgb"].reshape(-1, 3), rtol=0, atol=2e-5 * scale)
 
 
-@pytest.mark.parametrize("prec", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("prec", ["f16x3", "f16", "bf16", "f32"])
 def test_points_on_and_behind_the_camera_plane(ops, dev, prec):
     g = load_golden("adv_plane")
     sc = dscene(ops, dev, "plane_mini")
@@ -115,14 +115,17 @@ def test_points_on_and_behind_the_camera_plane(ops, dev, prec):
     for which, seed in (("coarse", 11), ("fine", 12)):
         state = {k: v.to(dev) for k, v in mlp_params(seed).items()}
         ref = g[f"out_{which}"]
-        forms = [(ops.pack_mlp(state, prec), None)]
-        if prec != "f32":
-            forms.append((ops.pack_mlp(state, prec, folded=True), ops.fold_latent(sc, state, prec)))
+        if prec == "f16x3":  # the default precision: always folded (fp32 tables), held to the exact path's bar
+            forms = [(ops.pack_mlp(state, prec), ops.fold_latent(sc, state, prec))]
+        else:
+            forms = [(ops.pack_mlp(state, prec), None)]
+            if prec != "f32":
+                forms.append((ops.pack_mlp(state, prec, folded=True), ops.fold_latent(sc, state, prec)))
         for pk, tab in forms:
             out = ops.eval_points(sc, pk, xyz, vd, tables=tab).cpu().numpy()
             assert np.isfinite(out).all(), "the reference's output is finite on these points (NaN coordinate -> texel 0)"
             e = np.abs(out[..., :3] - ref[..., :3])
-            if prec == "f32":
+            if prec in ("f32", "f16x3"):
                 assert e.max() <= 2e-5
             else:
                 assert e.max() <= PREC_TOL[prec]["rgb_max"] and e.mean() <= PREC_TOL[prec]["rgb_mean"]
@@ -171,11 +174,13 @@ def test_surface_like_density_render(ops, dev, name, prec, fold):
     assert st["pastfar_frac"] <= 0.26, st  # only the forced rays (every 4th)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("name", ADVERSARIAL_SCENARIOS)
-def test_surface_like_density_render_fp32_path(ops, dev, name):
-    g, out, z_f, span = _render(ops, dev, name, "f32", False)
+def test_surface_like_density_render_fp32_path(ops, dev, name, prec):
+    """the exact path AND the shipped default ("f16x3": split operands + fp32 tables) at the same bars"""
+    g, out, z_f, span = _render(ops, dev, name, prec, prec == "f16x3")
     st = robust_render_stats(out["fine"]["rgb"].cpu().numpy(), out["fine"]["depth"].cpu().numpy(), z_f.cpu().numpy(), g, span)
-    print(f"ADV {name:24s} f32 fine PSNR {st['psnr']:6.1f} dB (all rays {st['psnr_all']:6.1f}) depth p99/span "
+    print(f"ADV {name:24s} {prec} fine PSNR {st['psnr']:6.1f} dB (all rays {st['psnr_all']:6.1f}) depth p99/span "
           f"{st['depth_p99_over_span']:.2e} bin-flip {st['bin_flip_frac']:.4f} past-far rays {st['pastfar_frac']:.3f} "
           f"(disagree {st['pastfar_disagree_frac']:.3f})")
     assert st["psnr"] >= 70.0 and st["depth_p99_over_span"] <= 1e-3 and st["bin_flip_frac"] <= 0.01, st

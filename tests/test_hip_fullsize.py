@@ -110,3 +110,31 @@ def test_full_size_render_matches_oracle_and_f32_path(ops, dev, cases, name, pre
         assert pso >= tol["psnr"], f"{name} {prec} {p}: PSNR vs CPU oracle {pso:.1f} dB"
         edo = (depth[:N_ORACLE] - c["ref"][p]["depth"][0]).abs().numpy()
         assert np.percentile(edo, 99) <= tol["depth_p99"] * span
+
+
+def test_full_size_render_at_the_default_precision_holds_the_fp32_bars(ops, dev, cases):
+    """The SHIPPED / timed precision ("f16x3": split operands, lin_z folded into fp32 tables) at BASELINE configs[2] / [3] full
+    size -- the reference's real eval loads (eval/eval.py:264-281): 16 384 srn_car rays / 8 192 border-inclusive DTU rays, the
+    multi-view instantiations with the view sum parked in the L2 scratch, 32-bit texel offsets of the 176 MiB grid.  Held to the
+    bars of the exact-fp32 path (tests/test_hip_f32.py): coarse |rgb| <= 2e-5, depth <= 1e-4 of the span, PSNR >= 85 dB -- vs the
+    CPU oracle on 1 024 rays and vs the exact-fp32 HIP path on all of them; the fine pass (a discontinuous function of the coarse
+    weights: searchsorted bin, nerf.py:138) within the same bounds except for <= 2 % of the rays (helpers.assert_close_frac)."""
+    from helpers import assert_close_frac
+    for name, c in cases.items():
+        pk = [ops.pack_mlp(st, "f16x3") for st in c["st"]]
+        tabs = tuple(ops.fold_latent(c["sc"], st, "f16x3") for st in c["st"])
+        out = ops.render_forward(c["sc"], pk[0], pk[1], c["rays"], 64, 128, 16, c["nz"], white_bkgd=c["meta"]["white_bkgd"],
+                                 tables=tabs)
+        span = float(c["meta"]["z_far"] - c["meta"]["z_near"])
+        for p in ("coarse", "fine"):
+            flips = 0.0 if p == "coarse" else 2e-2
+            rgb, depth = out[p]["rgb"].cpu(), out[p]["depth"].cpu()
+            assert torch.isfinite(rgb).all() and torch.isfinite(depth).all()
+            for what, r_rgb, r_depth, n in (("f32 HIP path", c["f32"][p]["rgb"], c["f32"][p]["depth"], rgb.shape[0]),
+                                            ("CPU oracle", c["ref"][p]["rgb"][0], c["ref"][p]["depth"][0], N_ORACLE)):
+                assert_close_frac(rgb[:n].numpy(), r_rgb.numpy(), 2e-5, max_frac=flips, loose_atol=0.05, what=f"{name} {p} rgb vs {what}")
+                assert_close_frac(depth[:n].numpy(), r_depth.numpy(), 1e-4 * span, max_frac=flips, loose_atol=0.05 * span,
+                                  what=f"{name} {p} depth vs {what}")
+                ps = O.psnr(rgb[:n], r_rgb)
+                print(f"FULLSIZE f16x3 {name} {p} vs {what}: PSNR {ps:.1f} dB, max |rgb| {(rgb[:n] - r_rgb).abs().max().item():.2e}")
+                assert ps >= 85.0, f"{name} {p}: PSNR vs {what} {ps:.1f} dB"

@@ -94,7 +94,7 @@ def test_eval_mode_and_default_noise_std_are_unchanged(dev):
     assert torch.equal(a.fine.rgb, b.fine.rgb)
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("f16", 2e-3)])
+@pytest.mark.parametrize("precision,tol", [("f16x3", 1e-4), ("f32", 1e-4), ("f16", 2e-3)])
 def test_single_process_multi_device_training(dev, precision, tol):
     """bind_parallel(net, [0, 0]): two shards (both replicas on the one device of the test box), loss on the concatenated
     outputs, backward -> the source network's gradients equal the unsharded ones (different dW summation order only)"""
@@ -132,7 +132,8 @@ def test_single_process_multi_device_training(dev, precision, tol):
     assert torch.isfinite(o1["fine"]["rgb"]).all()  # replicas were refreshed from the stepped source weights without error
 
 
-def test_multi_device_gradients_equal_single_device_with_fixed_noise(dev):
+@pytest.mark.parametrize("precision,bar", [("f16x3", 1e-3), ("f32", 1e-4)])
+def test_multi_device_gradients_equal_single_device_with_fixed_noise(dev, precision, bar):
     """same as above but noise-free sampling differences removed: n_fine = 0 and a zero jitter make the render a
     deterministic function of the rays, so sharded and unsharded gradients must agree to summation order"""
     from pixelnerf_amd.render import NeRFRenderer
@@ -142,7 +143,7 @@ def test_multi_device_gradients_equal_single_device_with_fixed_noise(dev):
     real_rand = torch.rand
 
     def run(gpus):
-        net, lat = make_train_net(dev, scene, "f32")
+        net, lat = make_train_net(dev, scene, precision)
         rend = NeRFRenderer(n_coarse=64, n_fine=0, n_fine_depth=0, white_bkgd=True, rng="torch").to(dev).train()
         par = rend.bind_parallel(net, gpus, simple_output=False).train()
         torch.rand = lambda *a, **k: real_rand(*a, **k) * 0 + 0.5  # mid-bin samples: no dependence on the draw sequence
@@ -161,7 +162,7 @@ def test_multi_device_gradients_equal_single_device_with_fixed_noise(dev):
     assert abs(l1 - l2) <= 1e-6 * max(1.0, abs(l1))
     for k in single:
         rel = float((multi[k] - single[k]).norm() / single[k].norm())
-        assert rel <= 1e-4, (k, rel)
+        assert rel <= bar, (k, rel)  # f16x3: the fp32-class gradient bar (each shard picks its own power-of-two gradient scale)
 
 
 def test_second_backward_raises_a_clear_error(dev):
