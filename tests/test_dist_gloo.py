@@ -200,21 +200,32 @@ def _train_worker(rank, world, port, B):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [7, 64])
-def test_sharded_training_gradients_equal_single_process(B):
+@pytest.mark.parametrize("world,B", [(2, 7), (2, 64), (4, 7), (4, 13)])  # 4 ranks: shards of 2,2,2,1 and 4,3,3,3 rays
+def test_sharded_training_gradients_equal_single_process(world, B):
     """the differentiable multi-process path (reference: DataParallel training, train/train.py:75; src/render/nerf.py:367-371):
     sharded forward, loss on the gathered outputs, ONE bucketed gradient all-reduce -> single-process gradients on every rank"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_train_worker, args=(2, port, B), nprocs=2, join=True)
+    mp.spawn(_train_worker, args=(world, port, B), nprocs=world, join=True)
 
 
-@pytest.mark.parametrize("B", [7, 64])  # uneven and even splits
-def test_sharded_render_and_scene_broadcast_world2(B):
+@pytest.mark.parametrize("world,B", [(2, 7), (2, 64), (4, 7), (4, 64)])  # uneven and even splits
+def test_sharded_render_and_scene_broadcast(world, B):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, B), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, B), nprocs=world, join=True)
+
+
+def test_eight_way_shards_of_the_dtu_image_and_the_weak_batch():
+    """the placements the 8-GPU scaling run uses (bench.py): 120 000 DTU rays -> 15 000 per rank; an uneven image; a batch with
+    fewer rays than ranks -- contiguous, ordered, covering, sizes within one ray of each other (DataParallel's dim-1 split)"""
+    for n, world in ((120000, 8), (120001, 8), (16384, 8), (5, 8), (65536 * 8, 8), (120000, 4)):
+        b = [shard_bounds(n, r, world) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1 and sorted(sizes, reverse=True) == sizes
+    assert shard_bounds(120000, 3, 8) == (45000, 60000)

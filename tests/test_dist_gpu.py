@@ -112,6 +112,32 @@ def test_bench_strong_dtu_two_ranks(repo_root, bcast):
     assert d["comm"]["grid_bytes"] == 3 * 512 * 150 * 200 * 4 and d["comm"]["bcast_ms_rank0"] > 0
 
 
+@pytest.mark.parametrize("n,workload,bcast", [(8, "sn64", "tree"), (8, "dtu", "flat"), (4, "dtu", "tree")])
+def test_bench_rehearsal_at_the_scaling_runs_rank_counts(repo_root, n, workload, bcast):
+    """the driver's 1/2/4/8 scaling run must hit no first-time code path other than RCCL's transport.  The same
+    bench command it will launch, at N = 8 (weak sn64; strong DTU: 15 000-ray shards of ONE 120 000-ray image, 8-way gather,
+    flat 1 -> 7 fan-out of the 176 MiB grid) and N = 4, on gloo with every rank on the one device of the test box."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--steps", "1", "--warmup", "1",
+           "--bcast", bcast, "--no-extras", "--no-peer", "--no-live-pmc"]
+    cmd += ["--workload", "dtu"] if workload == "dtu" else ["--rays", "15001"]  # an odd per-rank batch
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["value"] > 0 and d["dtype"] == "f16x3" and d["config"]["rccl_ranks"] == n
+    if workload == "dtu":
+        assert d["scaling"] == "strong" and d["config"]["rays_per_image"] == 120000 and d["config"]["rays_rank0"] == 120000 // n
+        assert d["comm"]["grid_bytes"] == 3 * 512 * 150 * 200 * 4 and d["comm"]["bcast_ms_rank0"] > 0
+    else:
+        assert d["scaling"] == "weak" and d["config"]["rays_per_gpu_per_step"] == 15001
+        assert abs(d["value"] - n * 15001 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]  # whole-job rate: all ranks' rays
+
+
 # ---------------------------------------------------------------- RCCL first contact (backend "nccl" on ROCm), world size 1
 # The GPU box has one device and RCCL refuses two ranks on one device, so the multi-rank tests above run on gloo.  These
 # run the SAME code paths on a real RCCL communicator of one rank: communicator creation with device_id binding,
