@@ -87,10 +87,11 @@ __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out, T *__r
         // feat_of(T, hh, r) for r = r0 .. r0+7 (r0 a multiple of 8) = two runs of four consecutive features, 8 apart
         int k;
         if (OWNK) {
-            const int body = s >> 2, j = s & 3;
-            if (body == 0) k = feat_of(wv * IT + (j >> 1), h, 8 * (j & 1));
+            constexpr int KSB = SL / 16;  // k-steps per wave block (4 at 8 waves)
+            const int blk = s / KSB, j = s % KSB;
+            if (blk == 0) k = feat_of(wv * IT + (j >> 1), h, 8 * (j & 1));
             else {
-                const int ss = ((wv + body) & (NW - 1)) * 4 + j;  // k-step of the image order this ring step stands for
+                const int ss = ((wv + blk) & (NW - 1)) * KSB + j;  // k-step of the image order this ring step stands for
                 k = feat_of(ss >> 1, ss & 1, 8 * h);
             }
         } else k = feat_of(s >> 1, s & 1, 8 * h);

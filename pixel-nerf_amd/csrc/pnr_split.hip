@@ -232,64 +232,81 @@ __device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][JT], char *s
 template <typename ST, int JT, bool GUARD>
 __device__ __forceinline__ void stage_own(f32x16 (&acc)[IT][JT], const f32x16 (&src)[IT][JT], char *smem, uint32_t waddr,
                                           SplitRing &R, int NS, [[maybe_unused]] float *amax) {
-    static_assert(IT == 2, "k-step j of the own block = (feature tile j >> 1, register half j & 1)");
+    // k-step jj of the own block = (feature tile jj >> 1, register half jj & 1); 2 IT k-steps = IT / 2 ring bodies of 4
+    static_assert(IT % 2 == 0, "whole ring bodies");
     h8 bh[2][JT], bl[2][JT];
-    auto make = [&](int j, int buf) {
+    auto make = [&](int jj, int buf) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = src[j >> 1][jt][8 * (j & 1) + e];
+            for (int e = 0; e < 8; ++e) v[e] = src[jj >> 1][jt][8 * (jj & 1) + e];
             split8<true, GUARD>(v, bh[buf][jt], bl[buf][jt], amax);
         }
     };
     make(0, 0);
-    const size_t pf = (size_t)R.pf_rs * (IT * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int cur = j & 1;
-        if (j + 1 < 4) make(j + 1, cur ^ 1);
-        h8 ah[IT], al[IT];
+    for (int body = 0; body < IT / 2; ++body) {
+        const size_t pf = (size_t)R.pf_rs * (IT * 1024);
 #pragma unroll
-        for (int it = 0; it < IT; ++it) { ah[it] = R.h[j][it]; al[it] = R.l[j][it]; }
+        for (int j = 0; j < 4; ++j) {
+            const int jj = body * 4 + j;
+            const int cur = jj & 1;
+            if (jj + 1 < 2 * IT) make(jj + 1, cur ^ 1);
+            h8 ah[IT], al[IT];
 #pragma unroll
-        for (int it = 0; it < IT; ++it)
+            for (int it = 0; it < IT; ++it) { ah[it] = R.h[j][it]; al[it] = R.l[j][it]; }
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(ah[it], bh[cur][jt], acc[it][jt]);
+            for (int it = 0; it < IT; ++it)
 #pragma unroll
-        for (int it = 0; it < IT; ++it)
+                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(ah[it], bh[cur][jt], acc[it][jt]);
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(ah[it], bl[cur][jt], acc[it][jt]);
+            for (int it = 0; it < IT; ++it)
 #pragma unroll
-        for (int it = 0; it < IT; ++it)
+                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(ah[it], bl[cur][jt], acc[it][jt]);
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(al[it], bh[cur][jt], acc[it][jt]);
-        // the same fragments, for the other waves: storage position of (feature tile j >> 1, register half j & 1), as write_split
+            for (int it = 0; it < IT; ++it)
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const uint32_t ad = waddr + jt * 32 * ROW_ACT + (j >> 1) * 64 + 16 * (j & 1);
-            *reinterpret_cast<h8 *>(smem + ST::A_HI + ad) = bh[cur][jt];
-            *reinterpret_cast<h8 *>(smem + ST::A_LO + ad) = bl[cur][jt];
-        }
+                for (int jt = 0; jt < JT; ++jt) acc[it][jt] = mf(al[it], bh[cur][jt], acc[it][jt]);
+            // the same fragments, for the other waves: storage position of (feature tile jj >> 1, register half jj & 1), as write_split
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
-            R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
-        }
-        // issue order of one k-step, pinned: the split of the NEXT k-step's 16 values (~40 VALU) is spread over this step's
-        // 12 MFMAs, the image stores and the ring refills of THIS step sit behind its later MFMAs -- left to itself hipcc puts
-        // all 16 refills behind the stage's last MFMA and runs the last 30 MFMAs back to back with the VALU work in front of them
+            for (int jt = 0; jt < JT; ++jt) {
+                const uint32_t ad = waddr + jt * 32 * ROW_ACT + (jj >> 1) * 64 + 16 * (jj & 1);
+                *reinterpret_cast<h8 *>(smem + ST::A_HI + ad) = bh[cur][jt];
+                *reinterpret_cast<h8 *>(smem + ST::A_LO + ad) = bl[cur][jt];
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
+                R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
+            }
+            // issue order of one k-step, pinned: the split of the NEXT k-step's 16 values (~40 VALU) is spread over this step's
+            // MFMAs, the image stores and the ring refills of THIS step sit behind its later MFMAs -- left to itself hipcc puts
+            // all refills behind the stage's last MFMA and runs the last MFMAs back to back with the VALU work in front of them
 #if !(defined(PNR_VARIANT) && defined(PNR_X_STAGE_NOPIN))
+            if constexpr (IT == 2) {
 #pragma unroll
-        for (int i = 0; i < 3 * IT * JT; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                          // up to 4 VALU
-            if (i >= 4 && i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS write  (i = 4, 6, 8, 10)
-            if (i >= 5 && i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read  (i = 5, 7, 9, 11)
-        }
+                for (int i = 0; i < 3 * IT * JT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                          // up to 4 VALU
+                    if (i >= 4 && i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS write  (i = 4, 6, 8, 10)
+                    if (i >= 5 && i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read  (i = 5, 7, 9, 11)
+                }
+            } else {
+                // 3 IT JT MFMAs, 2 JT image stores, 2 IT refills, ~20 JT VALU of the next k-step's split
+                constexpr int NM = 3 * IT * JT;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    if (i >= 4 && i < 4 + 2 * JT) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    if (i >= NM - 2 * IT - 2 && i < NM - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
 #endif
+        }
+        ring_advance(R, NS);
     }
-    ring_advance(R, NS);
 }
 
 // the other seven K blocks of the same linear, from the operand images: blocks (wv + 1) .. (wv + 7) mod 8, the order the stream
@@ -297,16 +314,21 @@ __device__ __forceinline__ void stage_own(f32x16 (&acc)[IT][JT], const f32x16 (&
 template <int JT>
 __device__ __forceinline__ void gemm_split_rot(f32x16 (&acc)[IT][JT], const char *smem, uint32_t a_rd0, uint32_t jstride,
                                                uint32_t lo_delta, int wv, SplitRing &R, int NS) {
+    constexpr int BLK = SL * 2;         // bytes of one wave's K block in an image row (128 at 8 waves)
+    constexpr int BODIES = SL / 64;     // ring bodies (4 k-steps of 16) per block
     h8 bh[2][JT], bl[2][JT];
-    uint32_t bhi0 = a_rd0 + (uint32_t)((wv + 1) & (NW - 1)) * 128;
+    uint32_t bhi0 = a_rd0 + (uint32_t)((wv + 1) & (NW - 1)) * BLK;
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
         bh[0][jt] = lds8<PH>(smem, bhi0 + jt * jstride);
         bl[0][jt] = lds8<PH>(smem, bhi0 + jt * jstride + lo_delta);
     }
 #pragma unroll 1
-    for (int m = 2; m <= NW; ++m) {
-        const uint32_t nxt = a_rd0 + (uint32_t)((wv + m) & (NW - 1)) * 128;  // (after the last block: this wave's own, read and dropped)
+    for (int mb = 2 * BODIES; mb < (NW + 1) * BODIES; ++mb) {   // body index counted in ring bodies: block m = mb / BODIES
+        const int m = mb / BODIES, sub = mb % BODIES;
+        // after this body's last k-step: the next 64 K of the same block, or the start of the next block
+        // (after the last block: this wave's own, read and dropped)
+        const uint32_t nxt = sub + 1 < BODIES ? bhi0 + 128 : a_rd0 + (uint32_t)((wv + m) & (NW - 1)) * BLK;
         const size_t pf = (size_t)R.pf_rs * (IT * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -337,6 +359,7 @@ __device__ __forceinline__ void gemm_split_rot(f32x16 (&acc)[IT][JT], const char
                 R.h[j][it] = gload8<PH>(R.base_h + pf + j * (IT * 1024) + it * 1024);
                 R.l[j][it] = gload8<PH>(R.base_l + pf + j * (IT * 1024) + it * 1024);
             }
+            constexpr int NM = 3 * IT * JT, PER = (NM - 2 * JT) / (2 * IT);
 #pragma unroll
             for (int i = 0; i < 2 * JT; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -344,10 +367,10 @@ __device__ __forceinline__ void gemm_split_rot(f32x16 (&acc)[IT][JT], const char
             }
 #pragma unroll
             for (int i = 0; i < 2 * IT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);  // PER MFMAs (2 at IT = JT = 2)
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // 1 VMEM read
             }
-            if constexpr (3 * IT * JT - 2 * JT - 4 * IT > 0) __builtin_amdgcn_sched_group_barrier(0x008, 3 * IT * JT - 2 * JT - 4 * IT, 0);
+            if constexpr (NM - 2 * JT - PER * 2 * IT > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 * JT - PER * 2 * IT, 0);
         }
         bhi0 = nxt;
         ring_advance(R, NS);
@@ -466,7 +489,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
     // static priority for the second-dispatched half of the workgroup (the arbitration loser of every segment when both waves of
     // a SIMD run at priority 0; MI355X_MICROARCH.md, "two waves per SIMD", item 4): one s_setprio before the main loop, no flips.
     // Same-box A/B: +0.9 % on sn64 / srn_car / DTU (profiles/r03_split_kernel_ab.txt).  Does not touch results.
-    if (wv >= NW / 2) __builtin_amdgcn_s_setprio(1);
+    if (NW > 4 && wv >= NW / 2) __builtin_amdgcn_s_setprio(1);
     SplitRing R;
     R.base_h = q.wstream + (size_t)wv * (RS_TOTAL_F * IT * 1024) + lane * 16;
     R.base_l = R.base_h + PACKED_BYTES;  // the tail blob follows the head blob (pnr_pack_mlp_split)
@@ -605,7 +628,13 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         for (int view = 0; view < NS; ++view) {
             __syncthreads();  // previous tile / view: every reader of the images / IN / META is done
             PNR_T(PH_SYNC_TOP);
-            if (MT == 64 || tid < MT * 8) geometry_item<PH, RAYS, ST>(q, smem, tile, view, tid % MT, tid / MT);
+            // 8 work items per point (projection, six frequency bands, padding): MT * 8 items over the workgroup's threads
+            if constexpr (MT * 8 <= NTHREADS) {
+                if (MT * 8 == NTHREADS || tid < MT * 8) geometry_item<PH, RAYS, ST>(q, smem, tile, view, tid % MT, tid / MT);
+            } else {
+#pragma unroll 1
+                for (int wi = tid; wi < MT * 8; wi += NTHREADS) geometry_item<PH, RAYS, ST>(q, smem, tile, view, wi % MT, wi / MT);
+            }
             __syncthreads();
             PNR_T(PH_GEOMETRY);
             gather_table_f32<2, ST>(q, smem, wv, lane, 0);

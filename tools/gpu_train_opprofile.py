@@ -42,11 +42,20 @@ class Spy(pd.TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         n = func.__name__
         if any(k in n for k in ("copy", "fill", "zero", "clone", "_to_copy", "cat", "add", "mul", "sub", "mean", "pow", "div", "sum", "gather", "index", "rand", "normal")):
-            st = traceback.extract_stack(limit=14)
-            site = next((f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(st) if "pixel-nerf_amd" in f.filename or "gpu_train_opprofile" in f.filename), "torch-internal")
+            st = traceback.extract_stack(limit=24)
+            site = next((f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(st)
+                         if "pixel-nerf_amd" in f.filename or "pixelnerf_amd" in f.filename or "gpu_train_opprofile" in f.filename), "torch-internal")
             sites[(n, site)] += 1
         return func(*args, **(kwargs or {}))
 N = 4
+# the dispatch mode is thread-local and the backward of the render Function runs on autograd's device thread: enter it there too
+from pixelnerf_amd import autograd as _ag
+for _fn in (_ag._RenderFunction,):
+    _orig = _fn.backward
+    def _wrapped(ctx, *g, _orig=_orig):
+        with Spy():
+            return _orig(ctx, *g)
+    _fn.backward = staticmethod(_wrapped)
 with Spy():
     for _ in range(N): step()
 torch.cuda.synchronize()
