@@ -9,6 +9,11 @@
 
 namespace pnr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// nn.Linear parameters are read through a 4-BYTE-aligned vector type: a parameter that is a view into a flat buffer (flattened /
+// FSDP-style storages, load_state_dict(assign=True) from an mmap) need not start on a 16-byte boundary.  gfx950 code objects run
+// in the target's unaligned-access mode, where this still compiles to one global_load_dwordx4; without that mode the compiler
+// splits the access instead of faulting.
+typedef float f32x4_param __attribute__((ext_vector_type(4), aligned(4)));
 
 // which nn.Linear feeds GEMM g, and how its K index is ordered in the stream
 struct GemmSrc {
@@ -77,7 +82,7 @@ __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out, T *__r
             if (k < D_IN) v[e] = src.w[f_out * D_IN + k];
         }
     } else if (src.kind == 1) {
-        const f32x4 *q = reinterpret_cast<const f32x4 *>(src.w + (size_t)f_out * C_LAT + s * 16 + h * 8);
+        const f32x4_param *q = reinterpret_cast<const f32x4_param *>(src.w + (size_t)f_out * C_LAT + s * 16 + h * 8);
         const f32x4 a = q[0], b = q[1];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
@@ -96,7 +101,7 @@ __global__ void pack_weights_kernel(PnrMlpWeights p, T *__restrict__ out, T *__r
             }
         } else k = feat_of(s >> 1, s & 1, 8 * h);
         const float *row = src.w + (size_t)f_out * D_HID + k;
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(row), b = *reinterpret_cast<const f32x4 *>(row + 8);
+        const f32x4 a = *reinterpret_cast<const f32x4_param *>(row), b = *reinterpret_cast<const f32x4_param *>(row + 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
     } else {
@@ -264,7 +269,7 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
         for (int u = 0; u < 4; ++u) {  // 128 rows x 8 float4 per operand: thread -> (row, 4 columns)
             const int e = t + u * 256, row = e >> 3, c4 = (e & 7) * 4;
             xv[u] = (m0 + row < M) ? *reinterpret_cast<const f32x4 *>(grid + (m0 + row) * C_LAT + k0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            wv[u] = *reinterpret_cast<const f32x4 *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
+            wv[u] = *reinterpret_cast<const f32x4_param *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
         }
         __syncthreads();  // the previous chunk's fragments have been read
 #pragma unroll
@@ -447,19 +452,13 @@ extern "C" int pnr_fold_latent_f32(const PnrScene *s, const PnrMlpWeights *w, fl
     if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: bad scene shape");
     const long long M = (long long)s->SB * s->NS * s->Hl * s->Wl;
     if ((M + 63) / 64 > 0x7fffffffLL) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: grid too large");
-    dim3 grid((unsigned)((M + 63) / 64), D_HID / 64, COMBINE_LAYER);
     FoldJobs jobs;
     for (int b = 0; b < COMBINE_LAYER; ++b) {
         if (!w->lin_z_w[b] || !w->lin_z_b[b]) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: null lin_z parameters");
         jobs.W[b] = w->lin_z_w[b]; jobs.bias[b] = w->lin_z_b[b];
     }
-#if defined(PNR_VARIANT) && defined(PNR_X_FOLD_F32MFMA)  // A/B twin: round 3's exact-fp32-MFMA fold
-    hipLaunchKernelGGL(fold_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, jobs, tables, M, 3.4028234664e38f);
-#else
-    (void)grid;
     dim3 sgrid((unsigned)((M + FS_TM - 1) / FS_TM), D_HID / FS_TN, COMBINE_LAYER);
     hipLaunchKernelGGL(fold_split_kernel, sgrid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, jobs, tables, M, saturation_guard_word());
-#endif
     return pnr_check_launch("pnr_fold_latent_f32");
 }
 
@@ -471,11 +470,7 @@ extern "C" int pnr_pack_mlp_split(const PnrMlpWeights *w, void *packed, void *st
     const size_t n = (size_t)RS_TOTAL_F * IT * (FRAG_ELEMS / 8) * NW;  // one thread per 8 elements
     const int threads = 256;
     const unsigned blocks = (unsigned)((n + threads - 1) / threads);
-#if defined(PNR_VARIANT) && defined(PNR_X_OLD_BLOCK)  // A/B twin of pnr_split.hip's block(): the image order for every K block
-    constexpr bool OWNK = false;
-#else
-    constexpr bool OWNK = true;
-#endif
+    constexpr bool OWNK = true;  // the K order pnr_split.hip's stage_own / gemm_split_rot consume
     hipLaunchKernelGGL((pack_weights_kernel<_Float16, true, false, OWNK>), dim3(blocks), dim3(threads), 0, st, *w, (_Float16 *)packed,
                        (_Float16 *)((char *)packed + PACKED_BYTES));  // heads and tails from one pass over the weights
     const int nb = NBIAS * NW * BIAS_FLOATS_PER_WAVE;

@@ -283,7 +283,6 @@ __device__ __forceinline__ void stage_own(f32x16 (&acc)[IT][JT], const f32x16 (&
             // issue order of one k-step, pinned: the split of the NEXT k-step's 16 values (~40 VALU) is spread over this step's
             // MFMAs, the image stores and the ring refills of THIS step sit behind its later MFMAs -- left to itself hipcc puts
             // all refills behind the stage's last MFMA and runs the last MFMAs back to back with the VALU work in front of them
-#if !(defined(PNR_VARIANT) && defined(PNR_X_STAGE_NOPIN))
             if constexpr (IT == 2) {
 #pragma unroll
                 for (int i = 0; i < 3 * IT * JT; ++i) {
@@ -303,7 +302,6 @@ __device__ __forceinline__ void stage_own(f32x16 (&acc)[IT][JT], const f32x16 (&
                     if (i >= NM - 2 * IT - 2 && i < NM - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             }
-#endif
         }
         ring_advance(R, NS);
     }
@@ -565,29 +563,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         if constexpr (TRAIN) put_mask(x, 2 * b, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
         __syncthreads();  // table rows / previous operand images are no longer read
         PNR_T(PH_BAR1);
-#if defined(PNR_VARIANT) && defined(PNR_X_OLD_BLOCK)  // A/B twin: round 3's form (whole split epilogue, barrier, all 8 K blocks from the images)
-        write_split<ST>(x, smem, a_wr);
-        PNR_T(PH_WRITE_X);
-        __syncthreads();
-        PNR_T(PH_BAR2);
-        if constexpr (TRAIN) dump_pair(q.s_a[b], b);
-        {
-            f32x16 net[IT][JT];
-            add_bias<true>(net, bias_lane, 1 + 2 * b);
-            gemm_split(net, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
-            PNR_T(PH_GEMM_FC0);
-            if constexpr (TRAIN) put_mask(net, 2 * b + 1, b < COMBINE_LAYER ? tr_mask_view : tr_mask_pooled);
-            __syncthreads();
-            PNR_T(PH_BAR3);
-            write_split<ST>(net, smem, a_wr);
-            PNR_T(PH_WRITE_NET);
-        }
-        __syncthreads();
-        PNR_T(PH_BAR4);
-        if constexpr (TRAIN) dump_pair(q.s_n[b], b);
-        add_bias<false>(x, bias_lane, 2 + 2 * b);
-        gemm_split(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, KS_BIG / 4, R, NS);
-#else
         {
             f32x16 net[IT][JT];
             add_bias<true>(net, bias_lane, 1 + 2 * b);
@@ -611,7 +586,6 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         PNR_T(PH_BAR4);
         if constexpr (TRAIN) dump_pair(q.s_n[b], b);
         gemm_split_rot<JT>(x, smem, a_rd0, 32 * ROW_ACT, ST::A_LO - ST::A_HI, wv, R, NS);         // fc_1
-#endif
         PNR_T(PH_GEMM_FC1_Z);
         if (lookup) {
             __syncthreads();

@@ -212,15 +212,20 @@ class PixelNeRFNet(torch.nn.Module):
     # reference's fp32 arithmetic for a network whose hidden activations grow that large.  The guarded instantiation of the
     # kernel (about 1 % slower) therefore runs on the FIRST call after the weights or the encoded scene changed (and on every
     # 16th training call); its verdict arrives asynchronously and is reported as a RuntimeWarning by a later call.
-    # PIXELNERF_SATURATION_GUARD=always / off overrides the policy.
+    # This is a SAMPLING policy, not a proof: saturation depends on the query points too, and inference batches after the first
+    # one for a given (weights, scene) run unguarded -- a ray batch that alone drives an activation past 65504 on a checkpoint
+    # whose first batch stayed in range is not reported.  PIXELNERF_SATURATION_GUARD=always guards every call (~1 % slower; every
+    # call's verdict is kept until it is reported), =off none.
     def _guard_begin(self, training=False):
         """-> True when this call runs guarded (the caller must call _guard_end)"""
         import os
+        if torch.cuda.is_current_stream_capturing():
+            return False  # (no Event.query() during a capture either: pending verdicts are reported by the next eager call)
         self._guard_report()
         if self._effective_precision() != "f16x3":
             return False
         mode = os.environ.get("PIXELNERF_SATURATION_GUARD", "auto")
-        if mode == "off" or torch.cuda.is_current_stream_capturing():
+        if mode == "off":
             return False
         mlps = [m for m in (self.mlp_coarse, self.mlp_fine) if m is not None]
         lat = self.encoder.latent

@@ -266,15 +266,19 @@ class ResnetFC(nn.Module):
         """entry = [fingerprint, stream, content fingerprint recorded?, times served from the cache].
         A training loop re-packs on every call (the optimizer-step count is part of the fingerprint) and never serves a stream
         twice: there the device-side content fingerprint (pnr_params_checksum, ~25 us per network per step) protects nothing, so
-        a stream that replaces one that was never re-used is packed WITHOUT it.  The first call that would re-use such a stream
-        packs once more, this time with the fingerprint -- from then on every hit is verified as described above."""
+        a stream that replaces one that was never re-used is packed WITHOUT it.  The first call that re-uses such a stream
+        records the fingerprint of the (unchanged) parameters behind it -- from then on every hit is verified as described above."""
         fp = self._fingerprint()
         ent = self._packed.get(key)
         checked = precision != "f32"
         fresh = ent is not None and ent[0] == fp
         if fresh and checked:
             if not ent[2]:
-                fresh = False                      # packed in a re-pack-every-call phase: take the fingerprint now
+                # packed in a re-pack-every-call phase, and now served a second time under the same fingerprint (mlp_fine=None
+                # training: both passes of a step ask for the coarse network's stream): the stream is current, only its content
+                # fingerprint is missing -- take THAT now (one ~25 us launch) instead of packing the whole stream again
+                self._content_record(key)
+                ent[2] = True
             elif self._content_verify(key):
                 fp, ent, fresh = self._fingerprint(), None, False
         if not fresh:

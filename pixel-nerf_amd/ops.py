@@ -644,15 +644,34 @@ SAT_LAYER_NAMES = ([f"relu(x) entering blocks.{b}.fc_0" if i == 0 else f"relu(ne
 
 
 def _sat_state(device, owner=None):
-    """flag words + their pinned host copy, per (device, owner): two networks on one device do not read each other's verdicts"""
+    """flag words + pinned host copies, per (device, owner): two networks on one device do not read each other's verdicts.
+    pending: [(event, pinned words)] of guarded calls whose flag copy is still on its way; carry: bits of copies that arrived
+    but were not handed to a poll yet.  A guarded call never overwrites the words of an earlier one."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, owner)
     st = _SAT.get(key)
     if st is None:
         st = dict(flags=torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", idx)),
-                  host=torch.zeros(2, dtype=torch.int32).pin_memory(), event=None, armed=False)
+                  pool=[], pending=[], carry=[0, 0], seen=False, armed=False)
         _SAT[key] = st
     return st
+
+
+def _sat_harvest(st, wait=False):
+    """fold every ARRIVED flag copy into st["carry"] (wait=True: all of them), hand its pinned words back to the pool"""
+    still = []
+    for ev, host in st["pending"]:
+        if wait:
+            ev.synchronize()
+        if wait or ev.query():
+            w = host.tolist()
+            st["carry"][0] |= int(w[0]) & 0xFFFFFFFF
+            st["carry"][1] |= int(w[1]) & 0xFFFFFFFF
+            st["seen"] = True
+            st["pool"].append(host)
+        else:
+            still.append((ev, host))
+    st["pending"] = still
 
 
 def saturation_guard_release(owner):
@@ -678,33 +697,35 @@ def saturation_guard_slot(device, slot, owner=None):
 
 
 def saturation_guard_disarm(device, owner=None):
-    """disarm, and send the flag words on their way to the host (asynchronous; saturation_guard_poll reads them)"""
+    """disarm, and send the flag words on their way to the host (asynchronous; saturation_guard_poll reads them).  Every guarded
+    call gets its own pinned words: under PIXELNERF_SATURATION_GUARD=always the previous call's copy is usually still in flight
+    when the next one ends, and re-using one buffer lost its bits."""
     st = _sat_state(device, owner)
     _lib.check(_lib.load().pnr_saturation_guard(None), "pnr_saturation_guard")
     if st["armed"]:
         st["armed"] = False
+        if len(st["pending"]) >= 8:  # bounded: fold the oldest copies in (blocks only when the GPU is 8 guarded calls behind)
+            _sat_harvest(st, wait=True)
+        host = st["pool"].pop() if st["pool"] else torch.zeros(2, dtype=torch.int32).pin_memory()
         with torch.cuda.device(st["flags"].device):
-            st["host"].copy_(st["flags"], non_blocking=True)
+            host.copy_(st["flags"], non_blocking=True)
             st["flags"].zero_()
-            st["event"] = torch.cuda.Event()
-            st["event"].record()
+            ev = torch.cuda.Event()
+            ev.record()
+        st["pending"].append((ev, host))
 
 
 def saturation_guard_poll(device, wait=False, owner=None):
-    """-> (bits of the coarse-network launches, bits of the fine-network launches) of the guarded calls whose flag copy has
-    arrived since the last poll, or None when nothing is pending / the copy is still in flight (wait=True blocks for it)"""
+    """-> (bits of the coarse-network launches, bits of the fine-network launches), OR-ed over the guarded calls whose flag copy
+    has arrived since the last poll, or None when none has (wait=True blocks for every copy in flight).  Must not be called
+    while the current stream is capturing (Event.query is illegal there): callers check that first."""
     st = _sat_state(device, owner)
-    ev = st["event"]
-    if ev is None:
+    _sat_harvest(st, wait=wait)
+    if not st["seen"]:
         return None
-    if wait:
-        ev.synchronize()
-    elif not ev.query():
-        return None
-    st["event"] = None
-    bits = [int(v) & 0xFFFFFFFF for v in st["host"].tolist()]
-    st["host"].zero_()
-    return bits[0], bits[1]
+    bits = (st["carry"][0], st["carry"][1])
+    st["carry"], st["seen"] = [0, 0], False
+    return bits
 
 
 def describe_saturation(bits):

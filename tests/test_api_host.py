@@ -247,3 +247,30 @@ def test_encoder_lookup_modes_gate_the_fused_kernels():
     got = enc.index(uv)  # a CPU tensor is fine here: this branch is plain torch
     want = torch.nn.functional.grid_sample(enc.latent, uv.unsqueeze(2), align_corners=True, mode="bilinear", padding_mode="zeros")[..., 0]
     assert got.shape == (2, 512, 3) and torch.equal(got, want)
+
+
+def test_saturation_guard_verdicts_accumulate_until_polled():
+    """a guarded call's flag words must survive until a poll reports them -- under PIXELNERF_SATURATION_GUARD=always
+    the previous call's copy is still in flight when the next call ends.  The harvest ORs every ARRIVED copy into the carry
+    and returns its pinned words to the pool; copies still in flight stay pending (host-side logic, fake events)."""
+    from pixelnerf_amd import ops
+
+    class Ev:
+        def __init__(self, done):
+            self.done, self.waited = done, False
+
+        def query(self):
+            return self.done
+
+        def synchronize(self):
+            self.done = self.waited = True
+
+    st = dict(pool=[], pending=[(Ev(True), torch.tensor([1 << 2, 0], dtype=torch.int32)),
+                                (Ev(False), torch.tensor([1 << 10, 1 << 3], dtype=torch.int32)),
+                                (Ev(True), torch.tensor([1 << 4, 1 << 11], dtype=torch.int32))], carry=[0, 0], seen=False)
+    ops._sat_harvest(st)
+    assert st["carry"] == [(1 << 2) | (1 << 4), 1 << 11] and st["seen"] and len(st["pending"]) == 1 and len(st["pool"]) == 2
+    ops._sat_harvest(st)  # the middle copy is still in flight: nothing new
+    assert st["carry"] == [(1 << 2) | (1 << 4), 1 << 11] and len(st["pending"]) == 1
+    ops._sat_harvest(st, wait=True)
+    assert st["carry"] == [(1 << 2) | (1 << 4) | (1 << 10), (1 << 11) | (1 << 3)] and not st["pending"] and len(st["pool"]) == 3

@@ -41,10 +41,10 @@ import torch.utils._python_dispatch as pd
 class Spy(pd.TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         n = func.__name__
-        if any(k in n for k in ("copy", "fill", "zero", "clone", "_to_copy", "cat", "add", "mul", "sub", "mean", "pow", "div", "sum", "gather", "index", "rand", "normal")):
+        if not any(k in n for k in ("view", "reshape", "detach", "alias", "expand", "permute", "transpose", "slice", "select", "unsqueeze", "squeeze", "t.default", "stride", "size", "is_", "empty", "_unsafe_view", "as_strided", "split", "unbind", "lift")):
             st = traceback.extract_stack(limit=24)
             site = next((f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(st)
-                         if "pixel-nerf_amd" in f.filename or "pixelnerf_amd" in f.filename or "gpu_train_opprofile" in f.filename), "torch-internal")
+                         if f.name not in ("__torch_dispatch__", "_wrapped") and ("pixel-nerf_amd" in f.filename or "pixelnerf_amd" in f.filename or "gpu_train_opprofile" in f.filename)), "torch-internal")
             sites[(n, site)] += 1
         return func(*args, **(kwargs or {}))
 N = 4
