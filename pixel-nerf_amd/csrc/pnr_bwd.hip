@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_kernel(const BwdParams q
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             f32x4 v = {Z[it][jt][4 * k], Z[it][jt][4 * k + 1], Z[it][jt][4 * k + 2], Z[it][jt][4 * k + 3]};
-                            *reinterpret_cast<f32x4 *>(dst + (size_t)jt * 32 * C_LAT + it * 32 + 8 * k) = v * inv_scale;
+                            __builtin_nontemporal_store(v * inv_scale, reinterpret_cast<f32x4 *>(dst + (size_t)jt * 32 * C_LAT + it * 32 + 8 * k));  // streamed past the L2 (dump_image)
                         }
                     }
             }
@@ -610,8 +610,13 @@ dw_split_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bsum[a] += (float)ah[a][e] + (float)al[a][e];
             }
+            // the next slab's rows (requested at the top of this slab, one k-step = 48 MFMAs per SIMD ago) go into the OTHER
+            // buffer -- its readers passed the barrier of the previous slab -- between the two k-steps: the 8 LDS stores per
+            // thread ride under the second k-step's MFMAs instead of standing between the last MFMA and the barrier
+            // (same-box A/B against storing after the last MFMA: 907.4 / 908.0 vs 918.8 / 914.4 us per launch, -1 %;
+            // profiles/r05_train_step_notes.md)
+            if (ks == 0 && more) store_slab(cur ^ 1);
         }
-        if (more) store_slab(cur ^ 1);  // the other buffer: its readers passed the barrier of the previous slab
         __syncthreads();
     }
     float *pz = part + ((size_t)job * jobs.nsplit + slice) * (D_HID * D_HID);

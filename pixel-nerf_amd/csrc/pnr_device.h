@@ -309,7 +309,11 @@ __device__ __forceinline__ void dump_image(const char *smem, uint32_t image, cha
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = wv * RPW + u0 + u;
-            if (row < rows_left) *reinterpret_cast<u32x4 *>(dst_tile + (size_t)row * (D_HID * 2) + lane * 16) = v[u];
+            // NON-TEMPORAL store (round 5): the operand / gradient rows are written once and read by a LATER kernel, 1.3 MB per tile
+            // against the 4 MB L2 the 32 CUs of an XCD share for the weight stream.  As ordinary stores they evicted the weight
+            // fragments the neighbouring CUs were about to read; streamed past the L2 the training forward runs 746 -> 617 us and
+            // the fp32-class backward chain 818 -> 694 us per launch (same-box A/B, profiles/r05_train_step_notes.md).
+            if (row < rows_left) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4 *>(dst_tile + (size_t)row * (D_HID * 2) + lane * 16));
         }
     }
 }

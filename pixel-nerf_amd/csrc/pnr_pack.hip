@@ -263,14 +263,17 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
         *reinterpret_cast<f16x4_t *>(hi) = h;
         *reinterpret_cast<f16x4_t *>(lo) = l;
     };
-    for (int k0 = 0; k0 < C_LAT; k0 += FS_K) {
-        f32x4 xv[4], wv[4];
+    f32x4 xv[4], wv[4];
+    auto fetch = [&](int k0) {  // 128 rows x 8 float4 per operand: thread -> (row, 4 columns)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // 128 rows x 8 float4 per operand: thread -> (row, 4 columns)
+        for (int u = 0; u < 4; ++u) {
             const int e = t + u * 256, row = e >> 3, c4 = (e & 7) * 4;
             xv[u] = (m0 + row < M) ? *reinterpret_cast<const f32x4 *>(grid + (m0 + row) * C_LAT + k0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
             wv[u] = *reinterpret_cast<const f32x4_param *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < C_LAT; k0 += FS_K) {
         __syncthreads();  // the previous chunk's fragments have been read
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -279,6 +282,11 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
             split4(wv[u], &sWh[row][c4], &sWl[row][c4]);
         }
         __syncthreads();
+        // round 5: the NEXT chunk's rows are on their way while this chunk's 24 MFMAs per wave run (the loop used to start with
+        // the loads).  Measured: no change (44.5 us for 4096 texels, 811 us = 524 TFLOP/s of executed MFMAs for the DTU grid) --
+        // the chunk is bounded by the split phase between the two barriers (~220 VALU + 16 LDS stores per thread with the
+        // matrix pipe idle), not by the load round trip; removing it means pre-split W and a 128 x 512 tile (X split once)
+        if (k0 + FS_K < C_LAT) fetch(k0 + FS_K);
 #pragma unroll
         for (int kk = 0; kk < FS_K / 16; ++kk) {
             f16x8_t ah[2], al[2], bh[2], bl[2];

@@ -389,6 +389,8 @@ __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem
     // wave-uniform (every lane reads the same META words), the arithmetic per point is unchanged (same rows, same order).
     // Same-box A/B against loading every point's rows (profiles/r04_split_kernel_ab.txt, session 9): lookups 30.2 k -> 19.7 k
     // cycles per tile; sn64 +1.1 %, srn_car +3.4 %, DTU +2.0 %.
+    // (The rows are ordinary, L2-allocating loads on purpose: neighbouring points and tiles hit the same texels.  Non-temporal loads
+    // measured -3 % on sn64, -5 % on srn_car, -11 % on DTU, same box: profiles/r05_split_kernel_ab.txt.)
     f32x4 v[GB][4][2];
     uint32_t last[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // offsets of the rows held in v[1]
 #pragma unroll 1
@@ -515,7 +517,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const f32x4 v = {a[it][jt][4 * k], a[it][jt][4 * k + 1], a[it][jt][4 * k + 2], a[it][jt][4 * k + 3]};
-                    *reinterpret_cast<f32x4 *>(d + (size_t)jt * 32 * D_HID + it * 32 + 8 * k) = v;
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(d + (size_t)jt * 32 * D_HID + it * 32 + 8 * k));  // streamed past the L2 (dump_image)
                 }
         }
     };
@@ -537,7 +539,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
                 for (int r = 0; r < 16; ++r) m16 |= (a[it][jt][r] > 0.f ? 1u : 0u) << r;
                 m |= (unsigned long long)m16 << ((it * JT + jt) * 16);
             }
-        (q.d_mask + (size_t)layer * tr_mask_layer)[word] = m;
+        __builtin_nontemporal_store(m, q.d_mask + (size_t)layer * tr_mask_layer + word);
     };
     // TRAIN: the operand images just published (head, tail) -> their 16-bit row sets, whole 1 KiB rows per wave instruction
     [[maybe_unused]] auto dump_pair = [&](char *head, int b) {
@@ -643,7 +645,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
                             const int i = (it * JT + jt) * 4 + k;
                             f32x4 v = {x[it][jt][4 * k], x[it][jt][4 * k + 1], x[it][jt][4 * k + 2], x[it][jt][4 * k + 3]};
                             if (!first) {  // 1 KiB per wave-instruction
-                                const f32x4 prev = ws[i * NTHREADS];
+                                const f32x4 prev = ws[i * NTHREADS];  // (ordinary, L2-resident accesses: non-temporal ones measured -1 ... -2.5 %)
                                 if (cmax) { v[0] = fmaxf(prev[0], v[0]); v[1] = fmaxf(prev[1], v[1]); v[2] = fmaxf(prev[2], v[2]); v[3] = fmaxf(prev[3], v[3]); }
                                 else v = prev + v;
                             }
@@ -988,7 +990,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) bwd_split_kernel(const BwdSp
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const f32x4 v = {Z[it][jt][4 * k], Z[it][jt][4 * k + 1], Z[it][jt][4 * k + 2], Z[it][jt][4 * k + 3]};
-                            *reinterpret_cast<f32x4 *>(dst + (size_t)jt * 32 * C_LAT + it * 32 + 8 * k) = v * inv_scale;
+                            __builtin_nontemporal_store(v * inv_scale, reinterpret_cast<f32x4 *>(dst + (size_t)jt * 32 * C_LAT + it * 32 + 8 * k));
                         }
                 }
             }

@@ -112,7 +112,7 @@ def test_bench_strong_dtu_two_ranks(repo_root, bcast):
     assert d["comm"]["grid_bytes"] == 3 * 512 * 150 * 200 * 4 and d["comm"]["bcast_ms_rank0"] > 0
 
 
-@pytest.mark.parametrize("n,workload,bcast", [(8, "sn64", "tree"), (8, "dtu", "flat"), (4, "dtu", "tree")])
+@pytest.mark.parametrize("n,workload,bcast", [(8, "sn64", "tree"), (8, "dtu", "tree"), (4, "dtu", "flat")])
 def test_bench_rehearsal_at_the_scaling_runs_rank_counts(repo_root, n, workload, bcast):
     """the driver's 1/2/4/8 scaling run must hit no first-time code path other than RCCL's transport.  The same
     bench command it will launch, at N = 8 (weak sn64; strong DTU: 15 000-ray shards of ONE 120 000-ray image, 8-way gather,
