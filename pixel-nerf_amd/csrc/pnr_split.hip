@@ -598,7 +598,18 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         }
     };
 
-    for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
+    // XCD-aware tile order (round 5): workgroup b runs on XCD b % 8 (placement -- relied on for speed only); every XCD takes ONE
+    // contiguous eighth of the tiles and its 32 CUs walk it side by side, so the CUs that share an L2 look up neighbouring rays'
+    // texels at the same time.  Same-box A/B against the plain grid-stride order (profiles/r05_split_kernel_ab.txt): sn64 +0.2 %,
+    // srn_car +0.4 %, DTU (553 MB of fp32 tables per network) +2.4 %.  Which tile a workgroup runs does not touch any result.
+    int t_begin = blockIdx.x, t_end = q.ntiles, t_step = gridDim.x;
+    if ((gridDim.x & 7) == 0) {
+        const int chunk = (q.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
+        t_begin = xcd * chunk + (blockIdx.x >> 3);
+        t_end = (xcd + 1) * chunk < q.ntiles ? (xcd + 1) * chunk : q.ntiles;
+        t_step = gridDim.x >> 3;
+    }
+    for (int tile = t_begin; tile < t_end; tile += t_step) {
         f32x16 x[IT][JT];
 #pragma unroll 1
         for (int view = 0; view < NS; ++view) {
