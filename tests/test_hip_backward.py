@@ -6,7 +6,7 @@ library GEMMs for dW) against torch autograd through the CPU oracle.
 Reference semantics: train/train.py:199-215 back-propagates MSE(coarse rgb) + MSE(fine rgb)
 through NeRFRenderer.forward into both ResnetFCs and encoder.latent, including the position
 gradient through the n_fine_depth samples (nerf.py:292: the coarse depth is NOT detached).  The
-comparison is against the oracle with exactly those semantics; tools/gpu_grad_check.py also
+comparison is against the oracle with exactly those semantics; tests/gpu_grad_check.py also
 prints how large that position term is (profiles/r01_grad_parity_table.txt).
 
 Tolerances (16-bit MFMA operands, fp32 accumulation, fp32 library GEMMs for dW):
@@ -24,7 +24,7 @@ import torch
 from helpers import golden_setup
 from oracle import pnr_oracle as O
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))  # gpu_grad_check.py (the gradient parity table, also a script) lives next to the tests
 
 pytestmark = pytest.mark.gpu
 
