@@ -60,8 +60,8 @@ MFMAS_PER_PRODUCT = {"f16": 1, "bf16": 1, "f16x3": 3}
 KERNEL_OF = {"f16": "pnr::eval_kernel", "bf16": "pnr::eval_kernel", "f16x3": "pnr::eval_split_kernel"}
 KERNEL_SOURCES = {"f16": ["pnr_mlp.hip", "pnr_device.h", "pnr_layout.h"], "bf16": ["pnr_mlp.hip", "pnr_device.h", "pnr_layout.h"],
                   "f16x3": ["pnr_split.hip", "pnr_device.h", "pnr_layout.h"]}
-PMC_PROFILE = {"f16": os.path.join("profiles", "r04_bench_f16_pmc_eval_kernel.json"),
-               "f16x3": os.path.join("profiles", "r04_bench_f16x3_pmc_eval_split_kernel.json")}
+PMC_PROFILE = {"f16": os.path.join("profiles", "r05_bench_f16_pmc_eval_kernel.json"),
+               "f16x3": os.path.join("profiles", "r05_bench_f16x3_pmc_eval_split_kernel.json")}
 DTYPE_NOTE = {"f16x3": "fp32-class: (head, tail) fp16 operand pairs, 3 f16 MFMAs per product, fp32 accumulate, fp32 tables; "
                        "per-point |rgb| <= 2e-5 vs the reference (the reference's own arithmetic class)",
               "f16": "fp16 MFMA operands, fp32 accumulate: narrower than the reference's fp32 (PSNR >= 52 dB bar)",
