@@ -350,7 +350,17 @@ def extra_render_config(dev, scene_name, n_img, n_oracle=128, n_f32=8192, steps=
             dt = (time.perf_counter() - t0) / steps
             fast = renderer(net, rs.to(dev)[None], _noise=nz)
             alg = R / dt * flop_per_ray(NS) / 1e12
-            out[prec] = {"rays_per_s": R / dt, "ms_per_call": dt * 1e3, "algorithmic_tflops": alg,
+            # the per-scene fold of lin_z into the grid on its own (both networks; inside ms_per_call above): the per-rank cost of a
+            # sharded render that does not shrink with the rank count
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                net._tables.clear()
+                net.tables(True), net.tables(False)
+            e1.record()
+            torch.cuda.synchronize()
+            fold_ms = e0.elapsed_time(e1) / 3
+            out[prec] = {"rays_per_s": R / dt, "ms_per_call": dt * 1e3, "fold_ms_both_networks": fold_ms, "algorithmic_tflops": alg,
                          "frac_of_f16_mfma_peak": alg / PEAK_TFLOPS,
                          "executed_mfma_tflops": alg * executed_fraction(NS, True) * MFMAS_PER_PRODUCT[prec],
                          "psnr_db_vs_cpu_oracle": O.psnr(fast.fine.rgb[0, :no].cpu(), ref["fine"]["rgb"][0]), "oracle_rays": no,

@@ -13,7 +13,7 @@ and the accumulation left in fp64 -- i.e. the operand error alone:
 Result (python oracle/sim_tail_precision.py sn64 srn_car; 6144 points each): per-point max |rgb| error vs fp64
     f16 7.2e-4 / 5.7e-4,  f16x3 9.8e-7 / 8.5e-7,  f8tail 2.9e-5 / 1.9e-5,  f6tail 3.2e-5 / 2.0e-5.
 The 8- and 6-bit tail schemes are 25x tighter than f16 and 30x looser than f16x3: not the reference's own arithmetic class,
-which is why DESIGN.md section 8 lists them as considered and not built.
+which is why docs/HISTORY.md section 8 lists them as considered and not built.
 """
 import sys, torch, numpy as np
 import os

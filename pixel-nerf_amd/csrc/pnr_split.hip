@@ -1,9 +1,11 @@
 // pnr_split.hip -- the fused per-point network at fp32-class accuracy on the f16 matrix cores (gfx950).
 //
-// fp32 MFMA peaks at 157 TFLOP/s on MI355X, 1/16 of the f16 rate; an fp32 product, however, is recovered to
-// ~2^-22 from three f16 products when both operands are split into a rounded-to-f16 head and an f16 tail,
-//       w = wh + wl,  x = xh + xl :   w x ~= wh xh + wh xl + wl xh        (the dropped wl xl is 2^-22 |w x|),
-// each product exact in the fp32 accumulator (11 x 11 significand bits).  This kernel runs the SAME fused chain
+// fp32 MFMA peaks at 157 TFLOP/s on MI355X, 1/16 of the f16 rate; an fp32 product, however, is recovered from
+// three f16 products when both operands are split into a rounded-to-f16 head and an f16 tail,
+//       w = wh + wl,  x = xh + xl :   w x ~= wh xh + wh xl + wl xh        (the dropped wl xl is <= 2^-22 |w x|),
+// each product exact in the fp32 accumulator (11 x 11 significand bits).  The representation itself is ~19 bits for the
+// weights, not 22: the tail of a typical |w| ~ 0.05 weight (|w - wh| <= 1.5e-5 < 6.1e-5) lies in the fp16 SUBNORMAL range and
+// carries ~8 bits.  Measured per-point error against the reference's fp32 outputs: 1.2-1.9e-6 (bar 2e-5).  This kernel runs the SAME fused chain
 // as pnr_mlp.hip -- residual stream in the accumulators, weights streamed L2 -> VGPR, activations through LDS,
 // lin_z folded into per-texel tables (fp32 tables here) -- with every operand carried as such a pair:
 //   weights      two packed streams (head, tail) with the layout of the 16-bit folded stream   (pnr_pack_mlp_split)
@@ -389,6 +391,10 @@ __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem
     // wave-uniform (every lane reads the same META words), the arithmetic per point is unchanged (same rows, same order).
     // Same-box A/B against loading every point's rows (profiles/r04_split_kernel_ab.txt, session 9): lookups 30.2 k -> 19.7 k
     // cycles per tile; sn64 +1.1 %, srn_car +3.4 %, DTU +2.0 %.
+    // (Wave-per-point, lanes along the channels: whole 1 KiB pieces of a row per instruction.  The LDS-free alternative -- every lane
+    // reading the 64 bytes of its own point's row that hold its own 16 features, blended straight into the accumulators, no barrier
+    // pair -- measured -2.4 % on sn64 / srn_car and -11.7 % on DTU: eight waves then fetch eight slices of every row at eight
+    // different times.  profiles/r05_split_kernel_ab.txt.)
     // (The rows are ordinary, L2-allocating loads on purpose: neighbouring points and tiles hit the same texels.  Non-temporal loads
     // measured -3 % on sn64, -5 % on srn_car, -11 % on DTU, same box: profiles/r05_split_kernel_ab.txt.)
     f32x4 v[GB][4][2];
