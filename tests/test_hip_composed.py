@@ -130,7 +130,7 @@ def test_resnetfc_of_any_shape_matches_oracle_with_gradients(dev, case, precisio
     # A ReLU input within rounding of zero may take the other branch in another arithmetic class (the fp32-class operators agree with
     # fp32 to ~1e-6, not bit for bit), which moves every upstream gradient by O(1 / sqrt(elements)) -- measured here once: ONE unit of
     # 20 480 flipped, 1.4e-3 on all gradients while every single operator was exact to 7e-7 on the same inputs
-    # (tools/gpu_debug_composed3.py).  The comparison is about the operators: of 19 seeded draws the input that stays FARTHEST from
+    # (a one-off probe of round 4, tools/gpu_debug_composed3.py in the git history).  The comparison is about the operators: of 19 seeded draws the input that stays FARTHEST from
     # a kink (min |relu input| / rms of its layer, from the oracle) is used -- ~1.6e-5 for the 450 000 ReLU inputs of the largest case.
     best = None
     for seed in range(1, 20):
