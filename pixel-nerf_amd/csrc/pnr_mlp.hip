@@ -294,7 +294,17 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
     unsigned long long *tim = q.tim;
     unsigned long long tlast = TIMING ? __builtin_readcyclecounter() : 0ull;
 
-    for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
+    // XCD-aware tile order, as in pnr_split.hip's eval_split_kernel: every XCD (workgroup b runs on XCD b % 8 -- for speed only) takes
+    // one contiguous eighth of the tiles, its 32 CUs walk it side by side and look up neighbouring rays' texels through the L2 they share
+    int t_begin = blockIdx.x, t_end = q.ntiles, t_step = gridDim.x;
+    if ((gridDim.x & 7) == 0) {
+        const int chunk = (q.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
+        t_begin = xcd * chunk + (blockIdx.x >> 3);
+        t_end = (xcd + 1) * chunk < q.ntiles ? (xcd + 1) * chunk : q.ntiles;
+        t_step = gridDim.x >> 3;
+    }
+    // (same-box A/B against the plain grid-stride order: sn64 +0.7 %, srn_car +0.4 %, DTU +1.4 %; profiles/r05_split_kernel_ab.txt)
+    for (int tile = t_begin; tile < t_end; tile += t_step) {
         f32x16 x[IT][JT];
         // training dumps: this lane's 32-byte slot in a (rows,512) array, row = [view*P +] point
         bool valid[JT];
