@@ -395,9 +395,6 @@ __device__ __forceinline__ void gather_table_f32(const EvalParams &q, char *smem
     // reading the 64 bytes of its own point's row that hold its own 16 features, blended straight into the accumulators, no barrier
     // pair -- measured -2.4 % on sn64 / srn_car and -11.7 % on DTU: eight waves then fetch eight slices of every row at eight
     // different times.  profiles/r05_split_kernel_ab.txt.)
-    // (Two points = 16 row loads in flight per round.  Giving the idle weight ring's 64 registers to the gather -- 4 points per round,
-    // two memory round trips per lookup instead of four, the same four k-steps requested again behind it -- measured -0.4 % on sn64 /
-    // srn_car and -2.6 % on DTU: the re-request is exposed in front of the next stage.  profiles/r05_split_kernel_ab.txt.)
     // (The rows are ordinary, L2-allocating loads on purpose: neighbouring points and tiles hit the same texels.  Non-temporal loads
     // measured -3 % on sn64, -5 % on srn_car, -11 % on DTU, same box: profiles/r05_split_kernel_ab.txt.)
     f32x4 v[GB][4][2];
