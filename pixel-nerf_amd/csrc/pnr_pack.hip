@@ -264,10 +264,15 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
         *reinterpret_cast<f16x4_t *>(lo) = l;
     };
     f32x4 xv[4], wv[4];
-    auto fetch = [&](int k0) {  // 128 rows x 8 float4 per operand: thread -> (row, 4 columns)
+    // thread -> (row, 4 columns) of a 128-row x 32-column chunk.  Rows of consecutive 8-lane groups are 4 apart (bits 0 and 2 of the
+    // group index swapped): the 16 lanes one ds_write_b64 cycle serves then hit 2 x 64 bytes that are 320 bytes = 16 banks (mod 32)
+    // apart -- with neighbouring rows (80 bytes apart) four banks were hit twice: 33 % of the LDS cycles were conflicts
+    // (profiles/r04_train_step_f16x3_pmc.txt)
+    auto row_of = [](int e) { const int g = e >> 3; return (g & ~5) | ((g & 1) << 2) | ((g >> 2) & 1); };
+    auto fetch = [&](int k0) {  // 128 rows x 8 float4 per operand
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int e = t + u * 256, row = e >> 3, c4 = (e & 7) * 4;
+            const int e = t + u * 256, row = row_of(e), c4 = (e & 7) * 4;
             xv[u] = (m0 + row < M) ? *reinterpret_cast<const f32x4 *>(grid + (m0 + row) * C_LAT + k0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
             wv[u] = *reinterpret_cast<const f32x4_param *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
         }
@@ -277,7 +282,7 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
         __syncthreads();  // the previous chunk's fragments have been read
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int e = t + u * 256, row = e >> 3, c4 = (e & 7) * 4;
+            const int e = t + u * 256, row = row_of(e), c4 = (e & 7) * 4;
             split4(xv[u], &sXh[row][c4], &sXl[row][c4]);
             split4(wv[u], &sWh[row][c4], &sWl[row][c4]);
         }
