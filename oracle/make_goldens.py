@@ -40,6 +40,8 @@ SCENARIOS = {
     "train_64_32":     ("train", 64, 32, 16, 32, False, True),   # SB=4 (config 5 shapes)
     "mv_mini_lindisp": ("mv_mini", 32, 16, 0, 32, True, True),   # SB=2 x NS=2, lindisp, Kfd=0
     "sn64_coarse_only_mlp": ("sn64", 16, 16, 16, 32, False, False),  # mlp_fine=None, Kf-Kfd=0
+    "dtu6_mini_64_128": ("dtu6_mini", 64, 128, 16, 48, False, True),   # NS=6: the reference's 6-view DTU eval (README.md:201)
+    "dtu9_mini_64_128": ("dtu9_mini", 64, 128, 16, 48, False, True),   # NS=9: the 9-view eval (README.md:202)
 }
 # adversarial scenarios: surface-like density (synthetic.surface_variant: sigma ~0 off a thin shell,
 # 50..300 on it -> peaked coarse weights), importance draw u2 = 1 - 2^-24 on column 0 of every 4th ray (searchsorted past the last cdf
@@ -257,6 +259,41 @@ def stage_goldens():
     return rec
 
 
+def manyview_stage_goldens():
+    """stage_goldens' PixelNeRFNet.forward / SpatialEncoder.index fixtures on the 6- and 9-view scenes (models.py:102-105
+    num_views_per_obj = 6 / 9; resnetfc.py:168-172 the mean over 6 / 9 rows), plus the view MAXIMUM over 9 rows (util.py:467-468).
+    A file of its own (stages_manyview.npz) so that stages.npz keeps regenerating bit-identically."""
+    rs = np.random.RandomState(199)
+    rec = {}
+    for scene_name in ("dtu6_mini", "dtu9_mini"):
+        scene, meta = synthetic.make_scene(scene_name, seed=SCENE_SEED)
+        net = build_reference_net(True)
+        set_encode_state(net, scene)
+        SB, NS = scene["SB"], scene["NS"]
+        B = 200
+        xyz = torch.from_numpy(rs.uniform(-1.0, 1.0, (SB, B, 3)).astype(np.float32))
+        xyz[:, :20] *= 4.0
+        vd = torch.from_numpy(rs.randn(SB, B, 3).astype(np.float32))
+        vd = vd / vd.norm(dim=-1, keepdim=True)
+        with torch.no_grad():
+            out_c = net(xyz, coarse=True, viewdirs=vd)
+            out_f = net(xyz, coarse=False, viewdirs=vd)
+            uv = torch.from_numpy(rs.uniform(-8, meta["W"] + 8, (SB * NS, 64, 2)).astype(np.float32))
+            idx = net.encoder.index(uv, None, net.image_shape)
+            net.mlp_coarse.combine_type = net.mlp_fine.combine_type = "max"
+            max_c = net(xyz, coarse=True, viewdirs=vd)
+            max_f = net(xyz, coarse=False, viewdirs=vd)
+        rec[f"{scene_name}_xyz"] = xyz.numpy()
+        rec[f"{scene_name}_viewdirs"] = vd.numpy()
+        rec[f"{scene_name}_out_coarse"] = out_c.numpy()
+        rec[f"{scene_name}_out_fine"] = out_f.numpy()
+        rec[f"{scene_name}_max_coarse"] = max_c.numpy()
+        rec[f"{scene_name}_max_fine"] = max_f.numpy()
+        rec[f"{scene_name}_uv"] = uv.numpy()
+        rec[f"{scene_name}_index"] = idx.numpy()
+    return rec
+
+
 def combine_max_goldens():
     """PixelNeRFNet.forward of the UNMODIFIED reference with `combine_type = "max"` on both ResnetFCs (util.combine_interleaved's
     other branch, src/util/util.py:467-468; resnetfc.py:168-172) on the multi-view scenes' stage points (tests/golden/stages.npz
@@ -384,17 +421,21 @@ def neighbour_goldens():
 
 
 GRAD_SCENARIOS = ("train_64_32", "srn_mini_64_128", "train_cfg5")  # SB=4 x NS=1 (config 5 shapes), NS=2 pooling, config 5 at FULL size
+# 3 source views -- what the reference trains DTU with (README.md:204; train/train.py:28,77,138-160 --nviews): a file of its own
+# (gradients_3view.npz) so that gradients.npz keeps regenerating bit-identically
+GRAD_SCENARIOS_3VIEW = ("dtu_mini_64_128", "train_mv3")  # SB=1 x NS=3; SB=2 x NS=3 (object-major rows under the 3-row mean)
 # gradient-only scenarios (no render fixture: rays and noise are regenerated from their seeds by the tests, exactly as below)
-GRAD_ONLY = {"train_cfg5": ("train", 64, 32, 16, 128, False, True)}  # BASELINE configs[4]: 4 objects x 128 rays, 64+32(16)
+GRAD_ONLY = {"train_cfg5": ("train", 64, 32, 16, 128, False, True),  # BASELINE configs[4]: 4 objects x 128 rays, 64+32(16)
+             "train_mv3": ("train_mv3", 64, 32, 16, 64, False, True)}  # DTU-style step: 2 objects x 3 views x 64 rays, 64+32(16)
 
-def gradient_goldens():
+def gradient_goldens(names=GRAD_SCENARIOS):
     """Gradients of the UNMODIFIED reference (torch autograd through NeRFRenderer.forward, train/train.py:199-215:
     MSE(coarse rgb) + MSE(fine rgb) against a seeded target) w.r.t. every ResnetFC parameter of both networks and
     encoder.latent, on the golden scenarios' rays and noise.  Frozen per tensor: L2 norm + a seeded subsample."""
     import render.nerf as ref_nerf
 
     rec = {}
-    for name in GRAD_SCENARIOS:
+    for name in names:
         scene_name, Kc, Kf, Kfd, n_rays, lindisp, use_fine = SCENARIOS[name] if name in SCENARIOS else GRAD_ONLY[name]
         scene, meta = synthetic.make_scene(scene_name, seed=SCENE_SEED)
         rays = synthetic.target_rays(meta, n_rays=n_rays)
@@ -451,7 +492,8 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "adv_plane", "neighbours", "gradients", "combine_max", "variants", "manifest"])
+    names = sys.argv[1:] or (list(SCENARIOS) + ["stages", "stages_manyview", "adv_plane", "neighbours", "gradients", "gradients_3view", "combine_max",
+                                "variants", "manifest"])
     for name in names:
         if name == "manifest":
             path = os.path.join(outdir, "state_dict_manifest.txt")
@@ -459,6 +501,7 @@ def main():
             print("wrote", path)
             continue
         rec = (stage_goldens() if name == "stages" else neighbour_goldens() if name == "neighbours" else plane_goldens() if name == "adv_plane"
+               else manyview_stage_goldens() if name == "stages_manyview" else gradient_goldens(GRAD_SCENARIOS_3VIEW) if name == "gradients_3view"
                else gradient_goldens() if name == "gradients" else combine_max_goldens() if name == "combine_max"
                else variants_goldens() if name == "variants" else run_scenario(name))
         path = os.path.join(outdir, name + ".npz")

@@ -186,22 +186,47 @@ def _needs_build():
     return False
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, jobs=None):
     """Compile the HIP sources for gfx950 into csrc/libpixelnerf_hip.so (hipcc cross-compiles
-    without a GPU).  No-op when the library is newer than every source."""
+    without a GPU).  No-op when the library is newer than every source.  One hipcc per translation unit, in parallel, objects
+    kept under build/obj_prod/ (a unit is recompiled when its source or any header is newer than its object), then one link."""
     if not force and not _needs_build():
         return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    objdir = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "build", "obj_prod")
+    os.makedirs(objdir, exist_ok=True)
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+
+    def compile_unit(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), newest_header):
+            return obj, None
+        cmd = [hipcc] + flags + ["-c", path, "-o", obj + f".tmp.{os.getpid()}"]
+        if verbose:
+            print(" ".join(cmd[:-1] + [obj]), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            return obj, res.stdout + res.stderr
+        os.replace(cmd[-1], obj)
+        return obj, None
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_unit, SOURCES))
+    errors = [e for _, e in results if e]
+    if errors:
+        raise PixelNerfHipError("hipcc failed:\n" + "\n".join(errors))
     tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in results] + ["-o", tmp]
     if verbose:
-        print(" ".join(cmd).replace(tmp, LIB_PATH))
+        print(" ".join(cmd).replace(tmp, LIB_PATH), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         if os.path.exists(tmp):
             os.remove(tmp)
-        raise PixelNerfHipError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise PixelNerfHipError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, LIB_PATH)  # atomic: a process that already mapped the old file keeps it
     return LIB_PATH
 

@@ -168,14 +168,15 @@ __device__ __forceinline__ void gemm_split(f32x16 (&acc)[IT][JT], const char *sm
 // tail = f16(v - head): one v_fma_mix{lo,hi}_f16 per value (fp32 FMA of the f16 head taken straight out of its packed
 // register, times -1, plus v; result rounded once to f16) -- the same bits as convert-back + subtract + convert
 // (v - head is exact in fp32), 5 VALU operations per pair instead of 8.
-// GUARD: `amax` follows the largest value split (one v_max3_f32 per pair): the fp16-range guard of pnr_saturation_guard().
+// GUARD: `amax` (a packed f16 pair) follows the largest HEAD produced, one v_pk_maximum3_f16 per FOUR values (gfx950; the
+// IEEE-2019 maximum: a NaN head sticks): the fp16-range guard of pnr_saturation_guard().  Half the VALU cost of following the
+// fp32 inputs with v_max3_f32 (round 5), which is what lets the guard run on every inference call (round 6).  Heads are >= 0
+// behind the relu, so no magnitudes are needed; a head of 65504 means v >= 65488 (round to nearest): the guard fires 16 below
+// the exact saturation point.
 template <bool RELU, bool GUARD = false>
-__device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo, [[maybe_unused]] float *amax = nullptr) {
+__device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo, [[maybe_unused]] uint32_t *amax = nullptr) {
+    static_assert(RELU || !GUARD, "the guard follows relu'd heads");
     u32x4 uh, ul;
-    if constexpr (GUARD) {  // on the INPUT values (v_max3_f32 per pair; negative values cannot raise it, relu or not the magnitude matters)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *amax = RELU ? fmaxf(*amax, fmaxf(v[2 * k], v[2 * k + 1])) : fmaxf(*amax, fmaxf(fabsf(v[2 * k]), fabsf(v[2 * k + 1])));
-    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         f32x2 p = {v[2 * k], v[2 * k + 1]};
@@ -192,6 +193,12 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8 &hi, h8 &lo, [[ma
         asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(uh[k]), "v"(p[0]));
         asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(uh[k]), "v"(p[1]));
         ul[k] = l;
+    }
+    if constexpr (GUARD) {  // (the operands are v_cvt_pk results, never straight MFMA outputs: inline asm is safe here)
+        uint32_t m = *amax;
+        asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(m) : "v"(uh[0]), "v"(uh[1]));
+        asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(m) : "v"(uh[2]), "v"(uh[3]));
+        *amax = m;
     }
     hi = __builtin_bit_cast(h8, uh);
     lo = __builtin_bit_cast(h8, ul);
@@ -233,7 +240,7 @@ __device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][JT], char *s
 // chunked = whole and sharded = unsharded stay bit for bit.
 template <typename ST, int JT, bool GUARD>
 __device__ __forceinline__ void stage_own(f32x16 (&acc)[IT][JT], const f32x16 (&src)[IT][JT], char *smem, uint32_t waddr,
-                                          SplitRing &R, int NS, [[maybe_unused]] float *amax) {
+                                          SplitRing &R, int NS, [[maybe_unused]] uint32_t *amax) {
     // k-step jj of the own block = (feature tile jj >> 1, register half jj & 1); 2 IT k-steps = IT / 2 ring bodies of 4
     static_assert(IT % 2 == 0, "whole ring bodies");
     h8 bh[2][JT], bl[2][JT];
@@ -554,15 +561,15 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         dump_image<MT>(smem, ST::A_HI, head + (size_t)rows * (D_HID * 2), tr_rows_left, wv, lane);
         dump_image<MT>(smem, ST::A_LO, head + total + (size_t)rows * (D_HID * 2), tr_rows_left, wv, lane);
     };
-    // fp16-range guard (GUARD instantiation, pnr_saturation_guard): bit l of sat_bits = "a value >= 65504 (the largest fp16: heads
-    // saturate there) went into the operand image of layer l" (2b: relu(x) entering blocks[b].fc_0, 2b+1: relu(net) entering
+    // fp16-range guard (GUARD instantiation, pnr_saturation_guard): bit l of sat_bits = "a head of 65504 (the largest fp16: heads
+    // saturate there; i.e. a value >= 65488) went into the operand image of layer l" (2b: relu(x) entering blocks[b].fc_0, 2b+1: relu(net) entering
     // fc_1, 10: the stream in front of lin_out), bit 11 = a non-finite network output
     [[maybe_unused]] uint32_t sat_bits = 0;
-    [[maybe_unused]] float amax = 0.f;
+    [[maybe_unused]] uint32_t amax = 0u;  // packed f16 pair: the running maximum of the heads (split8)
     [[maybe_unused]] auto sat_note = [&](int layer) {
-        if constexpr (GUARD) {
-            if (amax >= 65504.f) sat_bits |= 1u << layer;
-            amax = 0.f;
+        if constexpr (GUARD) {  // either half >= 0x7BFF: 65504, +inf or a NaN
+            if ((amax & 0x7FFFu) >= 0x7BFFu || (amax & 0x7FFF0000u) >= 0x7BFF0000u) sat_bits |= 1u << layer;
+            amax = 0u;
         }
     };
     // one residual block on x (resnetfc.py:66-88); lookup: lin_z[b+1] via table b+1 behind it.

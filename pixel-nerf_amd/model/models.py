@@ -209,13 +209,14 @@ class PixelNeRFNet(torch.nn.Module):
 
     # ---- fp16-range guard of the fp32-class precision (ops.saturation_guard_*; include/pixelnerf_hip.h).  "f16x3" represents
     # every operand as an fp16 (head, tail) pair: exact to ~2^-22 up to 65504, SATURATING beyond -- silently outside the
-    # reference's fp32 arithmetic for a network whose hidden activations grow that large.  The guarded instantiation of the
-    # kernel (about 1 % slower) therefore runs on the FIRST call after the weights or the encoded scene changed (and on every
-    # 16th training call); its verdict arrives asynchronously and is reported as a RuntimeWarning by a later call.
-    # This is a SAMPLING policy, not a proof: saturation depends on the query points too, and inference batches after the first
-    # one for a given (weights, scene) run unguarded -- a ray batch that alone drives an activation past 65504 on a checkpoint
-    # whose first batch stayed in range is not reported.  PIXELNERF_SATURATION_GUARD=always guards every call (~1 % slower; every
-    # call's verdict is kept until it is reported), =off none.
+    # reference's fp32 arithmetic for a network whose hidden activations grow that large.  A drop-in for fp32 results must not
+    # do that silently, so EVERY inference call runs the guarded instantiation of the kernel by default (round 6; two
+    # v_pk_maximum3_f16 per eight operand values, priced in the benchmark line) and every 16th training call does (the weights
+    # move slowly; the TRAIN instantiation is the register-tightest one); a verdict arrives asynchronously -- no host
+    # synchronisation -- and is reported as a RuntimeWarning by the next call (or by _guard_report(wait=True)).
+    # PIXELNERF_SATURATION_GUARD=sample restores the round-5 policy at inference (only the first call after the weights or the
+    # encoded scene changed: a later ray batch that alone saturates goes unreported), =always also guards every training call,
+    # =off none.
     def _guard_begin(self, training=False):
         """-> True when this call runs guarded (the caller must call _guard_end)"""
         import os
@@ -233,7 +234,8 @@ class PixelNeRFNet(torch.nn.Module):
         n = self.__dict__.get("_guard_calls", 0)
         self.__dict__["_guard_calls"] = n + 1
         # (training: the weights change every step -- the key would fire every time; every 16th call instead)
-        due = mode == "always" or (training and n % 16 == 0) or (not training and key != self.__dict__.get("_guard_key"))
+        due = (mode == "always" or (training and n % 16 == 0)
+               or (not training and (mode != "sample" or key != self.__dict__.get("_guard_key"))))
         if not due:
             return False
         self.__dict__["_guard_key"] = key

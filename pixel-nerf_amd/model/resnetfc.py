@@ -266,24 +266,28 @@ class ResnetFC(nn.Module):
         """entry = [fingerprint, stream, content fingerprint recorded?, times served from the cache].
         A training loop re-packs on every call (the optimizer-step count is part of the fingerprint) and never serves a stream
         twice: there the device-side content fingerprint (pnr_params_checksum, ~25 us per network per step) protects nothing, so
-        a stream that replaces one that was never re-used is packed WITHOUT it.  The first call that re-uses such a stream
-        records the fingerprint of the (unchanged) parameters behind it -- from then on every hit is verified as described above."""
+        a stream that replaces one that was never re-used is packed WITHOUT it -- but only while gradients are being taken: a
+        stream packed under no_grad / in eval mode (a validation pass between optimizer steps) always gets its fingerprint.
+        The first call that RE-USES a stream packed without a fingerprint packs it again (and re-folds the tables), recording one (recording
+        the checksum of the current parameters instead would bless a stream that a `.data` write has already made stale -- e.g. a
+        validation forward with EMA weights swapped in and back through `p.data.copy_` right after `opt.step`).  That costs one
+        extra pack on the first step of an mlp_fine=None training run only: from the second step on the replaced stream HAS been
+        re-used, so its successor is packed with a fingerprint and every hit is verified as described above."""
         fp = self._fingerprint()
         ent = self._packed.get(key)
         checked = precision != "f32"
         fresh = ent is not None and ent[0] == fp
         if fresh and checked:
             if not ent[2]:
-                # packed in a re-pack-every-call phase, and now served a second time under the same fingerprint (mlp_fine=None
-                # training: both passes of a step ask for the coarse network's stream): the stream is current, only its content
-                # fingerprint is missing -- take THAT now (one ~25 us launch) instead of packing the whole stream again
-                self._content_record(key)
-                ent[2] = True
+                # never verified against the parameters: cannot be trusted on a re-use.  Drop it AND what depends on the
+                # fingerprint (the folded lin_z tables): the epoch bump re-folds them from the live parameters too
+                self.invalidate_packed()
+                fp, ent, fresh = self._fingerprint(), None, False
             elif self._content_verify(key):
                 fp, ent, fresh = self._fingerprint(), None, False
         if not fresh:
             # the previous stream's buffer is overwritten in place (its users are earlier launches on the same stream)
-            record = checked and (ent is None or ent[3] > 0 or ent[0] == fp)
+            record = checked and (ent is None or ent[3] > 0 or ent[0] == fp or not self.training or not torch.is_grad_enabled())
             ent = [fp, build(None if ent is None else ent[1]), record, 0]
             self._packed[key] = ent
             if record:

@@ -160,6 +160,31 @@ SCENES = {
                      z_near=0.1, z_far=5.0, radius=2.0,
                      src=[(-20.0, -15.0), (0.0, -25.0), (20.0, -15.0)],
                      tgt=(0.0, -15.0), white_bkgd=False, blender=False),
+    # the reference's 6- and 9-view DTU evaluations (README.md:201-202: `-P '22 25 28 40 44 48'` / 9 views; models.py:102-105
+    # num_views_per_obj, resnetfc.py:168-172 the pooled mean over 6 / 9 rows): dtu_mini's geometry (black background, fx != fy,
+    # off-centre principal point) seen from a ring of source cameras, some of them steep enough that part of the object projects
+    # outside their image (border-clamped lookups in several views at once)
+    "dtu6_mini": dict(W=40, H=30, NS=6, SB=1, Hl=15, Wl=20, focal=(72.3, 70.1), c=(20.5, 14.25),
+                      z_near=0.1, z_far=5.0, radius=2.0,
+                      src=[(-50.0, -15.0), (-30.0, -35.0), (-10.0, -10.0), (10.0, -30.0), (30.0, -5.0), (50.0, -20.0)],
+                      tgt=(0.0, -15.0), white_bkgd=False, blender=False),
+    "dtu9_mini": dict(W=40, H=30, NS=9, SB=1, Hl=15, Wl=20, focal=(72.3, 70.1), c=(20.5, 14.25),
+                      z_near=0.1, z_far=5.0, radius=2.0,
+                      src=[(-80.0, -15.0), (-60.0, -35.0), (-40.0, -10.0), (-20.0, -30.0), (0.0, -5.0), (20.0, -25.0),
+                           (40.0, -12.0), (60.0, -40.0), (80.0, -20.0)],
+                      tgt=(0.0, -15.0), white_bkgd=False, blender=False),
+    # full DTU grid under the 9-view recipe: 9 x 512 x 150 x 200 fp32 = 553 MB, folded tables 1.66 GB per network
+    "dtu_9v": dict(W=400, H=300, NS=9, SB=1, Hl=150, Wl=200, focal=(723.0, 723.0), c=(200.0, 150.0),
+                   z_near=0.1, z_far=5.0, radius=2.0,
+                   src=[(-80.0, -15.0), (-60.0, -35.0), (-40.0, -10.0), (-20.0, -30.0), (0.0, -5.0), (20.0, -25.0),
+                        (40.0, -12.0), (60.0, -40.0), (80.0, -20.0)],
+                   tgt=(0.0, -15.0), white_bkgd=False, blender=False),
+    # DTU-style training (README.md:204 "in training, we always provide 3-views"; train/train.py:138-160 --nviews): 2 objects x 3
+    # source views, black background, fx != fy -- the backward of the 3-row view mean with object-major rows
+    "train_mv3": dict(W=40, H=30, NS=3, SB=2, Hl=15, Wl=20, focal=(72.3, 70.1), c=(20.5, 14.25),
+                      z_near=0.1, z_far=5.0, radius=2.0,
+                      src=[(-20.0, -15.0), (0.0, -25.0), (20.0, -15.0), (100.0, -20.0), (125.0, -10.0), (150.0, -30.0)],
+                      tgt=(0.0, -15.0), white_bkgd=False, blender=False),
     # BASELINE config (5) geometry: 4 objects x 1 view (S5)
     "train": dict(W=64, H=64, NS=1, SB=4, Hl=32, Wl=32, focal=(119.4256, 119.4256), c=(32.0, 32.0),
                   z_near=1.2, z_far=4.0, radius=2.732,

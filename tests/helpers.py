@@ -16,12 +16,34 @@ ADVERSARIAL_SCENARIOS = ["adv_surface_sn64", "adv_surface_srn", "adv_surface_dtu
 RENDER_SCENARIOS = [
     "sn64_c32", "sn64_64_128", "srn_mini_64_128", "dtu_mini_64_128", "train_64_32",
     "mv_mini_lindisp", "sn64_coarse_only_mlp",
+    "dtu6_mini_64_128", "dtu9_mini_64_128",  # NS = 6 / 9: the reference's 6- and 9-view DTU evaluations (README.md:201-202)
 ]
+
+# scenes with per-point stage fixtures (stages.npz + stages_manyview.npz); the multi-view ones also carry view-maximum outputs
+STAGE_SCENES = ["sn64", "dtu_mini", "mv_mini", "dtu6_mini", "dtu9_mini"]
+MV_STAGE_SCENES = ["dtu_mini", "mv_mini", "dtu6_mini", "dtu9_mini"]
+
+# fixtures frozen in a second file so the first keeps regenerating bit-identically: loaded as one dict under the first's name
+_MERGED = {"stages": ("stages_manyview",), "gradients": ("gradients_3view",)}
+
+
+@functools.lru_cache(maxsize=None)
+def _load_npz(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return {k: z[k] for k in z.files}
 
 
 def load_golden(name):
-    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
-    return {k: z[k] for k in z.files}
+    g = dict(_load_npz(name))
+    for extra in _MERGED.get(name, ()):
+        e = _load_npz(extra)
+        assert not set(e) & set(g), "fixture files share keys"
+        g.update(e)
+    if name == "combine_max":  # the many-view maxima live next to their points in stages_manyview.npz
+        for k, v in _load_npz("stages_manyview").items():
+            if "_max_" in k:
+                g[k.replace("_max_", "_out_")] = v
+    return g
 
 
 @functools.lru_cache(maxsize=None)
@@ -98,7 +120,10 @@ def robust_render_stats(rgb, depth, z_fine, g, span):
 
 # gradient-only scenarios of tests/golden/gradients.npz (oracle/make_goldens.py GRAD_ONLY): no render fixture -- rays, noise
 # and networks are regenerated from their seeds exactly as the generator does
-GRAD_ONLY = {"train_cfg5": ("train", 64, 32, 16, 128, False, True)}  # BASELINE configs[4] at full size: 4 objects x 128 rays
+GRAD_ONLY = {"train_cfg5": ("train", 64, 32, 16, 128, False, True),   # BASELINE configs[4] at full size: 4 objects x 128 rays
+             "train_mv3": ("train_mv3", 64, 32, 16, 64, False, True)}  # DTU-style step: 2 objects x 3 source views x 64 rays
+# every scenario with gradients frozen from the reference's own autograd (gradients.npz + gradients_3view.npz)
+GRAD_SCENARIOS = ["train_64_32", "srn_mini_64_128", "train_cfg5", "dtu_mini_64_128", "train_mv3"]
 
 
 def grad_setup(name):

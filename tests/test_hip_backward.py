@@ -381,7 +381,7 @@ def test_fused_chain_latent_and_input_gradients(dev, name, prec):
         assert err <= 2e-5 * max(ref.abs().max().item(), 1e-12) + 1e-12, f"{what}: max err {err:.3e} vs scale {ref.abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("name", ["train_64_32", "srn_mini_64_128"])
+@pytest.mark.parametrize("name", ["train_64_32", "srn_mini_64_128", "dtu_mini_64_128"])  # NS = 1 (SB = 4), 2, 3
 def test_hip_gradients_match_reference_autograd_goldens(dev, name):
     """HIP training path vs the gradients of the UNMODIFIED reference's own backward (tests/golden/gradients.npz,
     frozen by oracle/make_goldens.py): loss to 2e-3 relative, every one of the 61 gradient tensors within 3e-2

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import grad_setup, load_golden
+from helpers import GRAD_SCENARIOS, grad_setup, load_golden
 from testdata import synthetic
 
 pytestmark = pytest.mark.gpu
@@ -74,7 +74,7 @@ def _train_grads(dev, name, precision, loss_scale=1.0):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3-gemms"])  # exact fp32 MFMA / split-operand fused / split-operand GEMM per layer
-@pytest.mark.parametrize("name", ["train_64_32", "srn_mini_64_128", "train_cfg5"])
+@pytest.mark.parametrize("name", GRAD_SCENARIOS)  # incl. the 3-view ones (README.md:204: DTU trains with 3 views): dtu_mini, train_mv3
 def test_fp32_gradients_match_reference_autograd(dev, name, precision):
     loss, grads, gg = train_grads(dev, name, precision)
     ref_loss = float(gg[f"{name}_loss"])

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import RENDER_SCENARIOS, assert_close_frac, golden_setup, load_golden, mlp_params, scene_for
+from helpers import RENDER_SCENARIOS, assert_close_frac, golden_setup, load_golden, mlp_params, scene_for, STAGE_SCENES
 from oracle import pnr_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -43,7 +43,7 @@ def packed(ops, dev, seed, prec="f32"):
     return ops.pack_mlp({k: v.to(dev) for k, v in mlp_params(seed).items()}, prec)
 
 
-@pytest.mark.parametrize("scene_name", ["sn64", "dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("scene_name", STAGE_SCENES)
 def test_f32_eval_points_matches_reference(ops, dev, scene_name):
     g = load_golden("stages")
     sc = dscene(ops, dev, scene_name)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden, mlp_params, scene_for
+from helpers import load_golden, mlp_params, scene_for, STAGE_SCENES
 
 pytestmark = pytest.mark.gpu
 
@@ -112,7 +112,7 @@ def test_positional_encoding_operator_forward_backward(ops, dev, d_in, F, includ
     assert (x.grad.cpu() - x2.grad).abs().max().item() <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("name", ["sn64", "dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("name", STAGE_SCENES)
 def test_spatial_encoder_index_matches_reference(ops, dev, name):
     g = load_golden("stages")
     s, meta = scene_for(name)
@@ -146,7 +146,7 @@ def _encoder_with_grid(dev, s):
     return enc
 
 
-@pytest.mark.parametrize("name", ["sn64", "dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("name", STAGE_SCENES)
 def test_spatial_encoder_index_operator_matches_reference(dev, name):
     """SpatialEncoder.index called on its own (src/model/encoder.py:80-109) is the HIP operator pnr_grid_index: against the
     outputs of the reference's own `index` on the same grid and pixel coordinates (goldens), incl. points outside the image."""

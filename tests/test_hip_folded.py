@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import RENDER_SCENARIOS, golden_setup, load_golden, mlp_params, scene_for
+from helpers import RENDER_SCENARIOS, golden_setup, load_golden, mlp_params, scene_for, STAGE_SCENES
 from oracle import pnr_oracle as O
 from test_hip_parity import PREC_TOL
 
@@ -54,7 +54,7 @@ def test_tables_are_lin_z_of_the_grid(ops, dev):
 
 
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
-@pytest.mark.parametrize("scene_name", ["sn64", "dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("scene_name", STAGE_SCENES)
 def test_folded_eval_points_matches_reference(ops, dev, scene_name, prec):
     g = load_golden("stages")
     tol = PREC_TOL[prec]

@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import RENDER_SCENARIOS, assert_close_frac, golden_setup, load_golden, mlp_params, scene_for
+from helpers import RENDER_SCENARIOS, assert_close_frac, golden_setup, load_golden, mlp_params, scene_for, STAGE_SCENES
 from oracle import pnr_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -130,7 +130,7 @@ def test_nchw_to_nhwc(ops, dev):
 
 
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
-@pytest.mark.parametrize("scene_name", ["sn64", "dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("scene_name", STAGE_SCENES)
 def test_eval_points_matches_reference(ops, dev, scene_name, prec):
     """net(xyz, coarse=, viewdirs=) against PixelNeRFNet.forward of the reference (goldens)."""
     g = load_golden("stages")

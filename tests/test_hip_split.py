@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import RENDER_SCENARIOS, assert_close_frac, golden_setup, load_golden, mlp_params, scene_for
+from helpers import RENDER_SCENARIOS, assert_close_frac, golden_setup, load_golden, mlp_params, scene_for, MV_STAGE_SCENES, STAGE_SCENES
 from oracle import pnr_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -57,7 +57,7 @@ def test_split_tables_are_lin_z_of_the_grid_in_fp32(ops, dev):
         assert (got - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("scene_name", ["sn64", "dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("scene_name", STAGE_SCENES)
 def test_split_eval_points_matches_reference(ops, dev, scene_name):
     g = load_golden("stages")
     sc = dscene(ops, dev, scene_name)
@@ -218,8 +218,8 @@ def test_saturation_guard_names_the_layer_that_left_the_fp16_range(ops, dev):
 
 
 def test_renderer_warns_once_when_a_checkpoint_leaves_the_fp16_range(dev):
-    """API level: the first render on new weights runs guarded; its verdict is reported by the NEXT call as a RuntimeWarning that
-    names network and layer.  In-range weights: no warning, and the guard does not run again on unchanged weights / scene."""
+    """API level: every inference render runs guarded (round 6 default); a verdict is reported by the NEXT call as a
+    RuntimeWarning that names network and layer.  In-range weights: no warning, same bits call after call."""
     import warnings
     from pixelnerf_amd.render import NeRFRenderer
     from test_api_gpu import build_net
@@ -232,8 +232,9 @@ def test_renderer_warns_once_when_a_checkpoint_leaves_the_fp16_range(dev):
         a = rend(net, rays.to(dev), _noise=nz)
         torch.cuda.synchronize()
         b = rend(net, rays.to(dev), _noise=nz)
-        assert torch.equal(a.fine.rgb, b.fine.rgb)  # guarded (first) and plain (second) call: same bits
+        assert torch.equal(a.fine.rgb, b.fine.rgb)
         assert net.__dict__["_guard_calls"] == 2
+        assert net._guard_report(wait=True) == (0, 0)  # both calls ran guarded and both verdicts are clean
     with torch.no_grad():
         net.mlp_fine.lin_z[1].weight.mul_(1e5)  # only the FINE network leaves the range, at block 1 (the weights themselves stay inside)
         rend(net, rays.to(dev), _noise=nz)      # guarded: new weights
@@ -242,8 +243,63 @@ def test_renderer_warns_once_when_a_checkpoint_leaves_the_fp16_range(dev):
             rend(net, rays.to(dev), _noise=nz)
 
 
+def _border_row_scene(dev):
+    """sn64 with the top and bottom texel rows of the encoded grid at 3e4 in every channel (inside the fp16 range: the per-texel fold
+    is clean; lin_z[0] of such a texel is ~N(0, 4e4^2) per hidden feature: dozens of features beyond 65504): the centre rays of the target view project onto rows
+    7..23 of the 32 only (v = 14.4 .. 45.5 px of 64), the same rays from an origin shifted by (40, 40, 40) onto v = 68..69 px --
+    below the source image, i.e. border-clamped onto the bottom row.  -> (scene, in-range rays, saturating rays), (1, 256, 8) each"""
+    from testdata import synthetic
+    scene, meta = synthetic.make_scene("sn64")
+    scene = dict(scene)
+    lat = scene["latent"].clone()
+    lat[:, :, 0, :] = 3e4
+    lat[:, :, -1, :] = 3e4
+    scene["latent"] = lat
+    inside = synthetic.target_rays(meta).reshape(64, 64, 8)[24:40, 24:40].reshape(1, -1, 8).contiguous()
+    outside = inside.clone()
+    outside[..., :3] += 40.0
+    return scene, inside.to(dev), outside.to(dev)
+
+
+@pytest.mark.parametrize("mode", ["default", "sample"])
+def test_second_batch_that_alone_saturates_is_reported(dev, monkeypatch, mode):
+    """saturation depends on the QUERY POINTS too.  Same weights, same encoded scene; the first ray batch
+    stays in range, the second one alone looks up texels that drive block 0 past 65504.  Default policy (every inference call
+    guarded): the second batch is reported.  PIXELNERF_SATURATION_GUARD=sample (the round-5 policy, kept as the opt-out): only the
+    first call after encode() is guarded and the second batch's saturated render goes unreported -- pinned here as the
+    documented behaviour of the opt-out."""
+    import warnings
+    from pixelnerf_amd.render import NeRFRenderer
+    from test_api_gpu import build_net
+    if mode == "sample":
+        monkeypatch.setenv("PIXELNERF_SATURATION_GUARD", "sample")
+    else:
+        monkeypatch.delenv("PIXELNERF_SATURATION_GUARD", raising=False)
+    scene, inside, outside = _border_row_scene(dev)
+    net = build_net(dev, scene, precision="f16x3")
+    rend = NeRFRenderer(n_coarse=64, n_fine=128, n_fine_depth=16, white_bkgd=True).to(dev).eval()
+    with torch.no_grad():
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            rend(net, inside)                        # first batch after "encode": in range
+            assert net._guard_report(wait=True) == (0, 0)
+        out = rend(net, outside)                     # second batch: border-clamped onto the 3e4 rows
+        assert torch.isfinite(out.fine.rgb).all()    # (heads saturate, nothing overflows)
+        if mode == "default":
+            with pytest.warns(RuntimeWarning, match=r"coarse network: .*blocks\.0\.fc_0"):
+                net._guard_report(wait=True)
+            rend(net, outside)                       # ... or by the next call, like any verdict
+            torch.cuda.synchronize()
+            with pytest.warns(RuntimeWarning, match=r"65504"):
+                rend(net, inside)
+        else:
+            with warnings.catch_warnings():
+                warnings.simplefilter("error", RuntimeWarning)
+                assert net._guard_report(wait=True) is None  # nothing ran guarded: nothing to report
+
+
 # ---------------------------------------------------------------- combine_type = "max" (util.py:467-468)
-@pytest.mark.parametrize("scene_name", ["dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("scene_name", MV_STAGE_SCENES)
 @pytest.mark.parametrize("precision,bar_rgb,bar_sigma", [("f16x3", 2e-5, 1e-4), ("f32", 2e-5, 1e-4), ("f16", 6e-3, 2e-2)])
 def test_view_maximum_matches_reference(ops, dev, scene_name, precision, bar_rgb, bar_sigma):
     """the reference with both ResnetFCs at combine_type "max" (tests/golden/combine_max.npz, frozen from the unmodified reference):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (ADVERSARIAL_SCENARIOS, RENDER_SCENARIOS, assert_close_frac, robust_render_stats, golden_setup, load_golden, mlp_params,
+from helpers import (GRAD_SCENARIOS, MV_STAGE_SCENES, STAGE_SCENES, ADVERSARIAL_SCENARIOS, RENDER_SCENARIOS, assert_close_frac, robust_render_stats, golden_setup, load_golden, mlp_params,
                      scene_for)
 from oracle import pnr_oracle as O
 from testdata import synthetic
@@ -24,7 +24,7 @@ def test_positional_encoding_matches_reference():
     np.testing.assert_allclose(out.numpy(), g["posenc_out"], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("scene_name", ["sn64", "dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("scene_name", STAGE_SCENES)
 def test_index_latent_matches_reference_grid_sample(scene_name):
     g = load_golden("stages")
     scene, _ = scene_for(scene_name)
@@ -33,7 +33,7 @@ def test_index_latent_matches_reference_grid_sample(scene_name):
     np.testing.assert_allclose(out.numpy(), g[f"{scene_name}_index"], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("scene_name", ["sn64", "dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("scene_name", STAGE_SCENES)
 def test_pixelnerf_forward_matches_reference(scene_name):
     g = load_golden("stages")
     scene, _ = scene_for(scene_name)
@@ -46,7 +46,7 @@ def test_pixelnerf_forward_matches_reference(scene_name):
         np.testing.assert_allclose(out[..., 3].numpy(), ref[..., 3], rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("scene_name", ["dtu_mini", "mv_mini"])
+@pytest.mark.parametrize("scene_name", MV_STAGE_SCENES)
 def test_pixelnerf_forward_with_max_pooling_matches_reference(scene_name):
     """combine_type = "max" (src/util/util.py:467-468): the reference's own outputs with both ResnetFCs switched to the view
     maximum (tests/golden/combine_max.npz) -- and they differ from the view mean by O(1), so the branch is really exercised"""
@@ -206,7 +206,7 @@ def test_bbox_pixels_matches_reference_bbox_sample():
 # ------------------------------------------------------------------ gradients (BASELINE config 5)
 
 
-@pytest.mark.parametrize("name", ["train_64_32", "srn_mini_64_128", "train_cfg5"])
+@pytest.mark.parametrize("name", GRAD_SCENARIOS)  # incl. the 3-view scenarios of gradients_3view.npz (README.md:204)
 def test_oracle_autograd_matches_reference_autograd(name):
     """torch autograd through the oracle vs the UNMODIFIED reference's own backward (tests/golden/gradients.npz:
     per-tensor L2 norm + seeded subsample of every ResnetFC gradient of both networks and of encoder.latent,
