@@ -83,7 +83,10 @@ struct EvalParams {
 
 // phase ids of the TIMING instantiation (wave 0 of workgroup 0, s_memtime ticks)
 enum Phase { PH_SYNC_TOP = 0, PH_GEOMETRY, PH_GATHER, PH_GEMM_IN_Z0, PH_BAR1, PH_WRITE_X, PH_BAR2, PH_GEMM_FC0, PH_BAR3,
-             PH_WRITE_NET, PH_BAR4, PH_GEMM_FC1_Z, PH_LIN_OUT, PH_BAR_OUT, PH_FINAL, PH_TABLE, NPHASE };
+             PH_WRITE_NET, PH_BAR4, PH_GEMM_FC1_Z, PH_LIN_OUT, PH_BAR_OUT, PH_FINAL, PH_TABLE,
+             // sub-phases of the fp32-class kernel's own-K stages (round 6; they split PH_WRITE_X / PH_WRITE_NET further: the
+             // stage's remaining time -- waiting for the image stores, loop exit -- stays under those two)
+             PH_OWN_BIAS, PH_OWN_PROLOGUE, PH_OWN_KSTEPS, NPHASE };
 #define PNR_T(ph)                                                         \
     do {                                                                  \
         if constexpr (TIMING) {                                           \

@@ -238,9 +238,11 @@ __device__ __forceinline__ void write_split(const f32x16 (&acc)[IT][JT], char *s
 // the blocks of waves wv+1 .. wv+7 (mod 8) in the image's storage order (pnr_pack.hip, OWNK).  Per output element the 512
 // products are summed in a wave-dependent block order -- fixed per (feature, wave), identical for every point and tile size:
 // chunked = whole and sharded = unsharded stay bit for bit.
-template <typename ST, int JT, bool GUARD>
+struct NoMark { __device__ __forceinline__ void operator()(int) const {} };
+// MARK: the TIMING instantiation's clock (sub-phases PH_OWN_PROLOGUE / PH_OWN_KSTEPS); a no-op everywhere else
+template <typename ST, int JT, bool GUARD, typename MARK = NoMark>
 __device__ __forceinline__ void stage_own(f32x16 (&acc)[IT][JT], const f32x16 (&src)[IT][JT], char *smem, uint32_t waddr,
-                                          SplitRing &R, int NS, [[maybe_unused]] uint32_t *amax) {
+                                          SplitRing &R, int NS, [[maybe_unused]] uint32_t *amax, MARK mark = MARK()) {
     // k-step jj of the own block = (feature tile jj >> 1, register half jj & 1); 2 IT k-steps = IT / 2 ring bodies of 4
     static_assert(IT % 2 == 0, "whole ring bodies");
     h8 bh[2][JT], bl[2][JT];
@@ -254,6 +256,7 @@ __device__ __forceinline__ void stage_own(f32x16 (&acc)[IT][JT], const f32x16 (&
         }
     };
     make(0, 0);
+    mark(PH_OWN_PROLOGUE);  // accumulator drain + the first k-step's split
 #pragma unroll
     for (int body = 0; body < IT / 2; ++body) {
         const size_t pf = (size_t)R.pf_rs * (IT * 1024);
@@ -314,6 +317,7 @@ __device__ __forceinline__ void stage_own(f32x16 (&acc)[IT][JT], const f32x16 (&
         }
         ring_advance(R, NS);
     }
+    mark(PH_OWN_KSTEPS);
 }
 
 // the other seven K blocks of the same linear, from the operand images: blocks (wv + 1) .. (wv + 7) mod 8, the order the stream
@@ -572,6 +576,7 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             amax = 0u;
         }
     };
+    [[maybe_unused]] auto own_mark = [&](int ph) { PNR_T(ph); };
     // one residual block on x (resnetfc.py:66-88); lookup: lin_z[b+1] via table b+1 behind it.
     // Every 512-wide linear = stage_own (split epilogue + this wave's own K block, from registers) | barrier | gemm_split_rot
     auto block = [&](f32x16 (&x)[IT][JT], int b, bool lookup) {
@@ -581,7 +586,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         {
             f32x16 net[IT][JT];
             add_bias<true>(net, bias_lane, 1 + 2 * b);
-            stage_own<ST, JT, GUARD>(net, x, smem, a_wr, R, NS, &amax);                            // fc_0, own block
+            if constexpr (TIMING) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the bias has ARRIVED when the stage's clock starts (diagnostic: also drains the ring)
+            own_mark(PH_OWN_BIAS);
+            stage_own<ST, JT, GUARD>(net, x, smem, a_wr, R, NS, &amax, own_mark);                  // fc_0, own block
             sat_note(2 * b);
             PNR_T(PH_WRITE_X);
             __syncthreads();
@@ -593,7 +600,8 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
             __syncthreads();
             PNR_T(PH_BAR3);
             add_bias<false>(x, bias_lane, 2 + 2 * b);
-            stage_own<ST, JT, GUARD>(x, net, smem, a_wr, R, NS, &amax);                            // fc_1, own block
+            own_mark(PH_OWN_BIAS);
+            stage_own<ST, JT, GUARD>(x, net, smem, a_wr, R, NS, &amax, own_mark);                  // fc_1, own block
             sat_note(2 * b + 1);
             PNR_T(PH_WRITE_NET);
         }

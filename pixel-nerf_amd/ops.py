@@ -827,7 +827,7 @@ def debug_set_x_dump(t):
 
 
 PHASES = ["sync_top", "geometry", "gather", "gemm_in_z0", "bar1", "write_x", "bar2", "gemm_fc0", "bar3", "write_net",
-          "bar4", "gemm_fc1_z", "lin_out", "bar_out", "final", "table"]
+          "bar4", "gemm_fc1_z", "lin_out", "bar_out", "final", "table", "own_bias", "own_prologue", "own_ksteps"]
 
 
 def debug_phase_timing(scene, packed, rays, z, tables=None):

@@ -274,3 +274,54 @@ def test_saturation_guard_verdicts_accumulate_until_polled():
     assert st["carry"] == [(1 << 2) | (1 << 4), 1 << 11] and len(st["pending"]) == 1
     ops._sat_harvest(st, wait=True)
     assert st["carry"] == [(1 << 2) | (1 << 4) | (1 << 10), (1 << 11) | (1 << 3)] and not st["pending"] and len(st["pool"]) == 3
+
+
+def test_packed_cache_never_blesses_a_stream_it_did_not_fingerprint():
+    """ResnetFC._cached, driven with a fake builder on CPU.  A stream packed in the re-pack-every-call phase
+    of a training loop carries no content fingerprint.  When such a stream is served a SECOND time under an unchanged cache key
+    (a `.data` write moves neither `_version` nor the optimizer-step count) it must be BUILT AGAIN from the live parameters and the
+    fingerprint epoch must move (the folded lin_z tables hang on it) -- recording the checksum of the current parameters for the
+    old stream would bless a stale stream.  Streams packed under no_grad / in eval mode are fingerprinted at once."""
+    mlp = make_model(default_model_conf()).mlp_coarse
+    built, recorded, verified = [], [], []
+    mlp._content_record = lambda key: recorded.append(key)
+    mlp._content_verify = lambda key: verified.append(key) or False
+
+    def build(out):
+        built.append(out)
+        return object()
+
+    key = ("f16x3", True)
+    mlp.train()
+    with torch.enable_grad():
+        s1 = mlp._cached(key, "f16x3", build)                       # first pack: fingerprinted
+        assert len(built) == 1 and recorded == [key]
+        mlp.__dict__["_opt_steps"] = mlp.__dict__.get("_opt_steps", 0) + 1   # an optimizer step
+        s2 = mlp._cached(key, "f16x3", build)                       # replaces a never re-used stream: no fingerprint
+        assert s2 is not s1 and len(built) == 2 and recorded == [key]
+        epoch = mlp.__dict__.get("_epoch", 0)
+        s3 = mlp._cached(key, "f16x3", build)                       # RE-USE of the unfingerprinted stream: built again, not blessed
+        assert s3 is not s2 and len(built) == 3 and recorded == [key, key]
+        assert mlp.__dict__["_epoch"] == epoch + 1                  # dependants (folded tables) re-derive from the live parameters
+        assert verified == []
+        s4 = mlp._cached(key, "f16x3", build)                       # now a fingerprinted stream: served from the cache, verified
+        assert s4 is s3 and len(built) == 3 and verified == [key]
+        mlp.__dict__["_opt_steps"] += 1
+        mlp._cached(key, "f16x3", build)                            # replaces a stream that WAS re-used: fingerprinted from the start
+        assert len(built) == 4 and recorded == [key, key, key]
+    mlp.__dict__["_opt_steps"] += 1
+    mlp._cached(key, "f16x3", build)
+    mlp.__dict__["_opt_steps"] += 1
+    with torch.no_grad():                                           # validation pass between steps: always fingerprinted
+        n = len(recorded)
+        mlp._cached(key, "f16x3", build)
+        assert len(recorded) == n + 1
+    mlp.eval()
+    mlp.__dict__["_opt_steps"] += 1
+    n = len(recorded)
+    mlp._cached(key, "f16x3", build)                                # eval mode: likewise
+    assert len(recorded) == n + 1
+    # the exact-fp32 form holds pointers, not a copy: never fingerprinted, never re-built on a hit
+    b0 = len(built)
+    a = mlp._cached("f32-key", "f32", build)
+    assert mlp._cached("f32-key", "f32", build) is a and len(built) == b0 + 1
