@@ -426,8 +426,8 @@ int pnr_render_views(const PnrScene *scene /*host*/, const void *packed_coarse, 
  * magnitude).  Random-init networks stay four orders of magnitude below the limit; a checkpoint need not.
  * pnr_saturation_guard(flags) arms the guard for the CALLING HOST THREAD: until it is called again with
  * NULL, every launch of a split-operand network kernel on that thread runs the instantiation that
- * follows the largest value entering each operand image (one v_max3_f32 per pair in the split epilogue,
- * ~1 % of the kernel) and ORs into flags[0] (coarse-network launches and the direct pnr_eval_*_split
+ * follows the largest operand head produced (one v_pk_maximum3_f16 per four values in the split epilogue,
+ * 1.15 % of the kernel; a head of 65504 means a value >= 65488) and ORs into flags[0] (coarse-network launches and the direct pnr_eval_*_split
  * entries) / flags[1] (fine-network launches of pnr_render_*):
  *   bit 2b    a value >= 65504 in relu(x) entering blocks[b].fc_0        (b = 0..4)
  *   bit 2b+1  a value >= 65504 in relu(net) entering blocks[b].fc_1
