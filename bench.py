@@ -308,9 +308,10 @@ def encode_timing(dev, n_img=16, reps=5):
     return out
 
 
-def extra_render_config(dev, scene_name, n_img, n_oracle=128, n_f32=8192, steps=3):
+def extra_render_config(dev, scene_name, n_img, n_oracle=128, n_f32=8192, steps=3, precisions=("f16x3", "f16")):
     """One of BASELINE configs[2] (srn_car 128x128, 2 views) / configs[3] on one GPU (DTU 400x300, 3 views, 176 MiB
-    grid): rays/s through render_par(rays) at 64+128 for the fp32-class path and the f16 path, PSNR of a ray sample spread
+    grid) / the reference's 9-view DTU evaluation (README.md:202: dtu_9v, 553 MB grid, 1.66 GB of tables per network;
+    11.51 GFLOP/ray = 256 x (9 x 4.7616 + 2.1012) MFLOP): rays/s through render_par(rays) at 64+128 for the fp32-class path and the f16 path, PSNR of a ray sample spread
     over the whole image (border pixels included) vs the CPU oracle and vs the exact-fp32 HIP path.  Untimed extras."""
     from oracle import pnr_oracle as O
     from testdata import synthetic
@@ -338,7 +339,7 @@ def extra_render_config(dev, scene_name, n_img, n_oracle=128, n_f32=8192, steps=
         no = min(n_oracle, rs.shape[0])
         ref = O.render(scene, mlps[0], mlps[1], rs[None, :no], {k: v[:no] for k, v in noise.items()}, 64, 128, 16,
                        white_bkgd=meta["white_bkgd"])
-        for prec in ("f16x3", "f16"):
+        for prec in precisions:
             net.precision = prec
             render_par(rays[None])
             torch.cuda.synchronize()
@@ -370,6 +371,105 @@ def extra_render_config(dev, scene_name, n_img, n_oracle=128, n_f32=8192, steps=
     del net, renderer
     torch.cuda.empty_cache()
     return out
+
+
+def extra_eval_object_loop(dev, n_views=24, n_obj=4):
+    """SURVEY 8f rows f1-f4 measured as the LOOP they replace.  One sn64 object = encode one 64x64 source view
+    + render 24 target views at 64+128 + the evaluation epilogue, in two forms over the same network and the same HIP renderer:
+      (i)  reference-shaped, eval/eval.py:247-290,327-329: util.gen_rays on the HOST -> .to(device) -> render_par per 50 000-ray
+           chunk -> .cpu() per chunk -> torch.cat / clamp / numpy uint8 / numpy PSNR per view;
+      (ii) pnr_render_views (poses -> pixels in one C call, rays never materialised) + pnr_eval_epilogue (clamp, uint8, normalised
+           depth, per-view PSNR on the device), ONE device-to-host copy at the end.
+    Both draw their jitter in-kernel; the timed (i) is the plain loop (one Philox key per chunk), so its images differ from (ii)'s by
+    the draws.  The untimed identity check runs (i) with the chunk's place in the whole ray set handed to the renderer
+    (ray_id_offset / ray_id_stride / one key: what the multi-device wrapper does): then the uint8 images must be IDENTICAL."""
+    import numpy as np
+    from pixelnerf_amd import ops, util
+    from testdata import synthetic
+    scene, meta, net, renderer, mlps = build(dev, "f16x3", "sn64")
+    W, H, P = meta["W"], meta["H"], meta["W"] * meta["H"]
+    z_near, z_far, focal_xy, c_xy = meta["z_near"], meta["z_far"], meta["focal"], meta["c"]
+    rs = np.random.RandomState(7)
+    images = torch.from_numpy(rs.uniform(-1, 1, (n_obj, 1 + n_views, 3, H, W)).astype(np.float32))  # view 0 = source, 1.. = ground truth
+    src_pose = synthetic.pose_spherical(30.0, -20.0, meta["radius"])[None]
+    tgt_poses = torch.stack([synthetic.pose_spherical(45.0 + 13.0 * i, -20.0, meta["radius"]) for i in range(n_views)])
+    focal = torch.tensor(focal_xy[0], dtype=torch.float32)[None]
+    c = torch.tensor(c_xy, dtype=torch.float32)[None]
+    render_par = renderer.bind_parallel(net, None, simple_output=True).eval()
+    ray_batch = 50000  # eval/eval.py:135-137 (eval_batch_size = ray_batch_size = 50 000 in the shipped confs)
+
+    def ref_shaped(o, place_chunks=False, key=None, device_rays=False):
+        if device_rays:  # (identity check only) the gen_rays KERNEL: the same bits pnr_render_views regenerates per pixel
+            all_rays = util.gen_rays(tgt_poses.to(dev), W, H, focal, z_near, z_far, c=c).reshape(-1, 8)
+        else:
+            all_rays = util.gen_rays(tgt_poses, W, H, focal, z_near, z_far, c=c).reshape(-1, 8).to(device=dev)   # host rays + upload
+        rays_spl = torch.split(all_rays, ray_batch, dim=0)
+        net.encode(images[o, :1].to(device=dev).unsqueeze(0), src_pose.to(dev).unsqueeze(0), focal.to(dev), c=c.to(dev))
+        all_rgb, all_depth, lo = [], [], 0
+        for rays in rays_spl:
+            if place_chunks:
+                renderer.ray_id_offset, renderer.ray_id_stride, renderer._seed_override = lo, all_rays.shape[0], key
+            rgb, depth = render_par(rays[None])
+            all_rgb.append(rgb[0].cpu())
+            all_depth.append(depth[0].cpu())
+            lo += rays.shape[0]
+        renderer.ray_id_offset, renderer.ray_id_stride, renderer._seed_override = 0, 0, None
+        all_rgb, all_depth = torch.cat(all_rgb, dim=0), torch.cat(all_depth, dim=0)
+        depth_n = ((all_depth - z_near) / (z_far - z_near)).reshape(n_views, H, W).numpy()
+        rgb01 = torch.clamp(all_rgb.reshape(n_views, H, W, 3), 0.0, 1.0).numpy()
+        u8 = (rgb01 * 255).astype(np.uint8)
+        gt = (images[o, 1:] * 0.5 + 0.5).permute(0, 2, 3, 1).contiguous().numpy()
+        psnr = [-10.0 * np.log10(np.mean((rgb01[v].astype(np.float64) - gt[v]) ** 2)) for v in range(n_views)]  # compare_psnr, data_range 1
+        return u8, depth_n, np.array(psnr)
+
+    def hip_side(o, key=None):
+        net.encode(images[o, :1].to(device=dev).unsqueeze(0), src_pose.to(dev).unsqueeze(0), focal.to(dev), c=c.to(dev))
+        pk_c, pk_f = net.packed(True), net.packed(False)
+        guarded = net._guard_begin()  # the fp16-range guard, as every render_par call of form (i) runs it
+        try:
+            out = ops.render_views(net.scene(), pk_c, pk_f, tgt_poses.to(dev), W, H, focal_xy, z_near, z_far, 64, 128, 16, None, c=c_xy,
+                                   white_bkgd=meta["white_bkgd"], tables=(net.tables(True), net.tables(False)),
+                                   seed=renderer._next_seed(dev) if key is None else key)
+        finally:
+            if guarded:
+                net._guard_end()
+        gt = (images[o, 1:].to(dev) * 0.5 + 0.5).permute(0, 2, 3, 1).reshape(n_views, P, 3).contiguous()
+        ep = ops.eval_epilogue(out["fine"]["rgb"].reshape(n_views, P, 3), out["fine"]["depth"].reshape(n_views, P), z_near, z_far, gt)
+        packed = torch.cat([ep["rgb_u8"].reshape(n_views, -1).float(), ep["depth_norm"], ep["psnr"].float()[:, None]], dim=1).cpu()  # ONE D2H
+        u8 = packed[:, :P * 3].to(torch.uint8).reshape(n_views, H, W, 3).numpy()
+        return u8, packed[:, P * 3:P * 4].reshape(n_views, H, W).numpy(), packed[:, -1].double().numpy()
+
+    res = {"workload": "one sn64 object = encode 1 source view (ResNet-34, 64x64) + %d target views of 64x64 at 64+128 + eval epilogue; "
+                       "%d objects per timing; precision f16x3" % (n_views, n_obj)}
+    with torch.no_grad():
+        ref_shaped(0), hip_side(0)  # warm: packs, folds, encoder graph
+        torch.cuda.synchronize()
+        for name, fn in (("reference_shaped_loop", ref_shaped), ("render_views_plus_epilogue", hip_side)):
+            t0 = time.perf_counter()
+            for o in range(n_obj):
+                last = fn(o)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n_obj
+            res[name] = {"ms_per_object": dt * 1e3, "images_per_s": n_views / dt, "rays_per_s": n_views * P / dt,
+                         "mean_psnr_db_vs_random_gt": float(np.mean(last[2]))}
+        res["speedup"] = res["reference_shaped_loop"]["ms_per_object"] / res["render_views_plus_epilogue"]["ms_per_object"]
+        key = 0x1234567
+        b = hip_side(1, key=key)
+        for name, dr in (("same_draws_check", True), ("same_draws_check_host_rays", False)):
+            a = ref_shaped(1, place_chunks=True, key=key, device_rays=dr)
+            diff = np.abs(a[0].astype(np.int32) - b[0].astype(np.int32))
+            res[name] = {"u8_images_identical": bool(diff.max() == 0), "u8_max_abs_diff": int(diff.max()),
+                         "u8_values_differing": int((diff > 0).sum()), "u8_values": int(diff.size),
+                         "depth_norm_max_abs_diff": float(np.abs(a[1] - b[1]).max()),
+                         "psnr_db_max_abs_diff": float(np.abs(a[2] - b[2]).max())}
+        res["same_draws_check"]["what"] = ("form (i) with rays from the gen_rays KERNEL and every chunk placed in the whole ray set: the bits of form (ii).  "
+                                           "`same_draws_check_host_rays`: the reference's host-side util.gen_rays differs from the kernel in the last bit of "
+                                           "some ray directions; a uint8 value changes where a colour sits on a truncation boundary")
+        mse = np.mean((ref_shaped(2)[0].astype(np.float64) - hip_side(2)[0].astype(np.float64)) ** 2)
+        res["psnr_db_between_u8_images_independent_draws"] = float(10 * np.log10(255.0 ** 2 / max(mse, 1e-12)))
+    del net, renderer
+    torch.cuda.empty_cache()
+    return res
 
 
 def extra_train_step(dev, prec, scene_name="train", steps=40, warmup=8, with_graph=True):
@@ -931,7 +1031,9 @@ def main():
                             ("train_step_torch_eager_gpu_baseline", lambda: train_step_eager_torch(dev)),
                             ("train_step_fp32_validation_path", lambda: extra_train_step(dev, "f32", steps=5, warmup=2, with_graph=False)),
                             ("srn_car", lambda: extra_render_config(dev, "srn_car", 4)),
-                            ("dtu", lambda: extra_render_config(dev, "dtu", 1))):
+                            ("dtu", lambda: extra_render_config(dev, "dtu", 1)),
+                            ("dtu_9v", lambda: extra_render_config(dev, "dtu_9v", 1, n_oracle=32, n_f32=2048, steps=2, precisions=("f16x3",))),
+                            ("eval_object_loop", lambda: extra_eval_object_loop(dev))):
                 if key == "train_step_torch_eager_gpu_baseline" and args.no_eager_baseline:
                     continue
                 try:
