@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256, STAGES == 2 ? 2 : 3) gemm3_kernel(const G
                 ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (m < g.M) {
                     const float *src = g.A + m * g.a_rs + k;
-                    if (k + 3 < k_end && (g.a_rs & 3) == 0) ra[u] = *reinterpret_cast<const f32x4 *>(src);
+                    if (k + 3 < k_end && (g.a_rs & 3) == 0) ra[u] = *reinterpret_cast<const f32x4_param *>(src);
                     else
                         for (int e = 0; e < 4; ++e)
                             if (k + e < k_end) ra[u][e] = src[e];
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256, STAGES == 2 ? 2 : 3) gemm3_kernel(const G
                 ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (k < k_end) {
                     const float *src = g.A + k * g.a_ks + m;
-                    if (m + 3 < g.M && (g.a_ks & 3) == 0) ra[u] = *reinterpret_cast<const f32x4 *>(src);
+                    if (m + 3 < g.M && (g.a_ks & 3) == 0) ra[u] = *reinterpret_cast<const f32x4_param *>(src);
                     else
                         for (int e = 0; e < 4; ++e)
                             if (m + e < g.M) ra[u][e] = src[e];
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256, STAGES == 2 ? 2 : 3) gemm3_kernel(const G
                 rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (n < g.N) {
                     const float *src = g.B + (long long)n * g.b_rs + k;
-                    if (k + 3 < k_end && (g.b_rs & 3) == 0) rb[u] = *reinterpret_cast<const f32x4 *>(src);
+                    if (k + 3 < k_end && (g.b_rs & 3) == 0) rb[u] = *reinterpret_cast<const f32x4_param *>(src);
                     else
                         for (int e = 0; e < 4; ++e)
                             if (k + e < k_end) rb[u][e] = src[e];
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(256, STAGES == 2 ? 2 : 3) gemm3_kernel(const G
                 rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (k < k_end) {
                     const float *src = g.B + k * g.b_ks + n;
-                    if (n + 3 < g.N && (g.b_ks & 3) == 0) rb[u] = *reinterpret_cast<const f32x4 *>(src);
+                    if (n + 3 < g.N && (g.b_ks & 3) == 0) rb[u] = *reinterpret_cast<const f32x4_param *>(src);
                     else
                         for (int e = 0; e < 4; ++e)
                             if (n + e < g.N) rb[u][e] = src[e];

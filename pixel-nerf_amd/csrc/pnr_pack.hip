@@ -13,7 +13,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // FSDP-style storages, load_state_dict(assign=True) from an mmap) need not start on a 16-byte boundary.  gfx950 code objects run
 // in the target's unaligned-access mode, where this still compiles to one global_load_dwordx4; without that mode the compiler
 // splits the access instead of faulting.
-typedef float f32x4_param __attribute__((ext_vector_type(4), aligned(4)));
 
 // which nn.Linear feeds GEMM g, and how its K index is ordered in the stream
 struct GemmSrc {
@@ -345,8 +344,8 @@ constexpr int CK_TOTAL4 = (D_HID * D_IN + D_HID + 3 * (D_HID * C_LAT + D_HID) + 
 constexpr int CK_BLOCKS = (CK_TOTAL4 + 256 * CK_PER_THREAD - 1) / (256 * CK_PER_THREAD);  // 420
 __global__ void __launch_bounds__(256)
 params_checksum_kernel(PnrMlpWeights p, unsigned long long *ws, unsigned long long *out, const unsigned long long *expect, int *flag) {
-    // The 30 tensors are walked as ONE virtual array of 16-byte chunks (every element count is a multiple of 4, torch
-    // allocations are 16-byte aligned): a thread owns 16 chunks a block-stride apart (210 workgroups: one round on 256 CUs), finds each chunk's tensor in a prefix
+    // The 30 tensors are walked as ONE virtual array of 16-byte chunks (every element count is a multiple of 4; the loads make no
+    // alignment assumption beyond 4 bytes: u32x4_param): a thread owns 16 chunks a block-stride apart (210 workgroups: one round on 256 CUs), finds each chunk's tensor in a prefix
     // table and issues its loads back to back -- one memory round trip for the whole 13.75 MB (the first version walked the
     // tensors one after the other inside every thread: 13 dependent round trips, 40 us).
     const float *ptr[30];
@@ -360,28 +359,28 @@ params_checksum_kernel(PnrMlpWeights p, unsigned long long *ws, unsigned long lo
         for (int b = 0; b < 5; ++b) { add(p.fc1_w[b], D_HID * D_HID); add(p.fc1_b[b], D_HID); }
         add(p.lin_out_w, D_OUT * D_HID); add(p.lin_out_b, D_OUT);
     }
-    uint4 x[CK_PER_THREAD];
+    u32x4 x[CK_PER_THREAD];
     int pos[CK_PER_THREAD];
 #pragma unroll
     for (int u = 0; u < CK_PER_THREAD; ++u) {
         const int c = (u * CK_BLOCKS + blockIdx.x) * 256 + threadIdx.x;
         pos[u] = c;
-        x[u] = make_uint4(0u, 0u, 0u, 0u);
+        x[u] = u32x4{0u, 0u, 0u, 0u};
         if (c < CK_TOTAL4) {
             const float *base = ptr[0];
             int begin = 0;
 #pragma unroll
             for (int k = 0; k < 29; ++k)  // static indexing only: the tables stay in registers
                 if (c >= end4[k]) { base = ptr[k + 1]; begin = end4[k]; }
-            x[u] = reinterpret_cast<const uint4 *>(base)[c - begin];
+            x[u] = reinterpret_cast<const u32x4_param *>(base)[c - begin];
         }
     }
     unsigned long long acc = 0ull;
 #pragma unroll
     for (int u = 0; u < CK_PER_THREAD; ++u) {
         const unsigned long long w = 8ull * (unsigned long long)pos[u] + 1ull;  // odd weight of the chunk's first element
-        acc += (unsigned long long)x[u].x * w + (unsigned long long)x[u].y * (w + 2ull) + (unsigned long long)x[u].z * (w + 4ull) +
-               (unsigned long long)x[u].w * (w + 6ull);
+        acc += (unsigned long long)x[u][0] * w + (unsigned long long)x[u][1] * (w + 2ull) + (unsigned long long)x[u][2] * (w + 4ull) +
+               (unsigned long long)x[u][3] * (w + 6ull);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);

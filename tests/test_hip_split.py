@@ -348,3 +348,56 @@ def test_view_maximum_through_the_model_api_and_training_guard(dev):
     net.mlp_coarse.lin_in.weight.requires_grad_(True)
     with pytest.raises(NotImplementedError, match="combine_type='max'"):
         rend.train()(net, rays.to(dev), _noise=nz)
+
+
+def test_parameters_viewed_at_a_4_byte_offset_into_a_flat_buffer(ops, dev):
+    """ONE alignment contract for every kernel that reads PnrMlpWeights pointers.  The parameters are caller
+    memory: views into a flat buffer (`flat[1:]`: 4-byte aligned, not 16) must give the bits of separately allocated tensors through
+    the packers (f16x3 and f16 streams), the per-texel fold, the exact-fp32 GEMM path, the content checksum behind the packed-weight
+    cache and the fp32-class training backward."""
+    import ctypes
+    p = mlp_params(11)
+    flat = torch.empty(sum(v.numel() for v in p.values()) + 1, dtype=torch.float32, device=dev)
+    off, mis = 1, {}
+    for k, v in p.items():
+        mis[k] = flat[off:off + v.numel()].view(v.shape)
+        mis[k].copy_(v)
+        off += v.numel()
+    ali = {k: v.to(dev) for k, v in p.items()}
+    assert all(t.data_ptr() % 16 != 0 for t in list(mis.values())[:1]) and all(t.data_ptr() % 4 == 0 for t in mis.values())
+    sc = dscene(ops, dev, "mv_mini")
+    g = load_golden("stages")
+    xyz, vd = torch.from_numpy(g["mv_mini_xyz"]).to(dev), torch.from_numpy(g["mv_mini_viewdirs"]).to(dev)
+    for prec in ("f16x3", "f16", "f32"):
+        outs = []
+        for state in (ali, mis):
+            if prec == "f32":
+                outs.append(ops.eval_points(sc, ops.pack_mlp(state, "f32"), xyz, vd))
+            else:
+                outs.append(ops.eval_points(sc, ops.pack_mlp(state, prec, folded=True), xyz, vd, tables=ops.fold_latent(sc, state, prec)))
+        assert torch.equal(outs[0], outs[1]), prec
+    # the content fingerprint (pnr_params_checksum): same parameters, same 64-bit sum, wherever they live
+    lib = ops._lib.load()
+    sums = []
+    for state in (ali, mis):
+        w, keep = ops._weights_struct(state)
+        ws = torch.zeros(lib.pnr_params_checksum_ws_bytes() // 8, dtype=torch.int64, device=dev)
+        out = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops._lib.check(lib.pnr_params_checksum(ctypes.byref(w), ops._p(ws), ops._p(out), None, None, ops._stream()), "pnr_params_checksum")
+        sums.append(int(out.item()))
+    assert sums[0] == sums[1] and sums[0] != 0
+    # fp32-class training backward through the C ABI's weight struct (pnr_mlp_backward_split reads the raw parameters)
+    s, meta = scene_for("mv_mini")
+    from testdata import synthetic
+    rays = synthetic.target_rays(meta, n_rays=24).reshape(-1, 8).to(dev)
+    z = ops.sample_coarse(rays, torch.rand(rays.shape[0], 32, generator=torch.Generator().manual_seed(5)).to(dev))
+    gout = torch.randn(rays.shape[0], 32, 4, generator=torch.Generator().manual_seed(6)).to(dev) * 1e-3
+    grads = []
+    for state in (ali, mis):
+        pk, tab = ops.pack_mlp(state, "f16x3"), ops.fold_latent(sc, state, "f16x3")
+        out, saved = ops.eval_ray_samples_split_train(sc, pk, tab, rays, z)
+        gr, d_zlat, _ = ops.mlp_backward_split(ops.pack_mlp(state, "f32"), saved, gout.reshape(-1, 4))
+        grads.append((out, gr, d_zlat))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][2], grads[1][2])
+    for k in grads[0][1]:
+        assert torch.equal(grads[0][1][k], grads[1][1][k]), k
