@@ -12,12 +12,6 @@ namespace pnr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// Loads through a PnrMlpWeights pointer: the parameters are CALLER memory and may be views into a flat buffer at any 4-byte
-// offset (torch's own allocations are 16-byte aligned, a `flat[1:]` view is not).  Every kernel that reads a parameter tensor with
-// vector loads goes through these 4-byte-aligned types -- global_load_dwordx4 either way, without the compiler assuming more
-// (one alignment contract for pack, fold, checksum, the fp32 GEMMs and the backward transposes).
-typedef float f32x4_param __attribute__((ext_vector_type(4), aligned(4)));
-typedef unsigned int u32x4_param __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

@@ -18,6 +18,14 @@
 
 namespace pnr {
 
+// Loads through a PnrMlpWeights pointer: the parameters are CALLER memory and may be views into a flat buffer at any 4-byte
+// offset (torch's own allocations are 16-byte aligned, a `flat[1:]` view is not).  Every kernel that reads a parameter tensor with
+// vector loads goes through these 4-byte-aligned types -- global_load_dwordx4 either way, without the compiler assuming more
+// (one alignment contract for pack, fold, checksum, the fp32 GEMMs and the backward transposes).
+typedef float f32x4_param __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int u32x4_param __attribute__((ext_vector_type(4), aligned(4)));
+
+
 constexpr int C_LAT = 512;   // latent channels (encoder.latent_size, encoder.py:68)
 constexpr int D_HID = 512;   // d_hidden
 constexpr int D_IN = 42;     // 39 positional code + 3 view direction (models.py:47-60)

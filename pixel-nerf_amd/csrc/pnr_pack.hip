@@ -9,6 +9,7 @@
 
 namespace pnr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // nn.Linear parameters are read through a 4-BYTE-aligned vector type: a parameter that is a view into a flat buffer (flattened /
 // FSDP-style storages, load_state_dict(assign=True) from an mmap) need not start on a 16-byte boundary.  gfx950 code objects run
 // in the target's unaligned-access mode, where this still compiles to one global_load_dwordx4; without that mode the compiler
