@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "pnr_common.h"
@@ -52,6 +53,23 @@ extern "C" int pnr_device_info(int *num_cus, int *lds_bytes_per_block) {
     if (num_cus) *num_cus = prop.multiProcessorCount;
     if (lds_bytes_per_block) *lds_bytes_per_block = pnr::LDS_TOTAL;
     return PNR_OK;
+}
+
+int pnr::device_xcd_count() {
+    // the override is read per call (a getenv, no device work): tests switch the tile order inside one process
+    if (const char *ov = std::getenv("PIXELNERF_XCD_COUNT")) {
+        const int n = std::atoi(ov);
+        return n > 0 ? n : 0;
+    }
+    static int cached[64];  // per device ordinal; 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || n <= 0) n = 1;
+        cached[dev] = n;
+    }
+    return cached[dev];
 }
 
 // ---- fp16-range guard of the fp32-class ("f16x3") kernels

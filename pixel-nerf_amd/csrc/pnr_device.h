@@ -59,6 +59,7 @@ struct EvalParams {
     int per_obj;       // rays per object (A) or points per object (B)
     long long P;       // total points
     int ntiles;
+    int n_xcd;         // XCDs workgroups are dealt to round-robin (device_xcd_count(); 0 / 1: plain grid-stride tile order)
     float *out;        // (P,4)
     float *mv_ws;      // multi-view: per-workgroup scratch for the parked view sum (MT x 512 fp32 each)
     float *dbg;        // optional debug dump of the final residual stream x (P,512), may be null
@@ -80,6 +81,25 @@ struct EvalParams {
     // GUARD instantiation of the split-operand kernel: one word that collects "layer l saw a value beyond the fp16 range" bits
     unsigned int *sat_flag;
 };
+
+// Tile order of the fused evaluation kernels (eval_kernel, eval_split_kernel).  Workgroup b runs on XCD b % n_xcd (the
+// dispatcher deals workgroups to the XCDs round-robin -- relied on for speed only, never for a result): every XCD takes ONE
+// contiguous n_xcd-th of the tiles and its CUs walk it side by side, so the CUs that share an L2 look up neighbouring rays'
+// texels at the same time.  n_xcd comes from the host (device_xcd_count(): hipDeviceAttributeNumberOfXccs of the current
+// partition mode, PIXELNERF_XCD_COUNT overrides); 0 / 1, or a grid that is not a multiple of it, give the plain grid-stride
+// order.  Every tile is visited exactly once either way (tests/test_hip_split.py runs both orders).
+// Same-box A/B against grid-stride (profiles/r05_split_kernel_ab.txt): sn64 +0.2 %, srn_car +0.4 %, DTU +2.4 % (f16x3).
+struct TileRange { int begin, end, step; };
+__device__ __forceinline__ TileRange tile_range(int ntiles, int n_xcd) {
+    TileRange r = {(int)blockIdx.x, ntiles, (int)gridDim.x};
+    if (n_xcd > 1 && gridDim.x % (unsigned)n_xcd == 0) {
+        const int chunk = (ntiles + n_xcd - 1) / n_xcd, xcd = blockIdx.x % (unsigned)n_xcd;
+        r.begin = xcd * chunk + blockIdx.x / (unsigned)n_xcd;
+        r.end = (xcd + 1) * chunk < ntiles ? (xcd + 1) * chunk : ntiles;
+        r.step = gridDim.x / (unsigned)n_xcd;
+    }
+    return r;
+}
 
 // phase ids of the TIMING instantiation (wave 0 of workgroup 0, s_memtime ticks)
 enum Phase { PH_SYNC_TOP = 0, PH_GEOMETRY, PH_GATHER, PH_GEMM_IN_Z0, PH_BAR1, PH_WRITE_X, PH_BAR2, PH_GEMM_FC0, PH_BAR3,

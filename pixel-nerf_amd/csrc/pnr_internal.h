@@ -40,6 +40,11 @@ int mlp_backward_split_chain(const void *packed_bwd_split, const unsigned long l
 unsigned int *saturation_guard_word();
 void saturation_guard_slot(int slot);
 
+// XCDs the dispatcher deals workgroups to round-robin on the current device (hipDeviceAttributeNumberOfXccs, i.e. of the
+// current compute-partition mode: 8 in SPX, 1 in CPX; PIXELNERF_XCD_COUNT=n overrides, 0 selects the plain grid-stride
+// tile order); cached per process.  Feeds EvalParams::n_xcd / tile_range() (pnr_device.h).  Defined in pnr_api.hip.
+int device_xcd_count();
+
 // per (device, stream) scratch for the parked view sum of multi-view launches (one tile of fp32 accumulators per workgroup),
 // allocated at the first multi-view launch on a stream and kept; NULL on allocation failure.  Defined in pnr_mlp.hip.
 float *mv_scratch(hipStream_t st, size_t bytes);

@@ -294,17 +294,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_kernel(const EvalParams
     unsigned long long *tim = q.tim;
     unsigned long long tlast = TIMING ? __builtin_readcyclecounter() : 0ull;
 
-    // XCD-aware tile order, as in pnr_split.hip's eval_split_kernel: every XCD (workgroup b runs on XCD b % 8 -- for speed only) takes
-    // one contiguous eighth of the tiles, its 32 CUs walk it side by side and look up neighbouring rays' texels through the L2 they share
-    int t_begin = blockIdx.x, t_end = q.ntiles, t_step = gridDim.x;
-    if ((gridDim.x & 7) == 0) {
-        const int chunk = (q.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
-        t_begin = xcd * chunk + (blockIdx.x >> 3);
-        t_end = (xcd + 1) * chunk < q.ntiles ? (xcd + 1) * chunk : q.ntiles;
-        t_step = gridDim.x >> 3;
-    }
-    // (same-box A/B against the plain grid-stride order: sn64 +0.7 %, srn_car +0.4 %, DTU +1.4 %; profiles/r05_split_kernel_ab.txt)
-    for (int tile = t_begin; tile < t_end; tile += t_step) {
+    // XCD-aware tile order (pnr_device.h tile_range; same-box A/B against plain grid-stride: sn64 +0.7 %, srn_car +0.4 %, DTU +1.4 %)
+    const TileRange order = tile_range(q.ntiles, q.n_xcd);
+    for (int tile = order.begin; tile < order.end; tile += order.step) {
         f32x16 x[IT][JT];
         // training dumps: this lane's 32-byte slot in a (rows,512) array, row = [view*P +] point
         bool valid[JT];
@@ -552,6 +544,7 @@ static int launch(EvalParams &q, bool mv, hipStream_t st) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_kernel)");
     {
+        q.n_xcd = device_xcd_count();
         ProfileScope prof(st);
         hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, q);
     }
@@ -629,6 +622,7 @@ extern "C" int pnr_debug_phase_timing(const PnrScene *s, const void *packed, con
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute");
     const int grid = q.ntiles < num_cus() ? q.ntiles : num_cus();
+    q.n_xcd = device_xcd_count();
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, q);
     return pnr_check_launch("eval_kernel<timing>");
 }

@@ -45,6 +45,13 @@ namespace pnr {
 typedef Prec<PNR_PREC_F16> PH;
 typedef PH::T8 h8;
 
+// The split kernels are generic in the wave count (stage_own, gemm_split_rot, the geometry loop, the own-K packing: IT = 4, BODIES = 2
+// at NW = 4), but only the 8-wave form is parity-tested; the 4-wave build exists for timing (profiles/r05_split_gemm_ubench.txt: -13 %)
+// and has to ask for itself.
+#if !defined(PNR_VARIANT)
+static_assert(NW == 8, "pnr_split.hip: the product build is 8 waves per workgroup (other wave counts: variant builds, timing only)");
+#endif
+
 // LDS map: two activation images (head / tail), two lin_in operand images, corner metadata, lin_out partials.
 // The fp32 table rows (2 KiB + 16 B pad per point) are looked up into the space of the two activation images
 // while those are free (tile start, and after fc_1 of blocks 0-1 has finished reading).
@@ -619,18 +626,9 @@ __global__ void __launch_bounds__(NTHREADS, NW / 4) eval_split_kernel(const Eval
         }
     };
 
-    // XCD-aware tile order (round 5): workgroup b runs on XCD b % 8 (placement -- relied on for speed only); every XCD takes ONE
-    // contiguous eighth of the tiles and its 32 CUs walk it side by side, so the CUs that share an L2 look up neighbouring rays'
-    // texels at the same time.  Same-box A/B against the plain grid-stride order (profiles/r05_split_kernel_ab.txt): sn64 +0.2 %,
-    // srn_car +0.4 %, DTU (553 MB of fp32 tables per network) +2.4 %.  Which tile a workgroup runs does not touch any result.
-    int t_begin = blockIdx.x, t_end = q.ntiles, t_step = gridDim.x;
-    if ((gridDim.x & 7) == 0) {
-        const int chunk = (q.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
-        t_begin = xcd * chunk + (blockIdx.x >> 3);
-        t_end = (xcd + 1) * chunk < q.ntiles ? (xcd + 1) * chunk : q.ntiles;
-        t_step = gridDim.x >> 3;
-    }
-    for (int tile = t_begin; tile < t_end; tile += t_step) {
+    // XCD-aware tile order (pnr_device.h tile_range; which tile a workgroup runs does not touch any result)
+    const TileRange order = tile_range(q.ntiles, q.n_xcd);
+    for (int tile = order.begin; tile < order.end; tile += order.step) {
         f32x16 x[IT][JT];
 #pragma unroll 1
         for (int view = 0; view < NS; ++view) {
@@ -1127,6 +1125,7 @@ static int split_launch(const PnrScene *s, const void *packed, const void *table
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(eval_split_kernel)");
     {
+        q.n_xcd = device_xcd_count();
         ProfileScope prof(st);  // HIP events around the launch on ITS stream when pnr_profile_enable(1) is active
         hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, q);
     }

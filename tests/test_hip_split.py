@@ -124,6 +124,27 @@ def test_split_variants_agree_and_match_the_exact_fp32_path_at_full_size(ops, de
     assert e[..., :3].max().item() <= 2e-5 and (e[..., 3] / exact[..., 3].clamp(min=1.0)).max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+@pytest.mark.parametrize("name,nrays", [("sn64", 4096), ("sn64", 120), ("sn64", 37), ("mv_mini", 776)])
+def test_tile_order_does_not_touch_a_bit(ops, dev, monkeypatch, precision, name, nrays):
+    """pnr_device.h tile_range(): the XCD-aware order (device XCD count), the plain grid-stride order (PIXELNERF_XCD_COUNT=0)
+    and XCD counts that do / do not divide the grid (4, 3, 32) visit every tile exactly once: identical outputs, no tile left
+    at its initial value -- on grids that fill the chip, on short ones (fewer tiles than XCDs x CUs) and on multi-view scenes."""
+    from testdata import synthetic
+    s, meta = scene_for(name)
+    sc = dscene(ops, dev, name)
+    state = {k: v.to(dev) for k, v in mlp_params(11).items()}
+    pk, tab = ops.pack_mlp(state, precision), ops.fold_latent(sc, state, precision)
+    rays = synthetic.target_rays(meta).reshape(-1, 8)[:nrays].contiguous().to(dev)
+    z = ops.sample_coarse(rays, torch.rand(rays.shape[0], 64, device=dev))
+    monkeypatch.delenv("PIXELNERF_XCD_COUNT", raising=False)
+    ref = ops.eval_ray_samples(sc, pk, rays, z, tables=tab)
+    assert torch.isfinite(ref).all()
+    for n in ("0", "1", "3", "4", "8", "32"):
+        monkeypatch.setenv("PIXELNERF_XCD_COUNT", n)
+        assert torch.equal(ref, ops.eval_ray_samples(sc, pk, rays, z, tables=tab)), f"tile order with {n} XCDs"
+
+
 def test_split_api_scope(ops, dev):
     """PixelNeRFNet(precision='f16x3'): single- and multi-view scenes run the split kernel; a 16-bit table set is refused."""
     from pixelnerf_amd import _lib

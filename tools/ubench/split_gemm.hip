@@ -20,7 +20,7 @@
 //
 // Build + run (one MI355X):  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/split_gemm.hip -o /tmp/split_gemm && /tmp/split_gemm
 // Output: one line per form -- us per launch, points x GEMMs per second, executed MFMA TFLOP/s (3 MFMAs per product), and the
-// rate relative to the shipped form.  tools/ubench/run_split_gemm.sh wraps it (+ rocprofv3 register counts).
+// rate relative to the shipped form (register counts: tools/kernel_regs.py on the binary).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
