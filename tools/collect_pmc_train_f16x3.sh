@@ -14,9 +14,14 @@ run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
 run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-python - "$OUT" <<'PY'
-import csv, glob, os, sys
+python - "$OUT" "$REPO" <<'PY'
+import csv, glob, hashlib, os, sys
 out = sys.argv[1]
+# identity of the kernels these counters were collected on: hash of the training-step units + shared headers
+h = hashlib.sha256()
+for f in ("pnr_bwd.hip", "pnr_pack.hip", "pnr_split.hip", "pnr_device.h", "pnr_layout.h"):
+    h.update(open(os.path.join(sys.argv[2], "pixel-nerf_amd", "csrc", f), "rb").read())
+print("# _kernel_source_sha16 %s  (sha256 of pnr_bwd.hip + pnr_pack.hip + pnr_split.hip + pnr_device.h + pnr_layout.h, first 16 hex digits)" % h.hexdigest()[:16])
 acc = {}
 for path in sorted(glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)):
     per = {}
