@@ -346,10 +346,13 @@ int pnr_lin_out_grad(const float *g_out, const void *x5, long long P, int precis
                      float *db, void *workspace, void *stream);
 
 /* d(encoder.latent) += bilinear scatter of d_zlat (rows_v,512) fp32 (natural channel order) to
- * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (caller zero-initialises; accumulates).  Grids of up to 5120
- * texels per image (64 x 64 and smaller) are accumulated in LDS slabs -- 64-bit fixed point at 2^-40 of the
- * workgroup's largest |gradient|, order-independent -- and reach HBM with one atomic per touched element and
- * workgroup; larger grids use global fp32 atomics throughout.  (encoder.py:96-109 backward) */
+ * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (caller zero-initialises; accumulates).  Grids of up to 5116
+ * texels per image (64 x 64 and smaller) are accumulated in fp64 LDS slabs, one per (image, 16- / 8- / 4-channel slice),
+ * fed per ray segment (consecutive samples in one grid cell); a slab reaches HBM with plain read-add-write when one
+ * workgroup owns its (image, slice) -- SB*NS*slices >= the compute units -- and with one atomic per touched element and
+ * workgroup otherwise; larger grids use global fp32 atomics throughout.  Uses the per-stream scratch of the multi-view
+ * kernels (grown on demand: the first call on a stream must not sit inside a graph capture).
+ * (encoder.py:96-109 backward) */
 int pnr_latent_scatter(const PnrScene *scene /*host*/, const float *rays, const float *z, int R,
                        int rays_per_obj, int K, const float *d_zlat, float *d_latent_nhwc, void *stream);
 

@@ -14,8 +14,8 @@
 //                         MFMAs per product -- the weight gradients of the fused fp32-class training path.
 //   composite_bwd_kernel  backward of the alpha compositing (nerf.py:223-249), wavefront per ray.
 //                         also emits dL/dz through the deltas and depth = sum w z.
-//   latent_scatter_*      d(interpolated latent) -> d(feature grid): bilinear scatter-add (small grids: a
-//                         64-bit fixed-point slab in LDS per (image, channel slice); large: global atomics).
+//   latent_scatter_*      d(interpolated latent) -> d(feature grid): bilinear scatter-add (small grids: an fp64
+//                         slab in LDS per (image, channel slice) fed per ray segment; large: global atomics).
 //   position_bwd_kernel   dL/dz through the network inputs (positional code, projection, bilinear
 //                         coordinates): the reference's position gradient through the n_fine_depth
 //                         samples (nerf.py:292), for all points or for the depth samples only.
@@ -838,39 +838,128 @@ latent_scatter_kernel(const EvalParams q, const float *__restrict__ d_zlat, floa
         }
 }
 
-// Small grids (Hl*Wl <= SLAB_MAX_TEXELS, e.g. the 32x32 / 64x64 grids of sn64 / SRN): dozens of samples hit
-// every texel, so global atomics serialise on a few thousand addresses.  Instead one workgroup owns an
-// (image, CS-channel slice) slab of the gradient grid in LDS: it walks a slice of that image's object's points,
-// accumulates the four bilinear corners into the slab, and adds the slab to HBM once (one global atomic per
-// non-zero slab element; the workgroups that split an object's points share the (image, slice)).
+// Small grids (the 32x32 / 64x64 grids of sn64 / SRN, anything whose (image, 4-channel) slab fits the LDS): dozens of samples
+// hit every texel, so global atomics serialise on a few thousand addresses.  Instead a workgroup owns an (image, CS-channel
+// slice) slab of the gradient grid in LDS (CS = 16 / 8 / 4 by what fits), walks the points of that image's object, and adds
+// the slab to HBM once.  When there are at least as many (image, slice) pairs as compute units ONE workgroup walks all
+// points and the slab goes out with plain read-add-write; otherwise psplit workgroups share the pair and meet in HBM with
+// atomics (config 5 at CS = 16: 4 images x 32 slices x 2).
 //
-// The slab is 64-bit FIXED POINT and accumulated with ds_add_u64: gfx950 executes LDS fp32 atomic adds one lane at a
-// time for the whole CU (192 clocks per wave instruction, 0.33 lanes/clk/CU, independent of the address pattern), 64-bit
-// integer adds at 35-39 clocks per instruction AND overlapped across waves (tools/ubench/lds_atomic.hip: 7 lanes/clk/CU
-// at 4 waves) -- the fp32-atomic form of this kernel spent 175 of its 210 us in them.  Scale: a power of two that puts
-// the workgroup's max |gradient| (found first, LDS max on the float bits) at 2^40: 2^23 contributions of headroom,
-// resolution 2^-40 of the max -- finer than the fp32 sum it replaces wherever that matters -- and the slab sum no
-// longer depends on the order of the adds.
-//
-// Thread = a run of 8 consecutive samples x ALL channels of the slice: it projects its own points (the texel /
-// weight bookkeeping is per point, not per channel), reads CS*4 contiguous bytes of each gradient row, and keeps an
-// fp32 register accumulator per corner that goes to the slab only when the corner's texel changes -- consecutive
-// samples of a ray mostly share their grid cell.  A workgroup covers 2048 samples per round; the host splits an
-// object's points so that one round is the normal case (the run's gradients are then loaded once, for max and sum).
+// What bounded the round-2..5 form of this kernel (thread = run of 8 consecutive samples x 8 channels, register accumulator
+// per corner flushed when ITS texel changes; 64-bit fixed-point slab) -- tools/ubench/lds_atomic.hip + timing twins,
+// profiles/r06_scatter_notes.md:
+//   * the NUMBER of LDS atomic instructions, not their lanes: a 64-bit LDS atomic costs ~7.5 clocks of the CU's LDS pipe per
+//     wave instruction whether 64 lanes or one are active.  Merging the adds of a run removed 70 % of the lane adds and not
+//     one instruction -- some lane of the wave changes texel at every step, so every flush site executes;
+//   * VALU: 64 slices each projected every point (~100 instructions), and every add converted fp32 -> int64 (17 instructions
+//     in hipcc's expansion: 4350 of the kernel's 7700 static instructions);
+//   * the L1: a lane read its 32 bytes of a 2 KiB gradient row as two dwordx4 -- 16 waves x 64 lines in flight against
+//     256 lines of cache, each line fetched twice for a quarter of its bytes.
+// Here the merge is done BEFORE lanes are assigned:
+//   * scatter_segments_kernel projects every (view, point) ONCE -- the clamped grid position (ix, iy) of project_point,
+//     8 bytes per point -- and cuts every ray into SEGMENTS: consecutive samples that share the cell (floor ix, floor iy),
+//     i.e. all four corners, at most SEG_B of them; per image a sorted list of segment starts (ballot + scan compaction,
+//     SEG_NSUB workgroups per image);
+//   * latent_scatter_owner_kernel: lane = (segment, 4 channels); the CS / 4 lanes of a segment read adjacent 16-byte pieces of a
+//     row in ONE load instruction.  A lane sums w_c * grad over its segment in fp32 registers and issues its 16 LDS adds once,
+//     every lane of the wave active; segment bounds are requested two segments ahead, samples one segment ahead.
+// The slab is fp64 and takes ds_add_f64 (39 clocks per wave instruction like ds_add_u64, 4.0 lanes/clk/CU with all 64 lanes on
+// random banks; ds_add_f32 is executed one lane at a time for the whole CU: 192 clocks): no common scale, so no max pass over the
+// gradients, no clamp, one conversion per add.  An fp32 value is exact in fp64 and a texel sums ~1e2-1e3 of them: the slab
+// holds the sum to 2^-53, and its fp32 rounding can differ between two orders of the adds only on near-ties (the repeat
+// runs of tools/gpu_scatter_bench.py agree bit for bit; not guaranteed).
+// Same-box A/B, config 5 (4 x 32x32; 32 768 / 49 152 points), us per call: round-5 kernel 90 / 119, this one 48 / 59 (of which
+// 5 are the segment pass); 4 x 64x64 grid: 400 -> 143-170.  What is left is the 16 ds_add_f64 per segment lane (~50 M lane adds
+// per pass at 4 per clock and CU: ~25 us) and the chain list -> rows behind them.
 constexpr int SLAB_MAX_BYTES = 160 * 1024;  // whole LDS
-constexpr int SLAB_RUN = 8;                 // consecutive samples per thread
-constexpr int SLAB_PTS = 256 * SLAB_RUN;    // samples per workgroup round
+constexpr int OWNER_NT = 1024;
+constexpr int SEG_NT = 1024;
+constexpr int SEG_B = 4;  // longest segment = samples per trip of the owner kernel (divides 64: a wave boundary is a cut)
+
+constexpr int SEG_NSUB = 16;  // sub-ranges of an object's samples, one workgroup of scatter_segments_kernel each
+
+#pragma clang fp contract(off)
+// Workgroup (image = obj * NS + view, sub-range j of the object's samples: sub_len consecutive samples, a multiple of 64):
+// coords[view * P + point] = (ix, iy); segs[(img * SEG_NSUB + j) * sub_len + k], k < nseg[img * SEG_NSUB + j] = first sample
+// (index inside the object, ascending) of the k-th segment that starts in the sub-range.  A segment ends where the next one
+// starts, or with its sub-range.
+__global__ void __launch_bounds__(SEG_NT)
+scatter_segments_kernel(const EvalParams q, float2 *__restrict__ coords, int *__restrict__ segs, int *__restrict__ nseg,
+                        const int sub_len) {
+    __shared__ int wave_total[SEG_NT / 64];
+    __shared__ int carry;  // segments written by the previous rounds
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int img = blockIdx.x / SEG_NSUB, sub = blockIdx.x % SEG_NSUB, obj = img / q.NS, view = img % q.NS;
+    const int pts = q.per_obj * q.K;  // < 2^31 (P is)
+    const int s_begin = sub * sub_len, s_end = s_begin + sub_len < pts ? s_begin + sub_len : pts;
+    const size_t row0 = (size_t)view * q.P + (size_t)obj * pts;
+    int *list = segs + (size_t)blockIdx.x * sub_len;
+    const float *pose = q.poses + (size_t)img * 12;
+    const float *fo = q.focal + (q.n_focal > 1 ? obj * 2 : 0);
+    const float *cc = q.c + (q.n_c > 1 ? obj * 2 : 0);
+    const float Wl = (float)q.Wl, Hl = (float)q.Hl;
+    const float lsx = Wl / (Wl - 1.f) * 2.f, lsy = Hl / (Hl - 1.f) * 2.f;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = s_begin; base < s_end; base += SEG_NT) {
+        const int s = base + t;
+        int cell = -1;
+        if (s < s_end) {
+            const int g = obj * pts + s;
+            const int r = g / q.K;
+            const float *ray = q.rays + (size_t)r * 8;
+            const float zz = q.z[g];
+            const float X = ray[0] + zz * ray[3], Y = ray[1] + zz * ray[4], Z = ray[2] + zz * ray[5];
+            // project_point's op order (pnr_device.h)
+            const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
+            const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
+            const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
+            const float xc0 = xr0 + pose[3], xc1 = xr1 + pose[7], xc2 = xr2 + pose[11];
+            float u = -xc0 / xc2; u = u * fo[0]; u = u + cc[0];
+            float v = -xc1 / xc2; v = v * fo[1]; v = v + cc[1];
+            const float gx = u * (lsx / q.img_w) - 1.f, gy = v * (lsy / q.img_h) - 1.f;
+            float ix = ((gx + 1.f) / 2.f) * (Wl - 1.f), iy = ((gy + 1.f) / 2.f) * (Hl - 1.f);
+            ix = fminf(Wl - 1.f, fmaxf(ix, 0.f));
+            iy = fminf(Hl - 1.f, fmaxf(iy, 0.f));
+            if (!(ix == ix)) ix = 0.f;  // NaN (point on the camera plane): as project_point
+            if (!(iy == iy)) iy = 0.f;
+            coords[row0 + s] = make_float2(ix, iy);
+            cell = (int)floorf(iy) * q.Wl + (int)floorf(ix);
+        }
+        // segment start: first sample of a ray, a cell that differs from the previous sample's, or every SEG_B-th sample (a
+        // segment is ONE trip of the owner kernel's loads: a ray that leaves the image clamps to one border cell for dozens of
+        // samples, and the wave that held such a lane waited for 16 dependent trips -- 100 k of the kernel's 130 k cycles)
+        const int prev = __shfl_up(cell, 1, 64);
+        const bool head = s < s_end && (s % SEG_B == 0 || s % q.K == 0 || cell != prev);
+        const unsigned long long m = __ballot(head);
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (lane == 0) wave_total[wv] = __popcll(m);
+        __syncthreads();
+        int off = carry, total = 0;
+#pragma unroll
+        for (int w = 0; w < SEG_NT / 64; ++w) {
+            const int c = wave_total[w];
+            if (w < wv) off += c;
+            total += c;
+        }
+        if (head) list[off + before] = s;
+        __syncthreads();
+        if (t == 0) carry += total;
+    }
+    __syncthreads();
+    if (t == 0) nseg[blockIdx.x] = carry;
+}
+
 template <int CS>
-__global__ void __launch_bounds__(256)
-latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat, float *__restrict__ d_latent, const int ysplit,
-                           const int row) {  // row: u64 slots per texel (CS + 1: bank-spreading pad, or CS when it must)
-    extern __shared__ unsigned long long slab[];  // [Hl*Wl][row]
-    __shared__ unsigned wg_max;
-    constexpr int NV = CS / 4;  // 16-byte loads per sample
+__global__ void __launch_bounds__(OWNER_NT)
+latent_scatter_owner_kernel(const EvalParams q, const float *__restrict__ d_zlat, const float2 *__restrict__ coords,
+                            const int *__restrict__ segs, const int *__restrict__ nseg, const int sub_len,
+                            float *__restrict__ d_latent, const int psplit, const int row) {
+    extern __shared__ double dslab[];  // [Hl*Wl][row]
+    constexpr int LPS = CS / 4;        // lanes per segment (4 channels = one 16-byte load per sample and lane)
+    constexpr int GRP = 32 / CS;       // slices that share a 128-byte line of a d_zlat / d_latent row
     const int t = threadIdx.x;
-    const int texels = q.Hl * q.Wl;
-    const int nslices = C_LAT / CS;
-    constexpr int GRP = 32 / CS;  // slices that share a 128-byte line of a d_zlat / d_latent row
+    const int texels = q.Hl * q.Wl, nslices = C_LAT / CS;
     // XCD-aware placement (as in dw_kernel): the slices that share 128-byte lines form a group that lands on ONE XCD
     // (consecutive per-XCD slots), so a line is fetched into one L2 once
     const int lid = blockIdx.x, ngroups = gridDim.x / GRP, full = (ngroups >> 3) * (8 * GRP);
@@ -878,113 +967,118 @@ latent_scatter_slab_kernel(const EvalParams q, const float *__restrict__ d_zlat,
     if (lid < full) { const int k = lid >> 3; grp = (k / GRP) * 8 + (lid & 7); sub = k % GRP; }
     else { const int rem = lid - full; grp = full / GRP + rem / GRP; sub = rem % GRP; }
     const int cs = (grp % (nslices / GRP)) * GRP + sub;
-    const int yslice = (grp / (nslices / GRP)) % ysplit;
-    const int img = grp / ((nslices / GRP) * ysplit);     // img = obj * NS + view
+    const int pslice = (grp / (nslices / GRP)) % psplit;
+    const int img = grp / ((nslices / GRP) * psplit);  // img = obj * NS + view
     const int obj = img / q.NS, view = img % q.NS;
-    for (int i = t; i < texels * row; i += 256) slab[i] = 0ull;
-    if (t == 0) wg_max = 0u;
+    for (int i = t; i < texels * row; i += OWNER_NT) dslab[i] = 0.0;
     const long long pts = (long long)q.per_obj * q.K;  // points of this object
-    const long long g_begin = (long long)obj * pts;
-    long long per = (pts + ysplit - 1) / ysplit;
-    per = (per + SLAB_PTS - 1) / SLAB_PTS * SLAB_PTS;
-    const long long p_begin = (long long)yslice * per, p_end = p_begin + per < pts ? p_begin + per : pts;
-    const uint32_t rowbase = (uint32_t)img * (uint32_t)texels;
-    const float *pose = q.poses + (size_t)img * 12;
-    const float *grad = d_zlat + ((size_t)view * q.P + (size_t)g_begin) * C_LAT + cs * CS;
-    f32x4 v[SLAB_RUN][NV];
-    auto load_run = [&](long long b0) {
-#pragma unroll
-        for (int j = 0; j < SLAB_RUN; ++j)
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                v[j][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (b0 + j < p_end) v[j][u] = reinterpret_cast<const f32x4 *>(grad + (size_t)(b0 + j) * C_LAT)[u];
-            }
-    };
-    // ---- max |gradient| of this workgroup's samples (rounds beyond the first are read twice: rare, see the host side)
-    const long long b_first = p_begin + (long long)t * SLAB_RUN;
-    float m = 0.f;
-    for (long long b0 = b_first + SLAB_PTS; b0 < p_end; b0 += SLAB_PTS) {
-        load_run(b0);
-#pragma unroll
-        for (int j = 0; j < SLAB_RUN; ++j)
-#pragma unroll
-            for (int u = 0; u < NV; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][u][e]));
+    const size_t row0 = (size_t)view * q.P + (size_t)obj * pts;  // first row of this (view, object) in d_zlat / coords
+    const float *grad = d_zlat + row0 * C_LAT + cs * CS;
+    const float2 *xy = coords + row0;
+    // this image's segment lists: SEG_NSUB sub-ranges, read as one list through the running sums of their counts
+    const int *list = segs + (size_t)img * SEG_NSUB * sub_len;
+    __shared__ int pre[SEG_NSUB + 1];
+    if (t == 0) {
+        int run = 0;
+        for (int j = 0; j < SEG_NSUB; ++j) { pre[j] = run; run += nseg[img * SEG_NSUB + j]; }
+        pre[SEG_NSUB] = run;
     }
-    load_run(b_first);
-#pragma unroll
-    for (int j = 0; j < SLAB_RUN; ++j)
-#pragma unroll
-        for (int u = 0; u < NV; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][u][e]));
-    __syncthreads();  // slab zeroed, wg_max initialised
-    if (m == m) atomicMax(&wg_max, __float_as_uint(fminf(m, 3.0e38f)));  // non-negative floats order like their bits; NaN: skipped
     __syncthreads();
-    // scale 2^(40 - exponent(max)); the exponent is clamped so that scale and 1/scale stay normal numbers
-    int ex = (int)(wg_max >> 23) - 127;
-    ex = ex < -80 ? -80 : (ex > 80 ? 80 : ex);
-    const float scale = __uint_as_float((uint32_t)(127 + 40 - ex) << 23);
-    const float inv_scale = __uint_as_float((uint32_t)(127 - 40 + ex) << 23);
-    for (long long b0 = b_first; b0 < p_end; b0 += SLAB_PTS) {
-        if (b0 != b_first) load_run(b0);
-        int cur[4] = {-1, -1, -1, -1};
-        float acc[4][CS];
+    const int n = pre[SEG_NSUB];
+    const int per = (n + psplit - 1) / psplit;
+    const int i_begin = pslice * per, i_end = i_begin + per < n ? i_begin + per : n;
+    const int Wl = q.Wl, Hl = q.Hl;
+    __syncthreads();  // slab zeroed
+    // lane = (segment, 4-channel part of the slice): the LPS lanes of a segment read LPS * 16 contiguous bytes of a gradient row
+    // with ONE load instruction (a lane that read its 32 bytes as two dwordx4 fetched the line twice: 16 waves x 64 lines in
+    // flight against the 256 lines of the L1)
+    const int part = t % LPS;
+    // segment i -> [s0, s1): sub-range j with pre[j] <= i < pre[j + 1] (binary search over the SEG_NSUB = 16 running sums in LDS)
+    auto seg_bounds = [&](int i, int &s0, int &s1) {
+        int j = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int step = SEG_NSUB / 2; step > 0; step >>= 1) j += i >= pre[j + step] ? step : 0;
+        const int k = i - pre[j];
+        const int *lj = list + (size_t)j * sub_len;
+        const int sub_end = (j + 1) * sub_len < (int)pts ? (j + 1) * sub_len : (int)pts;
+        s0 = lj[k];
+        s1 = i + 1 < pre[j + 1] ? lj[k + 1] : sub_end;
+    };
+    // a segment is at most SEG_B samples: all its loads are issued before the first use
+    auto load_batch = [&](int sb, int s1, float2 (&pos)[SEG_B], f32x4 (&v)[SEG_B]) {
 #pragma unroll
-            for (int e = 0; e < CS; ++e) acc[c][e] = 0.f;
-        auto flush = [&](int c) {
-#pragma unroll
-            for (int e = 0; e < CS; ++e) {
-                // |f| <= 8 * 2^41 for finite inputs; Inf is clamped and NaN dropped here (a diverged step still poisons the
-                // weight gradients through the other kernels).  No per-element branch: the adds of a flush go out back to back
-                float f = acc[c][e] * scale;
-                f = f == f ? __builtin_amdgcn_fmed3f(f, -9.0e18f, 9.0e18f) : 0.f;
-                atomicAdd(&slab[cur[c] * row + e], (unsigned long long)(long long)f);
-            }
-        };
-#pragma unroll
-        for (int j = 0; j < SLAB_RUN; ++j) {
-            if (b0 + j < p_end) {
-                const int g = (int)(g_begin + b0 + j);
-                const int r = g / q.K;
-                const float *ray = q.rays + (size_t)r * 8;
-                const float zz = q.z[g];
-                const float X = ray[0] + zz * ray[3], Y = ray[1] + zz * ray[4], Z = ray[2] + zz * ray[5];
-                const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
-                const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
-                const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
-                const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, true);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int tex = (int)(pr.off[c] / C_LAT - rowbase);
-                    if (tex != cur[c]) {
-                        if (cur[c] >= 0) flush(c);
-                        cur[c] = tex;
-#pragma unroll
-                        for (int e = 0; e < CS; ++e) acc[c][e] = 0.f;
-                    }
-                    const float w = pr.w[c];
-#pragma unroll
-                    for (int u = 0; u < NV; ++u)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[c][4 * u + e] += w * v[j][u][e];
-                }
+        for (int b = 0; b < SEG_B; ++b) {
+            pos[b] = make_float2(0.f, 0.f);
+            v[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (sb + b < s1) {
+                pos[b] = xy[sb + b];
+                v[b] = reinterpret_cast<const f32x4 *>(grad + (size_t)(sb + b) * C_LAT)[part];
             }
         }
+    };
+    // Two-deep software pipeline over this lane's segments: a segment's bounds come out of the list (one round trip), its
+    // samples out of the gradient rows (a second one that depends on the first) -- taken one after the other, ~8 segments
+    // per lane were a chain of 16 loaded round trips (~2 us each at this access pattern).  The bounds are requested two
+    // segments ahead and the first batch one segment ahead.
+    constexpr int STRIDE = OWNER_NT / LPS;
+    int i = i_begin + t / LPS;
+    int s0 = 0, s1 = 0, s0n = 0, s1n = 0;
+    float2 pos[SEG_B];
+    f32x4 v[SEG_B];
+    if (i < i_end) { seg_bounds(i, s0, s1); load_batch(s0, s1, pos, v); }
+    if (i + STRIDE < i_end) seg_bounds(i + STRIDE, s0n, s1n);
+    for (; i < i_end; i += STRIDE) {
+        int s0nn = 0, s1nn = 0;
+        if (i + 2 * STRIDE < i_end) seg_bounds(i + 2 * STRIDE, s0nn, s1nn);
+        float2 posn[SEG_B];
+        f32x4 vn[SEG_B];
+        if (i + STRIDE < i_end) load_batch(s0n, s1n, posn, vn);
+        const float ix0 = floorf(pos[0].x), iy0 = floorf(pos[0].y);  // the segment's cell
+        const float ix1 = ix0 + 1.f, iy1 = iy0 + 1.f;
+        const int x0 = (int)ix0, y0 = (int)iy0;
+        const bool x_in = x0 + 1 <= Wl - 1, y_in = y0 + 1 <= Hl - 1;  // out-of-range corner has weight 0 (project_point)
+        f32x4 acc[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (cur[c] >= 0) flush(c);
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto accumulate = [&](const float2 (&ps)[SEG_B], const f32x4 (&vs)[SEG_B]) {
+#pragma unroll
+            for (int b = 0; b < SEG_B; ++b) {
+                // corner weights of project_point from (ix, iy); slots beyond the segment carry zero gradients
+                const float2 p = ps[b];
+                float w[4] = {(ix1 - p.x) * (iy1 - p.y), (p.x - ix0) * (iy1 - p.y), (ix1 - p.x) * (p.y - iy0), (p.x - ix0) * (p.y - iy0)};
+                if (!x_in) { w[1] = 0.f; w[3] = 0.f; }
+                if (!y_in) { w[2] = 0.f; w[3] = 0.f; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c][e] += w[c] * vs[b][e];
+            }
+        };
+        accumulate(pos, v);  // s1 - s0 <= SEG_B: scatter_segments_kernel cuts there
+        const int x1 = min(x0 + 1, Wl - 1), y1 = min(y0 + 1, Hl - 1);
+        const int tex[4] = {y0 * Wl + x0, y0 * Wl + x1, y1 * Wl + x0, y1 * Wl + x1};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double *dst = dslab + tex[c] * row + part * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dst + e, (double)acc[c][e]);  // ds_add_f64, no return
+        }
+        s0 = s0n; s1 = s1n; s0n = s0nn; s1n = s1nn;
+#pragma unroll
+        for (int b = 0; b < SEG_B; ++b) { pos[b] = posn[b]; v[b] = vn[b]; }
     }
     __syncthreads();
-    for (int i = t; i < texels * CS; i += 256) {
-        const long long sv = (long long)slab[(i / CS) * row + (i % CS)];
-        if (sv != 0) atomicAdd(d_latent + ((size_t)rowbase + i / CS) * C_LAT + cs * CS + (i % CS), (float)sv * inv_scale);
+    float *out = d_latent + (size_t)img * texels * C_LAT + cs * CS;
+    for (int i = t; i < texels * CS; i += OWNER_NT) {
+        const double sv = dslab[(i / CS) * row + (i % CS)];
+        if (sv != 0.0) {
+            float *dst = out + (size_t)(i / CS) * C_LAT + (i % CS);
+            if (psplit == 1) *dst += (float)sv;  // this workgroup is the only writer of the (image, slice) in this launch
+            else atomicAdd(dst, (float)sv);
+        }
     }
 }
+#pragma clang fp contract(fast)
 
 // dL/dz through the network inputs; one wavefront per (view, point).
 // ranks == nullptr: every point, the result is accumulated into d_z[point].
@@ -1505,22 +1599,40 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
     const int texels = q.Hl * q.Wl;
     // small grid: LDS slabs.  8 channels per slab with a padded row when that fits the LDS, else 4 (64x64: unpadded)
     int cs = 0, row = 0;
-    if ((size_t)texels * 9 * 8 <= SLAB_MAX_BYTES - 64) { cs = 8; row = 9; }
-    else if ((size_t)texels * 5 * 8 <= SLAB_MAX_BYTES - 64) { cs = 4; row = 5; }
-    else if ((size_t)texels * 4 * 8 <= SLAB_MAX_BYTES - 64) { cs = 4; row = 4; }
+    if ((size_t)texels * 17 * 8 <= SLAB_MAX_BYTES - 128) { cs = 16; row = 17; }
+    else if ((size_t)texels * 9 * 8 <= SLAB_MAX_BYTES - 128) { cs = 8; row = 9; }
+    else if ((size_t)texels * 5 * 8 <= SLAB_MAX_BYTES - 128) { cs = 4; row = 5; }
+    else if ((size_t)texels * 4 * 8 <= SLAB_MAX_BYTES - 128) { cs = 4; row = 4; }
     if (cs) {
         const size_t lds = (size_t)texels * row * 8;
-        auto k = cs == 8 ? latent_scatter_slab_kernel<8> : latent_scatter_slab_kernel<4>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           SLAB_MAX_BYTES - 64);
-        if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(latent_scatter_slab_kernel)");
         const long long pts = (long long)rays_per_obj * K;
-        // one round of 2048 samples per workgroup while that keeps the slab flushes (one per workgroup) in proportion:
-        // at most 8 workgroups share an (image, slice)
-        int psplit = (int)((pts + SLAB_PTS - 1) / SLAB_PTS);
+        // one workgroup per (image, slice) takes all of the image's segments; they are split only when there are fewer
+        // (image, slice) pairs than compute units (and never below ~one segment per thread: a segment is >= 1 sample)
+        const int owners = q.SB * q.NS * (C_LAT / cs);
+        int psplit = (bwd_num_cus() + owners - 1) / owners;
+        const long long rounds = (pts + 4LL * OWNER_NT - 1) / (4LL * OWNER_NT);
+        if (psplit > rounds) psplit = (int)rounds;
         if (psplit > 8) psplit = 8;
-        hipLaunchKernelGGL(k, dim3((unsigned)(q.SB * q.NS * (C_LAT / cs) * psplit)), dim3(256), lds, (hipStream_t)stream, q, d_zlat,
-                           d_latent_nhwc, psplit, row);
+        if (psplit < 1) psplit = 1;
+        // scratch (per (device, stream), shared with the multi-view kernels' view-sum scratch -- stream-ordered uses):
+        // coords NS*P float2 | segment starts, SEG_NSUB x sub_len ints per image | segment counts, SEG_NSUB ints per image
+        const int images = q.SB * q.NS;
+        const size_t coords_bytes = (size_t)q.NS * q.P * sizeof(float2);
+        const int sub_len = (int)(((pts + SEG_NSUB - 1) / SEG_NSUB + 63) / 64 * 64);
+        const size_t segs_bytes = (size_t)images * SEG_NSUB * sub_len * sizeof(int);
+        char *scratch = reinterpret_cast<char *>(mv_scratch((hipStream_t)stream, coords_bytes + segs_bytes + (size_t)images * SEG_NSUB * sizeof(int)));
+        if (!scratch) return pnr_fail(PNR_E_HIP, "pnr_latent_scatter: cannot allocate the projected-coordinates scratch");
+        float2 *coords = reinterpret_cast<float2 *>(scratch);
+        int *segs = reinterpret_cast<int *>(scratch + coords_bytes);
+        int *nseg = reinterpret_cast<int *>(scratch + coords_bytes + segs_bytes);
+        auto k = cs == 16 ? latent_scatter_owner_kernel<16> : (cs == 8 ? latent_scatter_owner_kernel<8> : latent_scatter_owner_kernel<4>);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           SLAB_MAX_BYTES - 128);
+        if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(latent_scatter_owner_kernel)");
+        hipLaunchKernelGGL(scatter_segments_kernel, dim3((unsigned)(images * SEG_NSUB)), dim3(SEG_NT), 0, (hipStream_t)stream, q, coords,
+                           segs, nseg, sub_len);
+        hipLaunchKernelGGL(k, dim3((unsigned)(owners * psplit)), dim3(OWNER_NT), lds, (hipStream_t)stream, q, d_zlat, coords, segs, nseg,
+                           sub_len, d_latent_nhwc, psplit, row);
         return pnr_check_launch("pnr_latent_scatter");
     }
     const long long n = ((q.P + SCATTER_RUN - 1) / SCATTER_RUN) * q.NS;  // wavefronts

@@ -172,11 +172,14 @@ def test_training_converges_on_a_fixed_batch(dev):
     assert losses[-1] < 0.6 * losses[0], losses
 
 
-# LDS-slab kernel (8 channels, padded rows / 4 channels, padded / 4 channels, unpadded: 64x64) / global-atomic kernel (5760 texels)
-@pytest.mark.parametrize("Hl,Wl", [(16, 16), (50, 60), (64, 64), (72, 80)])
-def test_latent_scatter_matches_autograd(dev, Hl, Wl):
+# LDS-slab kernel (16 / 8 / 4 channels with padded rows, 4 channels unpadded: 64x64; one owner per (image, slice) or -- 600 rays x 20
+# samples on 4 x 32 slices -- two workgroups per pair that meet in HBM with atomics; K = 10 / 20: ray boundaries off the segment
+# grid) / global-atomic kernel (5760 texels)
+@pytest.mark.parametrize("Hl,Wl,n_rays,K", [(16, 16, 24, 10), (40, 40, 24, 10), (50, 60, 24, 10), (64, 64, 24, 10), (72, 80, 24, 10),
+                                           (16, 16, 600, 20), (32, 32, 128, 96)])
+def test_latent_scatter_matches_autograd(dev, Hl, Wl, n_rays, K):
     """d(interpolated latent) -> d(feature grid) for SB=2 x NS=2, against autograd through the oracle's lookup
-    (encoder.py:80-109).  fp32 on both sides (the slab kernel sums in 64-bit fixed point at 2^-40 of the max); 1e-5 relative."""
+    (encoder.py:80-109).  fp32 on both sides (the slab kernel sums per-segment fp32 partial sums in fp64); 1e-5 relative."""
     from helpers import scene_for
     from pixelnerf_amd import ops
     from testdata import synthetic
@@ -185,11 +188,10 @@ def test_latent_scatter_matches_autograd(dev, Hl, Wl):
     gen = torch.Generator().manual_seed(21)
     scene["latent"] = torch.randn(4, 512, Hl, Wl, generator=gen)
     SB, NS = scene["SB"], scene["NS"]
-    rays = synthetic.target_rays(meta, n_rays=24)  # (2, 24, 8)
+    rays = synthetic.target_rays(meta, n_rays=n_rays)  # (2, n_rays, 8)
     r = rays.reshape(-1, 8)
-    K = 10
     z = O.sample_coarse(r, torch.rand(r.shape[0], K, generator=gen), K)
-    B = 24 * K
+    B = n_rays * K
     P = SB * B
     d_zlat = torch.randn(NS * P, 512, generator=gen)
     d_zlat[5] = 0.0
@@ -504,10 +506,10 @@ def test_fused_optimizer_updates_reach_the_kernels(dev):
 
 
 @pytest.mark.parametrize("scale", [1e-20, 1.0, 1e20])
-def test_latent_scatter_fixed_point_follows_the_gradient_scale(dev, scale):
-    """The LDS slab of the latent scatter is 64-bit fixed point at 2^40 / (workgroup's max |gradient|): the result must
-    be the same relative to the input scale from 1e-20 to 1e20, zeros stay zeros, and a few huge entries must not wipe
-    out ordinary ones (resolution 2^-40 of the max)."""
+def test_latent_scatter_follows_the_gradient_scale(dev, scale):
+    """The LDS slab of the latent scatter (fp64 since round 6; 64-bit fixed point at 2^40 / max |gradient| before) has no
+    scale of its own: the result must be the same relative to the input scale from 1e-20 to 1e20, zeros stay zeros, and
+    a few huge entries must not wipe out ordinary ones."""
     from helpers import scene_for
     from pixelnerf_amd import ops
     from testdata import synthetic

@@ -134,7 +134,7 @@ def test_tile_order_does_not_touch_a_bit(ops, dev, monkeypatch, precision, name,
     s, meta = scene_for(name)
     sc = dscene(ops, dev, name)
     state = {k: v.to(dev) for k, v in mlp_params(11).items()}
-    pk, tab = ops.pack_mlp(state, precision), ops.fold_latent(sc, state, precision)
+    pk, tab = ops.pack_mlp(state, precision, folded=precision == "f16"), ops.fold_latent(sc, state, precision)
     rays = synthetic.target_rays(meta).reshape(-1, 8)[:nrays].contiguous().to(dev)
     z = ops.sample_coarse(rays, torch.rand(rays.shape[0], 64, device=dev))
     monkeypatch.delenv("PIXELNERF_XCD_COUNT", raising=False)
