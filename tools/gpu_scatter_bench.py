@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """pnr_latent_scatter (d z_lat -> d feature grid) on the training workloads: config 5 (4 objects x 128 rays, 32x32 grids) coarse (64 samples)
-and fine (96) passes, the 2 x 2-view scene, an srn-sized 64x64 grid; HIP events, us per call (coordinate pre-pass included).
-PIXELNERF_SCATTER_V1=1 selects the round-2..5 slab kernel for the A/B."""
+and fine (96) passes, the 2 x 2-view scene, an srn-sized 64x64 grid; HIP events, us per call (segment pre-pass included).
+A/B against another library: PIXELNERF_HIP_LIB=build/libpnr_<name>.so PIXELNERF_ALLOW_VARIANT=1 (profiles/r06_scatter_notes.md)."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 from pixelnerf_amd import ops
 from testdata import synthetic
 dev = torch.device("cuda:0")
-tag = "v1-slab" if os.environ.get("PIXELNERF_SCATTER_V1") == "1" else "owner"
+tag = os.path.basename(os.environ.get("PIXELNERF_HIP_LIB", "product"))
 gen = torch.Generator().manual_seed(3)
 for name, K, hw in (("train", 64, None), ("train", 96, None), ("train_mv", 96, None), ("train", 96, 64)):
     s, meta = synthetic.make_scene(name)
