@@ -176,7 +176,11 @@ class _RenderFunction(torch.autograd.Function):
         net = cfg["net"]
         dev = rays.device
         need_latent = ctx.needs_input_grad[2]
-        d_lat = torch.zeros((ctx.latent_shape[0], ctx.latent_shape[2], ctx.latent_shape[3], ctx.latent_shape[1]),
+        # one zeroed grid gradient PER PASS, summed at the end: pnr_latent_scatter's LDS-slab form leaves at most two atomic adds
+        # per element and call (its owner workgroups split the points at most two ways on a full-size batch), and two terms onto
+        # zero commute -- the latent gradient, and with it the whole step, is then bit-reproducible.  Accumulating the fine and
+        # the coarse pass into ONE buffer made the second call's adds land on non-zero values in either order.
+        d_lat = torch.zeros((len(ctx.passes), ctx.latent_shape[0], ctx.latent_shape[2], ctx.latent_shape[3], ctx.latent_shape[1]),
                             dtype=torch.float32, device=dev) if need_latent else None
         shared = net.mlp_fine is None  # fine pass ran on the coarse network (models.py:242)
         gsum = [None, None]
@@ -203,7 +207,7 @@ class _RenderFunction(torch.autograd.Function):
             slot = 0 if (ps["coarse"] or shared) else 1
             gsum[slot] = grads if gsum[slot] is None else {k: gsum[slot][k] + v for k, v in grads.items()}
             if need_latent:
-                ops.latent_scatter(scene, rays, ps["z"], d_zlat, d_lat)
+                ops.latent_scatter(scene, rays, ps["z"], d_zlat, d_lat[i])
             if pos:
                 # only the depth samples carry position gradient: compositing part (dz) + network-input part at their
                 # sorted positions, through the clamp z = max(min(depth + n*std, far), near)   (nerf.py:157-160,292)
@@ -214,7 +218,7 @@ class _RenderFunction(torch.autograd.Function):
             ps["dumps"].release()
             ps["dumps"] = None
         ctx.passes = None  # release the 16-bit operand dumps (~12 KB per point and view) as soon as they are used
-        out = [None, None, d_lat.permute(0, 3, 1, 2).contiguous() if need_latent else None]
+        out = [None, None, (d_lat[0] if d_lat.shape[0] == 1 else d_lat.sum(0)).permute(0, 3, 1, 2).contiguous() if need_latent else None]
         n_each = len(PARAM_NAMES)
         for slot in range(ctx.n_params // n_each):
             g = gsum[slot]

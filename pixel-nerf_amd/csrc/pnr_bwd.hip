@@ -21,6 +21,7 @@
 //                         samples (nerf.py:292), for all points or for the depth samples only.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "pnr_common.h"
@@ -1603,6 +1604,14 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
     else if ((size_t)texels * 9 * 8 <= SLAB_MAX_BYTES - 128) { cs = 8; row = 9; }
     else if ((size_t)texels * 5 * 8 <= SLAB_MAX_BYTES - 128) { cs = 4; row = 5; }
     else if ((size_t)texels * 4 * 8 <= SLAB_MAX_BYTES - 128) { cs = 4; row = 4; }
+    int force_psplit = 0;
+    if (const char *e = getenv("PNR_SCATTER_FORM")) {  // experiment hook "cs,psplit": force the slice width (16 / 8 / 4) and the point split
+        int fcs = 0, fps = 0;
+        if (sscanf(e, "%d,%d", &fcs, &fps) >= 1 && (fcs == 16 || fcs == 8 || fcs == 4) && fcs <= cs) {
+            cs = fcs; row = (size_t)texels * (cs + 1) * 8 <= SLAB_MAX_BYTES - 128 ? cs + 1 : cs;
+            force_psplit = fps;
+        }
+    }
     if (cs) {
         const size_t lds = (size_t)texels * row * 8;
         const long long pts = (long long)rays_per_obj * K;
@@ -1614,6 +1623,7 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
         if (psplit > rounds) psplit = (int)rounds;
         if (psplit > 8) psplit = 8;
         if (psplit < 1) psplit = 1;
+        if (force_psplit >= 1 && force_psplit <= 8) psplit = force_psplit;
         // scratch (per (device, stream), shared with the multi-view kernels' view-sum scratch -- stream-ordered uses):
         // coords NS*P float2 | segment starts, SEG_NSUB x sub_len ints per image | segment counts, SEG_NSUB ints per image
         const int images = q.SB * q.NS;
