@@ -185,11 +185,12 @@ class PixelNeRFNet(torch.nn.Module):
         p = self._effective_precision()
         return p == "f16x3" or (self.fold and p != "f32")
 
-    def packed(self, coarse=True, folded=None):
+    def packed(self, coarse=True, folded=None, training_pass=False):
         """models.py:242: the fine network falls back to the coarse one when mlp_fine is None.
-        folded: None = what inference uses (self.fold); the training path asks for the full stream."""
+        folded: None = what inference uses (self.fold); the training path asks for the full stream.
+        training_pass: the differentiable path is asking (ResnetFC._cached)."""
         mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
-        return mlp.packed(self._effective_precision(), folded=self._folding() if folded is None else folded)
+        return mlp.packed(self._effective_precision(), folded=self._folding() if folded is None else folded, training_pass=training_pass)
 
     def tables(self, coarse=True):
         """lin_z folded into the current scene's grid for the coarse / fine network (None when fold is off);

@@ -254,20 +254,25 @@ class ResnetFC(nn.Module):
         st["flag_host"].copy_(st["flag"], non_blocking=True)
         return False
 
-    def packed(self, precision="f16", folded=False):
+    def packed(self, precision="f16", folded=False, training_pass=False):
+        """training_pass: the caller is the differentiable path (autograd.py) -- see _cached"""
         if not self.supported():
             raise NotImplementedError(
                 "fused HIP network supports d_in=42, d_latent=512, d_hidden=512, n_blocks=5, "
                 "combine_layer=3, combine_type average | max (conf/default_mv.conf); got a different ResnetFC")
         return self._cached((precision, bool(folded)), precision,
-                            lambda out: ops.pack_mlp(None, precision, folded=folded, weights=self._wstruct(), out=out))
+                            lambda out: ops.pack_mlp(None, precision, folded=folded, weights=self._wstruct(), out=out), training_pass)
 
-    def _cached(self, key, precision, build):
+    def _cached(self, key, precision, build, training_pass=False):
         """entry = [fingerprint, stream, content fingerprint recorded?, times served from the cache].
         A training loop re-packs on every call (the optimizer-step count is part of the fingerprint) and never serves a stream
         twice: there the device-side content fingerprint (pnr_params_checksum, ~25 us per network per step) protects nothing, so
         a stream that replaces one that was never re-used is packed WITHOUT it -- but only while gradients are being taken: a
         stream packed under no_grad / in eval mode (a validation pass between optimizer steps) always gets its fingerprint.
+        "Gradients are being taken" = the differentiable path says so (training_pass=True from autograd.py: its kernels run INSIDE
+        torch.autograd.Function.forward / backward, where torch.is_grad_enabled() is False -- read there, the flag made every
+        training step fingerprint every stream it packed: 4 x 21 us per step, round 6's sessions until r06_s24) or, for any other
+        caller, train mode with grad enabled.
         The first call that RE-USES a stream packed without a fingerprint packs it again (and re-folds the tables), recording one (recording
         the checksum of the current parameters instead would bless a stream that a `.data` write has already made stale -- e.g. a
         validation forward with EMA weights swapped in and back through `p.data.copy_` right after `opt.step`).  That costs one
@@ -287,7 +292,8 @@ class ResnetFC(nn.Module):
                 fp, ent, fresh = self._fingerprint(), None, False
         if not fresh:
             # the previous stream's buffer is overwritten in place (its users are earlier launches on the same stream)
-            record = checked and (ent is None or ent[3] > 0 or ent[0] == fp or not self.training or not torch.is_grad_enabled())
+            taking_grads = training_pass or (self.training and torch.is_grad_enabled())
+            record = checked and (ent is None or ent[3] > 0 or ent[0] == fp or not taking_grads)
             ent = [fp, build(None if ent is None else ent[1]), record, 0]
             self._packed[key] = ent
             if record:
@@ -297,9 +303,9 @@ class ResnetFC(nn.Module):
         return ent[1]
 
     def packed_bwd(self, precision="f16"):
-        """transposed weight streams for the backward data-gradient chain (training)."""
+        """transposed weight streams for the backward data-gradient chain (training: always the differentiable path)."""
         return self._cached(("bwd", precision), precision,
-                            lambda out: ops.pack_mlp(None, precision, backward=True, weights=self._wstruct(), out=out))
+                            lambda out: ops.pack_mlp(None, precision, backward=True, weights=self._wstruct(), out=out), True)
 
     def forward(self, zx, combine_inner_dims=(1,), combine_index=None, dim_size=None):
         """src/model/resnetfc.py:132-184 on explicit rows zx (..., d_latent + d_in).  The renderer never comes here for the

@@ -316,6 +316,26 @@ def test_packed_cache_never_blesses_a_stream_it_did_not_fingerprint():
         n = len(recorded)
         mlp._cached(key, "f16x3", build)
         assert len(recorded) == n + 1
+    # the differentiable path packs INSIDE torch.autograd.Function.forward / backward, where grad mode is off: it says what it is
+    # (training_pass=True) instead of being taken for a validation pass -- a training loop must not fingerprint every step
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            assert not torch.is_grad_enabled()
+            mlp.__dict__["_opt_steps"] += 1
+            mlp._cached(key, "f16x3", build, True)
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2.0
+
+    mlp.__dict__["_opt_steps"] += 1
+    mlp._cached(key, "f16x3", build, True)                          # (replaces the validation pass's stream)
+    for _ in range(3):
+        n, b = len(recorded), len(built)
+        _Fn.apply(torch.ones(1, requires_grad=True)).backward()
+        assert len(recorded) == n and len(built) == b + 1           # re-packed every step, never fingerprinted
     mlp.eval()
     mlp.__dict__["_opt_steps"] += 1
     n = len(recorded)
