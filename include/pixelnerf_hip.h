@@ -75,7 +75,7 @@ int pnr_version(int *major, int *minor);
 /* ABI revision of THIS header: bumped whenever a struct layout or an entry point's argument list changes.  The
  * library returns the value it was compiled with; a binding must compare it with the header it was written against
  * before the first call (pixelnerf_amd/_lib.py does, and refuses a stale or foreign .so). */
-#define PNR_ABI_VERSION 6
+#define PNR_ABI_VERSION 7
 int pnr_abi_version(void);
 int pnr_device_info(int *num_cus, int *lds_bytes_per_block);
 
@@ -350,11 +350,15 @@ int pnr_lin_out_grad(const float *g_out, const void *x5, long long P, int precis
  * texels per image (64 x 64 and smaller) are accumulated in fp64 LDS slabs, one per (image, 16- / 8- / 4-channel slice),
  * fed per ray segment (consecutive samples in one grid cell); a slab reaches HBM with plain read-add-write when one
  * workgroup owns its (image, slice) -- SB*NS*slices >= the compute units -- and with one atomic per touched element and
- * workgroup otherwise; larger grids use global fp32 atomics throughout.  Uses the per-stream scratch of the multi-view
- * kernels (grown on demand: the first call on a stream must not sit inside a graph capture).
- * (encoder.py:96-109 backward) */
+ * workgroup otherwise (at most two per element for 4 images of 32 x 32: onto a zeroed buffer the result is then
+ * bit-reproducible); larger grids use global fp32 atomics throughout.
+ * workspace: pnr_latent_scatter_workspace_bytes() bytes of device memory (projected positions + segment lists of the
+ * slab form; 0 for the large grids, workspace may then be NULL), owned by the caller so that the call can sit inside a
+ * HIP-graph capture (ABI rev 7; rev 6 kept a per-stream scratch inside the library).  (encoder.py:96-109 backward) */
+size_t pnr_latent_scatter_workspace_bytes(const PnrScene *scene /*host*/, int R, int rays_per_obj, int K);
 int pnr_latent_scatter(const PnrScene *scene /*host*/, const float *rays, const float *z, int R,
-                       int rays_per_obj, int K, const float *d_zlat, float *d_latent_nhwc, void *stream);
+                       int rays_per_obj, int K, const float *d_zlat, float *d_latent_nhwc, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 /* ---- alpha compositing -------------------------------------------------------------------
  * NeRFRenderer.composite after the model call, src/render/nerf.py:178-182 and :223-249.

@@ -21,6 +21,7 @@
 //                         samples (nerf.py:292), for all points or for the depth samples only.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1587,8 +1588,31 @@ extern "C" int pnr_depth_sample_backward(const PnrScene *s, const float *rays, c
     return pnr_check_launch("pnr_depth_sample_backward");
 }
 
+// slab form of the scatter for this grid: channels per slab (16 / 8 with a padded row when that fits the LDS, else 4; 64x64:
+// unpadded) and u64 slots per texel row; cs = 0: the grid does not fit, global atomics
+static void scatter_form(int texels, int &cs, int &row) {
+    cs = 0; row = 0;
+    if ((size_t)texels * 17 * 8 <= SLAB_MAX_BYTES - 128) { cs = 16; row = 17; }
+    else if ((size_t)texels * 9 * 8 <= SLAB_MAX_BYTES - 128) { cs = 8; row = 9; }
+    else if ((size_t)texels * 5 * 8 <= SLAB_MAX_BYTES - 128) { cs = 4; row = 5; }
+    else if ((size_t)texels * 4 * 8 <= SLAB_MAX_BYTES - 128) { cs = 4; row = 4; }
+}
+// workspace of the slab form: coords NS*P float2 | segment starts, SEG_NSUB x sub_len ints per image | counts, SEG_NSUB ints per image
+static int scatter_sub_len(long long pts) { return (int)(((pts + SEG_NSUB - 1) / SEG_NSUB + 63) / 64 * 64); }
+static size_t scatter_ws_bytes(int images, int NS, long long P, long long pts) {
+    return (size_t)NS * P * sizeof(float2) + (size_t)images * SEG_NSUB * scatter_sub_len(pts) * sizeof(int) + (size_t)images * SEG_NSUB * sizeof(int);
+}
+
+extern "C" size_t pnr_latent_scatter_workspace_bytes(const PnrScene *s, int R, int rays_per_obj, int K) {
+    if (!s || R <= 0 || K <= 0 || rays_per_obj <= 0) return 0;
+    int cs, row;
+    scatter_form(s->Hl * s->Wl, cs, row);
+    if (!cs) return 0;
+    return scatter_ws_bytes(s->SB * s->NS, s->NS, (long long)R * K, (long long)rays_per_obj * K);
+}
+
 extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const float *z, int R, int rays_per_obj, int K,
-                                  const float *d_zlat, float *d_latent_nhwc, void *stream) {
+                                  const float *d_zlat, float *d_latent_nhwc, void *workspace, size_t workspace_bytes, void *stream) {
     if (!s || !rays || !z || !d_zlat || !d_latent_nhwc || R <= 0 || K <= 0 || rays_per_obj <= 0)
         return pnr_fail(PNR_E_INVALID, "pnr_latent_scatter: bad argument");
     if ((long long)rays_per_obj * s->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_latent_scatter: R != SB * rays_per_obj");
@@ -1598,12 +1622,8 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
     q.img_w = s->img_w; q.img_h = s->img_h;
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
     const int texels = q.Hl * q.Wl;
-    // small grid: LDS slabs.  8 channels per slab with a padded row when that fits the LDS, else 4 (64x64: unpadded)
-    int cs = 0, row = 0;
-    if ((size_t)texels * 17 * 8 <= SLAB_MAX_BYTES - 128) { cs = 16; row = 17; }
-    else if ((size_t)texels * 9 * 8 <= SLAB_MAX_BYTES - 128) { cs = 8; row = 9; }
-    else if ((size_t)texels * 5 * 8 <= SLAB_MAX_BYTES - 128) { cs = 4; row = 5; }
-    else if ((size_t)texels * 4 * 8 <= SLAB_MAX_BYTES - 128) { cs = 4; row = 4; }
+    int cs, row;
+    scatter_form(texels, cs, row);
     int force_psplit = 0;
     if (const char *e = getenv("PNR_SCATTER_FORM")) {  // experiment hook "cs,psplit": force the slice width (16 / 8 / 4) and the point split
         int fcs = 0, fps = 0;
@@ -1624,14 +1644,14 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
         if (psplit > 8) psplit = 8;
         if (psplit < 1) psplit = 1;
         if (force_psplit >= 1 && force_psplit <= 8) psplit = force_psplit;
-        // scratch (per (device, stream), shared with the multi-view kernels' view-sum scratch -- stream-ordered uses):
-        // coords NS*P float2 | segment starts, SEG_NSUB x sub_len ints per image | segment counts, SEG_NSUB ints per image
         const int images = q.SB * q.NS;
         const size_t coords_bytes = (size_t)q.NS * q.P * sizeof(float2);
-        const int sub_len = (int)(((pts + SEG_NSUB - 1) / SEG_NSUB + 63) / 64 * 64);
+        const int sub_len = scatter_sub_len(pts);
         const size_t segs_bytes = (size_t)images * SEG_NSUB * sub_len * sizeof(int);
-        char *scratch = reinterpret_cast<char *>(mv_scratch((hipStream_t)stream, coords_bytes + segs_bytes + (size_t)images * SEG_NSUB * sizeof(int)));
-        if (!scratch) return pnr_fail(PNR_E_HIP, "pnr_latent_scatter: cannot allocate the projected-coordinates scratch");
+        if (!workspace || workspace_bytes < scatter_ws_bytes(images, q.NS, q.P, pts) || ((uintptr_t)workspace & 15) != 0)
+            return pnr_fail(PNR_E_INVALID, "pnr_latent_scatter: workspace missing, misaligned (16 bytes) or smaller than "
+                                           "pnr_latent_scatter_workspace_bytes()");
+        char *scratch = reinterpret_cast<char *>(workspace);
         float2 *coords = reinterpret_cast<float2 *>(scratch);
         int *segs = reinterpret_cast<int *>(scratch + coords_bytes);
         int *nseg = reinterpret_cast<int *>(scratch + coords_bytes + segs_bytes);

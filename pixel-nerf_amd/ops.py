@@ -1271,9 +1271,13 @@ def latent_scatter(scene, rays, z, d_zlat, d_latent_nhwc):
     z = _f32(z, "z", (R, None))
     K = z.shape[1]
     d_zlat = _f32(d_zlat, "d_zlat", (scene.NS * R * K, 512))
+    per_obj = max(R // scene.SB, 1)
+    # workspace from torch's allocator (projected positions + segment lists of the LDS-slab form): capture-safe, stream-ordered
+    nbytes = int(lib.pnr_latent_scatter_workspace_bytes(scene.ref, R, per_obj, K))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=rays.device) if nbytes else None
     with torch.cuda.device(rays.device):
-        _lib.check(lib.pnr_latent_scatter(scene.ref, _p(rays), _p(z), R, max(R // scene.SB, 1), K, _p(d_zlat),
-                                          _p(d_latent_nhwc), _stream()), "pnr_latent_scatter")
+        _lib.check(lib.pnr_latent_scatter(scene.ref, _p(rays), _p(z), R, per_obj, K, _p(d_zlat), _p(d_latent_nhwc),
+                                          _p(ws) if ws is not None else None, nbytes, _stream()), "pnr_latent_scatter")
     return d_latent_nhwc
 
 
