@@ -349,9 +349,9 @@ int pnr_lin_out_grad(const float *g_out, const void *x5, long long P, int precis
  * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (caller zero-initialises; accumulates).  Grids of up to 5116
  * texels per image (64 x 64 and smaller) are accumulated in fp64 LDS slabs, one per (image, 16- / 8- / 4-channel slice),
  * fed per ray segment (consecutive samples in one grid cell); a slab reaches HBM with plain read-add-write when one
- * workgroup owns its (image, slice) -- SB*NS*slices >= the compute units -- and with one atomic per touched element and
- * workgroup otherwise (at most two per element for 4 images of 32 x 32: onto a zeroed buffer the result is then
- * bit-reproducible); larger grids use global fp32 atomics throughout.
+ * workgroup owns its (image, slice), and with one atomic per touched element otherwise -- never more than two workgroups
+ * per pair (the slice width follows the image count), so onto a ZEROED buffer the result is bit-reproducible; larger grids
+ * use global fp32 atomics throughout (order-dependent in the last bit).
  * workspace: pnr_latent_scatter_workspace_bytes() bytes of device memory (projected positions + segment lists of the
  * slab form; 0 for the large grids, workspace may then be NULL), owned by the caller so that the call can sit inside a
  * HIP-graph capture (ABI rev 7; rev 6 kept a per-stream scratch inside the library).  (encoder.py:96-109 backward) */

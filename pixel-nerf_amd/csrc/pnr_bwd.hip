@@ -844,8 +844,9 @@ latent_scatter_kernel(const EvalParams q, const float *__restrict__ d_zlat, floa
 // hit every texel, so global atomics serialise on a few thousand addresses.  Instead a workgroup owns an (image, CS-channel
 // slice) slab of the gradient grid in LDS (CS = 16 / 8 / 4 by what fits), walks the points of that image's object, and adds
 // the slab to HBM once.  When there are at least as many (image, slice) pairs as compute units ONE workgroup walks all
-// points and the slab goes out with plain read-add-write; otherwise psplit workgroups share the pair and meet in HBM with
-// atomics (config 5 at CS = 16: 4 images x 32 slices x 2).
+// points and the slab goes out with plain read-add-write; otherwise TWO workgroups share the pair and meet in HBM with
+// atomics (config 5 at CS = 16: 4 images x 32 slices x 2) -- never more (scatter_form picks the slice width by the image
+// count): two adds onto a zeroed element commute, so the result does not depend on their order.
 //
 // What bounded the round-2..5 form of this kernel (thread = run of 8 consecutive samples x 8 channels, register accumulator
 // per corner flushed when ITS texel changes; 64-bit fixed-point slab) -- tools/ubench/lds_atomic.hip + timing twins,
@@ -1588,14 +1589,26 @@ extern "C" int pnr_depth_sample_backward(const PnrScene *s, const float *rays, c
     return pnr_check_launch("pnr_depth_sample_backward");
 }
 
-// slab form of the scatter for this grid: channels per slab (16 / 8 with a padded row when that fits the LDS, else 4; 64x64:
-// unpadded) and u64 slots per texel row; cs = 0: the grid does not fit, global atomics
-static void scatter_form(int texels, int &cs, int &row) {
+// slab form of the scatter: channels per slab (16 / 8 / 4) and fp64 slots per texel row (padded by one when that fits the LDS;
+// 64x64: unpadded); cs = 0: the grid does not fit, global atomics.  Of the widths that fit, the widest one whose (image, slice)
+// pairs fill the chip with at most TWO workgroups per pair is taken (4+ images of 32x32: 16 channels; 2 images: 8; 1 image: 4):
+// wider slices read the gradient rows in longer pieces (profiles/r06_scatter_notes.md section 4), and at most two atomic adds per
+// grid element keep the result independent of their order (onto a zeroed buffer two terms commute).
+static bool slab_row(int texels, int cs, int &row) {
+    if ((size_t)texels * (cs + 1) * 8 <= SLAB_MAX_BYTES - 128) { row = cs + 1; return true; }
+    if (cs == 4 && (size_t)texels * 4 * 8 <= SLAB_MAX_BYTES - 128) { row = 4; return true; }
+    return false;
+}
+static void scatter_form(int texels, int images, int &cs, int &row) {
     cs = 0; row = 0;
-    if ((size_t)texels * 17 * 8 <= SLAB_MAX_BYTES - 128) { cs = 16; row = 17; }
-    else if ((size_t)texels * 9 * 8 <= SLAB_MAX_BYTES - 128) { cs = 8; row = 9; }
-    else if ((size_t)texels * 5 * 8 <= SLAB_MAX_BYTES - 128) { cs = 4; row = 5; }
-    else if ((size_t)texels * 4 * 8 <= SLAB_MAX_BYTES - 128) { cs = 4; row = 4; }
+    const int cus = bwd_num_cus();
+    for (int c = 16; c >= 4; c >>= 1) {
+        int r = 0;
+        if (!slab_row(texels, c, r)) continue;
+        if (!cs) { cs = c; row = r; }                                      // the widest that fits, unless a narrower one fills the chip
+        if (2 * images * (C_LAT / c) >= cus) { cs = c; row = r; return; }  // ... with <= 2 workgroups per (image, slice)
+    }
+    if (cs) { int r = 0; if (slab_row(texels, 4, r)) { cs = 4; row = r; } }  // very few images: the most pairs there are
 }
 // workspace of the slab form: coords NS*P float2 | segment starts, SEG_NSUB x sub_len ints per image | counts, SEG_NSUB ints per image
 static int scatter_sub_len(long long pts) { return (int)(((pts + SEG_NSUB - 1) / SEG_NSUB + 63) / 64 * 64); }
@@ -1606,7 +1619,7 @@ static size_t scatter_ws_bytes(int images, int NS, long long P, long long pts) {
 extern "C" size_t pnr_latent_scatter_workspace_bytes(const PnrScene *s, int R, int rays_per_obj, int K) {
     if (!s || R <= 0 || K <= 0 || rays_per_obj <= 0) return 0;
     int cs, row;
-    scatter_form(s->Hl * s->Wl, cs, row);
+    scatter_form(s->Hl * s->Wl, s->SB * s->NS, cs, row);
     if (!cs) return 0;
     return scatter_ws_bytes(s->SB * s->NS, s->NS, (long long)R * K, (long long)rays_per_obj * K);
 }
@@ -1623,12 +1636,13 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
     q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = (long long)R * K;
     const int texels = q.Hl * q.Wl;
     int cs, row;
-    scatter_form(texels, cs, row);
+    scatter_form(texels, q.SB * q.NS, cs, row);
     int force_psplit = 0;
     if (const char *e = getenv("PNR_SCATTER_FORM")) {  // experiment hook "cs,psplit": force the slice width (16 / 8 / 4) and the point split
         int fcs = 0, fps = 0;
-        if (sscanf(e, "%d,%d", &fcs, &fps) >= 1 && (fcs == 16 || fcs == 8 || fcs == 4) && fcs <= cs) {
-            cs = fcs; row = (size_t)texels * (cs + 1) * 8 <= SLAB_MAX_BYTES - 128 ? cs + 1 : cs;
+        int frow = 0;
+        if (cs && sscanf(e, "%d,%d", &fcs, &fps) >= 1 && (fcs == 16 || fcs == 8 || fcs == 4) && slab_row(texels, fcs, frow)) {
+            cs = fcs; row = frow;
             force_psplit = fps;
         }
     }
@@ -1641,7 +1655,7 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
         int psplit = (bwd_num_cus() + owners - 1) / owners;
         const long long rounds = (pts + 4LL * OWNER_NT - 1) / (4LL * OWNER_NT);
         if (psplit > rounds) psplit = (int)rounds;
-        if (psplit > 8) psplit = 8;
+        if (psplit > 2) psplit = 2;  // (scatter_form: at most two adds per grid element)
         if (psplit < 1) psplit = 1;
         if (force_psplit >= 1 && force_psplit <= 8) psplit = force_psplit;
         const int images = q.SB * q.NS;

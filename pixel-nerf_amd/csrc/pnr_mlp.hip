@@ -501,21 +501,29 @@ float *mv_scratch(hipStream_t st, size_t bytes) {
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
-    // growing the table allocates: illegal inside a HIP-graph capture -- the first multi-view launch on a stream (or the first
-    // one that needs more) must happen outside of one (a warm-up call does it); inside a capture only an existing slot is handed out
+    // growing the table allocates: illegal inside a HIP-graph capture.  A capture runs on a stream of its own (torch.cuda.graph), which
+    // no warm-up call has ever seen: the launch being captured then BORROWS the largest scratch another stream of this device
+    // already owns (the warm-up's).  That is ordered correctly as long as the replayed graph and multi-view launches on that
+    // other stream do not run at the same time -- the one restriction of capturing a multi-view call.
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     for (auto &sl : slots)
         if (sl.dev == dev && sl.st == st) {
             if (sl.bytes >= bytes) return sl.p;
-            if (capturing) return nullptr;
+            if (capturing) break;
             (void)hipFree(sl.p);
             sl.p = nullptr; sl.bytes = 0;
             if (hipMalloc(&sl.p, bytes) != hipSuccess) return nullptr;
             sl.bytes = bytes;
             return sl.p;
         }
-    if (capturing) return nullptr;
+    if (capturing) {
+        float *best = nullptr;
+        size_t best_bytes = 0;
+        for (auto &sl : slots)
+            if (sl.dev == dev && sl.bytes >= bytes && sl.bytes > best_bytes) { best = sl.p; best_bytes = sl.bytes; }
+        return best;  // nullptr: no multi-view launch has run on this device outside of a capture yet
+    }
     Slot sl = {dev, st, nullptr, bytes};
     if (hipMalloc(&sl.p, bytes) != hipSuccess) return nullptr;
     slots.push_back(sl);
