@@ -60,8 +60,8 @@ MFMAS_PER_PRODUCT = {"f16": 1, "bf16": 1, "f16x3": 3}
 KERNEL_OF = {"f16": "pnr::eval_kernel", "bf16": "pnr::eval_kernel", "f16x3": "pnr::eval_split_kernel"}
 KERNEL_SOURCES = {"f16": ["pnr_mlp.hip", "pnr_device.h", "pnr_layout.h"], "bf16": ["pnr_mlp.hip", "pnr_device.h", "pnr_layout.h"],
                   "f16x3": ["pnr_split.hip", "pnr_device.h", "pnr_layout.h"]}
-PMC_PROFILE = {"f16": os.path.join("profiles", "r05_bench_f16_pmc_eval_kernel.json"),
-               "f16x3": os.path.join("profiles", "r05_bench_f16x3_pmc_eval_split_kernel.json")}
+PMC_PROFILE = {"f16": os.path.join("profiles", "r06_bench_f16_pmc_eval_kernel.json"),
+               "f16x3": os.path.join("profiles", "r06_bench_f16x3_pmc_eval_split_kernel.json")}
 DTYPE_NOTE = {"f16x3": "fp32-class: (head, tail) fp16 operand pairs, 3 f16 MFMAs per product, fp32 accumulate, fp32 tables; "
                        "per-point |rgb| <= 2e-5 vs the reference (the reference's own arithmetic class)",
               "f16": "fp16 MFMA operands, fp32 accumulate: narrower than the reference's fp32 (PSNR >= 52 dB bar)",
@@ -398,13 +398,14 @@ def extra_eval_object_loop(dev, n_views=24, n_obj=4):
     render_par = renderer.bind_parallel(net, None, simple_output=True).eval()
     ray_batch = 50000  # eval/eval.py:135-137 (eval_batch_size = ray_batch_size = 50 000 in the shipped confs)
 
-    def ref_shaped(o, place_chunks=False, key=None, device_rays=False):
+    def ref_shaped(o, place_chunks=False, key=None, device_rays=False, encode=True):
         if device_rays:  # (identity check only) the gen_rays KERNEL: the same bits pnr_render_views regenerates per pixel
             all_rays = util.gen_rays(tgt_poses.to(dev), W, H, focal, z_near, z_far, c=c).reshape(-1, 8)
         else:
             all_rays = util.gen_rays(tgt_poses, W, H, focal, z_near, z_far, c=c).reshape(-1, 8).to(device=dev)   # host rays + upload
         rays_spl = torch.split(all_rays, ray_batch, dim=0)
-        net.encode(images[o, :1].to(device=dev).unsqueeze(0), src_pose.to(dev).unsqueeze(0), focal.to(dev), c=c.to(dev))
+        if encode:
+            net.encode(images[o, :1].to(device=dev).unsqueeze(0), src_pose.to(dev).unsqueeze(0), focal.to(dev), c=c.to(dev))
         all_rgb, all_depth, lo = [], [], 0
         for rays in rays_spl:
             if place_chunks:
@@ -456,13 +457,17 @@ def extra_eval_object_loop(dev, n_views=24, n_obj=4):
         key = 0x1234567
         b = hip_side(1, key=key)
         for name, dr in (("same_draws_check", True), ("same_draws_check_host_rays", False)):
-            a = ref_shaped(1, place_chunks=True, key=key, device_rays=dr)
+            # on the scene hip_side(1) encoded: the torch / MIOpen ResNet-34 trunk is not reproducible from call to call on these boxes
+            # (layer2 / layer3 outputs of the SAME image differ by 4e-6 / 4e-5, tools/experiments/enc_diag.py: its 8x8 and 4x4 maps run
+            # split-K convolutions); a second encode would put ulp-level differences under both forms and a white pixel at 1 - 1 ulp
+            # truncates to 254 (sessions r06_s20 / s24 / s30: ~12 000 of 294 912 values off by one; r06_s9 / s27: none)
+            a = ref_shaped(1, place_chunks=True, key=key, device_rays=dr, encode=False)
             diff = np.abs(a[0].astype(np.int32) - b[0].astype(np.int32))
             res[name] = {"u8_images_identical": bool(diff.max() == 0), "u8_max_abs_diff": int(diff.max()),
                          "u8_values_differing": int((diff > 0).sum()), "u8_values": int(diff.size),
                          "depth_norm_max_abs_diff": float(np.abs(a[1] - b[1]).max()),
                          "psnr_db_max_abs_diff": float(np.abs(a[2] - b[2]).max())}
-        res["same_draws_check"]["what"] = ("form (i) with rays from the gen_rays KERNEL and every chunk placed in the whole ray set: the bits of form (ii).  "
+        res["same_draws_check"]["what"] = ("on ONE encoded scene (the torch trunk is not bit-reproducible between two encodes), form (i) with rays from the gen_rays KERNEL and every chunk placed in the whole ray set: the bits of form (ii).  "
                                            "`same_draws_check_host_rays`: the reference's host-side util.gen_rays differs from the kernel in the last bit of "
                                            "some ray directions; a uint8 value changes where a colour sits on a truncation boundary")
         mse = np.mean((ref_shaped(2)[0].astype(np.float64) - hip_side(2)[0].astype(np.float64)) ** 2)
