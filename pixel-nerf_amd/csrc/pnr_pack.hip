@@ -3,6 +3,8 @@
 // transpose of the encoder feature grid.  gfx950.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pnr_common.h"
 #include "pnr_internal.h"
 #include "pnr_layout.h"
@@ -333,6 +335,154 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
     if (sat && amax >= 65504.f) atomicOr(sat, 1u << 12);
 }
 
+
+// The fold for LARGE grids (round 6; DTU: 90 000 texels, 3 tables x 2 networks per scene and per rank of a sharded render).  The
+// 128 x 128 kernel above spends a chunk as split (VALU, matrix pipe idle) | barrier | 24 MFMAs per wave | barrier at four waves
+// per workgroup: 24.8 % MFMA-busy.  Here the structure of dw_split_kernel (pnr_bwd.hip): 256 texels x 256 features per 512-thread
+// workgroup (8 waves of 64 x 128 = 2 x 4 MFMA tiles, 48 MFMAs per wave and chunk), the four operand images (X / W, head / tail)
+// DOUBLE-buffered in LDS -- the next chunk's rows are requested at the top of a chunk and split + stored into the other buffer
+// between its two k-steps, under the MFMAs -- one barrier per chunk.  64-byte image rows (32 halves, no padding) with the 16-byte
+// units of a row XOR-swizzled by (row >> 1) & 3: the eight rows one ds_read_b128 cycle serves land on eight different
+// 4-bank groups; 128 KiB of LDS.  Workgroups are placed XCD-aware: the six (column tile, table) workgroups of a 256-texel
+// row tile take consecutive slots of ONE XCD, so its 512 KiB of grid rows cross the fabric once.
+// Same-box A/B (profiles/r06_fold_notes.md): DTU grid 840 -> 675 us per network (629 TFLOP/s of executed MFMAs), srn_car 80 -> 68 us;
+// 4096 texels and fewer stay on the 128 x 128 kernel (45 vs 60 us: 96 workgroups of this one do not fill the chip).  Timing twins of
+// this kernel on the DTU grid: no global loads 595, no table stores 555, no split / LDS stores 537 us -- what is left is the
+// fragment-read + MFMA loop itself at two waves per SIMD with one barrier per chunk (the 128 accumulator registers of the 64 x 128
+// wave tile leave no room to double-buffer the fragments).
+constexpr int FB_TM = 256, FB_TN = 256, FB_K = 32;
+constexpr int FB_IMG = FB_TM * FB_K * 2;  // bytes of one image (256 rows x 64 B)
+constexpr int FB_LDS = 2 * 4 * FB_IMG;     // [buffer][Xh, Xl, Wh, Wl]
+__global__ void __launch_bounds__(512)
+fold_split_big_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__restrict__ tables, long long M, int ngroups,
+                      unsigned int *sat) {
+    extern __shared__ __attribute__((aligned(16))) char fb[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // (XCD, slot) -> (row tile, column tile, table)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int group = (slot / 6) * 8 + xcd, sub = slot % 6;
+    if (group >= ngroups) return;
+    const int tab = sub >> 1;
+    const float *__restrict__ W = jobs.W[tab];
+    const float *__restrict__ bias = jobs.bias[tab];
+    float *__restrict__ table = tables + (size_t)tab * (size_t)M * D_HID;
+    const long long m0 = (long long)group * FB_TM;
+    const int n0 = (sub & 1) * FB_TN;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 128;  // wave tile: 64 texels x 128 features
+    const int i = lane & 31, kh = lane >> 5;
+    __builtin_amdgcn_s_setreg(1473, 1);  // MODE.FP16_OVFL = 1 (hwreg(HW_REG_MODE, 23, 1)): f16 conversions saturate, as in the fused kernels
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float amax = 0.f;
+    // byte offset of (row, 16-byte unit u) inside an image
+    auto img_off = [](int row, int u) { return row * 64 + ((u ^ ((row >> 1) & 3)) << 4); };
+    f32x4 xv[4], wv[4];
+    // thread -> (row, 4 columns) of a 256-row x 32-column chunk: 8 consecutive threads read one row's 128 bytes
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = t + u * 512, row = e >> 3, c4 = (e & 7) * 4;
+            xv[u] = (m0 + row < M) ? *reinterpret_cast<const f32x4 *>(grid + (m0 + row) * C_LAT + k0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            wv[u] = *reinterpret_cast<const f32x4_param *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
+        }
+    };
+    auto split_store = [&](int buf) {
+        char *base = fb + buf * (4 * FB_IMG);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = t + u * 512, row = e >> 3, c4 = (e & 7) * 4;
+            const int off = img_off(row, c4 >> 3) + (c4 & 4) * 2;  // 8 bytes: 4 halves
+            // head = f16(v), tail = f16(v - head) as pnr_split.hip's split8 makes them: MODE.FP16_OVFL is set, so the conversions
+            // SATURATE at the fp16 limit like the operands of the kernel that reads the tables (an out-of-range grid value or weight
+            // gives a large finite table entry and raises the guard bit, never inf - inf); one v_cvt_pk_f16_f32 per pair + one
+            // v_fma_mix{lo,hi}_f16 per value (fp32 FMA of the packed f16 head times -1 plus v, rounded once: the bits of
+            // convert-back + subtract + convert) -- 1.5 VALU per value where clamp / convert / subtract / clamp / convert took 8
+            uint32_t xh[2], xl[2], wh[2], wl[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float x0 = xv[u][2 * c], x1 = xv[u][2 * c + 1], w0 = wv[u][2 * c], w1 = wv[u][2 * c + 1];
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                xh[c] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){x0, x1}, f16x2_t));
+                wh[c] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){w0, w1}, f16x2_t));
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(xl[c]) : "v"(xh[c]), "v"(x0));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(xl[c]) : "v"(xh[c]), "v"(x1));
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(wl[c]) : "v"(wh[c]), "v"(w0));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(wl[c]) : "v"(wh[c]), "v"(w1));
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x0), fabsf(x1)), fmaxf(fabsf(w0), fabsf(w1))));
+            }
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2_t *>(base + off) = u32x2_t{xh[0], xh[1]};
+            *reinterpret_cast<u32x2_t *>(base + FB_IMG + off) = u32x2_t{xl[0], xl[1]};
+            *reinterpret_cast<u32x2_t *>(base + 2 * FB_IMG + off) = u32x2_t{wh[0], wh[1]};
+            *reinterpret_cast<u32x2_t *>(base + 3 * FB_IMG + off) = u32x2_t{wl[0], wl[1]};
+        }
+    };
+    fetch(0);
+    split_store(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < C_LAT; k0 += FB_K, cur ^= 1) {
+        const bool more = k0 + FB_K < C_LAT;
+        if (more) fetch(k0 + FB_K);  // in flight under this chunk's MFMAs
+        const char *sXh = fb + cur * (4 * FB_IMG), *sXl = sXh + FB_IMG, *sWh = sXh + 2 * FB_IMG, *sWl = sXh + 3 * FB_IMG;
+#pragma unroll
+        for (int kk = 0; kk < FB_K / 16; ++kk) {
+            f16x8_t ah[2], al[2], bh[4], bl[4];
+            const int u = kk * 2 + kh;  // this lane's 16-byte unit of the row: k = 16 kk + 8 kh
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int o = img_off(wm + a * 32 + i, u);
+                ah[a] = *reinterpret_cast<const f16x8_t *>(sXh + o);
+                al[a] = *reinterpret_cast<const f16x8_t *>(sXl + o);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int o = img_off(wn + b * 32 + i, u);
+                bh[b] = *reinterpret_cast<const f16x8_t *>(sWh + o);
+                bl[b] = *reinterpret_cast<const f16x8_t *>(sWl + o);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            // the next chunk goes into the OTHER buffer (its readers passed the barrier of the previous chunk) between the two
+            // k-steps: its split and its 16 LDS stores per thread ride under the second k-step's MFMAs
+            if (kk == 0 && more) split_store(cur ^ 1);
+        }
+        __syncthreads();
+    }
+    // D layout: column = lane & 31 -> feature, row (r & 3) + 8 (r >> 2) + 4 kh -> texel
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n0 + wn + b * 32 + i;
+        const float bn = bias[n];
+        const int slot_n = slot_of(n);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < M) table[m * D_HID + slot_n] = acc[a][b][r] + bn;
+            }
+    }
+    if (sat && amax >= 65504.f) atomicOr(sat, 1u << 12);
+}
+
+
 }  // namespace pnr
 
 namespace pnr {
@@ -469,6 +619,18 @@ extern "C" int pnr_fold_latent_f32(const PnrScene *s, const PnrMlpWeights *w, fl
     for (int b = 0; b < COMBINE_LAYER; ++b) {
         if (!w->lin_z_w[b] || !w->lin_z_b[b]) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32: null lin_z parameters");
         jobs.W[b] = w->lin_z_w[b]; jobs.bias[b] = w->lin_z_b[b];
+    }
+    // large grids: 256 x 256 tiles, double-buffered (fold_split_big_kernel); small ones keep the 128 x 128 kernel, whose 4-wave
+    // workgroups fill the chip at a few thousand texels (PNR_FOLD_BIG_MIN_TEXELS: the crossover, measured -- profiles/r06_fold_notes.md)
+    static const long long big_min = [] { const char *e = getenv("PNR_FOLD_BIG_MIN_TEXELS"); return e ? atoll(e) : 8192LL; }();
+    if (M >= big_min) {
+        const int ngroups = (int)((M + FB_TM - 1) / FB_TM);
+        const unsigned wgs = (unsigned)((ngroups + 7) / 8) * 8u * 6u;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fold_split_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+        if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(fold_split_big_kernel)");
+        hipLaunchKernelGGL(fold_split_big_kernel, dim3(wgs), dim3(512), FB_LDS, (hipStream_t)stream, s->latent_nhwc, jobs, tables, M, ngroups,
+                           saturation_guard_word());
+        return pnr_check_launch("pnr_fold_latent_f32");
     }
     dim3 sgrid((unsigned)((M + FS_TM - 1) / FS_TM), D_HID / FS_TN, COMBINE_LAYER);
     hipLaunchKernelGGL(fold_split_kernel, sgrid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, jobs, tables, M, saturation_guard_word());

@@ -57,6 +57,30 @@ def test_split_tables_are_lin_z_of_the_grid_in_fp32(ops, dev):
         assert (got - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(3, 75, 101), (1, 128, 128), (2, 64, 64), (1, 90, 91), (1, 64, 100)])
+def test_split_tables_of_large_grids(ops, dev, shape):
+    """grids of 8192 texels and more take fold_split_big_kernel (256 x 256 tiles, double-buffered swizzled LDS images): the same bar
+    as the small-grid kernel against an fp64 product, on ragged texel counts (22 725 = 88 x 256 + 197; 8190: the 128 x 128 kernel
+    just below the crossover), exact multiples of the tile (16 384, 8192) and a count whose last row tile holds one texel row group
+    (6400 = 25 x 256)"""
+    from pixelnerf_amd import _lib
+    n, Hl, Wl = shape
+    gen = torch.Generator().manual_seed(4)
+    lat = torch.randn(n, 512, Hl, Wl, generator=gen)
+    lat[0, :, 0, 0] *= 50.0  # a texel with large entries: the (head, tail) split carries them
+    s, _ = scene_for("dtu_mini")
+    sc = ops.make_scene(lat.to(dev), s["poses"][:n].to(dev), s["focal"].to(dev), s["c"].to(dev), s["image_shape"], n)
+    p = mlp_params(12)
+    tab = ops.fold_latent(sc, {k: v.to(dev) for k, v in p.items()}, "f16x3")
+    perm = ops.storage_perm().long()
+    grid = lat.permute(0, 2, 3, 1).double()
+    for b in range(3):
+        ref = grid @ p[f"lin_z.{b}.weight"].double().t() + p[f"lin_z.{b}.bias"].double()
+        got = torch.empty_like(ref)
+        got[..., perm] = tab[b].cpu().double()
+        assert (got - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max())), (shape, b, float((got - ref).abs().max()))
+
+
 @pytest.mark.parametrize("scene_name", STAGE_SCENES)
 def test_split_eval_points_matches_reference(ops, dev, scene_name):
     g = load_golden("stages")
