@@ -371,11 +371,15 @@ fold_split_big_kernel(const float *__restrict__ grid, const FoldJobs jobs, float
     const int wm = (w >> 1) * 64, wn = (w & 1) * 128;  // wave tile: 64 texels x 128 features
     const int i = lane & 31, kh = lane >> 5;
     __builtin_amdgcn_s_setreg(1473, 1);  // MODE.FP16_OVFL = 1 (hwreg(HW_REG_MODE, 23, 1)): f16 conversions saturate, as in the fused kernels
-    f32x16_t acc[2][4];
+    // computed TRANSPOSED like the fused kernels (table^T = W grid^T; A = W fragment, B = grid fragment): a lane's 16 D registers of
+    // a tile are then features feat_of(T, kh, 0..15) of ONE texel = 16 CONSECUTIVE slots of the table row in storage order
+    // (pnr_layout.h): 64 contiguous bytes, four 16-byte stores -- 32 store instructions per thread where the texel-major form
+    // issued 128 scattered dwords
+    f32x16_t acc[4][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float amax = 0.f;
@@ -433,51 +437,56 @@ fold_split_big_kernel(const float *__restrict__ grid, const FoldJobs jobs, float
         const char *sXh = fb + cur * (4 * FB_IMG), *sXl = sXh + FB_IMG, *sWh = sXh + 2 * FB_IMG, *sWl = sXh + 3 * FB_IMG;
 #pragma unroll
         for (int kk = 0; kk < FB_K / 16; ++kk) {
-            f16x8_t ah[2], al[2], bh[4], bl[4];
+            f16x8_t ah[4], al[4], bh[2], bl[2];  // A: W rows (features), B: grid rows (texels)
             const int u = kk * 2 + kh;  // this lane's 16-byte unit of the row: k = 16 kk + 8 kh
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int o = img_off(wm + a * 32 + i, u);
-                ah[a] = *reinterpret_cast<const f16x8_t *>(sXh + o);
-                al[a] = *reinterpret_cast<const f16x8_t *>(sXl + o);
+            for (int a = 0; a < 4; ++a) {
+                const int o = img_off(wn + a * 32 + i, u);
+                ah[a] = *reinterpret_cast<const f16x8_t *>(sWh + o);
+                al[a] = *reinterpret_cast<const f16x8_t *>(sWl + o);
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int o = img_off(wn + b * 32 + i, u);
-                bh[b] = *reinterpret_cast<const f16x8_t *>(sWh + o);
-                bl[b] = *reinterpret_cast<const f16x8_t *>(sWl + o);
+            for (int b = 0; b < 2; ++b) {
+                const int o = img_off(wm + b * 32 + i, u);
+                bh[b] = *reinterpret_cast<const f16x8_t *>(sXh + o);
+                bl[b] = *reinterpret_cast<const f16x8_t *>(sXl + o);
             }
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
             // the next chunk goes into the OTHER buffer (its readers passed the barrier of the previous chunk) between the two
             // k-steps: its split and its 16 LDS stores per thread ride under the second k-step's MFMAs
             if (kk == 0 && more) split_store(cur ^ 1);
         }
         __syncthreads();
     }
-    // D layout: column = lane & 31 -> feature, row (r & 3) + 8 (r >> 2) + 4 kh -> texel
+    // D layout: column = lane & 31 -> texel, row (r & 3) + 8 (r >> 2) + 4 kh -> feature feat_of(T, kh, r) = slot 32 T + 16 kh + r
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int n = n0 + wn + b * 32 + i;
-        const float bn = bias[n];
-        const int slot_n = slot_of(n);
+    for (int a = 0; a < 4; ++a) {
+        const int f0 = n0 + wn + a * 32;  // first feature of the tile (a multiple of 32: its slots are f0 .. f0 + 31)
+        float bv[16];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int r = 0; r < 16; ++r) bv[r] = bias[f0 + (r & 3) + 8 * (r >> 2) + 4 * kh];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (m < M) table[m * D_HID + slot_n] = acc[a][b][r] + bn;
+        for (int b = 0; b < 2; ++b) {
+            const long long m = m0 + wm + b * 32 + i;
+            if (m < M) {
+                float *dst = table + m * D_HID + f0 + 16 * kh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4 *>(dst + 4 * q) = f32x4{acc[a][b][4 * q] + bv[4 * q], acc[a][b][4 * q + 1] + bv[4 * q + 1],
+                                                                    acc[a][b][4 * q + 2] + bv[4 * q + 2], acc[a][b][4 * q + 3] + bv[4 * q + 3]};
             }
+        }
     }
     if (sat && amax >= 65504.f) atomicOr(sat, 1u << 12);
 }
