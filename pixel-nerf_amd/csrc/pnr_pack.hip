@@ -252,48 +252,61 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float amax = 0.f;
+    __builtin_amdgcn_s_setreg(1473, 1);  // MODE.FP16_OVFL = 1 (hwreg(HW_REG_MODE, 23, 1)): f16 conversions saturate, as in the fused kernels
     auto split4 = [&](const f32x4 v, _Float16 *hi, _Float16 *lo) {
-        f16x4_t h, l;
+        // heads and tails SATURATE at the fp16 limit like the operands of the kernel that reads the tables (MODE.FP16_OVFL): an
+        // out-of-range grid value or weight gives a large finite table entry (and raises the guard bit), never inf - inf.
+        // head = v_cvt_pk_f16_f32 per pair, tail = one v_fma_mix{lo,hi}_f16 per value (fp32 FMA of the packed head times -1 plus v,
+        // rounded once: the bits of convert-back + subtract + convert; pnr_split.hip split8) -- round 6: 1.5 VALU per value, was 8
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        uint32_t h[2], l[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // heads and tails SATURATE at the fp16 limit like the operands of the kernel that reads the tables (MODE.FP16_OVFL
-            // there): an out-of-range grid value or weight gives a large finite table entry (and raises the guard bit), never inf - inf
-            h[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
-            l[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e] - (float)h[e], -65504.f, 65504.f);
-            amax = fmaxf(amax, fabsf(v[e]));
+        for (int c = 0; c < 2; ++c) {
+            const float a = v[2 * c], b = v[2 * c + 1];
+            h[c] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){a, b}, f16x2_t));
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l[c]) : "v"(h[c]), "v"(a));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[c]) : "v"(h[c]), "v"(b));
+            amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
         }
-        *reinterpret_cast<f16x4_t *>(hi) = h;
-        *reinterpret_cast<f16x4_t *>(lo) = l;
+        *reinterpret_cast<u32x2_t *>(hi) = u32x2_t{h[0], h[1]};
+        *reinterpret_cast<u32x2_t *>(lo) = u32x2_t{l[0], l[1]};
     };
-    f32x4 xv[4], wv[4];
+    // Register ring of FS_DEPTH chunks of both operands; chunks are requested FS_DEPTH - 1 ahead.  Round 6 measured depth 4 (256
+    // registers): 1024- and 4096-texel grids -- what this kernel serves since fold_split_big_kernel took the large ones -- stay at
+    // 46 us per network either way (16 chunks of two barriers each on 96-384 four-wave workgroups: not a load-latency chain), the
+    // DTU grid went 840 -> 720 us; depth 2 (one chunk ahead, ~130 registers, four workgroups per CU) is kept.
+    constexpr int FS_DEPTH = 2;
+    f32x4 xv[FS_DEPTH][4], wv[FS_DEPTH][4];
     // thread -> (row, 4 columns) of a 128-row x 32-column chunk.  Rows of consecutive 8-lane groups are 4 apart (bits 0 and 2 of the
     // group index swapped): the 16 lanes one ds_write_b64 cycle serves then hit 2 x 64 bytes that are 320 bytes = 16 banks (mod 32)
     // apart -- with neighbouring rows (80 bytes apart) four banks were hit twice: 33 % of the LDS cycles were conflicts
     // (profiles/r04_train_step_f16x3_pmc.txt)
     auto row_of = [](int e) { const int g = e >> 3; return (g & ~5) | ((g & 1) << 2) | ((g >> 2) & 1); };
-    auto fetch = [&](int k0) {  // 128 rows x 8 float4 per operand
+    auto fetch = [&](int k0, f32x4 (&x)[4], f32x4 (&wq)[4]) {  // 128 rows x 8 float4 per operand
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = t + u * 256, row = row_of(e), c4 = (e & 7) * 4;
-            xv[u] = (m0 + row < M) ? *reinterpret_cast<const f32x4 *>(grid + (m0 + row) * C_LAT + k0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            wv[u] = *reinterpret_cast<const f32x4_param *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
+            x[u] = (m0 + row < M) ? *reinterpret_cast<const f32x4 *>(grid + (m0 + row) * C_LAT + k0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            wq[u] = *reinterpret_cast<const f32x4_param *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < C_LAT; k0 += FS_K) {
+#pragma unroll
+    for (int d = 0; d < FS_DEPTH - 1; ++d) fetch(d * FS_K, xv[d], wv[d]);
+#pragma unroll
+    for (int kc = 0; kc < C_LAT / FS_K; ++kc) {  // fully unrolled (16 chunks): the ring slot is a compile-time index
+        constexpr int NCH = C_LAT / FS_K;
+        const int slot = kc % FS_DEPTH;
         __syncthreads();  // the previous chunk's fragments have been read
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = t + u * 256, row = row_of(e), c4 = (e & 7) * 4;
-            split4(xv[u], &sXh[row][c4], &sXl[row][c4]);
-            split4(wv[u], &sWh[row][c4], &sWl[row][c4]);
+            split4(xv[slot][u], &sXh[row][c4], &sXl[row][c4]);
+            split4(wv[slot][u], &sWh[row][c4], &sWl[row][c4]);
         }
         __syncthreads();
-        // round 5: the NEXT chunk's rows are on their way while this chunk's 24 MFMAs per wave run (the loop used to start with
-        // the loads).  Measured: no change (44.5 us for 4096 texels, 811 us = 524 TFLOP/s of executed MFMAs for the DTU grid) --
-        // the chunk is bounded by the split phase between the two barriers (~220 VALU + 16 LDS stores per thread with the
-        // matrix pipe idle), not by the load round trip; removing it means pre-split W and a 128 x 512 tile (X split once)
-        if (k0 + FS_K < C_LAT) fetch(k0 + FS_K);
+        if (kc + FS_DEPTH - 1 < NCH) fetch((kc + FS_DEPTH - 1) * FS_K, xv[(kc + FS_DEPTH - 1) % FS_DEPTH], wv[(kc + FS_DEPTH - 1) % FS_DEPTH]);
 #pragma unroll
         for (int kk = 0; kk < FS_K / 16; ++kk) {
             f16x8_t ah[2], al[2], bh[2], bl[2];
