@@ -358,7 +358,7 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
 // units of a row XOR-swizzled by (row >> 1) & 3: the eight rows one ds_read_b128 cycle serves land on eight different
 // 4-bank groups; 128 KiB of LDS.  Workgroups are placed XCD-aware: the six (column tile, table) workgroups of a 256-texel
 // row tile take consecutive slots of ONE XCD, so its 512 KiB of grid rows cross the fabric once.
-// Same-box A/B (profiles/r06_fold_notes.md): DTU grid 840 -> 675 us per network (629 TFLOP/s of executed MFMAs), srn_car 80 -> 68 us;
+// Same-box A/B (profiles/r06_fold_notes.md): DTU grid 840 -> 640 us per network (664 TFLOP/s of executed MFMAs), srn_car 80 -> 65 us;
 // 4096 texels and fewer stay on the 128 x 128 kernel (45 vs 60 us: 96 workgroups of this one do not fill the chip).  Timing twins of
 // this kernel on the DTU grid: no global loads 595, no table stores 555, no split / LDS stores 537 us -- what is left is the
 // fragment-read + MFMA loop itself at two waves per SIMD with one barrier per chunk (the 128 accumulator registers of the 64 x 128
@@ -442,11 +442,11 @@ fold_split_big_kernel(const float *__restrict__ grid, const FoldJobs jobs, float
     };
     fetch(0);
     split_store(0);
+    fetch(FB_K);  // one register set: chunk c + 2 is requested right behind the split of chunk c + 1, a whole chunk before its use
     __syncthreads();
     int cur = 0;
     for (int k0 = 0; k0 < C_LAT; k0 += FB_K, cur ^= 1) {
         const bool more = k0 + FB_K < C_LAT;
-        if (more) fetch(k0 + FB_K);  // in flight under this chunk's MFMAs
         const char *sXh = fb + cur * (4 * FB_IMG), *sXl = sXh + FB_IMG, *sWh = sXh + 2 * FB_IMG, *sWl = sXh + 3 * FB_IMG;
 #pragma unroll
         for (int kk = 0; kk < FB_K / 16; ++kk) {
@@ -477,8 +477,13 @@ fold_split_big_kernel(const float *__restrict__ grid, const FoldJobs jobs, float
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
             // the next chunk goes into the OTHER buffer (its readers passed the barrier of the previous chunk) between the two
-            // k-steps: its split and its 16 LDS stores per thread ride under the second k-step's MFMAs
-            if (kk == 0 && more) split_store(cur ^ 1);
+            // k-steps: its split and its 16 LDS stores per thread ride under the second k-step's MFMAs; the chunk after it is
+            // requested at once (requested at the top of a chunk instead, the rows had half a chunk to arrive: the fetch registers
+            // are re-used, so hipcc cannot issue the loads before the previous values are split)
+            if (kk == 0 && more) {
+                split_store(cur ^ 1);
+                if (k0 + 2 * FB_K < C_LAT) fetch(k0 + 2 * FB_K);
+            }
         }
         __syncthreads();
     }
@@ -495,7 +500,7 @@ fold_split_big_kernel(const float *__restrict__ grid, const FoldJobs jobs, float
             if (m < M) {
                 float *dst = table + m * D_HID + f0 + 16 * kh;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q)  // (ordinary stores: non-temporal ones measured 636 -> 980 us on the DTU grid, profiles/r06_fold_notes.md)
                     *reinterpret_cast<f32x4 *>(dst + 4 * q) = f32x4{acc[a][b][4 * q] + bv[4 * q], acc[a][b][4 * q + 1] + bv[4 * q + 1],
                                                                     acc[a][b][4 * q + 2] + bv[4 * q + 2], acc[a][b][4 * q + 3] + bv[4 * q + 3]};
             }
