@@ -346,15 +346,18 @@ int pnr_lin_out_grad(const float *g_out, const void *x5, long long P, int precis
                      float *db, void *workspace, void *stream);
 
 /* d(encoder.latent) += bilinear scatter of d_zlat (rows_v,512) fp32 (natural channel order) to
- * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (caller zero-initialises; accumulates).  Grids of up to 5116
- * texels per image (64 x 64 and smaller) are accumulated in fp64 LDS slabs, one per (image, 16- / 8- / 4-channel slice),
+ * d_latent_nhwc (SB*NS,Hl,Wl,512) fp32 (caller zero-initialises; accumulates).  Grids of up to 2274
+ * texels per image (32 x 32 and the like) are accumulated in fp64 LDS slabs, one per (image, 16- / 8-channel slice),
  * fed per ray segment (consecutive samples in one grid cell); a slab reaches HBM with plain read-add-write when one
  * workgroup owns its (image, slice), and with one atomic per touched element otherwise -- never more than two workgroups
- * per pair (the slice width follows the image count), so onto a ZEROED buffer the result is bit-reproducible; larger grids
- * use global fp32 atomics throughout (order-dependent in the last bit).
- * workspace: pnr_latent_scatter_workspace_bytes() bytes of device memory (projected positions + segment lists of the
- * slab form; 0 for the large grids, workspace may then be NULL), owned by the caller so that the call can sit inside a
- * HIP-graph capture (ABI rev 7; rev 6 kept a per-stream scratch inside the library).  (encoder.py:96-109 backward) */
+ * per pair (the slice width follows the image count), so onto a ZEROED buffer the result is bit-reproducible.  Larger grids
+ * (64 x 64, DTU's 150 x 200) are cut into tiles of 32 x 32 texels: one owner workgroup per (image, tile, 16-channel slice)
+ * takes the segments whose corners touch its tile from a binned list and writes the tile back with plain read-add-write
+ * (every texel has one owner; fp64 sums, no HBM atomics).  Objects of 2^29 samples or more, grids of more than 8192 tiles
+ * and PIXELNERF_SCATTER_TILED=0 take global fp32 atomics (order-dependent in the last bit).
+ * workspace: pnr_latent_scatter_workspace_bytes() bytes of device memory, 16-byte aligned (projected positions, segment
+ * lists, tile lists; 0 only on the global-atomic path, workspace may then be NULL), owned by the caller so that the call can
+ * sit inside a HIP-graph capture (ABI rev 7; rev 6 kept a per-stream scratch inside the library).  (encoder.py:96-109 backward) */
 size_t pnr_latent_scatter_workspace_bytes(const PnrScene *scene /*host*/, int R, int rays_per_obj, int K);
 int pnr_latent_scatter(const PnrScene *scene /*host*/, const float *rays, const float *z, int R,
                        int rays_per_obj, int K, const float *d_zlat, float *d_latent_nhwc, void *workspace,

@@ -772,7 +772,8 @@ composite_bwd_kernel(const float *__restrict__ rays, const float *__restrict__ z
 }
 
 // ---------------------------------------------------------------- latent scatter-add
-// One wavefront per (view, run of SCATTER_RUN consecutive points); lane handles channels 8*lane..+7.
+// (global fp32 atomics: since round 6 only the fallback for objects of 2^29+ samples, grids of > 8192 tiles and PIXELNERF_SCATTER_TILED=0 --
+// every other grid takes the LDS-slab forms further down.)  One wavefront per (view, run of SCATTER_RUN consecutive points); lane handles channels 8*lane..+7.
 // Consecutive samples of a ray mostly fall into the same grid cell, so each of the 4 bilinear
 // corners keeps a register accumulator that is flushed with atomics only when its texel changes
 // (run-length merging: ~5x fewer atomics on the 32x32 sn64 grid).
@@ -1079,6 +1080,183 @@ latent_scatter_owner_kernel(const EvalParams q, const float *__restrict__ d_zlat
             if (psplit == 1) *dst += (float)sv;  // this workgroup is the only writer of the (image, slice) in this launch
             else atomicAdd(dst, (float)sv);
         }
+    }
+}
+
+// ---- LARGE grids (DTU: 150 x 200 texels per image; anything whose (image, 4-channel) slab does not fit the LDS).  Rounds 2-5 sent
+// them through global fp32 atomics (latent_scatter_kernel above): 25 M atomics per call of a 1-object x 3-view DTU training step,
+// 965 us -- the largest kernel of that step -- and order-dependent.  Round 6: the slab form with the image cut into TILES of
+// 32 x 32 texels.  A workgroup owns (image, tile, 16-channel slice): its slab is the tile (139 KiB of fp64), it takes the ray
+// segments that touch the tile -- a segment's four corners can straddle up to four tiles, so it is listed in each -- adds only the
+// corners that lie INSIDE the tile, and writes the tile back with plain read-add-write: every texel has one owner.
+//   scatter_segments_kernel  (as above)           coords, segment starts per image
+//   tile_bin_kernel<COUNT>                         per (image, tile): how many segments touch it
+//   tile_scan_kernel                               running sums -> list offsets
+//   tile_bin_kernel<FILL>                          segment (start | length - 1 << 29) into the lists of the tiles it touches (one atomic per entry:
+//                                                  the order inside a list is not fixed -- the fp64 slab sum does not depend on it beyond 2^-53)
+//   latent_scatter_tiled_kernel                    lane = (list entry, 4 channels): one trip of <= SEG_B samples, 16 predicated ds_add_f64
+constexpr int TILE_W = 32, TILE_TEXELS = TILE_W * TILE_W, TILE_CS = 16, TILE_ROW = TILE_CS + 1;
+constexpr int TILE_LDS = TILE_TEXELS * TILE_ROW * 8;  // 139,264 B
+
+struct TileGeom { int tx, ty, ntiles; };  // tiles per image row / column, per image
+__device__ __forceinline__ void tiles_of_cell(int x0, int y0, int Wl, int Hl, int tx, int (&tiles)[4], int &n) {
+    const int x1 = min(x0 + 1, Wl - 1), y1 = min(y0 + 1, Hl - 1);
+    const int ax = x0 / TILE_W, bx = x1 / TILE_W, ay = y0 / TILE_W, by = y1 / TILE_W;
+    n = 0;
+    tiles[n++] = ay * tx + ax;
+    if (bx != ax) tiles[n++] = ay * tx + bx;
+    if (by != ay) {
+        tiles[n++] = by * tx + ax;
+        if (bx != ax) tiles[n++] = by * tx + bx;
+    }
+}
+
+// Workgroup = 256 slots of the segment list of one (image, sub-range): every touched tile is first counted in an LDS histogram
+// (ranks from the returning LDS atomic), then ONE global atomic per (workgroup, tile) -- the counters are a hundred addresses, and
+// one global atomic per list entry serialised on them (2 x 66 us for the 36 k segments of a DTU step; 2 x ~5 us this way).
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+tile_bin_kernel(const EvalParams q, const float2 *__restrict__ coords, const int *__restrict__ segs, const int *__restrict__ nseg,
+                const int sub_len, const TileGeom tg, int *__restrict__ tile_cnt, const int *__restrict__ tile_off,
+                int *__restrict__ cursor, unsigned *__restrict__ entries) {
+    extern __shared__ int hist[];  // [ntiles] counts, [ntiles] bases (FILL)
+    const int t = threadIdx.x, k = blockIdx.x * 256 + t, lj = blockIdx.y;
+    const int n_list = nseg[lj];
+    if (blockIdx.x * 256 >= n_list) return;  // uniform
+    for (int i = t; i < tg.ntiles; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int img = lj / SEG_NSUB, j = lj % SEG_NSUB, obj = img / q.NS, view = img % q.NS;
+    const int pts = q.per_obj * q.K;
+    int tiles[4], rank[4], n = 0;
+    unsigned entry = 0;
+    if (k < n_list) {
+        const int *list = segs + (size_t)lj * sub_len;
+        const int s0 = list[k];
+        const int sub_end = (j + 1) * sub_len < pts ? (j + 1) * sub_len : pts;
+        const int s1 = k + 1 < n_list ? list[k + 1] : sub_end;
+        const float2 p0 = coords[(size_t)view * q.P + (size_t)obj * pts + s0];
+        tiles_of_cell((int)floorf(p0.x), (int)floorf(p0.y), q.Wl, q.Hl, tg.tx, tiles, n);
+        entry = (unsigned)s0 | ((unsigned)(s1 - s0 - 1) << 29);
+        for (int c = 0; c < n; ++c) rank[c] = atomicAdd(hist + tiles[c], 1);
+    }
+    __syncthreads();
+    for (int i = t; i < tg.ntiles; i += 256) {
+        const int c = hist[i];
+        if (c) {
+            if (!FILL) atomicAdd(tile_cnt + img * tg.ntiles + i, c);
+            else hist[tg.ntiles + i] = atomicAdd(cursor + img * tg.ntiles + i, c);
+        }
+    }
+    if (FILL) {
+        __syncthreads();
+        for (int c = 0; c < n; ++c) entries[tile_off[img * tg.ntiles + tiles[c]] + hist[tg.ntiles + tiles[c]] + rank[c]] = entry;
+    }
+}
+
+// tile_off[i] = sum of tile_cnt[0 .. i) over all (image, tile) pairs, one workgroup; clears the FILL pass's cursors
+__global__ void __launch_bounds__(1024) tile_scan_kernel(const int *__restrict__ tile_cnt, int n, int *__restrict__ tile_off, int *__restrict__ cursor) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int v = base + t < n ? tile_cnt[base + t] : 0;
+        part[t] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan (n is a few hundred: one round)
+            const int add = t >= o ? part[t - o] : 0;
+            __syncthreads();
+            part[t] += add;
+            __syncthreads();
+        }
+        if (base + t < n) { tile_off[base + t] = carry + part[t] - v; cursor[base + t] = 0; }
+        __syncthreads();
+        if (t == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (t == 0) tile_off[n] = carry;
+}
+
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(OWNER_NT)
+latent_scatter_tiled_kernel(const EvalParams q, const float *__restrict__ d_zlat, const float2 *__restrict__ coords,
+                            const unsigned *__restrict__ entries, const int *__restrict__ tile_off, const TileGeom tg,
+                            float *__restrict__ d_latent) {
+    extern __shared__ double dslab[];  // [32 x 32 texels][TILE_ROW]
+    constexpr int LPS = TILE_CS / 4, NSL = C_LAT / TILE_CS, GRP = 32 / TILE_CS;
+    const int t = threadIdx.x;
+    // XCD-aware placement as in the slab kernel: the slices that share 128-byte lines get consecutive slots of ONE XCD
+    const int lid = blockIdx.x, ngroups = gridDim.x / GRP, full = (ngroups >> 3) * (8 * GRP);
+    int grp, sub;
+    if (lid < full) { const int k = lid >> 3; grp = (k / GRP) * 8 + (lid & 7); sub = k % GRP; }
+    else { const int rem = lid - full; grp = full / GRP + rem / GRP; sub = rem % GRP; }
+    const int cs = (grp % (NSL / GRP)) * GRP + sub;
+    const int it = grp / (NSL / GRP);  // (image, tile)
+    const int img = it / tg.ntiles, tile = it % tg.ntiles;
+    const int obj = img / q.NS, view = img % q.NS;
+    const int tx0 = (tile % tg.tx) * TILE_W, ty0 = (tile / tg.tx) * TILE_W;
+    const int e_begin = tile_off[it], e_end = tile_off[it + 1];
+    if (e_begin == e_end) return;  // no ray crosses this tile: nothing to add (uniform over the workgroup)
+    for (int i = t; i < TILE_TEXELS * TILE_ROW; i += OWNER_NT) dslab[i] = 0.0;
+    const long long pts = (long long)q.per_obj * q.K;
+    const size_t row0 = (size_t)view * q.P + (size_t)obj * pts;
+    const float *grad = d_zlat + row0 * C_LAT + cs * TILE_CS;
+    const float2 *xy = coords + row0;
+    const int Wl = q.Wl, Hl = q.Hl;
+    const int part = t % LPS;
+    __syncthreads();
+    for (int i = e_begin + t / LPS; i < e_end; i += OWNER_NT / LPS) {
+        const unsigned en = entries[i];
+        const int s0 = (int)(en & 0x1fffffffu), len = (int)(en >> 29) + 1;
+        float2 pos[SEG_B];
+        f32x4 v[SEG_B];
+#pragma unroll
+        for (int b = 0; b < SEG_B; ++b) {
+            pos[b] = make_float2(0.f, 0.f);
+            v[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (b < len) {
+                pos[b] = xy[s0 + b];
+                v[b] = reinterpret_cast<const f32x4 *>(grad + (size_t)(s0 + b) * C_LAT)[part];
+            }
+        }
+        const float ix0 = floorf(pos[0].x), iy0 = floorf(pos[0].y);  // the segment's cell
+        const float ix1 = ix0 + 1.f, iy1 = iy0 + 1.f;
+        const int x0 = (int)ix0, y0 = (int)iy0;
+        const bool x_in = x0 + 1 <= Wl - 1, y_in = y0 + 1 <= Hl - 1;  // out-of-range corner has weight 0 (project_point)
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < SEG_B; ++b) {
+            const float2 p = pos[b];  // slots beyond the segment carry zero gradients
+            float w[4] = {(ix1 - p.x) * (iy1 - p.y), (p.x - ix0) * (iy1 - p.y), (ix1 - p.x) * (p.y - iy0), (p.x - ix0) * (p.y - iy0)};
+            if (!x_in) { w[1] = 0.f; w[3] = 0.f; }
+            if (!y_in) { w[2] = 0.f; w[3] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][e] += w[c] * v[b][e];
+        }
+        const int x1 = min(x0 + 1, Wl - 1), y1 = min(y0 + 1, Hl - 1);
+        const int cx[4] = {x0, x1, x0, x1}, cy[4] = {y0, y0, y1, y1};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int lx = cx[c] - tx0, ly = cy[c] - ty0;
+            if ((unsigned)lx < (unsigned)TILE_W && (unsigned)ly < (unsigned)TILE_W) {  // this tile owns the corner's texel
+                double *dst = dslab + (ly * TILE_W + lx) * TILE_ROW + part * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dst + e, (double)acc[c][e]);  // ds_add_f64, no return
+            }
+        }
+    }
+    __syncthreads();
+    float *out = d_latent + (size_t)img * Hl * Wl * C_LAT + cs * TILE_CS;
+    for (int i = t; i < TILE_TEXELS * TILE_CS; i += OWNER_NT) {
+        const int tex = i / TILE_CS, ch = i % TILE_CS;
+        const int x = tx0 + tex % TILE_W, y = ty0 + tex / TILE_W;
+        const double sv = dslab[tex * TILE_ROW + ch];
+        if (sv != 0.0 && x < Wl && y < Hl) out[(size_t)(y * Wl + x) * C_LAT + ch] += (float)sv;  // the only writer of this texel
     }
 }
 #pragma clang fp contract(fast)
@@ -1616,12 +1794,41 @@ static size_t scatter_ws_bytes(int images, int NS, long long P, long long pts) {
     return (size_t)NS * P * sizeof(float2) + (size_t)images * SEG_NSUB * scatter_sub_len(pts) * sizeof(int) + (size_t)images * SEG_NSUB * sizeof(int);
 }
 
+// large grids (tiled form) add: per (image, tile) counts | offsets (+1) | cursors | list entries, at most four per segment
+static pnr::TileGeom tile_geom(int Hl, int Wl) {
+    pnr::TileGeom g;
+    g.tx = (Wl + pnr::TILE_W - 1) / pnr::TILE_W; g.ty = (Hl + pnr::TILE_W - 1) / pnr::TILE_W; g.ntiles = g.tx * g.ty;
+    return g;
+}
+static size_t scatter_tiled_extra_bytes(int images, int ntiles, int NS, long long P) {
+    return ((size_t)images * ntiles * 3 + 1) * sizeof(int) + 4 * (size_t)NS * P * sizeof(unsigned);
+}
+// Grids whose slab only fits 4 channels wide (2275 .. 5116 texels: the 64 x 64 grids of SRN-sized images) read the gradient rows in
+// 16-byte pieces; cut into tiles they read 64-byte pieces like the small grids (4 x 64 x 64: 165 -> see profiles/r06_scatter_notes.md).
+// PNR_SCATTER_TILED_MIN_TEXELS moves the crossover (experiment hook).
+static bool scatter_prefers_tiles(int cs, int texels) {
+    static const long long min_texels = [] { const char *e = getenv("PNR_SCATTER_TILED_MIN_TEXELS"); return e ? atoll(e) : -1LL; }();
+    if (min_texels >= 0) return texels >= min_texels;
+    int r = 0;
+    return cs == 4 && !slab_row(texels, 8, r);  // (one or two small images also get cs == 4 -- for the pair count; they stay slabs)
+}
+// the tiled form needs 29-bit sample indices inside an object; beyond that (and with PIXELNERF_SCATTER_TILED=0) the global-atomic kernel runs
+static bool scatter_tiled_ok(long long pts, int ntiles = 1) {
+    if (ntiles > 8192) return false;  // (the binning histogram lives in LDS: 2 x 4 bytes per tile)
+    static const bool off = [] { const char *e = getenv("PIXELNERF_SCATTER_TILED"); return e && e[0] == '0'; }();
+    return !off && pts < (1LL << 29);
+}
+
 extern "C" size_t pnr_latent_scatter_workspace_bytes(const PnrScene *s, int R, int rays_per_obj, int K) {
     if (!s || R <= 0 || K <= 0 || rays_per_obj <= 0) return 0;
     int cs, row;
     scatter_form(s->Hl * s->Wl, s->SB * s->NS, cs, row);
-    if (!cs) return 0;
-    return scatter_ws_bytes(s->SB * s->NS, s->NS, (long long)R * K, (long long)rays_per_obj * K);
+    const long long P = (long long)R * K, pts = (long long)rays_per_obj * K;
+    if (scatter_prefers_tiles(cs, s->Hl * s->Wl) && scatter_tiled_ok(pts, tile_geom(s->Hl, s->Wl).ntiles)) cs = 0;
+    if (cs) return scatter_ws_bytes(s->SB * s->NS, s->NS, P, pts);
+    if (!scatter_tiled_ok(pts, tile_geom(s->Hl, s->Wl).ntiles)) return 0;
+    return (scatter_ws_bytes(s->SB * s->NS, s->NS, P, pts) + 15) / 16 * 16 +
+           scatter_tiled_extra_bytes(s->SB * s->NS, tile_geom(s->Hl, s->Wl).ntiles, s->NS, P);
 }
 
 extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const float *z, int R, int rays_per_obj, int K,
@@ -1637,6 +1844,7 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
     const int texels = q.Hl * q.Wl;
     int cs, row;
     scatter_form(texels, q.SB * q.NS, cs, row);
+    if (scatter_prefers_tiles(cs, texels) && scatter_tiled_ok((long long)rays_per_obj * K, tile_geom(q.Hl, q.Wl).ntiles)) cs = 0;
     int force_psplit = 0;
     if (const char *e = getenv("PNR_SCATTER_FORM")) {  // experiment hook "cs,psplit": force the slice width (16 / 8 / 4) and the point split
         int fcs = 0, fps = 0;
@@ -1677,6 +1885,41 @@ extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const fl
                            segs, nseg, sub_len);
         hipLaunchKernelGGL(k, dim3((unsigned)(owners * psplit)), dim3(OWNER_NT), lds, (hipStream_t)stream, q, d_zlat, coords, segs, nseg,
                            sub_len, d_latent_nhwc, psplit, row);
+        return pnr_check_launch("pnr_latent_scatter");
+    }
+    const long long pts_obj = (long long)rays_per_obj * K;
+    if (scatter_tiled_ok(pts_obj, tile_geom(q.Hl, q.Wl).ntiles)) {
+        // large grid: 32 x 32-texel tiles, one owner workgroup per (image, tile, 16-channel slice) (latent_scatter_tiled_kernel)
+        const int images = q.SB * q.NS;
+        const TileGeom tg = tile_geom(q.Hl, q.Wl);
+        const size_t base_bytes = (scatter_ws_bytes(images, q.NS, q.P, pts_obj) + 15) / 16 * 16;
+        if (!workspace || workspace_bytes < base_bytes + scatter_tiled_extra_bytes(images, tg.ntiles, q.NS, q.P) || ((uintptr_t)workspace & 15) != 0)
+            return pnr_fail(PNR_E_INVALID, "pnr_latent_scatter: workspace missing, misaligned (16 bytes) or smaller than "
+                                           "pnr_latent_scatter_workspace_bytes()");
+        char *scratch = reinterpret_cast<char *>(workspace);
+        const size_t coords_bytes = (size_t)q.NS * q.P * sizeof(float2);
+        const int sub_len = scatter_sub_len(pts_obj);
+        const size_t segs_bytes = (size_t)images * SEG_NSUB * sub_len * sizeof(int);
+        float2 *coords = reinterpret_cast<float2 *>(scratch);
+        int *segs = reinterpret_cast<int *>(scratch + coords_bytes);
+        int *nseg = reinterpret_cast<int *>(scratch + coords_bytes + segs_bytes);
+        const int IT = images * tg.ntiles;
+        int *tile_cnt = reinterpret_cast<int *>(scratch + base_bytes);
+        int *tile_off = tile_cnt + IT, *cursor = tile_off + IT + 1;
+        unsigned *entries = reinterpret_cast<unsigned *>(cursor + IT);
+        hipStream_t st = (hipStream_t)stream;
+        hipError_t e = hipMemsetAsync(tile_cnt, 0, (size_t)IT * sizeof(int), st);
+        if (e != hipSuccess) return pnr_check_hip(e, "hipMemsetAsync(tile counts)");
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(latent_scatter_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS);
+        if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(latent_scatter_tiled_kernel)");
+        hipLaunchKernelGGL(scatter_segments_kernel, dim3((unsigned)(images * SEG_NSUB)), dim3(SEG_NT), 0, st, q, coords, segs, nseg, sub_len);
+        const dim3 bgrid((unsigned)((sub_len + 255) / 256), (unsigned)(images * SEG_NSUB));
+        const size_t bin_lds = 2 * (size_t)tg.ntiles * sizeof(int);
+        hipLaunchKernelGGL(tile_bin_kernel<false>, bgrid, dim3(256), bin_lds, st, q, coords, segs, nseg, sub_len, tg, tile_cnt, tile_off, cursor, entries);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_cnt, IT, tile_off, cursor);
+        hipLaunchKernelGGL(tile_bin_kernel<true>, bgrid, dim3(256), bin_lds, st, q, coords, segs, nseg, sub_len, tg, tile_cnt, tile_off, cursor, entries);
+        hipLaunchKernelGGL(latent_scatter_tiled_kernel, dim3((unsigned)(IT * (C_LAT / TILE_CS))), dim3(OWNER_NT), TILE_LDS, st, q, d_zlat, coords,
+                           entries, tile_off, tg, d_latent_nhwc);
         return pnr_check_launch("pnr_latent_scatter");
     }
     const long long n = ((q.P + SCATTER_RUN - 1) / SCATTER_RUN) * q.NS;  // wavefronts

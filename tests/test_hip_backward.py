@@ -175,9 +175,10 @@ def test_training_converges_on_a_fixed_batch(dev):
 
 # LDS-slab kernel (16 / 8 / 4 channels with padded rows, 4 channels unpadded: 64x64; one owner per (image, slice) or -- 600 rays x 20
 # samples on 4 x 32 slices -- two workgroups per pair that meet in HBM with atomics; K = 10 / 20: ray boundaries off the segment
-# grid) / global-atomic kernel (5760 texels)
+# grid) / large grids (5760 texels = 3 x 3 tiles with ragged edges; the DTU grid 150 x 200; 33 x 97: a tile row of ONE texel row): the
+# tiled form -- a workgroup per (image, 32 x 32-texel tile, 16-channel slice), segments listed in every tile their corners touch
 @pytest.mark.parametrize("Hl,Wl,n_rays,K", [(16, 16, 24, 10), (40, 40, 24, 10), (50, 60, 24, 10), (64, 64, 24, 10), (72, 80, 24, 10),
-                                           (16, 16, 600, 20), (32, 32, 128, 96)])
+                                           (16, 16, 600, 20), (32, 32, 128, 96), (150, 200, 64, 24), (33, 97, 200, 16)])
 def test_latent_scatter_matches_autograd(dev, Hl, Wl, n_rays, K):
     """d(interpolated latent) -> d(feature grid) for SB=2 x NS=2, against autograd through the oracle's lookup
     (encoder.py:80-109).  fp32 on both sides (the slab kernel sums per-segment fp32 partial sums in fp64); 1e-5 relative."""

@@ -11,7 +11,8 @@ from testdata import synthetic
 dev = torch.device("cuda:0")
 tag = os.path.basename(os.environ.get("PIXELNERF_HIP_LIB", "product"))
 gen = torch.Generator().manual_seed(3)
-for name, K, hw in (("train", 64, None), ("train", 96, None), ("train_mv", 96, None), ("train", 96, 64)):
+torch.manual_seed(3)
+for name, K, hw in (("train", 64, None), ("train", 96, None), ("train_mv", 96, None), ("train", 96, 64), ("dtu", 96, None)):
     s, meta = synthetic.make_scene(name)
     lat = s["latent"] if hw is None else torch.randn(s["latent"].shape[0], 512, hw, hw, generator=gen)
     sc = ops.make_scene(lat.to(dev), s["poses"].to(dev), s["focal"].to(dev), s["c"].to(dev), s["image_shape"], s["NS"])
