@@ -1032,6 +1032,7 @@ def main():
                             ("train_step_multiview", lambda: extra_train_step(dev, "f16", "train_mv", steps=20, warmup=4, with_graph=False)),
                             ("train_step_fp32_class", lambda: extra_train_step(dev, "f16x3", steps=16, warmup=4, with_graph=True)),
                             ("train_step_fp32_class_multiview", lambda: extra_train_step(dev, "f16x3", "train_mv", steps=12, warmup=3, with_graph=False)),
+                            ("train_step_fp32_class_dtu", lambda: extra_train_step(dev, "f16x3", "dtu", steps=12, warmup=3, with_graph=False)),
                             ("train_step_fp32_class_gemm_per_layer", lambda: train_step_unfused_twin(dev)),
                             ("train_step_torch_eager_gpu_baseline", lambda: train_step_eager_torch(dev)),
                             ("train_step_fp32_validation_path", lambda: extra_train_step(dev, "f32", steps=5, warmup=2, with_graph=False)),

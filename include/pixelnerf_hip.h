@@ -75,7 +75,7 @@ int pnr_version(int *major, int *minor);
 /* ABI revision of THIS header: bumped whenever a struct layout or an entry point's argument list changes.  The
  * library returns the value it was compiled with; a binding must compare it with the header it was written against
  * before the first call (pixelnerf_amd/_lib.py does, and refuses a stale or foreign .so). */
-#define PNR_ABI_VERSION 7
+#define PNR_ABI_VERSION 8
 int pnr_abi_version(void);
 int pnr_device_info(int *num_cus, int *lds_bytes_per_block);
 
@@ -135,6 +135,18 @@ size_t pnr_packed_mlp_split_bytes(void);
 int pnr_pack_mlp_split(const PnrMlpWeights *w /*host*/, void *packed_split, void *stream);
 size_t pnr_folded_tables_f32_bytes(const PnrScene *scene /*host*/);
 int pnr_fold_latent_f32(const PnrScene *scene /*host*/, const PnrMlpWeights *w /*host*/, float *tables_f32, void *stream);
+/* The same tables for the texels ONE training pass reads (ABI rev 8).  A training step re-folds lin_z every pass -- the
+ * weights moved -- and on a large grid most texels are not near any ray of the pass (DTU, 128 rays x 3 views: 37-43 k of
+ * 90 k).  rays (R,8), z (R,K) = the pass's samples: every (view, point) is projected with the forward kernels' own code, its
+ * four corner rows are marked, the marked rows are folded (same sums, same order: the bits of pnr_fold_latent_f32) and written
+ * at their texels' places; all other rows of tables_f32 keep what they held -- hand in a buffer that was zero-initialised once
+ * and use it only for a pnr_eval_ray_samples_split_train call on the SAME rays and z.  workspace:
+ * pnr_fold_latent_f32_rows_workspace_bytes() bytes of device memory, 16-byte aligned, caller-owned (graph capture).
+ * Takes grids of >= 8192 texels in total (smaller ones: pnr_fold_latent_f32 is one short launch). */
+size_t pnr_fold_latent_f32_rows_workspace_bytes(const PnrScene *scene /*host*/);
+int pnr_fold_latent_f32_rows(const PnrScene *scene /*host*/, const PnrMlpWeights *w /*host*/, const float *rays, const float *z,
+                             int R, int rays_per_obj, int K, float *tables_f32, void *workspace, size_t workspace_bytes,
+                             void *stream);
 int pnr_eval_ray_samples_split(const PnrScene *scene /*host*/, const void *packed_split, const void *tables_f32,
                                const float *rays, const float *z, int R, int rays_per_obj, int K, float *rgbsigma,
                                void *stream);

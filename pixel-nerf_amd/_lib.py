@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("PIXELNERF_HIP_LIB") or os.path.join(CSRC, "libpixelne
 SOURCES = ["pnr_api.hip", "pnr_pack.hip", "pnr_render.hip", "pnr_mlp.hip", "pnr_split.hip", "pnr_bwd.hip", "pnr_f32.hip", "pnr_encode.hip"]
 HEADERS = ["pnr_common.h", "pnr_layout.h", "pnr_device.h", "pnr_raysrc.h", "pnr_internal.h", os.path.join("..", "..", "include", "pixelnerf_hip.h")]
 
-ABI_VERSION = 7  # PNR_ABI_VERSION of the include/pixelnerf_hip.h this binding (struct layouts, argtypes below) was written against
+ABI_VERSION = 8  # PNR_ABI_VERSION of the include/pixelnerf_hip.h this binding (struct layouts, argtypes below) was written against
 PREC_F16, PREC_BF16, PREC_F32, PREC_F16X3 = 0, 1, 2, 3
 PRECISIONS = {"f16": PREC_F16, "fp16": PREC_F16, "bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -144,6 +144,8 @@ PROTOTYPES = {
     "pnr_linear": (_I, [_P, _P, _P, _P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P]),
     "pnr_linear_backward_workspace_bytes": (_SZ, [_I, _I]),
     "pnr_linear_backward": (_I, [_P, _P, _P, ctypes.c_longlong, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _I, _P]),
+    "pnr_fold_latent_f32_rows_workspace_bytes": (_SZ, [ctypes.POINTER(PnrScene)]),
+    "pnr_fold_latent_f32_rows": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "pnr_latent_scatter_workspace_bytes": (_SZ, [ctypes.POINTER(PnrScene), _I, _I, _I]),
     "pnr_latent_scatter": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "pnr_composite": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),

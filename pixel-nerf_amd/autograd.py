@@ -81,7 +81,7 @@ def _train_eval(net, scene, coarse, rays, z):
     ops.saturation_guard_slot(rays.device, 0 if coarse else 1)  # (when the fp16-range guard is armed for this call)
     if net.precision == "f16x3" and FUSED_SPLIT_TRAINING:
         pk = net.packed(coarse, training_pass=True)  # the folded split stream of inference (before tables(): packed() runs the content check)
-        return ops.eval_ray_samples_split_train(scene, pk, net.tables(coarse), rays, z)
+        return ops.eval_ray_samples_split_train(scene, pk, net.training_tables(coarse, rays, z, scene=scene), rays, z)  # (large grids: only the rows the pass reads)
     if net.precision in ("f32", "f16x3"):
         mlp = net.mlp_coarse if (coarse or net.mlp_fine is None) else net.mlp_fine
         return ops.eval_ray_samples_f32_train(scene, mlp.packed("f32"), rays, z, split=net.precision == "f16x3")

@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "pnr_common.h"
+#include "pnr_device.h"  // EvalParams, project_point: the sparse fold marks rows with the forward kernels' own projection
 #include "pnr_internal.h"
 #include "pnr_layout.h"
 
@@ -366,19 +367,28 @@ fold_split_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__
 constexpr int FB_TM = 256, FB_TN = 256, FB_K = 32;
 constexpr int FB_IMG = FB_TM * FB_K * 2;  // bytes of one image (256 rows x 64 B)
 constexpr int FB_LDS = 2 * 4 * FB_IMG;     // [buffer][Xh, Xl, Wh, Wl]
+// SPARSE (training on large grids, pnr_fold_latent_f32_rows): the row tile is a run of 256 entries of `rows` -- the texels one
+// training pass reads, in ascending order -- and M is the device-side count *nrows; a table row is written at its texel's
+// place, so the kernel that reads the tables is unchanged.  Every row is the same sum in the same order as in the dense form.
+template <bool SPARSE>
 __global__ void __launch_bounds__(512)
 fold_split_big_kernel(const float *__restrict__ grid, const FoldJobs jobs, float *__restrict__ tables, long long M, int ngroups,
-                      unsigned int *sat) {
+                      unsigned int *sat, const int *__restrict__ rows, const int *__restrict__ nrows) {
     extern __shared__ __attribute__((aligned(16))) char fb[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     // (XCD, slot) -> (row tile, column tile, table)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int group = (slot / 6) * 8 + xcd, sub = slot % 6;
     if (group >= ngroups) return;
+    const long long table_rows = M;  // rows of one table (its stride)
+    if (SPARSE) {
+        M = *nrows;
+        if ((long long)group * FB_TM >= M) return;  // uniform
+    }
     const int tab = sub >> 1;
     const float *__restrict__ W = jobs.W[tab];
     const float *__restrict__ bias = jobs.bias[tab];
-    float *__restrict__ table = tables + (size_t)tab * (size_t)M * D_HID;
+    float *__restrict__ table = tables + (size_t)tab * (size_t)table_rows * D_HID;
     const long long m0 = (long long)group * FB_TM;
     const int n0 = (sub & 1) * FB_TN;
     const int wm = (w >> 1) * 64, wn = (w & 1) * 128;  // wave tile: 64 texels x 128 features
@@ -399,12 +409,18 @@ fold_split_big_kernel(const float *__restrict__ grid, const FoldJobs jobs, float
     // byte offset of (row, 16-byte unit u) inside an image
     auto img_off = [](int row, int u) { return row * 64 + ((u ^ ((row >> 1) & 3)) << 4); };
     f32x4 xv[4], wv[4];
+    long long xrow[4];  // grid row of this thread's four chunk rows (SPARSE: through the list; -1 beyond its end)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long m = m0 + ((t + u * 512) >> 3);
+        xrow[u] = m < M ? (SPARSE ? (long long)rows[m] : m) : -1;
+    }
     // thread -> (row, 4 columns) of a 256-row x 32-column chunk: 8 consecutive threads read one row's 128 bytes
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = t + u * 512, row = e >> 3, c4 = (e & 7) * 4;
-            xv[u] = (m0 + row < M) ? *reinterpret_cast<const f32x4 *>(grid + (m0 + row) * C_LAT + k0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            xv[u] = xrow[u] >= 0 ? *reinterpret_cast<const f32x4 *>(grid + xrow[u] * C_LAT + k0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
             wv[u] = *reinterpret_cast<const f32x4_param *>(W + (size_t)(n0 + row) * C_LAT + k0 + c4);
         }
     };
@@ -498,7 +514,7 @@ fold_split_big_kernel(const float *__restrict__ grid, const FoldJobs jobs, float
         for (int b = 0; b < 2; ++b) {
             const long long m = m0 + wm + b * 32 + i;
             if (m < M) {
-                float *dst = table + m * D_HID + f0 + 16 * kh;
+                float *dst = table + (SPARSE ? (long long)rows[m] : m) * D_HID + f0 + 16 * kh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)  // (ordinary stores: non-temporal ones measured 636 -> 980 us on the DTU grid, profiles/r06_fold_notes.md)
                     *reinterpret_cast<f32x4 *>(dst + 4 * q) = f32x4{acc[a][b][4 * q] + bv[4 * q], acc[a][b][4 * q + 1] + bv[4 * q + 1],
@@ -507,6 +523,94 @@ fold_split_big_kernel(const float *__restrict__ grid, const FoldJobs jobs, float
         }
     }
     if (sat && amax >= 65504.f) atomicOr(sat, 1u << 12);
+}
+
+// ---- which texels does a training pass read?  (pnr_fold_latent_f32_rows)
+// A training step re-folds lin_z every pass (the weights moved), and on a large grid most of that work is for texels no ray of the
+// pass comes near: 128 rays x 64 / 96 samples x 3 views of a DTU step touch 37-43 k of the 90 k texels (4 objects: ~150 of 360 k).
+// fold_mark_kernel projects every (view, point) with the forward kernels' own code -- geometry_item's rotation and project_point
+// (pnr_device.h), the same operations in the same order without contraction: the same bits, hence the same four corner rows -- and
+// raises a byte per corner texel; fold_rows_count_kernel / fold_rows_compact_kernel turn the bytes into the ascending list of
+// marked rows (4096 texels per workgroup; a workgroup sums the counts of the ones before it).
+constexpr int FM_NT = 256, FR_NT = 1024, FR_PER_WG = 4 * FR_NT;
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(FM_NT) fold_mark_kernel(const EvalParams q, unsigned char *__restrict__ flags) {
+    const long long idx = (long long)blockIdx.x * FM_NT + threadIdx.x;
+    // the padding points of the last tile read texel (0, 0) of object 0's views with weight zero (geometry_item: valid == false)
+    if (idx < q.NS) flags[(size_t)idx * q.Hl * q.Wl] = 1;
+    if (idx >= q.P * q.NS) return;
+    const int view = (int)(idx / q.P), g = (int)(idx % q.P);
+    const int r = g / q.K;
+    const float *ray = q.rays + (size_t)r * 8;
+    const float ox = ray[0], oy = ray[1], oz = ray[2], dx = ray[3], dy = ray[4], dz = ray[5];
+    const float zz = q.z[g];
+    const float X = ox + zz * dx, Y = oy + zz * dy, Z = oz + zz * dz;
+    const int obj = r / q.per_obj;
+    const float *pose = q.poses + (size_t)(obj * q.NS + view) * 12;
+    const float xr0 = pose[0] * X + pose[1] * Y + pose[2] * Z;
+    const float xr1 = pose[4] * X + pose[5] * Y + pose[6] * Z;
+    const float xr2 = pose[8] * X + pose[9] * Y + pose[10] * Z;
+    const Proj pr = project_point(q, pose, obj, view, xr0, xr1, xr2, true);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) flags[pr.off[c] / (uint32_t)C_LAT] = 1;
+}
+#pragma clang fp contract(fast)
+
+__device__ __forceinline__ int popcount_bytes(uint32_t v) { return __popc(v & 0x01010101u); }
+
+__global__ void __launch_bounds__(FR_NT) fold_rows_count_kernel(const uint32_t *__restrict__ flags4, int *__restrict__ block_counts) {
+    __shared__ int part[FR_NT / 64];
+    const int t = threadIdx.x;
+    int c = popcount_bytes(flags4[(size_t)blockIdx.x * FR_NT + t]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((t & 63) == 0) part[t >> 6] = c;
+    __syncthreads();
+    if (t == 0) {
+        int s = 0;
+        for (int i = 0; i < FR_NT / 64; ++i) s += part[i];
+        block_counts[blockIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(FR_NT) fold_rows_compact_kernel(const uint32_t *__restrict__ flags4, const int *__restrict__ block_counts,
+                                                                  long long M, int *__restrict__ rows, int *__restrict__ nrows) {
+    __shared__ int part[FR_NT / 64];
+    __shared__ int base_s;
+    const int t = threadIdx.x, b = blockIdx.x;
+    // rows marked in the workgroups before this one
+    int before = 0;
+    for (int i = t; i < b; i += FR_NT) before += block_counts[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if ((t & 63) == 0) part[t >> 6] = before;
+    __syncthreads();
+    if (t == 0) {
+        int s = 0;
+        for (int i = 0; i < FR_NT / 64; ++i) s += part[i];
+        base_s = s;
+        if (b == (int)gridDim.x - 1) *nrows = s + block_counts[b];
+    }
+    __syncthreads();
+    const uint32_t v = flags4[(size_t)b * FR_NT + t] & 0x01010101u;
+    const int c = __popc(v);
+    int incl = c;  // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if ((t & 63) >= o) incl += up;
+    }
+    if ((t & 63) == 63) part[t >> 6] = incl;
+    __syncthreads();
+    int off = base_s + incl - c;
+    for (int i = 0; i < (t >> 6); ++i) off += part[i];
+    const long long first = (long long)b * FR_PER_WG + 4 * t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((v >> (8 * k)) & 1u) {
+            if (first + k < M) rows[off] = (int)(first + k);
+            ++off;
+        }
 }
 
 
@@ -653,15 +757,69 @@ extern "C" int pnr_fold_latent_f32(const PnrScene *s, const PnrMlpWeights *w, fl
     if (M >= big_min) {
         const int ngroups = (int)((M + FB_TM - 1) / FB_TM);
         const unsigned wgs = (unsigned)((ngroups + 7) / 8) * 8u * 6u;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fold_split_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fold_split_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
         if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(fold_split_big_kernel)");
-        hipLaunchKernelGGL(fold_split_big_kernel, dim3(wgs), dim3(512), FB_LDS, (hipStream_t)stream, s->latent_nhwc, jobs, tables, M, ngroups,
-                           saturation_guard_word());
+        hipLaunchKernelGGL(fold_split_big_kernel<false>, dim3(wgs), dim3(512), FB_LDS, (hipStream_t)stream, s->latent_nhwc, jobs, tables, M, ngroups,
+                           saturation_guard_word(), (const int *)nullptr, (const int *)nullptr);
         return pnr_check_launch("pnr_fold_latent_f32");
     }
     dim3 sgrid((unsigned)((M + FS_TM - 1) / FS_TM), D_HID / FS_TN, COMBINE_LAYER);
     hipLaunchKernelGGL(fold_split_kernel, sgrid, dim3(256), 0, (hipStream_t)stream, s->latent_nhwc, jobs, tables, M, saturation_guard_word());
     return pnr_check_launch("pnr_fold_latent_f32");
+}
+
+// fp32 tables of the texels ONE training pass reads (rays (R,8), z (R,K): the pass's samples); every other row of `tables` keeps
+// what it held.  workspace: marks (one byte per texel, padded to 4096) | per-workgroup counts | row count | row list
+static size_t fold_rows_blocks(long long M) { return (size_t)((M + pnr::FR_PER_WG - 1) / pnr::FR_PER_WG); }
+extern "C" size_t pnr_fold_latent_f32_rows_workspace_bytes(const PnrScene *s) {
+    if (!s || s->SB <= 0 || s->NS <= 0 || s->Hl <= 0 || s->Wl <= 0) return 0;
+    const long long M = (long long)s->SB * s->NS * s->Hl * s->Wl;
+    const size_t nb = fold_rows_blocks(M);
+    return nb * pnr::FR_PER_WG + (nb + 4 + (size_t)M) * sizeof(int);
+}
+
+extern "C" int pnr_fold_latent_f32_rows(const PnrScene *s, const PnrMlpWeights *w, const float *rays, const float *z, int R, int rays_per_obj,
+                                        int K, float *tables, void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace pnr;
+    if (!s || !w || !tables || !s->latent_nhwc || !rays || !z) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32_rows: null argument");
+    if (s->SB <= 0 || s->NS <= 0 || s->Hl < 2 || s->Wl < 2 || R <= 0 || K <= 0 || rays_per_obj <= 0)
+        return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32_rows: bad shape");
+    if ((long long)rays_per_obj * s->SB != R) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32_rows: R != SB * rays_per_obj");
+    const long long M = (long long)s->SB * s->NS * s->Hl * s->Wl, P = (long long)R * K;
+    if (M * C_LAT > 0xffffffffLL || P * s->NS > 0x7fffffffLL) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32_rows: grid or pass too large");
+    if (!workspace || workspace_bytes < pnr_fold_latent_f32_rows_workspace_bytes(s) || ((uintptr_t)workspace & 15) != 0)
+        return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32_rows: workspace missing, misaligned (16 bytes) or smaller than "
+                                       "pnr_fold_latent_f32_rows_workspace_bytes()");
+    FoldJobs jobs;
+    for (int b = 0; b < COMBINE_LAYER; ++b) {
+        if (!w->lin_z_w[b] || !w->lin_z_b[b]) return pnr_fail(PNR_E_INVALID, "pnr_fold_latent_f32_rows: null lin_z parameters");
+        jobs.W[b] = w->lin_z_w[b]; jobs.bias[b] = w->lin_z_b[b];
+    }
+    const size_t nb = fold_rows_blocks(M);
+    unsigned char *flags = reinterpret_cast<unsigned char *>(workspace);
+    int *block_counts = reinterpret_cast<int *>(flags + nb * FR_PER_WG);
+    int *nrows = block_counts + nb;
+    int *rows = nrows + 4;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(flags, 0, nb * FR_PER_WG, st);
+    if (e != hipSuccess) return pnr_check_hip(e, "hipMemsetAsync(fold marks)");
+    EvalParams q = {};
+    q.poses = s->poses; q.focal = s->focal; q.c = s->c;
+    q.SB = s->SB; q.NS = s->NS; q.Hl = s->Hl; q.Wl = s->Wl; q.n_focal = s->n_focal; q.n_c = s->n_c;
+    q.img_w = s->img_w; q.img_h = s->img_h;
+    q.rays = rays; q.z = z; q.K = K; q.per_obj = rays_per_obj; q.P = P;
+    const long long n = P * s->NS;
+    hipLaunchKernelGGL(fold_mark_kernel, dim3((unsigned)((n + FM_NT - 1) / FM_NT)), dim3(FM_NT), 0, st, q, flags);
+    hipLaunchKernelGGL(fold_rows_count_kernel, dim3((unsigned)nb), dim3(FR_NT), 0, st, reinterpret_cast<const uint32_t *>(flags), block_counts);
+    hipLaunchKernelGGL(fold_rows_compact_kernel, dim3((unsigned)nb), dim3(FR_NT), 0, st, reinterpret_cast<const uint32_t *>(flags), block_counts, M,
+                       rows, nrows);
+    const int ngroups = (int)((M + FB_TM - 1) / FB_TM);
+    const unsigned wgs = (unsigned)((ngroups + 7) / 8) * 8u * 6u;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(fold_split_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(fold_split_big_kernel<sparse>)");
+    hipLaunchKernelGGL(fold_split_big_kernel<true>, dim3(wgs), dim3(512), FB_LDS, st, s->latent_nhwc, jobs, tables, M, ngroups,
+                       saturation_guard_word(), (const int *)rows, (const int *)nrows);
+    return pnr_check_launch("pnr_fold_latent_f32_rows");
 }
 
 // split-operand stream: [head blob: folded f16 stream | biases | lin_out bias] [tail blob: folded f16 stream of w - f16(w)]

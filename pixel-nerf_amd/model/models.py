@@ -81,6 +81,7 @@ class PixelNeRFNet(torch.nn.Module):
         self.fold = bool(fold)
         self._scene = None
         self._tables = {}
+        self._sparse_tables = {}  # training_tables(): persistent buffers of the row-wise fold
         self._grad_sync = None  # set for the duration of a call by dist.ShardedRenderWrapper (gradient all-reduce across ranks)
 
     def __getstate__(self):
@@ -88,7 +89,7 @@ class PixelNeRFNet(torch.nn.Module):
         # the device-side scene descriptor (ctypes struct of raw pointers), the folded tables and a sharding wrapper's hook are
         # per-process caches of THIS object and are rebuilt on demand
         d = dict(self.__dict__)
-        d["_scene"], d["_tables"], d["_grad_sync"] = None, {}, None
+        d["_scene"], d["_tables"], d["_sparse_tables"], d["_grad_sync"] = None, {}, {}, None
         return d
 
     # ------------------------------------------------------------------ encode (PyTorch-ROCm)
@@ -207,6 +208,28 @@ class PixelNeRFNet(torch.nn.Module):
         if hit is None or hit[0] != key:
             self._tables[slot] = (key, ops.fold_latent(sc, dict(mlp.state_dict()), self._effective_precision()), sc)
         return self._tables[slot][1]
+
+    def training_tables(self, coarse, rays, z, scene=None):
+        """tables(coarse) for ONE training pass at precision 'f16x3' (autograd._train_eval).  The weights move every step, so a
+        training pass always re-folds; on a large grid most texels are not near any ray of the pass, and only the rows it reads are
+        folded (ops.fold_latent_rows: the same bits in those rows) into a persistent buffer that is zeroed once.  Rule: grids of
+        >= 8192 texels whose pass has fewer (view, point) pairs than the grid has texels -- DTU-sized training; config 5's 4 x 32 x 32
+        grids and every inference call keep the dense fold.  PIXELNERF_SPARSE_FOLD=0 / 1 forces the choice (1: any grid >= 8192)."""
+        import os
+        mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
+        sc = self.scene() if scene is None else scene
+        NV, Hl, Wl, _ = sc.latent_nhwc.shape
+        M, pairs = NV * Hl * Wl, rays.shape[0] * z.shape[1] * sc.NS
+        mode = os.environ.get("PIXELNERF_SPARSE_FOLD", "auto")
+        if M < 8192 or mode == "0" or (mode != "1" and pairs > M) or self._effective_precision() != "f16x3":
+            return self.tables(coarse)
+        slot = "coarse" if mlp is self.mlp_coarse else "fine"
+        key = (sc.latent_nhwc.device, NV, Hl, Wl)
+        hit = self._sparse_tables.get(slot)
+        if hit is None or hit[0] != key:
+            hit = (key, torch.zeros((3, NV, Hl, Wl, 512), dtype=torch.float32, device=sc.latent_nhwc.device))
+            self._sparse_tables[slot] = hit
+        return ops.fold_latent_rows(sc, dict(mlp.state_dict()), rays, z, hit[1])
 
     # ---- fp16-range guard of the fp32-class precision (ops.saturation_guard_*; include/pixelnerf_hip.h).  "f16x3" represents
     # every operand as an fp16 (head, tail) pair: exact to ~2^-22 up to 65504, SATURATING beyond -- silently outside the

@@ -157,6 +157,26 @@ def fold_latent(scene, state, precision="f16"):
     return tables
 
 
+def fold_latent_rows(scene, state, rays, z, tables):
+    """The 'f16x3' tables of fold_latent() for the texels ONE training pass reads (pnr_fold_latent_f32_rows): rays (R,8), z (R,K) =
+    the pass's samples.  Writes the marked rows of `tables` ((3, SB*NS, Hl, Wl, 512) fp32, zero-initialised once by the caller) in
+    place; use the buffer only for an eval_ray_samples_split_train call on the same rays and z.  Grids of >= 8192 texels."""
+    lib = _lib.load()
+    w, keep = _weights_struct(state)
+    NV, Hl, Wl, _ = scene.latent_nhwc.shape
+    if tables.dtype != torch.float32 or tuple(tables.shape) != (3, NV, Hl, Wl, 512) or not tables.is_contiguous():
+        raise _lib.PixelNerfHipError("fold_latent_rows: tables must be a contiguous (3, SB*NS, Hl, Wl, 512) fp32 tensor")
+    rays = _f32(rays, "rays", (None, 8))
+    R = rays.shape[0]
+    z = _f32(z, "z", (R, None))
+    nbytes = int(lib.pnr_fold_latent_f32_rows_workspace_bytes(scene.ref))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=scene.device)
+    with torch.cuda.device(scene.device):
+        _lib.check(lib.pnr_fold_latent_f32_rows(scene.ref, ctypes.byref(w), _p(rays), _p(z), R, max(R // scene.SB, 1), z.shape[1], _p(tables),
+                                                _p(ws), nbytes, _stream()), "pnr_fold_latent_f32_rows")
+    return tables
+
+
 def _check_fold(packed, tables, what):
     if packed.folded != (tables is not None):
         raise _lib.PixelNerfHipError(f"{what}: a folded network stream needs its fold_latent() tables (and only it takes them)")
