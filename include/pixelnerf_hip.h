@@ -371,6 +371,10 @@ int pnr_lin_out_grad(const float *g_out, const void *x5, long long P, int precis
  * lists, tile lists; 0 only on the global-atomic path, workspace may then be NULL), owned by the caller so that the call can
  * sit inside a HIP-graph capture (ABI rev 7; rev 6 kept a per-stream scratch inside the library).  (encoder.py:96-109 backward) */
 size_t pnr_latent_scatter_workspace_bytes(const PnrScene *scene /*host*/, int R, int rays_per_obj, int K);
+/* 1 when this call shape takes the tiled form (one owner workgroup per grid element, plain read-add-write): several calls may
+ * then accumulate into ONE buffer order-independently (a training step's fine and coarse pass); 0: give every call its own
+ * zeroed buffer and sum them for a bit-reproducible gradient (ABI rev 8) */
+int pnr_latent_scatter_single_owner(const PnrScene *scene /*host*/, int R, int rays_per_obj, int K);
 int pnr_latent_scatter(const PnrScene *scene /*host*/, const float *rays, const float *z, int R,
                        int rays_per_obj, int K, const float *d_zlat, float *d_latent_nhwc, void *workspace,
                        size_t workspace_bytes, void *stream);

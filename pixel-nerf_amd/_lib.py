@@ -147,6 +147,7 @@ PROTOTYPES = {
     "pnr_fold_latent_f32_rows_workspace_bytes": (_SZ, [ctypes.POINTER(PnrScene)]),
     "pnr_fold_latent_f32_rows": (_I, [ctypes.POINTER(PnrScene), ctypes.POINTER(PnrMlpWeights), _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "pnr_latent_scatter_workspace_bytes": (_SZ, [ctypes.POINTER(PnrScene), _I, _I, _I]),
+    "pnr_latent_scatter_single_owner": (_I, [ctypes.POINTER(PnrScene), _I, _I, _I]),
     "pnr_latent_scatter": (_I, [ctypes.POINTER(PnrScene), _P, _P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "pnr_composite": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "pnr_render_workspace_bytes": (_SZ, [_I, _I, _I]),

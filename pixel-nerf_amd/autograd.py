@@ -180,7 +180,13 @@ class _RenderFunction(torch.autograd.Function):
         # per element and call (its owner workgroups split the points at most two ways on a full-size batch), and two terms onto
         # zero commute -- the latent gradient, and with it the whole step, is then bit-reproducible.  Accumulating the fine and
         # the coarse pass into ONE buffer made the second call's adds land on non-zero values in either order.
-        d_lat = torch.zeros((len(ctx.passes), ctx.latent_shape[0], ctx.latent_shape[2], ctx.latent_shape[3], ctx.latent_shape[1]),
+        # Large grids take the scatter's tiled form -- one owner workgroup per element, plain read-add-write -- where accumulation is
+        # order-free anyway: ONE buffer for all passes (the same bits as the sum of per-pass buffers: 0 + a is exact), which saves a
+        # fill and a sum over a grid-sized tensor (DTU: 3 x 184 MB of traffic per step).
+        n_buf = len(ctx.passes)
+        if need_latent and n_buf > 1 and all(ops.latent_scatter_single_owner(scene, ps["z"].shape[0], ps["z"].shape[1]) for ps in ctx.passes):
+            n_buf = 1
+        d_lat = torch.zeros((n_buf, ctx.latent_shape[0], ctx.latent_shape[2], ctx.latent_shape[3], ctx.latent_shape[1]),
                             dtype=torch.float32, device=dev) if need_latent else None
         shared = net.mlp_fine is None  # fine pass ran on the coarse network (models.py:242)
         gsum = [None, None]
@@ -207,7 +213,7 @@ class _RenderFunction(torch.autograd.Function):
             slot = 0 if (ps["coarse"] or shared) else 1
             gsum[slot] = grads if gsum[slot] is None else {k: gsum[slot][k] + v for k, v in grads.items()}
             if need_latent:
-                ops.latent_scatter(scene, rays, ps["z"], d_zlat, d_lat[i])
+                ops.latent_scatter(scene, rays, ps["z"], d_zlat, d_lat[i if n_buf > 1 else 0])
             if pos:
                 # only the depth samples carry position gradient: compositing part (dz) + network-input part at their
                 # sorted positions, through the clamp z = max(min(depth + n*std, far), near)   (nerf.py:157-160,292)

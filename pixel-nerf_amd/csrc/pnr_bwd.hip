@@ -1831,6 +1831,18 @@ extern "C" size_t pnr_latent_scatter_workspace_bytes(const PnrScene *s, int R, i
            scatter_tiled_extra_bytes(s->SB * s->NS, tile_geom(s->Hl, s->Wl).ntiles, s->NS, P);
 }
 
+// 1: every element of the grid gradient is written by ONE workgroup with plain read-add-write (the tiled form): successive calls may
+// accumulate into one buffer and the result still does not depend on any execution order; 0: the two-workgroups-per-pair / global-atomic
+// forms, which are order-free only onto a zeroed buffer
+extern "C" int pnr_latent_scatter_single_owner(const PnrScene *s, int R, int rays_per_obj, int K) {
+    if (!s || R <= 0 || K <= 0 || rays_per_obj <= 0) return 0;
+    int cs, row;
+    scatter_form(s->Hl * s->Wl, s->SB * s->NS, cs, row);
+    const bool tiles_ok = scatter_tiled_ok((long long)rays_per_obj * K, tile_geom(s->Hl, s->Wl).ntiles);
+    if (getenv("PNR_SCATTER_FORM")) return 0;  // (experiment hook active: unknown form)
+    return ((cs == 0 || scatter_prefers_tiles(cs, s->Hl * s->Wl)) && tiles_ok) ? 1 : 0;
+}
+
 extern "C" int pnr_latent_scatter(const PnrScene *s, const float *rays, const float *z, int R, int rays_per_obj, int K,
                                   const float *d_zlat, float *d_latent_nhwc, void *workspace, size_t workspace_bytes, void *stream) {
     if (!s || !rays || !z || !d_zlat || !d_latent_nhwc || R <= 0 || K <= 0 || rays_per_obj <= 0)

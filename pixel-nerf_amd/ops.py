@@ -1284,6 +1284,12 @@ def mlp_backward(packed_bwd, fwd_dumps, g_out, grad_scale):
     return out
 
 
+def latent_scatter_single_owner(scene, R, K):
+    """True when latent_scatter() on (R rays, K samples) writes every grid element from ONE workgroup (large grids: the tiled form):
+    successive calls may then accumulate into one buffer without losing bit-reproducibility (pnr_latent_scatter_single_owner)."""
+    return bool(_lib.load().pnr_latent_scatter_single_owner(scene.ref, int(R), max(int(R) // scene.SB, 1), int(K)))
+
+
 def latent_scatter(scene, rays, z, d_zlat, d_latent_nhwc):
     lib = _lib.load()
     rays = _f32(rays, "rays", (None, 8))

@@ -137,6 +137,14 @@ def test_training_step_through_the_rowwise_fold_ends_in_the_dense_bits(monkeypat
     bad = [(n, float((a - b).abs().max())) for n, a, b in zip(names, sparse[1:], dense[1:]) if not torch.equal(a, b)]
     assert not bad, bad
     assert float(lat.grad.abs().max()) > 0
+    # the grid gradient of both passes accumulated in ONE buffer (large grids: the scatter's tiled form has one owner per element)
+    # = the sum of per-pass buffers, bit for bit
+    assert ops.latent_scatter_single_owner(net.scene(), rays.shape[0] * rays.shape[1], 64)
+    monkeypatch.setattr(ops, "latent_scatter_single_owner", lambda *a, **k: False)
+    body()
+    two = snapshot()
+    monkeypatch.undo()
+    assert torch.equal(two[-1], sparse[-1]) and two[0] == sparse[0]
     # captured: memset + mark + compaction + fold are plain stream work on caller-owned memory
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
