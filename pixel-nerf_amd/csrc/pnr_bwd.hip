@@ -21,6 +21,8 @@
 //                         samples (nerf.py:292), for all points or for the depth samples only.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -634,6 +636,227 @@ dw_split_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__
     if ((tile4 & 1) == 0 && (w & 1) == 0) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
+            float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+            if (kh == 0) bpart[((size_t)job * jobs.nsplit + slice) * D_HID + o0 + wo + a * 32 + i] = v;
+        }
+    }
+}
+
+// dw_split_kernel as ONE wave per SIMD (round 6; the launcher's default): 4 waves of 128 (o) x 128 (k) = 4 x 4 MFMA tiles,
+// 256 accumulator registers per lane (the AGPR half of the 512-register file a 256-thread workgroup owns), 16 fragments per k-step
+// for 48 MFMAs (the 8-wave form: 12 for 24 -- a third less LDS traffic per MFMA), and room for TWO fragment sets: the fragments of
+// k-step j + 1 are read while the MFMAs of k-step j issue, the slab barrier sits BETWEEN the two k-steps of a slab (every LDS read
+// of a slab is issued before it, so the other buffer may be overwritten right behind it), and no k-step starts with an LDS burst of
+// all waves behind a barrier.  What the 8-wave form does there (ISA): 24 transposing reads at the top of every k-step, waited for,
+// then 24 MFMAs; after the barrier of every second k-step all 8 waves read at once -- 96 KiB through the 128 B/clk LDS pipe = 768
+// clocks against 1536 clocks of MFMAs per k-step and SIMD.
+__global__ void __launch_bounds__(256)
+dw_split_wide_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart) {
+    typedef Prec<PNR_PREC_F16> P;
+    typedef _Float16 T;
+    constexpr int SR = 32, LDB = 576;
+    extern __shared__ __attribute__((aligned(16))) char dws[];  // [buf][dY head, dY tail, X head, X tail][SR * LDB]
+    constexpr int SLAB = SR * LDB;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int lid = blockIdx.x, ngroups = gridDim.x >> 2, full = (ngroups >> 3) * 32;
+    int grp, tile4;
+    if (lid < full) { const int k = lid >> 3; grp = (k >> 2) * 8 + (lid & 7); tile4 = k & 3; }
+    else { const int rem = lid - full; grp = (full >> 2) + (rem >> 2); tile4 = rem & 3; }
+    const int job = grp / jobs.nsplit, slice = grp - job * jobs.nsplit;
+    const long long rows = jobs.rows[job];
+    const int nx = jobs.nx[job];
+    const T *dYh = reinterpret_cast<const T *>(jobs.dY[job]), *dYl = dYh + (size_t)rows * D_HID;
+    const T *Xh = reinterpret_cast<const T *>(jobs.X[job]), *Xl = Xh + (size_t)rows * nx;
+    long long per = (rows + jobs.nsplit - 1) / jobs.nsplit;
+    per = (per + SR - 1) / SR * SR;
+    const int o0 = (tile4 >> 1) * 256, k0 = (tile4 & 1) * 256;
+    if (k0 >= nx) return;  // narrow X (lin_in): only the first column tile exists
+    const long long r_begin = (long long)slice * per;
+    const long long r_end = r_begin + per < rows ? r_begin + per : rows;
+    const int wo = (w >> 1) * 128, wk = (w & 1) * 128;  // wave tile: 128 (o) x 128 (k) = 4 x 4 MFMA tiles
+    const int i = lane & 31, kh = lane >> 5;
+    f32x16 acc[4][4];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // Staging: 4 x (dY head, dY tail, X head, X tail) 16-byte chunks per thread.  The pipelined loop takes FULL slabs only: its loads
+    // are unconditional (uniform base per slab + 32-bit lane offset) and go to LDS as they arrive -- no exec-mask branches and no
+    // selects, so the body is one basic block whose issue order is pinned, and nothing but the LDS stores of the NEXT k-step waits
+    // for a load.  A narrow X (lin_in: 64 of the 256 columns exist) reads column 0 in place of the missing ones: those columns of
+    // the partial products are never read (dw_reduce_kernel stops at the job's width).  A last partial slab of the slice (rows not
+    // a multiple of 32) runs behind the loop with predicated loads.
+    u32x4 vyh[4], vyl[4], vxh[4], vxl[4];
+    unsigned offy[4], offx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int chunk = t + u * 256;  // consecutive lanes -> consecutive 16-byte chunks of a row
+        const int srow = chunk >> 5, scol = (chunk & 31) * 8;
+        offy[u] = (unsigned)(srow * D_HID + scol);
+        offx[u] = (unsigned)(srow * nx + (k0 + scol < nx ? scol : 0));
+    }
+    const int lds_off = (t >> 5) * LDB + (t & 31) * 16;  // chunk u sits 8 rows further down
+    const size_t tail_y = (size_t)rows * D_HID, tail_x = (size_t)rows * nx;
+    auto load_slab = [&](long long r0) {
+        const T *by = dYh + (size_t)r0 * D_HID + o0, *bx = Xh + (size_t)r0 * nx + k0;  // uniform
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            vyh[u] = *reinterpret_cast<const u32x4 *>(by + offy[u]);
+            vyl[u] = *reinterpret_cast<const u32x4 *>(by + tail_y + offy[u]);
+            vxh[u] = *reinterpret_cast<const u32x4 *>(bx + offx[u]);
+            vxl[u] = *reinterpret_cast<const u32x4 *>(bx + tail_x + offx[u]);
+        }
+    };
+    auto store_slab = [&](int buf) {
+        char *base = dws + buf * (4 * SLAB) + lds_off;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *reinterpret_cast<u32x4 *>(base + u * 8 * LDB) = vyh[u];
+            *reinterpret_cast<u32x4 *>(base + SLAB + u * 8 * LDB) = vyl[u];
+            *reinterpret_cast<u32x4 *>(base + 2 * SLAB + u * 8 * LDB) = vxh[u];
+            *reinterpret_cast<u32x4 *>(base + 3 * SLAB + u * 8 * LDB) = vxl[u];
+        }
+    };
+    const int c16 = lane & 15;
+    const int frag_off = (8 * kh + (c16 >> 2)) * LDB + (16 * ((lane >> 4) & 1) + 4 * (c16 & 3)) * 2;
+    struct Frags { P::T8 ah[4], al[4], bh[4], bl[4]; };
+    auto read_frags = [&](Frags &f, int buf, int ks) {
+        const char *sYh = dws + buf * (4 * SLAB) + ks * 16 * LDB + frag_off, *sYl = sYh + SLAB, *sXh = sYh + 2 * SLAB, *sXl = sYh + 3 * SLAB;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f.ah[a] = tr_frag<P::T8, LDB>(sYh + (wo + a * 32) * 2);
+            f.al[a] = tr_frag<P::T8, LDB>(sYl + (wo + a * 32) * 2);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            f.bh[b] = tr_frag<P::T8, LDB>(sXh + (wk + b * 32) * 2);
+            f.bl[b] = tr_frag<P::T8, LDB>(sXl + (wk + b * 32) * 2);
+        }
+    };
+    const bool sums = (tile4 & 1) == 0 && (w & 1) == 0;
+    auto mfmas = [&](const Frags &f) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(f.ah[a], f.bh[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(f.ah[a], f.bl[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(f.al[a], f.bh[b], acc[a][b]);
+#if !(defined(PNR_VARIANT) && defined(PNR_X_DWW_NOSUM))
+        // column sums of dY (the bias gradient), formed in every wave -- a uniform branch would cut the pinned block in two -- and
+        // written by the waves that own them: v_dot2_f32_f16 against (1, 1), fp32 accumulate, 8 VALU per fragment pair
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 ones = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                bsum[a] = __builtin_amdgcn_fdot2(h2{f.ah[a][e], f.ah[a][e + 1]}, ones, bsum[a], false);
+                bsum[a] = __builtin_amdgcn_fdot2(h2{f.al[a][e], f.al[a][e + 1]}, ones, bsum[a], false);
+            }
+#endif
+    };
+    const int nrows = r_begin < r_end ? (int)(r_end - r_begin) : 0;
+    const int nfull = nrows / SR;  // slabs of the pipelined loop
+    if (nfull > 0) {
+        Frags f0, f1;
+        load_slab(r_begin);
+        store_slab(0);
+        __syncthreads();
+        load_slab(r_begin + (long long)min(1, nfull - 1) * SR);
+        read_frags(f0, 0, 0);
+#pragma unroll 1
+        for (int sl = 0; sl + 1 < nfull; ++sl) {
+            const int cur = sl & 1;
+            // k-step 0 of slab sl: its fragments were read under the previous k-step; read k-step 1's, then park slab sl + 1 (requested
+            // a whole k-step ago) in the other buffer -- its last readers waited for their data in front of the previous barrier
+            read_frags(f1, cur, 1);
+#if !(defined(PNR_VARIANT) && defined(PNR_X_DWW_NOSTORE))
+            store_slab(cur ^ 1);
+#endif
+            mfmas(f0);
+#pragma unroll
+            for (int n = 0; n < 32; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 transposing read
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // 1 VALU (addresses, bias sums)
+            }
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS store
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+#if !(defined(PNR_VARIANT) && defined(PNR_X_DWW_NOBARRIER))
+            __syncthreads();  // slab sl + 1 is visible; nobody reads buffer `cur` any more
+#endif
+#if !(defined(PNR_VARIANT) && defined(PNR_X_DWW_NOLOAD))
+            load_slab(r_begin + (long long)min(sl + 2, nfull - 1) * SR);  // (the last iteration re-requests the last slab: no branch)
+#endif
+            read_frags(f0, cur ^ 1, 0);
+            mfmas(f1);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 global load: all 16 right behind the barrier
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+#pragma unroll
+            for (int n = 0; n < 32; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+        }
+        // the last full slab
+        read_frags(f1, (nfull - 1) & 1, 1);
+        mfmas(f0);
+        mfmas(f1);
+    }
+    if (nrows > nfull * SR) {  // the slice's last, partial slab (rows not a multiple of 32): predicated loads, no pipelining
+        __syncthreads();
+        const long long r0 = r_begin + (long long)nfull * SR;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int srow = (t + u * 256) >> 5;
+            vyh[u] = vyl[u] = vxh[u] = vxl[u] = u32x4{0, 0, 0, 0};
+            if (r0 + srow < r_end) {
+                const T *by = dYh + (size_t)r0 * D_HID + o0, *bx = Xh + (size_t)r0 * nx + k0;
+                vyh[u] = *reinterpret_cast<const u32x4 *>(by + offy[u]);
+                vyl[u] = *reinterpret_cast<const u32x4 *>(by + tail_y + offy[u]);
+                vxh[u] = *reinterpret_cast<const u32x4 *>(bx + offx[u]);
+                vxl[u] = *reinterpret_cast<const u32x4 *>(bx + tail_x + offx[u]);
+            }
+        }
+        store_slab(0);
+        __syncthreads();
+        Frags f;
+        read_frags(f, 0, 0);
+        mfmas(f);
+        read_frags(f, 0, 1);
+        mfmas(f);
+    }
+    float *pz = part + ((size_t)job * jobs.nsplit + slice) * (D_HID * D_HID);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orow = o0 + wo + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                pz[(size_t)orow * D_HID + k0 + wk + b * 32 + i] = acc[a][b][r];
+            }
+    if (sums) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
             float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
             if (kh == 0) bpart[((size_t)job * jobs.nsplit + slice) * D_HID + o0 + wo + a * 32 + i] = v;
         }
@@ -1704,7 +1927,15 @@ extern "C" int pnr_weight_grad_batched(const PnrWeightGradJob *jobs, int n_jobs,
         constexpr int lds = 2 * 4 * 32 * 576;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dw_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(dw_split_kernel)");
-        hipLaunchKernelGGL(dw_split_kernel, grid, dim3(512), lds, st, J, part, bpart);
+        // one wave per SIMD with 128 x 128 wave tiles (dw_split_wide_kernel) since round 6: -12 % per launch, same partial sums bit
+        // for bit (the bias sums differ in summation order); PNR_DW_FORM=8wave selects the round-3..5 kernel (profiles/r06_dw_split_notes.md)
+        static const bool wide = [] { const char *e = getenv("PNR_DW_FORM"); return !(e && !strcmp(e, "8wave")); }();
+        if (wide) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(dw_split_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(dw_split_wide_kernel)");
+            hipLaunchKernelGGL(dw_split_wide_kernel, grid, dim3(256), lds, st, J, part, bpart);
+        } else
+            hipLaunchKernelGGL(dw_split_kernel, grid, dim3(512), lds, st, J, part, bpart);
     } else
         return pnr_fail(PNR_E_INVALID, "pnr_weight_grad_batched: unknown precision");
     hipLaunchKernelGGL(dw_reduce_kernel, dim3(D_HID * D_HID / 256, (unsigned)n_jobs), dim3(256), 0, st, J, part, bpart, out_scale, out_scale_dev);
