@@ -27,7 +27,7 @@ for path in sorted(glob.glob(os.path.join(out, "**", "*counter_collection.csv"),
     per = {}
     for row in csv.DictReader(open(path)):
         k = row["Kernel_Name"]
-        if not any(s in k for s in ("dw_split_kernel", "bwd_split_kernel", "eval_split_kernel", "latent_scatter", "fold_kernel", "fold_split_kernel", "gemm3", "lin_out_grad_f32")):
+        if not any(s in k for s in ("dw_split_kernel", "dw_split_wide_kernel", "bwd_split_kernel", "eval_split_kernel", "latent_scatter", "fold_kernel", "fold_split", "gemm3", "lin_out_grad_f32")):
             continue
         name = k.split("(")[0].replace("void pnr::", "")[:60]
         per.setdefault((name, row["Counter_Name"]), {}).setdefault(row["Dispatch_Id"], 0.0)

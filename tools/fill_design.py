@@ -60,7 +60,7 @@ V = {
     "STEP16": "%.2f" % ts16["ms_per_step"], "STEP16X": "%.1f" % (eager / ts16["ms_per_step"]),
     "EVALT": "%.0f" % pick(tr, "eval_split_kernel<true, false, false, true, false>"), "EVALB": pick(busy, "eval_split_kernel"),
     "BWDT": "%.0f" % pick(tr, "::bwd_split_kernel"), "BWDB": pick(busy, "bwd_split_kernel<"),
-    "DWT": "%.0f" % pick(tr, "dw_split_kernel"), "DWB": pick(busy, "dw_split_kernel"),
+    "DWT": "%.0f" % pick(tr, "dw_split_wide_kernel"), "DWB": pick(busy, "dw_split_wide_kernel"),
     "SCT": "%.0f" % pick(tr, "latent_scatter_owner_kernel"), "SEGT": "%.0f" % pick(tr, "scatter_segments_kernel"),
     "SCC": pick(conf, "latent_scatter_owner_kernel"),
     "OBJA": "%.1f" % o["reference_shaped_loop"]["ms_per_object"], "OBJB": "%.1f" % o["render_views_plus_epilogue"]["ms_per_object"],
