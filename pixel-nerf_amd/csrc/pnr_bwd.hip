@@ -863,207 +863,6 @@ dw_split_wide_kernel(const DwJobs jobs, float *__restrict__ part, float *__restr
     }
 }
 
-// dw_split_wide_kernel with the operand rows going global -> LDS DIRECTLY (global_load_lds_dwordx4; experiment, PNR_DW_FORM=lds).
-// No staging registers and no LDS store instructions: a slab is requested right behind the barrier that retires the last reader of
-// its buffer and has both k-steps up to the next barrier to arrive (96 MFMA slots against 64).  A wave instruction of that kind writes
-// 1 KiB of CONTIGUOUS LDS (lane l: 16 bytes at base + 16 l), so rows cannot be padded: they are 512 bytes (two per instruction) and
-// the 64-byte column tiles of row r are XOR-swizzled by r & 3 instead -- the four rows x 64 bytes that 32 lanes of a transposing read
-// touch land on 16 different 16-byte bank groups.  The lane's global address does the swizzle on the way in (the unit that lives at
-// physical position p of row r is logical unit p ^ 4 (r & 3)); the transposing reads undo it with a lane-constant tile offset.
-__global__ void __launch_bounds__(256)
-dw_split_lds_kernel(const DwJobs jobs, float *__restrict__ part, float *__restrict__ bpart) {
-    typedef Prec<PNR_PREC_F16> P;
-    typedef _Float16 T;
-    constexpr int SR = 32, LDB = 512;
-    extern __shared__ __attribute__((aligned(16))) char dws[];  // [buf][dY head, dY tail, X head, X tail][SR * LDB] = 128 KiB
-    constexpr int SLAB = SR * LDB;
-    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int lid = blockIdx.x, ngroups = gridDim.x >> 2, full = (ngroups >> 3) * 32;
-    int grp, tile4;
-    if (lid < full) { const int k = lid >> 3; grp = (k >> 2) * 8 + (lid & 7); tile4 = k & 3; }
-    else { const int rem = lid - full; grp = (full >> 2) + (rem >> 2); tile4 = rem & 3; }
-    const int job = grp / jobs.nsplit, slice = grp - job * jobs.nsplit;
-    const long long rows = jobs.rows[job];
-    const int nx = jobs.nx[job];
-    const T *dYh = reinterpret_cast<const T *>(jobs.dY[job]);
-    const T *Xh = reinterpret_cast<const T *>(jobs.X[job]);
-    long long per = (rows + jobs.nsplit - 1) / jobs.nsplit;
-    per = (per + SR - 1) / SR * SR;
-    const int o0 = (tile4 >> 1) * 256, k0 = (tile4 & 1) * 256;
-    if (k0 >= nx) return;  // narrow X (lin_in): only the first column tile exists
-    const long long r_begin = (long long)slice * per;
-    const long long r_end = r_begin + per < rows ? r_begin + per : rows;
-    const int wo = (w >> 1) * 128, wk = (w & 1) * 128;  // wave tile: 128 (o) x 128 (k) = 4 x 4 MFMA tiles
-    const int i = lane & 31, kh = lane >> 5;
-    f32x16 acc[4][4];
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    // ---- global -> LDS.  Instruction n (0..3) of wave w fills rows 2 w + 8 n and 2 w + 8 n + 1 of an operand slab: lane = (row of
-    // the pair, physical 16-byte unit); (row & 3) does not depend on n, so a lane has ONE global offset per operand
-    const int prow = 2 * w + (lane >> 5);
-    const int scol = ((lane & 31) ^ (4 * (prow & 3))) * 8;  // first column of the logical unit that lives at this lane's position
-    const unsigned goff_y = (unsigned)((prow * D_HID + scol) * 2);
-    const unsigned goff_x = (unsigned)((prow * nx + (k0 + scol < nx ? scol : 0)) * 2);
-    const size_t tail_y = (size_t)rows * D_HID * 2, tail_x = (size_t)rows * nx * 2;  // bytes from a head array to its tail array
-    typedef __attribute__((address_space(1))) const void *gptr_t;
-    typedef __attribute__((address_space(3))) void *lptr_t;
-    auto request_slab = [&](int buf, long long r0) {  // 16 wave instructions, nothing to wait for here
-        const char *by = reinterpret_cast<const char *>(dYh + (size_t)r0 * D_HID + o0);  // uniform
-        const char *bx = reinterpret_cast<const char *>(Xh + (size_t)r0 * nx + k0);
-        char *lb = dws + buf * (4 * SLAB) + 2 * w * LDB;  // uniform
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const char *gy = by + (size_t)n * 8 * D_HID * 2, *gx = bx + (size_t)n * 8 * nx * 2;
-            char *l = lb + n * 8 * LDB;
-            __builtin_amdgcn_global_load_lds((gptr_t)(gy + goff_y), (lptr_t)l, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(gy + tail_y + goff_y), (lptr_t)(l + SLAB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(gx + goff_x), (lptr_t)(l + 2 * SLAB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(gx + tail_x + goff_x), (lptr_t)(l + 3 * SLAB), 16, 0, 0);
-        }
-    };
-    // ---- transposing reads: row 16 ks + 8 kh + q (+ 4), q = (lane & 15) >> 2 = row & 3; column tile T of the wave's 128 columns sits at
-    // physical tile T ^ q
-    const int c16 = lane & 15, q = c16 >> 2;
-    const int lane_off = (8 * kh + q) * LDB + 32 * ((lane >> 4) & 1) + 16 * ((c16 & 3) >> 1) + 8 * (c16 & 1);
-    int toff[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) toff[a] = 64 * (a ^ q) + lane_off;
-    struct Frags { P::T8 ah[4], al[4], bh[4], bl[4]; };
-    auto read_frags = [&](Frags &f, int buf, int ks) {
-        const char *sYh = dws + buf * (4 * SLAB) + ks * 16 * LDB, *sYl = sYh + SLAB, *sXh = sYh + 2 * SLAB, *sXl = sYh + 3 * SLAB;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            f.ah[a] = tr_frag<P::T8, LDB>(sYh + wo * 2 + toff[a]);
-            f.al[a] = tr_frag<P::T8, LDB>(sYl + wo * 2 + toff[a]);
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            f.bh[b] = tr_frag<P::T8, LDB>(sXh + wk * 2 + toff[b]);
-            f.bl[b] = tr_frag<P::T8, LDB>(sXl + wk * 2 + toff[b]);
-        }
-    };
-    const bool sums = (tile4 & 1) == 0 && (w & 1) == 0;
-    auto mfmas = [&](const Frags &f) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(f.ah[a], f.bh[b], acc[a][b]);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(f.ah[a], f.bl[b], acc[a][b]);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(f.al[a], f.bh[b], acc[a][b]);
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 ones = {(_Float16)1.f, (_Float16)1.f};
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                bsum[a] = __builtin_amdgcn_fdot2(h2{f.ah[a][e], f.ah[a][e + 1]}, ones, bsum[a], false);
-                bsum[a] = __builtin_amdgcn_fdot2(h2{f.al[a][e], f.al[a][e + 1]}, ones, bsum[a], false);
-            }
-    };
-    const int nrows = r_begin < r_end ? (int)(r_end - r_begin) : 0;
-    const int nfull = nrows / SR;  // slabs of the pipelined loop
-    if (nfull > 0) {
-        Frags f0, f1;
-        request_slab(0, r_begin);
-        __syncthreads();  // (waits for the wave's own loads -- vmcnt(0) -- and for everybody else's)
-        request_slab(1, r_begin + (long long)min(1, nfull - 1) * SR);
-        read_frags(f0, 0, 0);
-#pragma unroll 1
-        for (int sl = 0; sl + 1 < nfull; ++sl) {
-            const int cur = sl & 1;
-            // k-step 0 of slab sl under the reads of its k-step 1; slab sl + 1 has been on its way into the other buffer since the
-            // previous barrier and must have arrived at this one
-            read_frags(f1, cur, 1);
-            mfmas(f0);
-#pragma unroll
-            for (int n = 0; n < 32; ++n) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 transposing read
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // 1 VALU
-            }
-            __syncthreads();  // slab sl + 1 is complete and visible; nobody reads buffer `cur` any more
-            request_slab(cur, r_begin + (long long)min(sl + 2, nfull - 1) * SR);  // (the last iteration re-requests the last slab: no branch)
-            read_frags(f0, cur ^ 1, 0);
-            mfmas(f1);
-#pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 global -> LDS request: all 16 right behind the barrier
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            }
-#pragma unroll
-            for (int n = 0; n < 32; ++n) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            }
-        }
-        // the last full slab
-        read_frags(f1, (nfull - 1) & 1, 1);
-        mfmas(f0);
-        mfmas(f1);
-    }
-    if (nrows > nfull * SR) {  // the slice's last, partial slab (rows not a multiple of 32): through registers, predicated, no pipelining
-        __syncthreads();  // (also retires the re-requested last slab: vmcnt(0) in front of the barrier)
-        const long long r0 = r_begin + (long long)nfull * SR;
-        const T *dYl = dYh + (size_t)rows * D_HID, *Xl = Xh + (size_t)rows * nx;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int srow = (t >> 5) + 8 * u, sc = (t & 31) * 8;
-            u32x4 vyh = {0, 0, 0, 0}, vyl = vyh, vxh = vyh, vxl = vyh;
-            if (r0 + srow < r_end) {
-                const size_t oy = (size_t)(r0 + srow) * D_HID + o0 + sc;
-                vyh = *reinterpret_cast<const u32x4 *>(dYh + oy);
-                vyl = *reinterpret_cast<const u32x4 *>(dYl + oy);
-                if (k0 + sc < nx) {
-                    const size_t ox = (size_t)(r0 + srow) * nx + k0 + sc;
-                    vxh = *reinterpret_cast<const u32x4 *>(Xh + ox);
-                    vxl = *reinterpret_cast<const u32x4 *>(Xl + ox);
-                }
-            }
-            char *dst = dws + srow * LDB + (((t & 31) ^ (4 * (srow & 3))) << 4);
-            *reinterpret_cast<u32x4 *>(dst) = vyh;
-            *reinterpret_cast<u32x4 *>(dst + SLAB) = vyl;
-            *reinterpret_cast<u32x4 *>(dst + 2 * SLAB) = vxh;
-            *reinterpret_cast<u32x4 *>(dst + 3 * SLAB) = vxl;
-        }
-        __syncthreads();
-        Frags f;
-        read_frags(f, 0, 0);
-        mfmas(f);
-        read_frags(f, 0, 1);
-        mfmas(f);
-    }
-    float *pz = part + ((size_t)job * jobs.nsplit + slice) * (D_HID * D_HID);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int orow = o0 + wo + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                pz[(size_t)orow * D_HID + k0 + wk + b * 32 + i] = acc[a][b][r];
-            }
-    if (sums) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
-            if (kh == 0) bpart[((size_t)job * jobs.nsplit + slice) * D_HID + o0 + wo + a * 32 + i] = v;
-        }
-    }
-}
-
 // dW = scale * sum_z part[job][z], db = scale * sum_z bpart[job][z]  (fixed summation order); blockIdx.y = job.
 // rows_st / cols_st: the operand that indexes the rows (dY) / columns (X) of dW was dumped in storage order;
 // the result is written in feature order (row e -> feature feat_of(e/32, (e%32)/16, e%16)).
@@ -2131,13 +1930,7 @@ extern "C" int pnr_weight_grad_batched(const PnrWeightGradJob *jobs, int n_jobs,
         // one wave per SIMD with 128 x 128 wave tiles (dw_split_wide_kernel) since round 6: -12 % per launch, same partial sums bit
         // for bit (the bias sums differ in summation order); PNR_DW_FORM=8wave selects the round-3..5 kernel (profiles/r06_dw_split_notes.md)
         static const bool wide = [] { const char *e = getenv("PNR_DW_FORM"); return !(e && !strcmp(e, "8wave")); }();
-        static const bool direct = [] { const char *e = getenv("PNR_DW_FORM"); return e && !strcmp(e, "lds"); }();
-        if (direct) {  // experiment: operand rows global -> LDS directly (profiles/r06_dw_split_notes.md)
-            constexpr int lds_d = 2 * 4 * 32 * 512;
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(dw_split_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_d);
-            if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(dw_split_lds_kernel)");
-            hipLaunchKernelGGL(dw_split_lds_kernel, grid, dim3(256), lds_d, st, J, part, bpart);
-        } else if (wide) {
+        if (wide) {
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(dw_split_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return pnr_check_hip(e, "hipFuncSetAttribute(dw_split_wide_kernel)");
             hipLaunchKernelGGL(dw_split_wide_kernel, grid, dim3(256), lds, st, J, part, bpart);
