@@ -480,14 +480,19 @@ def extra_eval_object_loop(dev, n_views=24, n_obj=4):
 def extra_train_step(dev, prec, scene_name="train", steps=40, warmup=8, with_graph=True):
     """BASELINE configs[4]: sn64 training step, 4 objects x 128 rays, 64 coarse + 32 fine (16 depth), ResnetFC d=512,
     forward + backward (+ Adam) through NeRFRenderer/_RenderWrapper in train mode (train/train.py:199-215).
-    scene_name "train_mv": the same step on a 2-object x 2-source-view scene (multi-view pooling in forward and backward)."""
+    scene_name "train_mv": the same step on a 2-object x 2-source-view scene (multi-view pooling in forward and backward);
+    "dtu": 1 object x 3 views on the full DTU grid; "dtu_train4": the reference's DTU training batch (README.md:204,253: 4 objects x
+    3 views x 128 rays; twelve 150 x 200 grids)."""
     from pixelnerf_amd.model import make_model
     from pixelnerf_amd.render import NeRFRenderer
     from pixelnerf_amd.util import DotMap
     from pixelnerf_amd.util.conf import default_model_conf
     from testdata import synthetic
-    scene, meta = synthetic.make_scene(scene_name)
+    big = scene_name == "dtu_train4"  # 12 full-size DTU grids: drawn on the device (timing only)
+    scene, meta = synthetic.make_scene(scene_name, with_latent=not big)
     SB, NS = scene["SB"], scene["NS"]
+    if big:
+        scene["latent"] = torch.randn((SB * NS, 512, meta["Hl"], meta["Wl"]), device=dev, generator=torch.Generator(device=dev).manual_seed(2)) * 0.5
     rays = synthetic.target_rays(meta, n_rays=128).to(dev)  # (SB,128,8)
     gt = torch.rand(SB, 128, 3, device=dev)
     net = make_model(default_model_conf(), precision=prec).to(dev).train()
@@ -1033,6 +1038,7 @@ def main():
                             ("train_step_fp32_class", lambda: extra_train_step(dev, "f16x3", steps=16, warmup=4, with_graph=True)),
                             ("train_step_fp32_class_multiview", lambda: extra_train_step(dev, "f16x3", "train_mv", steps=12, warmup=3, with_graph=False)),
                             ("train_step_fp32_class_dtu", lambda: extra_train_step(dev, "f16x3", "dtu", steps=12, warmup=3, with_graph=False)),
+                            ("train_step_fp32_class_dtu_batch4", lambda: extra_train_step(dev, "f16x3", "dtu_train4", steps=8, warmup=3, with_graph=False)),
                             ("train_step_fp32_class_gemm_per_layer", lambda: train_step_unfused_twin(dev)),
                             ("train_step_torch_eager_gpu_baseline", lambda: train_step_eager_torch(dev)),
                             ("train_step_fp32_validation_path", lambda: extra_train_step(dev, "f32", steps=5, warmup=2, with_graph=False)),

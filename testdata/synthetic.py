@@ -156,6 +156,11 @@ SCENES = {
     "dtu": dict(W=400, H=300, NS=3, SB=1, Hl=150, Wl=200, focal=(723.0, 723.0), c=(200.0, 150.0),
                 z_near=0.1, z_far=5.0, radius=2.0, src=[(-20.0, -15.0), (0.0, -25.0), (20.0, -15.0)],
                 tgt=(0.0, -15.0), white_bkgd=False, blender=False),
+    # the reference's DTU TRAINING batch (README.md:204,253: -B 4 objects, 3 source views each, 128 rays per object): twelve full-size
+    # grids (737 MB); the four objects see the same camera rig (target_rays() turns the target camera by 40 degrees per object)
+    "dtu_train4": dict(W=400, H=300, NS=3, SB=4, Hl=150, Wl=200, focal=(723.0, 723.0), c=(200.0, 150.0),
+                       z_near=0.1, z_far=5.0, radius=2.0, src=[(-20.0, -15.0), (0.0, -25.0), (20.0, -15.0)] * 4,
+                       tgt=(0.0, -15.0), white_bkgd=False, blender=False),
     "dtu_mini": dict(W=40, H=30, NS=3, SB=1, Hl=15, Wl=20, focal=(72.3, 70.1), c=(20.5, 14.25),
                      z_near=0.1, z_far=5.0, radius=2.0,
                      src=[(-20.0, -15.0), (0.0, -25.0), (20.0, -15.0)],
@@ -208,15 +213,17 @@ SCENES = {
 }
 
 
-def make_scene(name, seed=2, latent_scale=0.5):
+def make_scene(name, seed=2, latent_scale=0.5, with_latent=True):
     """Returns (scene, meta).  scene holds exactly what PixelNeRFNet.encode() leaves behind
     (SURVEY.md §3.4): latent NCHW (SB*NS,512,Hl,Wl), poses (SB*NS,3,4), focal (1,2), c (1,2),
     image_shape (2), NS, SB.  Source views are object-major: row = obj*NS + view."""
     g = SCENES[name]
     rs = np.random.RandomState(seed)
     NV = g["SB"] * g["NS"]
+    # (with_latent=False: timing-only callers of the largest scenes draw the grid on the device themselves -- 737 MB of
+    # single-threaded numpy draws take 20 s)
     latent = torch.from_numpy(
-        (rs.randn(NV, 512, g["Hl"], g["Wl"]) * latent_scale).astype(np.float32))
+        (rs.randn(NV, 512, g["Hl"], g["Wl"]) * latent_scale).astype(np.float32)) if with_latent else None
     pre = coord_from_blender() if g["blender"] else torch.eye(4)
     assert len(g["src"]) == NV
     src = torch.stack([pre @ pose_spherical(t, p, g["radius"]) for (t, p) in g["src"]], 0)

@@ -55,6 +55,7 @@ V = {
     "STEP": "%.2f" % ts["ms_per_step"], "STEPX": "%.1f" % (eager / ts["ms_per_step"]), "EAGER": "%.1f" % eager,
     "STEPR": "%.2f–%.2f" % (min(ms_rocprof), max(ms_rocprof)), "STEPMV": "%.2f" % e["train_step_fp32_class_multiview"]["ms_per_step"],
     "STEPDTU": "%.2f" % e["train_step_fp32_class_dtu"]["ms_per_step"],
+    "STEPDTU4": "%.1f" % e["train_step_fp32_class_dtu_batch4"]["ms_per_step"],
     "GRAPH": "%.2f" % ts["hip_graph"]["ms_per_step"], "TWIN": "%.1f" % e["train_step_fp32_class_gemm_per_layer"]["ms_per_step"],
     "F32": "%.1f" % e["train_step_fp32_validation_path"]["ms_per_step"],
     "STEP16": "%.2f" % ts16["ms_per_step"], "STEP16X": "%.1f" % (eager / ts16["ms_per_step"]),

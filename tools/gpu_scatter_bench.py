@@ -12,9 +12,13 @@ dev = torch.device("cuda:0")
 tag = os.path.basename(os.environ.get("PIXELNERF_HIP_LIB", "product"))
 gen = torch.Generator().manual_seed(3)
 torch.manual_seed(3)
-for name, K, hw in (("train", 64, None), ("train", 96, None), ("train_mv", 96, None), ("train", 96, 64), ("dtu", 96, None)):
-    s, meta = synthetic.make_scene(name)
-    lat = s["latent"] if hw is None else torch.randn(s["latent"].shape[0], 512, hw, hw, generator=gen)
+for name, K, hw in (("train", 64, None), ("train", 96, None), ("train_mv", 96, None), ("train", 96, 64), ("dtu", 96, None), ("dtu_train4", 96, None)):
+    big = name == "dtu_train4"  # the reference's DTU training batch: twelve 150 x 200 grids, drawn on the device
+    s, meta = synthetic.make_scene(name, with_latent=not big)
+    if big:
+        lat = torch.randn(s["SB"] * s["NS"], 512, meta["Hl"], meta["Wl"], device=dev)
+    else:
+        lat = s["latent"] if hw is None else torch.randn(s["latent"].shape[0], 512, hw, hw, generator=gen)
     sc = ops.make_scene(lat.to(dev), s["poses"].to(dev), s["focal"].to(dev), s["c"].to(dev), s["image_shape"], s["NS"])
     rays = synthetic.target_rays(meta, n_rays=128).reshape(-1, 8).to(dev)
     z = ops.sample_coarse(rays, torch.rand(rays.shape[0], K, device=dev))
