@@ -120,6 +120,19 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pnr_grad_scale(None, 10, None, None) == -1
     assert lib.pnr_weight_grad(None, None, 10, 0, 1.0, 0, 0, None, None, None, None) == -1
     assert lib.pnr_position_backward(None, None, None, 1, 1, 1, None, None, None, None) == -1
+    # round-6 entries (ABI rev 8): the row-wise fold of training passes on large grids, the scatter's ownership query
+    sc = _lib.PnrScene()
+    sc.SB, sc.NS, sc.Hl, sc.Wl = 2, 3, 150, 200
+    M = 2 * 3 * 150 * 200
+    nb = (M + 4095) // 4096
+    assert lib.pnr_fold_latent_f32_rows_workspace_bytes(ctypes.byref(sc)) == nb * 4096 + (nb + 4 + M) * 4
+    assert lib.pnr_fold_latent_f32_rows_workspace_bytes(None) == 0
+    assert lib.pnr_fold_latent_f32_rows(None, None, None, None, 4, 2, 8, None, None, 0, None) == -1
+    assert b"null argument" in lib.pnr_last_error()
+    assert lib.pnr_latent_scatter_single_owner(None, 4, 2, 8) == 0
+    assert lib.pnr_latent_scatter_single_owner(ctypes.byref(sc), 256, 128, 96) == 1   # DTU-sized grid: owner tiles
+    sc.Hl, sc.Wl = 32, 32
+    assert lib.pnr_latent_scatter_single_owner(ctypes.byref(sc), 256, 128, 96) == 0   # LDS slabs, two workgroups per (image, slice)
     # the stand-alone nn.Linear operator pair: sizes, precisions (exact fp32 / fp32-class only), operands, workspace, grad_scale
     assert lib.pnr_linear(None, None, None, None, None, 4, 0, 8, 0, _lib.PREC_F32, None) == -1
     assert lib.pnr_linear(64, 64, None, None, 64, 4, 8, 8, 0, _lib.PREC_F16, None) == -1
