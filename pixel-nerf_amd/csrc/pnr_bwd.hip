@@ -750,7 +750,6 @@ dw_split_wide_kernel(const DwJobs jobs, float *__restrict__ part, float *__restr
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = P::mfma(f.al[a], f.bh[b], acc[a][b]);
-#if !(defined(PNR_VARIANT) && defined(PNR_X_DWW_NOSUM))
         // column sums of dY (the bias gradient), formed in every wave -- a uniform branch would cut the pinned block in two -- and
         // written by the waves that own them: v_dot2_f32_f16 against (1, 1), fp32 accumulate, 8 VALU per fragment pair
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -762,7 +761,6 @@ dw_split_wide_kernel(const DwJobs jobs, float *__restrict__ part, float *__restr
                 bsum[a] = __builtin_amdgcn_fdot2(h2{f.ah[a][e], f.ah[a][e + 1]}, ones, bsum[a], false);
                 bsum[a] = __builtin_amdgcn_fdot2(h2{f.al[a][e], f.al[a][e + 1]}, ones, bsum[a], false);
             }
-#endif
     };
     const int nrows = r_begin < r_end ? (int)(r_end - r_begin) : 0;
     const int nfull = nrows / SR;  // slabs of the pipelined loop
@@ -778,10 +776,13 @@ dw_split_wide_kernel(const DwJobs jobs, float *__restrict__ part, float *__restr
             const int cur = sl & 1;
             // k-step 0 of slab sl: its fragments were read under the previous k-step; read k-step 1's, then park slab sl + 1 (requested
             // a whole k-step ago) in the other buffer -- its last readers waited for their data in front of the previous barrier
+            // k-step 0 of slab sl: its fragments were read under the previous k-step.  Read k-step 1's (32 slots), then park slab sl + 1 --
+            // requested two k-steps ago -- in the other buffer (its last readers waited for their data in front of the previous barrier)
+            // and request slab sl + 2 into every staging register right behind the LDS store that read it: 96 MFMA slots in flight
+            // (requested behind the barrier instead -- 64 slots -- the launch was 2.5 % slower: profiles/r06_dw_split_notes.md)
             read_frags(f1, cur, 1);
-#if !(defined(PNR_VARIANT) && defined(PNR_X_DWW_NOSTORE))
             store_slab(cur ^ 1);
-#endif
+            load_slab(r_begin + (long long)min(sl + 2, nfull - 1) * SR);  // (the last iteration re-requests the last slab: no branch)
             mfmas(f0);
 #pragma unroll
             for (int n = 0; n < 32; ++n) {
@@ -793,22 +794,12 @@ dw_split_wide_kernel(const DwJobs jobs, float *__restrict__ part, float *__restr
             for (int n = 0; n < 16; ++n) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS store
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 global load into the register it read
                 __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
             }
-#if !(defined(PNR_VARIANT) && defined(PNR_X_DWW_NOBARRIER))
             __syncthreads();  // slab sl + 1 is visible; nobody reads buffer `cur` any more
-#endif
-#if !(defined(PNR_VARIANT) && defined(PNR_X_DWW_NOLOAD))
-            load_slab(r_begin + (long long)min(sl + 2, nfull - 1) * SR);  // (the last iteration re-requests the last slab: no branch)
-#endif
             read_frags(f0, cur ^ 1, 0);
             mfmas(f1);
-#pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 global load: all 16 right behind the barrier
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            }
 #pragma unroll
             for (int n = 0; n < 32; ++n) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
