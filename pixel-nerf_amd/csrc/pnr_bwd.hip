@@ -1465,13 +1465,29 @@ latent_scatter_tiled_kernel(const EvalParams q, const float *__restrict__ d_zlat
         }
     }
     __syncthreads();
+    // write-back: read-add-write of the touched elements, this workgroup being their only writer.  Done element by element -- LDS read,
+    // branch, global load, add, store -- every touched element of a thread was a round trip of its own (a quarter of a tile's texels are
+    // touched: ~4 dependent trips per thread); here all 16 loads of a thread are issued first (an untouched element reads a valid
+    // dummy), then the touched ones are added and stored: one trip
     float *out = d_latent + (size_t)img * Hl * Wl * C_LAT + cs * TILE_CS;
-    for (int i = t; i < TILE_TEXELS * TILE_CS; i += OWNER_NT) {
+    constexpr int WB = TILE_TEXELS * TILE_CS / OWNER_NT;  // 16 elements per thread
+    static_assert(TILE_TEXELS * TILE_CS % OWNER_NT == 0, "write-back tiling");
+    float add[WB], old[WB];
+    float *dst[WB];
+#pragma unroll
+    for (int j = 0; j < WB; ++j) {
+        const int i = t + j * OWNER_NT;
         const int tex = i / TILE_CS, ch = i % TILE_CS;
         const int x = tx0 + tex % TILE_W, y = ty0 + tex / TILE_W;
         const double sv = dslab[tex * TILE_ROW + ch];
-        if (sv != 0.0 && x < Wl && y < Hl) out[(size_t)(y * Wl + x) * C_LAT + ch] += (float)sv;  // the only writer of this texel
+        const bool touched = sv != 0.0 && x < Wl && y < Hl;
+        add[j] = (float)sv;
+        dst[j] = touched ? out + (size_t)(y * Wl + x) * C_LAT + ch : nullptr;
+        old[j] = *(touched ? dst[j] : out);  // (`out` itself is always a valid address of the image)
     }
+#pragma unroll
+    for (int j = 0; j < WB; ++j)
+        if (dst[j]) *dst[j] = old[j] + add[j];
 }
 #pragma clang fp contract(fast)
 
